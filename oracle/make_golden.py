@@ -1,0 +1,362 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE'S OWN MODULES (CPU) in the build container.
+
+TEST INFRASTRUCTURE.  Run from the repo root:  python oracle/make_golden.py
+Needs /root/reference (read-only).  The fixtures hold inputs-by-recipe (closed-form
+``pmf_amd.utils.detinit``) and expected OUTPUTS only -- no reference source text.
+
+How the reference is imported (it cannot be imported as a package: tensorboardX,
+torchvision, nuscenes-devkit, cv2 are absent -- SURVEY.md 8c):
+  * pc_processor/models/salsanext.py, postproc/knn.py, loss/*.py, metrics/iou_eval.py,
+    utils/warmup_lr.py, dataset/semantic_kitti/parser.py: loaded by file path.
+  * pc_processor/models/pmf_net.py needs ``torchvision.models.resnet``; torchvision is a
+    THIRD-PARTY dependency that is not installed, so the camera backbone is supplied by this
+    repo's restatement (oracle/pmf_torch.py: BasicBlock/Bottleneck).  Everything else in
+    PMFNet (fusion blocks, ASPP, decoder, SalsaNext trunk, stem replacement) is reference code.
+    => camera-backbone parity is UNPINNED (stated in DESIGN.md); the rest is pinned.
+  * dataset/perspective_view_loader.py needs ``torchvision.transforms`` only to CONSTRUCT
+    transforms that the return_uproj path never applies; name-only placeholders are registered.
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+OUT = os.path.join(ROOT, "tests", "golden")
+
+from pmf_amd.utils.detinit import deterministic_init, det_tensor, synthetic_batch  # noqa: E402
+from oracle import pmf_torch as O  # noqa: E402
+from oracle import knn_ref, loader_ref  # noqa: E402,F401
+from oracle.cases import knn_case  # noqa: E402
+
+
+def _load(modname, relpath):
+    spec = importlib.util.spec_from_file_location(modname, os.path.join(REF, relpath))
+    m = importlib.util.module_from_spec(spec)
+    sys.modules[modname] = m
+    spec.loader.exec_module(m)
+    return m
+
+
+def import_reference():
+    # synthetic parent packages so relative imports resolve
+    for name in ("refpc", "refpc.models"):
+        pkg = types.ModuleType(name)
+        pkg.__path__ = []
+        sys.modules[name] = pkg
+    tv = types.ModuleType("torchvision")
+    tvm = types.ModuleType("torchvision.models")
+    tvr = types.ModuleType("torchvision.models.resnet")
+
+    def _mk(name):
+        def ctor(pretrained=False):
+            blk, cnt = O.RESNET_CFG[name]
+            net = O.ResNet(3, name)
+            net.relu = torch.nn.ReLU(inplace=True)
+            net.maxpool = torch.nn.MaxPool2d(3, 2, 1)
+            return net
+        return ctor
+    for n in O.RESNET_CFG:
+        setattr(tvr, n, _mk(n))
+    tvt = types.ModuleType("torchvision.transforms")
+    for n in ("ColorJitter", "Pad", "Compose", "RandomHorizontalFlip", "RandomRotation",
+              "RandomCrop", "CenterCrop"):
+        setattr(tvt, n, type(n, (), {"__init__": lambda self, *a, **k: None}))
+    tv.models, tv.transforms, tvm.resnet = tvm, tvt, tvr
+    sys.modules.update({"torchvision": tv, "torchvision.models": tvm,
+                        "torchvision.models.resnet": tvr, "torchvision.transforms": tvt})
+    R = types.SimpleNamespace()
+    R.salsanext = _load("refpc.models.salsanext", "pc_processor/models/salsanext.py")
+    R.pmf_net = _load("refpc.models.pmf_net", "pc_processor/models/pmf_net.py")
+    R.knn = _load("refpc_knn", "pc_processor/postproc/knn.py")
+    R.focal = _load("refpc_focal", "pc_processor/loss/focal_softmax.py")
+    R.lovasz = _load("refpc_lovasz", "pc_processor/loss/lovasz_softmax.py")
+    R.iou = _load("refpc_iou", "pc_processor/metrics/iou_eval.py")
+    R.warmup = _load("refpc_warmup", "pc_processor/utils/warmup_lr.py")
+    R.parser = _load("refpc_parser", "pc_processor/dataset/semantic_kitti/parser.py")
+    # loader: needs `pc_processor.dataset.preprocess.augmentor`
+    for name in ("pc_processor", "pc_processor.dataset", "pc_processor.dataset.preprocess"):
+        pkg = types.ModuleType(name)
+        pkg.__path__ = []
+        sys.modules[name] = pkg
+    aug = _load("pc_processor.dataset.preprocess.augmentor", "pc_processor/dataset/preprocess/augmentor.py")
+    sys.modules["pc_processor.dataset.preprocess"].augmentor = aug
+    R.loader = _load("refpc_loader", "pc_processor/dataset/perspective_view_loader.py")
+    return R
+
+
+def set_p0(model):
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout2d):
+            m.p = 0.0
+        if isinstance(m, O.DropSite):
+            m.p = 0.0
+
+
+def f32(t):
+    return t.detach().cpu().numpy().astype(np.float32)
+
+
+def grad_digest(model):
+    """per-parameter L2 norm + 8 sampled entries (fixed stride)."""
+    out = {}
+    for k, p in model.named_parameters():
+        g = p.grad.detach().reshape(-1)
+        idx = torch.linspace(0, g.numel() - 1, 8).long()
+        out[k] = np.concatenate([[g.double().norm().item()], g[idx].double().numpy()])
+    return out
+
+
+def blocks(R):
+    """G1/G2: per-block eval + train(p=0) outputs, running stats, input/param grads."""
+    S, Pn = R.salsanext, R.pmf_net
+    cases = {
+        "ResContextBlock": (lambda: S.ResContextBlock(8, 32), [(2, 8, 16, 32)]),
+        "ResBlock_pool": (lambda: S.ResBlock(32, 64, 0.2, pooling=True, drop_out=False), [(2, 32, 16, 32)]),
+        "ResBlock_nopool": (lambda: S.ResBlock(64, 64, 0.2, pooling=False), [(2, 64, 8, 16)]),
+        "UpBlock": (lambda: S.UpBlock(64, 32, 0.2), [(2, 64, 8, 16), (2, 64, 16, 32)]),
+        "Fusion": (lambda: Pn.ResidualBasedFusionBlock(32, 64), [(2, 32, 8, 16), (2, 64, 8, 16)]),
+        "ASPP": (lambda: Pn.ASPP(64, 64), [(2, 64, 8, 40)]),
+        "RGBDecoder": (lambda: Pn.RGBDecoder([16, 32, 64, 128], 20, 16),
+                       [[(1, 16, 16, 32), (1, 32, 8, 16), (1, 64, 4, 8), (1, 128, 2, 4)]]),
+    }
+    out = {}
+    for name, (ctor, shapes) in cases.items():
+        torch.manual_seed(0)
+        m = deterministic_init(ctor())
+        set_p0(m)
+
+        def mk_inputs():
+            ins = []
+            for i, s in enumerate(shapes):
+                if isinstance(s, list):
+                    ins.append([det_tensor("%s.in%d.%d" % (name, i, j), ss).requires_grad_(True)
+                                for j, ss in enumerate(s)])
+                else:
+                    ins.append(det_tensor("%s.in%d" % (name, i), s).requires_grad_(True))
+            return ins
+        for mode in ("eval", "train"):
+            m.train(mode == "train")
+            ins = mk_inputs()
+            y = m(*ins)
+            ys = list(y) if isinstance(y, (tuple, list)) else [y]
+            for j, yy in enumerate(ys):
+                out["%s.%s.out%d" % (name, mode, j)] = f32(yy)
+            if mode == "train":
+                loss = sum((yy * det_tensor("%s.gout%d" % (name, j), yy.shape)).sum() for j, yy in enumerate(ys))
+                loss.backward()
+                flat = [t for i in ins for t in (i if isinstance(i, list) else [i])]
+                for j, t in enumerate(flat):
+                    out["%s.train.gin%d" % (name, j)] = f32(t.grad)
+                for k, p in m.named_parameters():
+                    out["%s.train.gparam.%s" % (name, k)] = f32(p.grad)
+                for k, b in m.named_buffers():
+                    if "running" in k:
+                        out["%s.train.buf.%s" % (name, k)] = f32(b)
+    np.savez_compressed(os.path.join(OUT, "g12_blocks.npz"), **out)
+    print("g12_blocks: %d arrays" % len(out))
+
+
+def whole_net(R):
+    """G3: PMFNet-R34 (20 cls) / R50 (17 cls) / SalsaNext at 32x64; config-1 (64x512, bs 1) losses."""
+    out = {}
+    alpha = torch.linspace(0.2, 1.0, 20)
+    alpha[0] = 0
+    for tag, kw, n, h, w in (("r34", dict(nclasses=20, image_backbone="resnet34"), 2, 32, 64),
+                             ("r50", dict(nclasses=17, image_backbone="resnet50"), 1, 32, 64)):
+        m = deterministic_init(R.pmf_net.PMFNet(pcd_channels=5, img_channels=3, base_channels=32,
+                                                imagenet_pretrained=False, **kw))
+        set_p0(m)
+        hooks = {}
+        m.lidar_stream.logits.register_forward_hook(lambda mod, i, o: hooks.__setitem__("lidar", o))
+        m.camera_stream_decoder.conv.register_forward_hook(lambda mod, i, o: hooks.__setitem__("cam", o))
+        pcd, rgb, label, _ = synthetic_batch(n, h, w, kw["nclasses"], seed=1)
+        m.eval()
+        with torch.no_grad():
+            lp, cp = m(pcd, rgb)
+        out["%s.eval.lidar_logits" % tag] = f32(hooks["lidar"])
+        out["%s.eval.cam_logits" % tag] = f32(hooks["cam"])
+        out["%s.eval.lidar_prob" % tag] = f32(lp)
+        out["%s.eval.cam_prob" % tag] = f32(cp)
+        out["%s.nparams" % tag] = np.array([sum(p.numel() for p in m.parameters())])
+        out["%s.keys" % tag] = np.array(sorted(m.state_dict().keys()))
+        if tag != "r34":
+            continue
+        m.train()
+        lp, cp = m(pcd, rgb)
+        out["r34.train.lidar_logits"] = f32(hooks["lidar"])
+        out["r34.train.cam_logits"] = f32(hooks["cam"])
+        lov = R.lovasz.Lovasz_softmax(ignore=0)
+        foc = R.focal.FocalSoftmaxLoss(20, gamma=2, alpha=alpha.numpy(), softmax=False)
+        total, terms = reference_loss(lov, foc, lp, cp, label)
+        total.backward()
+        out["r34.train.losses"] = np.array([total.item()] + [terms[k].item() for k in
+                                                             ("foc", "lov", "foc_cam", "lov_cam", "per")])
+        for k, v in grad_digest(m).items():
+            out["r34.train.gdig." + k] = v
+        for k, b in m.named_buffers():
+            if k.endswith("running_mean") and ("downCntx.bn1" in k or "layer4.2.bn2" in k or "up_1a" in k):
+                out["r34.train.buf." + k] = f32(b)
+    # SalsaNext stand-alone (API row b)
+    s = deterministic_init(R.salsanext.SalsaNext(in_channels=5, nclasses=20, base_channels=32))
+    s.eval()
+    pcd, _, _, _ = synthetic_batch(1, 32, 64, 20, seed=2)
+    with torch.no_grad():
+        out["salsanext.eval.prob"] = f32(s(pcd))
+    np.savez_compressed(os.path.join(OUT, "g3_wholenet.npz"), **out)
+    print("g3_wholenet: %d arrays" % len(out))
+
+
+def reference_loss(lov, foc, lp, cp, label, lambda_=1.0, gamma_=0.5, tau=0.7):
+    """tasks/pmf/trainer.py:303-332 driven with the reference's loss modules."""
+    import math
+    kl = torch.nn.KLDivLoss(reduction="none")
+    mask = label.gt(0)
+    ncls = lp.shape[1]
+    llog = torch.log(lp.clamp(min=1e-8))
+    pent = -(lp * llog).sum(1) / math.log(ncls)
+    clog = torch.log(cp.clamp(min=1e-8))
+    ient = -(cp * clog).sum(1) / math.log(ncls)
+    t = {"foc": foc(lp, label, mask=mask), "lov": lov(lp, label),
+         "foc_cam": foc(cp, label, mask=mask), "lov_cam": lov(cp, label)}
+    pc, ic = 1 - pent, 1 - ient
+    d = pc - ic
+    wp = d.gt(0).float() * d.abs() * pc.ge(tau).float()
+    wi = d.lt(0).float() * d.abs() * ic.ge(tau).float()
+    t["per"] = (kl(llog, cp) * wi.unsqueeze(1)).mean() + (kl(clog, lp) * wp.unsqueeze(1)).mean()
+    total = t["foc"] + t["lov"] * lambda_ + t["foc_cam"] + t["lov_cam"] * lambda_ + t["per"] * gamma_
+    return total, t
+
+
+def losses_metrics(R):
+    """G6: focal / lovasz values+grads, IOUEval stats, WarmupCosineLR trace."""
+    out = {}
+    n, c, h, w = 2, 20, 16, 32
+    logits = det_tensor("g6.logits", (n, c, h, w), -3, 3)
+    logits2 = det_tensor("g6.logits2", (n, c, h, w), -3, 3)
+    _, _, label, _ = synthetic_batch(n, h, w, c, seed=3, fill=0.4)
+    alpha = torch.linspace(0.2, 1.0, c)
+    alpha[0] = 0
+    lov = R.lovasz.Lovasz_softmax(ignore=0)
+    foc = R.focal.FocalSoftmaxLoss(c, gamma=2, alpha=alpha.numpy(), softmax=False)
+    a = logits.clone().requires_grad_(True)
+    b = logits2.clone().requires_grad_(True)
+    lp, cp = torch.softmax(a, 1), torch.softmax(b, 1)
+    total, terms = reference_loss(lov, foc, lp, cp, label)
+    total.backward()
+    out["loss.values"] = np.array([total.item()] + [terms[k].item() for k in ("foc", "lov", "foc_cam", "lov_cam", "per")])
+    out["loss.grad_a"] = f32(a.grad)
+    out["loss.grad_b"] = f32(b.grad)
+    ev = R.iou.IOUEval(c, torch.device("cpu"), ignore=[0], is_distributed=False)
+    ev.addBatch(lp.argmax(1), label)
+    ev.addBatch(cp.argmax(1), label)
+    out["iou.conf"] = ev.conf_matrix.numpy()
+    for nm, fn in (("iou", ev.getIoU), ("acc", ev.getAcc), ("recall", ev.getRecall)):
+        mean, per = fn()
+        out["iou.%s" % nm] = np.concatenate([[mean.item()], per.numpy()])
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.SGD([p], lr=0.001, momentum=0.9)
+    sch = R.warmup.WarmupCosineLR(opt, lr=0.001, warmup_steps=5, momentum=0.9, max_steps=10)
+    trace = []
+    for _ in range(15):
+        opt.step()
+        sch.step()
+        trace.append(opt.param_groups[0]["lr"])
+    out["lr.trace"] = np.array(trace)
+    np.savez_compressed(os.path.join(OUT, "g6_losses.npz"), **out)
+    print("g6_losses: %d arrays" % len(out))
+
+
+def knn(R):
+    """G4: reference KNN labels on seeded synthetic cases (inputs regenerated by recipe in tests)."""
+    out = {}
+    for tag, seed, h, w, npts, kw in (("a", 11, 64, 512, 20000, {}), ("b", 12, 48, 160, 6000, {}),
+                                      ("ties", 13, 32, 64, 3000, {"quantize": True})):
+        pr, ur, am, px, py = knn_case(seed, h, w, npts, **kw)
+        post = R.knn.KNN({"knn": 5, "search": 5, "sigma": 1.0, "cutoff": 1.0}, 20)
+        lab = post(torch.from_numpy(pr), torch.from_numpy(ur), torch.from_numpy(am),
+                   torch.from_numpy(px), torch.from_numpy(py))
+        out["knn.%s.labels" % tag] = lab.numpy().astype(np.int16)
+    w = (1 - R.knn.get_gaussian_kernel(5, 1.0, 1)).numpy()
+    out["knn.inv_gauss"] = w.astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, "g4_knn.npz"), **out)
+    print("g4_knn: %d arrays" % len(out))
+
+
+def loader(R):
+    """G5: reference PerspectiveViewLoader (return_uproj path) + SemanticKitti.mapLidar2Camera."""
+    out = {}
+    from PIL import Image
+    for tag, seed, npts, h, w in (("a", 0, 5000, 96, 320), ("b", 5, 20000, 64, 208)):
+        M, pts, sem, img, lut = loader_ref.synthetic_frame(seed, npts, h, w)
+        ds = object.__new__(R.parser.SemanticKitti)
+        ds.has_image = True
+        ds.proj_matrix = {"00": M}
+        ds.class_map_lut = lut
+        ds.loadDataByIndex = lambda i: (pts, sem, np.zeros_like(sem))
+        ds.loadImage = lambda i: Image.fromarray(img)
+        ds.parsePathInfoByIndex = lambda i: ("00", "000000")
+        ds.pointcloud_files = [None]
+        cfg = {"augmentation": {}, "sensor": {"proj_h": h, "proj_w": w, "proj_ht": h, "proj_wt": w,
+                                              "h_pad": 0, "w_pad": 0}}
+        ld = R.loader.PerspectiveViewLoader(ds, cfg, is_train=False, return_uproj=True)
+        feat, mask, label, xd, yd, depth = ld[0]
+        out["loader.%s.proj" % tag] = np.concatenate([feat.numpy(), mask.numpy()[None], label.numpy()[None]], 0)
+        out["loader.%s.x_data" % tag] = xd.numpy()
+        out["loader.%s.y_data" % tag] = yd.numpy()
+        out["loader.%s.depth" % tag] = depth.numpy()
+    np.savez_compressed(os.path.join(OUT, "g5_loader.npz"), **out)
+    print("g5_loader: %d arrays" % len(out))
+
+
+def trainer_trace(R):
+    """G7: two consecutive optimisation steps (AdamW lidar / SGD-Nesterov camera, trainer.py:80-98,214-219)
+    on config-1 shapes (64x512, bs 1), dropout p=0."""
+    out = {}
+    m = deterministic_init(R.pmf_net.PMFNet(5, 3, 20, 32, False, "resnet34"))
+    set_p0(m)
+    m.train()
+    adam = torch.optim.AdamW([{"params": m.lidar_stream.parameters()}], lr=0.001)
+    sgd = torch.optim.SGD([{"params": m.camera_stream_encoder.parameters()},
+                           {"params": m.camera_stream_decoder.parameters()}],
+                          lr=0.001, nesterov=True, momentum=0.9, weight_decay=1e-5)
+    alpha = torch.linspace(0.2, 1.0, 20)
+    alpha[0] = 0
+    lov = R.lovasz.Lovasz_softmax(ignore=0)
+    foc = R.focal.FocalSoftmaxLoss(20, gamma=2, alpha=alpha.numpy(), softmax=False)
+    pcd, rgb, label, _ = synthetic_batch(1, 64, 512, 20, seed=1)
+    vals = []
+    for step in range(2):
+        lp, cp = m(pcd, rgb)
+        total, terms = reference_loss(lov, foc, lp, cp, label)
+        adam.zero_grad()
+        sgd.zero_grad()
+        total.backward()
+        adam.step()
+        sgd.step()
+        vals.append([total.item()] + [terms[k].item() for k in ("foc", "lov", "foc_cam", "lov_cam", "per")])
+    out["trace.losses"] = np.array(vals)
+    keys = ["lidar_stream.downCntx.conv1.weight", "lidar_stream.resBlock3.conv3.weight",
+            "lidar_stream.logits.bias", "camera_stream_encoder.conv1.weight",
+            "camera_stream_encoder.layer3.2.conv1.weight", "camera_stream_decoder.conv.weight",
+            "lidar_stream.fusionblock_2.attention.4.weight"]
+    sd = m.state_dict()
+    for k in keys:
+        out["trace.param." + k] = np.array([sd[k].double().sum().item(), sd[k].double().abs().sum().item()])
+    np.savez_compressed(os.path.join(OUT, "g7_trace.npz"), **out)
+    print("g7_trace: %d arrays" % len(out))
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    R = import_reference()
+    which = sys.argv[1:] or ["blocks", "whole_net", "losses_metrics", "knn", "loader", "trainer_trace"]
+    for name in which:
+        globals()[name](R)
