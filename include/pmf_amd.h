@@ -1,0 +1,274 @@
+/*
+ * pmf_amd.h -- C ABI of libpmf_amd.so: MI355X (gfx950) kernels for the PMF dual-branch fusion hot path.
+ *
+ * The reference (ICEORY/PMF) has NO FFI / plugin layer: every device op it runs comes from stock
+ * torch.nn modules.  This header is therefore the NEW drop-in boundary a maintainer
+ * binds instead of ATen for this path; each entry point cites the reference lines whose arithmetic it
+ * replaces.  Conventions:
+ *   - plain C, caller-owned DEVICE pointers (PyTorch's caching allocator), no allocation inside;
+ *   - every call enqueues on the given hipStream_t and returns without synchronising;
+ *   - return 0 on success, a hipError_t (>0) from the launch, or a negative PMF_E_* argument error;
+ *   - activations are NHWC fp32 (channel stride `ldc` floats per pixel); NCHW only at the model boundary;
+ *   - re-entrant, no mutable globals (one process per GPU, DDP).
+ */
+#ifndef PMF_AMD_H
+#define PMF_AMD_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* pmf_stream_t; /* hipStream_t */
+
+#define PMF_E_ARG      (-1)
+#define PMF_E_UNSUPPORTED (-2)
+
+#define PMF_MAX_SRC  5
+#define PMF_MAX_TAPS 49
+
+enum { PMF_ACT_NONE = 0, PMF_ACT_LRELU = 1, PMF_ACT_RELU = 2, PMF_ACT_SIGMOID = 3 };
+enum { PMF_SRC_RELU = 1, PMF_SRC_BCAST = 2 };
+
+/* One operand of a (virtual) channel-concat.  Value seen by the consumer at (n, y, x, c):
+ *     v = x[n,y,x,c] * scale[c] + shift[c]      (BatchNorm applied on load; optional)
+ *     v = max(v, 0)                              (PMF_SRC_RELU; conv -> BN -> ReLU ordering)
+ *     v = v * cmul[n*cmul_ld + c]                (Dropout2d (n,c) multiplier; optional)
+ * and 0 outside the image (zero padding applies AFTER the transform).  PMF_SRC_BCAST: H = W = 1 map
+ * broadcast over the output (ASPP image-level branch, pmf_net.py:122-125). */
+typedef struct {
+  const float* x;
+  const float* scale;
+  const float* shift;
+  const float* cmul;
+  int32_t C;        /* channels taken from this operand; multiple of 8 */
+  int32_t ldc;      /* floats between consecutive pixels */
+  int32_t H, W;
+  int32_t flags;
+  int32_t cmul_ld;
+} pmf_src_t;
+
+/* Generic convolution as an implicit GEMM on fp32 MFMA (v_mfma_f32_32x32x2_f32).
+ * Replaces nn.Conv2d forward AND (with transposed/flipped packed weights) its input-gradient for:
+ * 1x1, 2x2 dil 2, 3x3 dil 1/2/6/12/18, 7x7; stride 1/2 (salsanext.py:12-19,44-59,118-130,186;
+ * pmf_net.py:14-26,69-70,107-117,188-212; torchvision BasicBlock/Bottleneck).
+ *   out[n, oy*out_sy+out_oy, ox*out_sx+out_ox, co] (+)= ep( act( sum_t sum_k in_t(n, oy*in_stride+tdy[t], ox*in_stride+tdx[t], k) * w[t][k][co] + bias[co] ) )
+ * where k runs over the concatenated operands.  ep(): optional multiply by ep_cmul[n][co], optional ReLU mask
+ * (ep_relu_x*scale+shift > 0 at the output position), both used by the input-gradient form.
+ * stats (optional): per-channel sum and sum of squares of the activated output, accumulated with atomics
+ * into stats[0..Cout) / stats[Cout..2Cout) (train-mode BatchNorm that FOLLOWS the activation). */
+typedef struct {
+  int32_t N, OH, OW;      /* GEMM M-space: output positions computed */
+  int32_t Cout;
+  int32_t nsrc;
+  pmf_src_t src[PMF_MAX_SRC];
+  int32_t ntaps;
+  int8_t tdy[PMF_MAX_TAPS + 3], tdx[PMF_MAX_TAPS + 3];
+  int32_t in_stride;
+  int32_t gather;         /* 0: one LDS halo tile shared by all taps; 1: per-tap staging (big dilation) */
+  const float* w;         /* packed [ntaps][Ktot][ldw], Ktot = sum of src[i].C */
+  int32_t ldw;            /* >= Cout rounded up to 32; readable up to the tile edge */
+  const float* bias;      /* [Cout] or NULL */
+  int32_t act;
+  float* out;
+  int32_t out_ldc, out_H, out_W, out_sy, out_sx, out_oy, out_ox;
+  int32_t accumulate;
+  const float* ep_cmul;
+  int32_t ep_cmul_ld;
+  const float* ep_relu_x;
+  const float* ep_relu_scale;
+  const float* ep_relu_shift;
+  int32_t ep_relu_ldc;
+  float* stats;
+} pmf_conv_desc_t;
+
+int pmf_conv_fwd(const pmf_conv_desc_t* d, pmf_stream_t s);
+
+/* Weight gradient (+ nothing else): dW[t][k][co] = sum_{n,oy,ox} in_t(n, oy*s+tdy, ox*s+tdx, k) * dz[n,oy,ox,co].
+ * Two stages: per-block partial sums into `partial` (workspace, >= pmf_conv_wgrad_workspace() bytes),
+ * then a deterministic reduction that writes the gradient in the PyTorch OIHW layout
+ *   dw_oihw[(co*Cin_real + k)*KHW + tap_widx[t]]   (k < Cin_real; padded channels are dropped).
+ * Replaces the weight half of aten::convolution_backward for every conv of the path. */
+typedef struct {
+  int32_t N, OH, OW, Cout;
+  int32_t nsrc;
+  pmf_src_t src[PMF_MAX_SRC];
+  int32_t ntaps;
+  int8_t tdy[PMF_MAX_TAPS + 3], tdx[PMF_MAX_TAPS + 3];
+  int8_t tap_widx[PMF_MAX_TAPS + 3];
+  int32_t in_stride;
+  int32_t gather;
+  const float* dz;
+  int32_t dz_ldc;
+  float* partial;
+  int32_t nsplit;         /* pixel splits (grid.x); partial is [nsplit][ntaps][Ktot][Cout32] */
+  float* dw_oihw;
+  int32_t Cin_real, KHW;
+  int32_t accumulate;     /* dw_oihw += (stride-2 parity classes share one weight) */
+} pmf_wgrad_desc_t;
+
+int pmf_conv_wgrad(const pmf_wgrad_desc_t* d, pmf_stream_t s);
+int64_t pmf_conv_wgrad_workspace(const pmf_wgrad_desc_t* d);
+
+/* OIHW -> packed GEMM layout, all convs of the network in ONE launch (weights change every optimiser step).
+ * Job j writes dst[t][k][n] (dst is [ntaps][K_pad][ldw], padding pre-zeroed by the caller once):
+ *   transpose == 0 (forward):        n = co, k = ci :  w[co][ci][tap_idx[t]]
+ *   transpose == 1 (input gradient): n = ci, k = co :  w[co][ci][tap_idx[t]]
+ * Workgroup b of job j handles output-channel tile b / tiles_ci and input-channel tile b % tiles_ci
+ * (CT = pmf_pack_tile_ci(Cin, KHW) channels each); block_start = first workgroup of the job (ascending). */
+typedef struct {
+  const float* w;
+  float* dst;
+  int32_t Cout, Cin, KHW, ntaps, transpose, K_pad, ldw, CT, tiles_ci, block_start;
+  int8_t tap_idx[PMF_MAX_TAPS + 3];
+} pmf_pack_job_t;
+int pmf_pack_tile_ci(int32_t Cin, int32_t KHW);
+int pmf_pack_weights_batched(const pmf_pack_job_t* jobs_dev, int32_t njobs, int32_t total_blocks, pmf_stream_t s);
+
+/* ---- BatchNorm2d (eps 1e-5, momentum 0.1; salsanext.py:17,21,...; torchvision bn) ------------------------ */
+/* train: stats[2][C] (sum, sumsq over `count` elements) -> scale/shift for apply-on-load, saved mean/invstd,
+ * running_mean/var update (unbiased var), and zeroes nothing.  eval: running stats -> scale/shift. */
+int pmf_bn_finalize(const float* stats, float count, const float* gamma, const float* beta, float* running_mean,
+                    float* running_var, float momentum, float eps, float* scale, float* shift, float* save_mean,
+                    float* save_invstd, int32_t C, pmf_stream_t s);
+int pmf_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                       float eps, float* scale, float* shift, float* save_mean, float* save_invstd, int32_t C,
+                       pmf_stream_t s);
+/* backward, two passes over (gy, a):  red[0..C) = sum gy, red[C..2C) = sum gy*a   (must be zeroed by caller) */
+int pmf_bn_bwd_reduce(const float* gy, int32_t gy_ldc, const float* a, int32_t a_ldc, int64_t npix, int32_t C,
+                      float* red, pmf_stream_t s);
+/* dz = (gamma*invstd*(gy - sum_gy/M - ahat*sum_gy_ahat/M)) * act'(a);  dgamma, dbeta written; dbias (optional)
+ * accumulated = sum dz.  act: PMF_ACT_LRELU (a = lrelu(z): slope from sign of a) or PMF_ACT_NONE.
+ * train == 0 (eval-mode BN): dz = gamma*invstd_running * gy * act'. */
+int pmf_bn_bwd_apply(const float* gy, int32_t gy_ldc, const float* a, int32_t a_ldc, int64_t npix, int32_t C,
+                     const float* red, const float* gamma, const float* save_mean, const float* save_invstd,
+                     int32_t act, int32_t train, float* dz, int32_t dz_ldc, float* dgamma, float* dbeta,
+                     float* dbias, pmf_stream_t s);
+
+/* ---- element-wise / resampling ops (all NHWC fp32) ----------------------------------------------------- */
+typedef struct { /* a tensor operand with optional affine-on-load */
+  const float* x;
+  const float* scale;
+  const float* shift;
+  const float* cmul;
+  int32_t ldc, cmul_ld, flags;
+} pmf_view_t;
+
+/* out = act( va + vb )  with va/vb = affine views (vb optional).  Residual adds: salsanext.py:35,88;
+ * torchvision BasicBlock `out += identity; relu`.  stats optional as in conv. */
+int pmf_add_act(const pmf_view_t* a, const pmf_view_t* b, int32_t act, float* out, int32_t out_ldc, int64_t npix,
+                int32_t HW, int32_t C, pmf_stream_t s);
+/* backward of the above: g_in = g_out * act'(out) (relu mask from `out`), written or accumulated into ga / gb */
+int pmf_add_act_bwd(const float* gout, int32_t g_ldc, const float* out, int32_t out_ldc, int32_t act, float* ga,
+                    int32_t ga_ldc, int32_t ga_acc, float* gb, int32_t gb_ldc, int32_t gb_acc, int64_t npix,
+                    int32_t C, pmf_stream_t s);
+/* g *= act'(a) in place (+ optional dbias[c] += sum) for convs not followed by BN (salsanext.py:24-25,70-71). */
+int pmf_act_bwd(float* g, int32_t g_ldc, const float* a, int32_t a_ldc, int32_t act, float* dbias, int64_t npix,
+                int32_t C, pmf_stream_t s);
+/* AvgPool2d(3, stride 2, pad 1, count_include_pad) of view (salsanext.py:65,96) and its gradient */
+int pmf_avgpool3s2(const pmf_view_t* in, int32_t N, int32_t H, int32_t W, int32_t C, float* out, int32_t out_ldc,
+                   pmf_stream_t s);
+int pmf_avgpool3s2_bwd(const float* gout, int32_t g_ldc, int32_t N, int32_t H, int32_t W, int32_t C,
+                       const float* cmul, int32_t cmul_ld, float* gin, int32_t gin_ldc, int32_t acc, pmf_stream_t s);
+/* MaxPool2d(3, 2, 1) of relu(bn(x)) (torchvision stem, pmf_net.py:94-95); idx = window position of the max */
+int pmf_maxpool3s2(const pmf_view_t* in, int32_t N, int32_t H, int32_t W, int32_t C, float* out, int32_t out_ldc,
+                   uint8_t* idx, pmf_stream_t s);
+int pmf_maxpool3s2_bwd(const float* gout, int32_t g_ldc, const uint8_t* idx, int32_t N, int32_t H, int32_t W,
+                       int32_t C, const pmf_view_t* in, float* gin, int32_t gin_ldc, int32_t acc, pmf_stream_t s);
+/* nn.Upsample(scale 2, bilinear, align_corners=False) of a view (pmf_net.py:191-210) and gradient */
+int pmf_bilinear2x(const pmf_view_t* in, int32_t N, int32_t H, int32_t W, int32_t C, float* out, int32_t out_ldc,
+                   pmf_stream_t s);
+int pmf_bilinear2x_bwd(const float* gout, int32_t g_ldc, int32_t N, int32_t H, int32_t W, int32_t C, float* gin,
+                       int32_t gin_ldc, int32_t acc, pmf_stream_t s);
+/* PixelShuffle(2) of a view, times an output (n,c) multiplier (salsanext.py:137-139) and gradient */
+int pmf_pixel_shuffle2(const pmf_view_t* in, int32_t N, int32_t H, int32_t W, int32_t Cout, const float* out_cmul,
+                       int32_t out_cmul_ld, float* out, int32_t out_ldc, pmf_stream_t s);
+int pmf_pixel_shuffle2_bwd(const float* gout, int32_t g_ldc, int32_t N, int32_t H, int32_t W, int32_t Cout,
+                           const float* out_cmul, int32_t out_cmul_ld, const float* in_cmul, int32_t in_cmul_ld,
+                           float* gin, int32_t gin_ldc, int32_t acc, pmf_stream_t s);
+/* fusion gate: out = f * sigmoid(att) + pcd with f, att affine views (pmf_net.py:33-35) and gradient */
+int pmf_fusion_gate(const pmf_view_t* f, const pmf_view_t* att, const float* pcd, int32_t pcd_ldc, float* out,
+                    int32_t out_ldc, int64_t npix, int32_t C, pmf_stream_t s);
+int pmf_fusion_gate_bwd(const float* gout, int32_t g_ldc, const pmf_view_t* f, const pmf_view_t* att, float* gf,
+                        int32_t gf_ldc, int32_t gf_acc, float* gatt, int32_t gatt_ldc, float* gpcd, int32_t gpcd_ldc,
+                        int32_t gpcd_acc, int64_t npix, int32_t C, pmf_stream_t s);
+/* per-(n,c) spatial mean of a view (ASPP image pooling, pmf_net.py:122) and gradient (broadcast / HW) */
+int pmf_global_mean(const pmf_view_t* in, int32_t N, int32_t HW, int32_t C, float* out, pmf_stream_t s);
+int pmf_global_mean_bwd(const float* gout, int32_t N, int32_t HW, int32_t C, const float* cmul, int32_t cmul_ld,
+                        float* gin, int32_t gin_ldc, int32_t acc, pmf_stream_t s);
+/* column sums: out[z][c] += sum over the npix pixels of sample z of x[z][p][c], z < nz (x advances npix*ldc,
+ * out advances C per sample).  Bias gradients (nz = 1) and broadcast-operand gradients (nz = N). */
+int pmf_colsum(const float* x, int32_t ldc, int64_t npix, int32_t C, float* out, int32_t nz, pmf_stream_t s);
+/* softmax over channels of NHWC logits -> NCHW probabilities (pmf_net.py:176-178,221) and gradient
+ * dlogit[n,y,x,c] = p*(g - sum_k g_k p_k) from NCHW p, g. */
+int pmf_softmax_nhwc_to_nchw(const float* logits, int32_t ldc, int32_t N, int32_t HW, int32_t C, float* prob_nchw,
+                             pmf_stream_t s);
+int pmf_softmax_bwd_nchw_to_nhwc(const float* prob_nchw, const float* g_nchw, int32_t N, int32_t HW, int32_t C,
+                                 float* dlogits, int32_t ldc, pmf_stream_t s);
+/* model-boundary layout change with channel padding; input may be a strided NCHW view (trainer.py:296-297) */
+int pmf_nchw_to_nhwc(const float* x, int64_t stride_n, int64_t stride_c, int32_t N, int32_t C, int32_t HW,
+                     float* out, int32_t out_ldc, pmf_stream_t s);
+int pmf_fill(float* p, float v, int64_t n, pmf_stream_t s);
+
+/* ---- KNN post-processing (pc_processor/postproc/knn.py:55-143) ------------------------------------------ */
+/* labels[p] = vote over the `knn` nearest of the search x search window around (py[p], px[p]);
+ * inv_gauss = (1 - gaussian) window weights [search*search] (host-computed, knn.py:12-34,103-105).
+ * Integer result is bit-exact w.r.t. the oracle; ties broken by smaller window index. */
+int pmf_knn_vote(const float* proj_range, const float* unproj_range, const int64_t* proj_argmax, const int64_t* px,
+                 const int64_t* py, int32_t H, int32_t W, int64_t P, int32_t knn, int32_t search,
+                 const float* inv_gauss, float cutoff, int32_t nclasses, int64_t* labels, pmf_stream_t s);
+
+/* ---- perspective projection + scatter (perspective_view_loader.py:77-135, parser.py:209-227) ------------- */
+/* points f32[P][4], sem i32[P], image u8[h][w][3], proj f64[12] (device), lut i32[nlut].
+ * Writes proj_out f32[10][h][w] (depth,x,y,z,i,r,g,b,mask,label), keep u8[P], the compacted row/col indices
+ * (x_data,y_data i32[<=P]), depth f32[P] and *n_kept.  pix_idx i32[h*w] and blk_cnt i32[ceil(P/1024)+1] are
+ * caller workspaces.  Last point in file order wins on duplicate pixels. */
+int pmf_project_scatter(const float* points, const int32_t* sem, int64_t P, const uint8_t* image, int32_t h,
+                        int32_t w, const double* proj, const int32_t* lut, int32_t nlut, float* proj_out,
+                        uint8_t* keep, int32_t* x_data, int32_t* y_data, float* depth, int32_t* n_kept,
+                        int32_t* pix_idx, int32_t* blk_cnt, pmf_stream_t s);
+/* validation crop/pad (perspective_view_loader.py:71-74,138-141): dst[c][oh][ow] window copy with zero fill */
+int pmf_crop_pad(const float* src, int32_t C, int32_t h, int32_t w, int32_t top, int32_t left, float* dst,
+                 int32_t oh, int32_t ow, int32_t pad_top, int32_t pad_left, int32_t ch, int32_t cw, pmf_stream_t s);
+
+/* ---- plan executor: a whole forward (or backward) pass = one call --------------------------------------- */
+enum {
+  PMF_OP_CONV = 1, PMF_OP_WGRAD, PMF_OP_PACK, PMF_OP_BN_FINALIZE, PMF_OP_BN_EVAL, PMF_OP_BN_BWD_REDUCE,
+  PMF_OP_BN_BWD_APPLY, PMF_OP_ADD_ACT, PMF_OP_ADD_ACT_BWD, PMF_OP_ACT_BWD, PMF_OP_AVGPOOL, PMF_OP_AVGPOOL_BWD,
+  PMF_OP_MAXPOOL, PMF_OP_MAXPOOL_BWD, PMF_OP_BILINEAR, PMF_OP_BILINEAR_BWD, PMF_OP_PSHUFFLE, PMF_OP_PSHUFFLE_BWD,
+  PMF_OP_GATE, PMF_OP_GATE_BWD, PMF_OP_GMEAN, PMF_OP_GMEAN_BWD, PMF_OP_COLSUM, PMF_OP_SOFTMAX, PMF_OP_SOFTMAX_BWD,
+  PMF_OP_NCHW2NHWC, PMF_OP_FILL
+};
+
+/* generic argument record for the small ops (slot meaning documented next to each dispatcher case in plan.cpp) */
+typedef struct {
+  void* p[12];
+  int64_t l[4];
+  int32_t i[16];
+  float f[4];
+  pmf_view_t v[3];
+} pmf_small_args_t;
+
+typedef struct {
+  int32_t kind;
+  int32_t pad_;
+  union {
+    pmf_conv_desc_t conv;
+    pmf_wgrad_desc_t wgrad;
+    pmf_small_args_t sm;
+  } u;
+} pmf_op_t;
+
+/* runs ops[0..n) in order on stream s; returns 0 or the first error (index in *failed_at if non-NULL) */
+int pmf_plan_run(const pmf_op_t* ops, int32_t n, pmf_stream_t s, int32_t* failed_at);
+int pmf_plan_run_range(const pmf_op_t* ops, int32_t begin, int32_t end, pmf_stream_t s, int32_t* failed_at);
+/* pixel splits pmf_conv_wgrad will use for this descriptor (sizes `partial`) */
+int pmf_conv_wgrad_nsplit(const pmf_wgrad_desc_t* d);
+/* sizeof() of the structs above, for bindings to self-check: 0 src, 1 conv, 2 wgrad, 3 view, 4 small, 5 op, 6 pack job */
+int pmf_sizeof(int which);
+
+const char* pmf_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

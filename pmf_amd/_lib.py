@@ -1,0 +1,147 @@
+"""ctypes binding of libpmf_amd.so (include/pmf_amd.h).
+
+The product path has NO fallback: if the shared library is missing or its struct
+layout disagrees with this binding, importing a compute entry point raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpmf_amd.so")
+
+MAX_SRC, MAX_TAPS = 5, 49
+ACT_NONE, ACT_LRELU, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
+SRC_RELU, SRC_BCAST = 1, 2
+
+(OP_CONV, OP_WGRAD, OP_PACK, OP_BN_FINALIZE, OP_BN_EVAL, OP_BN_BWD_REDUCE, OP_BN_BWD_APPLY, OP_ADD_ACT,
+ OP_ADD_ACT_BWD, OP_ACT_BWD, OP_AVGPOOL, OP_AVGPOOL_BWD, OP_MAXPOOL, OP_MAXPOOL_BWD, OP_BILINEAR,
+ OP_BILINEAR_BWD, OP_PSHUFFLE, OP_PSHUFFLE_BWD, OP_GATE, OP_GATE_BWD, OP_GMEAN, OP_GMEAN_BWD, OP_COLSUM,
+ OP_SOFTMAX, OP_SOFTMAX_BWD, OP_NCHW2NHWC, OP_FILL) = range(1, 28)
+
+OP_NAMES = {v: k for k, v in list(globals().items()) if k.startswith("OP_")}
+
+
+class Src(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p), ("cmul", C.c_void_p),
+                ("C", C.c_int32), ("ldc", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("flags", C.c_int32), ("cmul_ld", C.c_int32)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("N", C.c_int32), ("OH", C.c_int32), ("OW", C.c_int32), ("Cout", C.c_int32), ("nsrc", C.c_int32),
+                ("src", Src * MAX_SRC), ("ntaps", C.c_int32),
+                ("tdy", C.c_int8 * (MAX_TAPS + 3)), ("tdx", C.c_int8 * (MAX_TAPS + 3)),
+                ("in_stride", C.c_int32), ("gather", C.c_int32), ("w", C.c_void_p), ("ldw", C.c_int32),
+                ("bias", C.c_void_p), ("act", C.c_int32), ("out", C.c_void_p),
+                ("out_ldc", C.c_int32), ("out_H", C.c_int32), ("out_W", C.c_int32), ("out_sy", C.c_int32),
+                ("out_sx", C.c_int32), ("out_oy", C.c_int32), ("out_ox", C.c_int32), ("accumulate", C.c_int32),
+                ("ep_cmul", C.c_void_p), ("ep_cmul_ld", C.c_int32), ("ep_relu_x", C.c_void_p),
+                ("ep_relu_scale", C.c_void_p), ("ep_relu_shift", C.c_void_p), ("ep_relu_ldc", C.c_int32),
+                ("stats", C.c_void_p)]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [("N", C.c_int32), ("OH", C.c_int32), ("OW", C.c_int32), ("Cout", C.c_int32), ("nsrc", C.c_int32),
+                ("src", Src * MAX_SRC), ("ntaps", C.c_int32),
+                ("tdy", C.c_int8 * (MAX_TAPS + 3)), ("tdx", C.c_int8 * (MAX_TAPS + 3)),
+                ("tap_widx", C.c_int8 * (MAX_TAPS + 3)),
+                ("in_stride", C.c_int32), ("gather", C.c_int32), ("dz", C.c_void_p), ("dz_ldc", C.c_int32),
+                ("partial", C.c_void_p), ("nsplit", C.c_int32), ("dw_oihw", C.c_void_p),
+                ("Cin_real", C.c_int32), ("KHW", C.c_int32), ("accumulate", C.c_int32)]
+
+
+class View(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p), ("cmul", C.c_void_p),
+                ("ldc", C.c_int32), ("cmul_ld", C.c_int32), ("flags", C.c_int32)]
+
+
+class SmallArgs(C.Structure):
+    _fields_ = [("p", C.c_void_p * 12), ("l", C.c_int64 * 4), ("i", C.c_int32 * 16), ("f", C.c_float * 4),
+                ("v", View * 3)]
+
+
+class _OpU(C.Union):
+    _fields_ = [("conv", ConvDesc), ("wgrad", WgradDesc), ("sm", SmallArgs)]
+
+
+class Op(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("pad_", C.c_int32), ("u", _OpU)]
+
+
+class PackJob(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("dst", C.c_void_p), ("Cout", C.c_int32), ("Cin", C.c_int32), ("KHW", C.c_int32),
+                ("ntaps", C.c_int32), ("transpose", C.c_int32), ("K_pad", C.c_int32), ("ldw", C.c_int32),
+                ("CT", C.c_int32), ("tiles_ci", C.c_int32), ("block_start", C.c_int32),
+                ("tap_idx", C.c_int8 * (MAX_TAPS + 3))]
+
+
+_lib = None
+
+
+class PMFLibraryError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libpmf_amd.so once; raise loudly (no fallback) if it is absent or ABI-incompatible."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PMFLibraryError(
+            "pmf_amd: %s not found -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C pmf_amd/csrc`).  There is no CPU / PyTorch fallback for the HIP hot path." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    L.pmf_sizeof.restype = C.c_int
+    L.pmf_sizeof.argtypes = [C.c_int]
+    for which, st in enumerate((Src, ConvDesc, WgradDesc, View, SmallArgs, Op, PackJob)):
+        if L.pmf_sizeof(which) != C.sizeof(st):
+            raise PMFLibraryError("pmf_amd ABI mismatch for %s: lib %d vs binding %d"
+                                  % (st.__name__, L.pmf_sizeof(which), C.sizeof(st)))
+    L.pmf_version.restype = C.c_char_p
+    L.pmf_plan_run.restype = C.c_int
+    L.pmf_plan_run.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(C.c_int32)]
+    L.pmf_plan_run_range.restype = C.c_int
+    L.pmf_plan_run_range.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_int32)]
+    L.pmf_conv_fwd.restype = C.c_int
+    L.pmf_conv_fwd.argtypes = [C.POINTER(ConvDesc), C.c_void_p]
+    L.pmf_conv_wgrad.restype = C.c_int
+    L.pmf_conv_wgrad.argtypes = [C.POINTER(WgradDesc), C.c_void_p]
+    L.pmf_conv_wgrad_nsplit.restype = C.c_int
+    L.pmf_conv_wgrad_nsplit.argtypes = [C.POINTER(WgradDesc)]
+    L.pmf_conv_wgrad_workspace.restype = C.c_int64
+    L.pmf_conv_wgrad_workspace.argtypes = [C.POINTER(WgradDesc)]
+    L.pmf_pack_tile_ci.restype = C.c_int
+    L.pmf_pack_tile_ci.argtypes = [C.c_int32, C.c_int32]
+    L.pmf_pack_weights_batched.restype = C.c_int
+    L.pmf_pack_weights_batched.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+    L.pmf_knn_vote.restype = C.c_int
+    L.pmf_knn_vote.argtypes = [C.c_void_p] * 5 + [C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32,
+                                                  C.c_void_p, C.c_float, C.c_int32, C.c_void_p, C.c_void_p]
+    L.pmf_project_scatter.restype = C.c_int
+    L.pmf_project_scatter.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32,
+                                      C.c_void_p, C.c_void_p, C.c_int32] + [C.c_void_p] * 8 + [C.c_void_p]
+    L.pmf_crop_pad.restype = C.c_int
+    L.pmf_crop_pad.argtypes = [C.c_void_p] + [C.c_int32] * 5 + [C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p]
+    L.pmf_fill.restype = C.c_int
+    L.pmf_fill.argtypes = [C.c_void_p, C.c_float, C.c_int64, C.c_void_p]
+    _lib = L
+    return L
+
+
+EXPORTS = [
+    "pmf_conv_fwd", "pmf_conv_wgrad", "pmf_conv_wgrad_workspace", "pmf_conv_wgrad_nsplit", "pmf_pack_tile_ci",
+    "pmf_pack_weights_batched", "pmf_bn_finalize", "pmf_bn_eval_affine", "pmf_bn_bwd_reduce", "pmf_bn_bwd_apply",
+    "pmf_add_act", "pmf_add_act_bwd", "pmf_act_bwd", "pmf_avgpool3s2", "pmf_avgpool3s2_bwd", "pmf_maxpool3s2",
+    "pmf_maxpool3s2_bwd", "pmf_bilinear2x", "pmf_bilinear2x_bwd", "pmf_pixel_shuffle2", "pmf_pixel_shuffle2_bwd",
+    "pmf_fusion_gate", "pmf_fusion_gate_bwd", "pmf_global_mean", "pmf_global_mean_bwd", "pmf_colsum",
+    "pmf_softmax_nhwc_to_nchw", "pmf_softmax_bwd_nchw_to_nhwc", "pmf_nchw_to_nhwc", "pmf_fill", "pmf_knn_vote",
+    "pmf_project_scatter", "pmf_crop_pad", "pmf_plan_run", "pmf_plan_run_range", "pmf_sizeof", "pmf_version",
+]
+
+
+def check(rc, what="pmf call", failed_at=None):
+    if rc != 0:
+        extra = "" if failed_at is None else " at op #%d" % failed_at
+        raise RuntimeError("%s failed with code %d%s (negative = argument error, positive = hipError_t)"
+                           % (what, rc, extra))

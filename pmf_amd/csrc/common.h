@@ -1,0 +1,54 @@
+// Internal helpers shared by the gfx950 kernels of libpmf_amd.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/pmf_amd.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define PMF_LAUNCH_CHECK()                         \
+  do {                                             \
+    hipError_t e_ = hipGetLastError();             \
+    if (e_ != hipSuccess) return (int)e_;          \
+  } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int round_up(int a, int b) { return cdiv(a, b) * b; }
+
+__device__ __forceinline__ float pmf_act(float v, int act) {
+  if (act == PMF_ACT_LRELU) return v > 0.f ? v : 0.01f * v;
+  if (act == PMF_ACT_RELU) return v > 0.f ? v : 0.f;
+  if (act == PMF_ACT_SIGMOID) return 1.f / (1.f + __expf(-v));
+  return v;
+}
+
+// value of a view element (4 consecutive channels), zero padding is the caller's business
+__device__ __forceinline__ f32x4 pmf_view_load4(const float* __restrict__ x, const float* __restrict__ scale,
+                                                const float* __restrict__ shift, const float* __restrict__ cmul,
+                                                int flags, size_t off, int c) {
+  f32x4 v = *(const f32x4*)(x + off);
+  if (scale) {
+    f32x4 sc = *(const f32x4*)(scale + c), sh = *(const f32x4*)(shift + c);
+    v = v * sc + sh;
+  }
+  if (flags & PMF_SRC_RELU) {
+    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+  }
+  if (cmul) v = v * *(const f32x4*)(cmul + c);
+  return v;
+}
+
+// geometry shared by conv forward / weight-gradient host code
+struct ConvGeom {
+  int segs_x_log2;  // 32-pixel segments across the tile (log2)
+  int th, tw;       // output tile (rows, cols)
+  int tiles_x, tiles_y;
+  int in_rows, in_cols;  // LDS input tile (halo mode: all taps; gather: one tap)
+  int dy_min, dx_min;
+  int Ktot;
+  int kc_alloc;     // rows per tap reserved in the LDS weight tile
+  int a_floats;     // floats reserved for the input tile
+  int tap_group;    // taps per weight sub-stage
+};

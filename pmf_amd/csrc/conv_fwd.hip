@@ -1,0 +1,267 @@
+// Implicit-GEMM convolution on fp32 MFMA (v_mfma_f32_32x32x2_f32), NHWC, LDS halo staging.  gfx950 only.
+//
+// GEMM view:  M = output pixels (32-pixel row segments), N = Cout, K = taps x concatenated input channels.
+// A 256-thread workgroup (4 waves) owns a TH x TW output tile = 4*MT segments of 32 pixels and BN output
+// channels; wave w owns segments [w*MT, w*MT+MT) x all BN channels  ->  MT x BN/32 accumulators of 32x32.
+// K loop: for every 16-channel chunk of every operand, the input tile INCLUDING ITS HALO is staged once in
+// LDS (with BatchNorm-apply / ReLU / Dropout2d multiplier folded into the load and zero padding applied
+// after it) and reused by all taps; the matching [taps][16][BN] slab of packed weights is staged next to it.
+// MFMA operands: A[i=lane&31][k=lane>>5] = one ds_read_b128 per 8 channels (pixel pitch 20 floats ->
+// conflict-free), B[k][j=lane&31] = ds_read_b32 from the [k][BN] slab (32 consecutive banks).
+// Epilogue: + bias, activation, optional (n,c) multiplier / ReLU mask (input-gradient form), optional
+// per-channel sum / sum-of-squares for the BatchNorm that follows, coalesced 128-B row stores.
+#include "common.h"
+
+#define KC 16
+#define APITCH 20
+#define TAPG 9
+
+template <int BN, int MT>
+__global__ __launch_bounds__(256) void conv_fwd_k(const pmf_conv_desc_t d, const ConvGeom g) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* __restrict__ As = smem;
+  float* __restrict__ Bs = smem + g.a_floats;
+  constexpr int NT = BN / 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int tile = blockIdx.x;
+  const int tx = tile % g.tiles_x, ty = tile / g.tiles_x;
+  const int n = blockIdx.z, n0 = blockIdx.y * BN;
+  const int oy0 = ty * g.th, ox0 = tx * g.tw;
+  const int is = d.in_stride;
+  const int in_cols = g.in_cols;
+  const int kca = g.kc_alloc;
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.f;
+
+  int segrow[MT], segcol[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    int s = wave * MT + m;
+    segrow[m] = s >> g.segs_x_log2;
+    segcol[m] = s & ((1 << g.segs_x_log2) - 1);
+  }
+
+  const int ngroups = d.gather ? d.ntaps : 1;
+  int k_base = 0;
+  for (int si = 0; si < d.nsrc; ++si) {
+    const float* __restrict__ sx = d.src[si].x;
+    const float* __restrict__ sscale = d.src[si].scale;
+    const float* __restrict__ sshift = d.src[si].shift;
+    const float* __restrict__ scm = d.src[si].cmul ? d.src[si].cmul + (size_t)n * d.src[si].cmul_ld : nullptr;
+    const int sC = d.src[si].C, sld = d.src[si].ldc, sflags = d.src[si].flags;
+    const bool bc = (sflags & PMF_SRC_BCAST) != 0;
+    const int sH = bc ? d.OH * is : d.src[si].H, sW = bc ? d.OW * is : d.src[si].W;
+    for (int c0 = 0; c0 < sC; c0 += KC) {
+      const int kc = min(KC, sC - c0);
+      const int nql = kc == 16 ? 2 : 1;   // log2(float4 per pixel)
+      const int kcl = kc == 16 ? 4 : 3;   // log2(kc)
+      for (int grp = 0; grp < ngroups; ++grp) {
+        const int gt0 = d.gather ? grp : 0;
+        const int gnt = d.gather ? 1 : d.ntaps;
+        const int gy0 = d.gather ? (int)d.tdy[grp] : g.dy_min;
+        const int gx0 = d.gather ? (int)d.tdx[grp] : g.dx_min;
+        __syncthreads();
+        {  // ---- stage the input tile (with halo)
+          const int total = (g.in_rows * in_cols) << nql;
+          for (int f = tid; f < total; f += 256) {
+            const int pix = f >> nql, q = f & ((1 << nql) - 1);
+            const int r = pix / in_cols, c = pix - r * in_cols;
+            const int iy = oy0 * is + gy0 + r, ix = ox0 * is + gx0 + c;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (iy >= 0 && iy < sH && ix >= 0 && ix < sW) {
+              const size_t off = bc ? (size_t)n * sld + c0 + q * 4
+                                    : ((size_t)(n * sH + iy) * sW + ix) * sld + c0 + q * 4;
+              v = pmf_view_load4(sx, sscale, sshift, scm, sflags, off, c0 + q * 4);
+            }
+            *(f32x4*)(As + pix * APITCH + q * 4) = v;
+          }
+        }
+        for (int sub = 0; sub < gnt; sub += g.tap_group) {
+          const int snt = min(g.tap_group, gnt - sub);
+          if (sub) __syncthreads();
+          {  // ---- stage the weight slab [snt][kc][BN]
+            constexpr int rowq = BN / 4;
+            const int totalB = snt * kc * rowq;
+            for (int f = tid; f < totalB; f += 256) {
+              const int row = f / rowq, q = f - row * rowq;
+              const int tl = row >> kcl, kk = row & (kc - 1);
+              const float* p = d.w + ((size_t)(gt0 + sub + tl) * g.Ktot + k_base + c0 + kk) * d.ldw + n0 + q * 4;
+              *(f32x4*)(Bs + (tl * kca + kk) * BN + q * 4) = *(const f32x4*)p;
+            }
+          }
+          __syncthreads();
+          for (int tl = 0; tl < snt; ++tl) {
+            const int t = gt0 + sub + tl;
+            const int ady = (int)d.tdy[t] - gy0, adx = (int)d.tdx[t] - gx0;
+            int abase[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+              abase[m] = ((segrow[m] * is + ady) * in_cols + (segcol[m] * 32 + li) * is + adx) * APITCH + lh * 4;
+            const float* bp = Bs + (tl * kca + lh * 4) * BN + li;
+            for (int kg = 0; kg < kc; kg += 8) {
+              f32x4 a[MT];
+#pragma unroll
+              for (int m = 0; m < MT; ++m) a[m] = *(const f32x4*)(As + abase[m] + kg);
+              float b[NT][4];
+#pragma unroll
+              for (int u = 0; u < NT; ++u)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) b[u][s] = bp[(kg + s) * BN + u * 32];
+#pragma unroll
+              for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                  for (int u = 0; u < NT; ++u)
+                    acc[m][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][s], b[u][s], acc[m][u], 0, 0, 0);
+            }
+          }
+        }
+      }
+      k_base += kc;
+    }
+  }
+
+  // ---- epilogue
+  float ssum[NT], ssq[NT];
+#pragma unroll
+  for (int u = 0; u < NT; ++u) ssum[u] = ssq[u] = 0.f;
+#pragma unroll
+  for (int u = 0; u < NT; ++u) {
+    const int co = n0 + u * 32 + li;
+    const bool cok = co < d.Cout;
+    const float bias = (cok && d.bias) ? d.bias[co] : 0.f;
+    const float ecm = (cok && d.ep_cmul) ? d.ep_cmul[(size_t)n * d.ep_cmul_ld + co] : 1.f;
+    float rs = 1.f, rt = 0.f;
+    if (cok && d.ep_relu_x && d.ep_relu_scale) { rs = d.ep_relu_scale[co]; rt = d.ep_relu_shift[co]; }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int oy = oy0 + segrow[m];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ox = ox0 + segcol[m] * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (cok && oy < d.OH && ox < d.OW) {
+          float v = pmf_act(acc[m][u][r] + bias, d.act);
+          const size_t opix = (size_t)(n * d.out_H + oy * d.out_sy + d.out_oy) * d.out_W + ox * d.out_sx + d.out_ox;
+          v *= ecm;
+          if (d.ep_relu_x) {
+            const float xr = d.ep_relu_x[opix * d.ep_relu_ldc + co] * rs + rt;
+            if (!(xr > 0.f)) v = 0.f;
+          }
+          float* op = d.out + opix * d.out_ldc + co;
+          if (d.accumulate) v += *op;
+          *op = v;
+          ssum[u] += v;
+          ssq[u] += v * v;
+        }
+      }
+    }
+  }
+  if (d.stats) {
+    __syncthreads();
+    float* red = smem;  // [4 waves][NT][32][2]
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+      float a = ssum[u] + __shfl_xor(ssum[u], 32);
+      float b = ssq[u] + __shfl_xor(ssq[u], 32);
+      if (lh == 0) {
+        red[((wave * NT + u) * 32 + li) * 2 + 0] = a;
+        red[((wave * NT + u) * 32 + li) * 2 + 1] = b;
+      }
+    }
+    __syncthreads();
+    if (tid < BN) {
+      const int u = tid >> 5, l = tid & 31, co = n0 + tid;
+      if (co < d.Cout) {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          a += red[((w * NT + u) * 32 + l) * 2 + 0];
+          b += red[((w * NT + u) * 32 + l) * 2 + 1];
+        }
+        atomicAdd(d.stats + co, a);
+        atomicAdd(d.stats + d.Cout + co, b);
+      }
+    }
+  }
+}
+
+static int floor_log2(int v) { int l = 0; while ((2 << l) <= v) ++l; return l; }
+
+// Chooses tile shape / staging mode; returns LDS bytes (or <0).
+int pmf_conv_geometry(int OH, int OW, int ntaps, const int8_t* tdy, const int8_t* tdx, int in_stride, int gather_req,
+                      int BN, int MT, int kc_alloc, ConvGeom* g, int* gather_out) {
+  const int nseg = 4 * MT;
+  // narrowest tile whose row count does not exceed (pow2-rounded) OH
+  int sx = 1;
+  while (sx < nseg && (nseg / sx) > OH) sx <<= 1;
+  while (sx > 1 && (sx / 2) * 32 >= OW && (nseg / (sx / 2)) <= OH) sx >>= 1;
+  g->segs_x_log2 = floor_log2(sx);
+  g->th = nseg / sx;
+  g->tw = 32 * sx;
+  g->tiles_x = cdiv(OW, g->tw);
+  g->tiles_y = cdiv(OH, g->th);
+  int dy_min = 127, dy_max = -127, dx_min = 127, dx_max = -127;
+  for (int t = 0; t < ntaps; ++t) {
+    dy_min = tdy[t] < dy_min ? tdy[t] : dy_min; dy_max = tdy[t] > dy_max ? tdy[t] : dy_max;
+    dx_min = tdx[t] < dx_min ? tdx[t] : dx_min; dx_max = tdx[t] > dx_max ? tdx[t] : dx_max;
+  }
+  g->dy_min = dy_min; g->dx_min = dx_min;
+  g->kc_alloc = kc_alloc;
+  int gather = gather_req;
+  for (;;) {
+    int rows = (g->th - 1) * in_stride + 1, cols = (g->tw - 1) * in_stride + 1;
+    if (!gather) { rows += dy_max - dy_min; cols += dx_max - dx_min; }
+    g->in_rows = rows; g->in_cols = cols;
+    g->a_floats = round_up(rows * cols * APITCH, 4);
+    g->tap_group = gather ? 1 : (ntaps < TAPG ? ntaps : TAPG);
+    int lds = (g->a_floats + g->tap_group * kc_alloc * BN) * 4;
+    if (lds < 2 * 4 * 64 * 2 * 4) lds = 2 * 4 * 64 * 2 * 4;  // room for the stats reduction
+    if (lds <= 150 * 1024 || gather) { *gather_out = gather; return lds; }
+    gather = 1;
+  }
+}
+
+template <int BN, int MT>
+static int launch(const pmf_conv_desc_t* d, hipStream_t s) {
+  ConvGeom g;
+  int Ktot = 0, cmax = 0;
+  for (int i = 0; i < d->nsrc; ++i) { Ktot += d->src[i].C; cmax = d->src[i].C > cmax ? d->src[i].C : cmax; }
+  int gather;
+  int lds = pmf_conv_geometry(d->OH, d->OW, d->ntaps, d->tdy, d->tdx, d->in_stride, d->gather, BN, MT,
+                              cmax < KC ? cmax : KC, &g, &gather);
+  if (lds > 160 * 1024) return PMF_E_UNSUPPORTED;
+  g.Ktot = Ktot;
+  pmf_conv_desc_t dd = *d;
+  dd.gather = gather;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)conv_fwd_k<BN, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  dim3 grid(g.tiles_x * g.tiles_y, cdiv(d->Cout, BN), d->N);
+  hipLaunchKernelGGL((conv_fwd_k<BN, MT>), grid, dim3(256), lds, s, dd, g);
+  PMF_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pmf_conv_fwd(const pmf_conv_desc_t* d, pmf_stream_t st) {
+  hipStream_t s = (hipStream_t)st;
+  if (!d || d->nsrc < 1 || d->nsrc > PMF_MAX_SRC || d->ntaps < 1 || d->ntaps > PMF_MAX_TAPS) return PMF_E_ARG;
+  if (d->ldw % 4 || d->in_stride < 1 || d->in_stride > 2) return PMF_E_ARG;
+  for (int i = 0; i < d->nsrc; ++i)
+    if (d->src[i].C % 8 || d->src[i].ldc % 4) return PMF_E_ARG;
+  const int BN = d->Cout > 32 ? 64 : 32;
+  // enough workgroups to fill 256 CUs: fall back to 128-pixel tiles on small maps
+  const long px = (long)d->N * cdiv(d->OH, 8) * cdiv(d->OW, 32) * cdiv(d->Cout, BN);
+  const int MT = px >= 512 ? 2 : 1;
+  if (BN == 64) return MT == 2 ? launch<64, 2>(d, s) : launch<64, 1>(d, s);
+  return MT == 2 ? launch<32, 2>(d, s) : launch<32, 1>(d, s);
+}

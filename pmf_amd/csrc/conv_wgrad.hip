@@ -1,0 +1,256 @@
+// Convolution weight gradient on fp32 MFMA (gfx950), NHWC, LDS halo staging, deterministic two-stage reduce.
+//
+// GEMM view per tap t:  dW_t[ci][co] = sum_pixels X_t[pixel][ci] * dz[pixel][co]   (M = 32 input channels,
+// N = BN output channels, K = pixels).  A workgroup owns one 32-channel chunk of the (virtually concatenated)
+// input, BN output channels and a batch of TB taps, and walks a strided list of 4x32-pixel tiles: per tile the
+// input chunk INCLUDING ITS HALO is staged once in LDS (BatchNorm-apply / ReLU / Dropout2d multiplier folded
+// into the load) next to the dz tile; wave w consumes row w of the tile, two pixels per v_mfma_f32_32x32x2_f32:
+//   A[i=ci=lane&31][k=lane>>5] = ds_read_b32 X[pixel+tap offset][ci]   (32 consecutive banks)
+//   B[k][j=co=lane&31]         = ds_read_b32 dz[pixel][co]
+// One A read per tap and one B read per pixel pair feed TB * BN/32 MFMAs.  The four waves' accumulators are
+// folded with LDS float atomics and written as one partial slab per workgroup; stage 2 sums the slabs in a
+// fixed order and writes the gradient directly in PyTorch's OIHW layout.
+#include "common.h"
+
+#define WG_ROWS 4
+#define WG_CI 32
+
+struct WgGeom {
+  int tiles_x, tiles_y, total_tiles;
+  int in_rows, in_cols, dy_min, dx_min;
+  int x_floats;
+  int Ktot, Cout32;
+  int nchunks;       // 32-channel chunks over all operands
+  int co_tiles, tap_batches;
+};
+
+template <int TB, int NT>
+__global__ __launch_bounds__(256) void conv_wgrad_k(const pmf_wgrad_desc_t d, const WgGeom g) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int BN = NT * 32;
+  float* __restrict__ Xs = smem;
+  float* __restrict__ Zs = smem + g.x_floats;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int split = blockIdx.x, chunk = blockIdx.y;
+  const int cot = blockIdx.z % g.co_tiles, tb = blockIdx.z / g.co_tiles;
+  const int co0 = cot * BN;
+  const int t0 = tb * TB;
+  const int nt = min(TB, d.ntaps - t0);
+  const int is = d.in_stride;
+
+  // locate the operand / channel offset of this chunk
+  int si = 0, c0 = 0, k0 = 0;
+  {
+    int rem = chunk;
+    for (;;) {
+      const int nch = (d.src[si].C + WG_CI - 1) / WG_CI;
+      if (rem < nch) { c0 = rem * WG_CI; k0 += c0; break; }
+      rem -= nch; k0 += d.src[si].C; ++si;
+    }
+  }
+  const float* __restrict__ sx = d.src[si].x;
+  const float* __restrict__ sscale = d.src[si].scale;
+  const float* __restrict__ sshift = d.src[si].shift;
+  const int sC = d.src[si].C, sld = d.src[si].ldc, sflags = d.src[si].flags;
+  const bool bc = (sflags & PMF_SRC_BCAST) != 0;
+  const int sH = bc ? d.OH * is : d.src[si].H, sW = bc ? d.OW * is : d.src[si].W;
+  const int kc = min(WG_CI, sC - c0);   // multiple of 8
+  const int nq = kc >> 2;
+
+  f32x16 acc[TB][NT];
+#pragma unroll
+  for (int t = 0; t < TB; ++t)
+#pragma unroll
+    for (int u = 0; u < NT; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+
+  const int gy0 = d.gather ? (int)d.tdy[t0] : g.dy_min;
+  const int gx0 = d.gather ? (int)d.tdx[t0] : g.dx_min;
+  int toff[TB];
+#pragma unroll
+  for (int t = 0; t < TB; ++t) {
+    const int tt = t0 + (t < nt ? t : 0);
+    toff[t] = (((int)d.tdy[tt] - gy0) * g.in_cols + ((int)d.tdx[tt] - gx0)) * WG_CI;
+  }
+
+  for (int tile = split; tile < g.total_tiles; tile += d.nsplit) {
+    const int tx = tile % g.tiles_x, ty = (tile / g.tiles_x) % g.tiles_y, n = tile / (g.tiles_x * g.tiles_y);
+    const int oy0 = ty * WG_ROWS, ox0 = tx * 32;
+    const float* __restrict__ scm = d.src[si].cmul ? d.src[si].cmul + (size_t)n * d.src[si].cmul_ld : nullptr;
+    __syncthreads();
+    {  // stage X (zero-fill missing channels of a short chunk so stale LDS never reaches the MFMA)
+      const int total = g.in_rows * g.in_cols * (WG_CI / 4);
+      for (int f = tid; f < total; f += 256) {
+        const int pix = f >> 3, q = f & 7;
+        const int r = pix / g.in_cols, c = pix - r * g.in_cols;
+        const int iy = oy0 * is + gy0 + r, ix = ox0 * is + gx0 + c;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (q < nq && iy >= 0 && iy < sH && ix >= 0 && ix < sW) {
+          const size_t off = bc ? (size_t)n * sld + c0 + q * 4 : ((size_t)(n * sH + iy) * sW + ix) * sld + c0 + q * 4;
+          v = pmf_view_load4(sx, sscale, sshift, scm, sflags, off, c0 + q * 4);
+        }
+        *(f32x4*)(Xs + pix * WG_CI + q * 4) = v;
+      }
+    }
+    {  // stage dz tile [4*32 pixels][BN]
+      constexpr int rq = BN / 4;
+      for (int f = tid; f < WG_ROWS * 32 * rq; f += 256) {
+        const int pix = f / rq, q = f - pix * rq;
+        const int oy = oy0 + (pix >> 5), ox = ox0 + (pix & 31);
+        const int co = co0 + q * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (oy < d.OH && ox < d.OW && co < d.Cout) {
+          const float* p = d.dz + ((size_t)(n * d.OH + oy) * d.OW + ox) * d.dz_ldc + co;
+          if (co + 3 < d.Cout) v = *(const f32x4*)p;
+          else { v.x = p[0]; if (co + 1 < d.Cout) v.y = p[1]; if (co + 2 < d.Cout) v.z = p[2]; }
+        }
+        *(f32x4*)(Zs + pix * BN + q * 4) = v;
+      }
+    }
+    __syncthreads();
+    const float* xrow = Xs + (wave * is * g.in_cols) * WG_CI + li;
+    const float* zrow = Zs + (wave * 32) * BN + li;
+#pragma unroll 2
+    for (int kp = 0; kp < 16; ++kp) {
+      const int px = 2 * kp + lh;
+      float b[NT];
+#pragma unroll
+      for (int u = 0; u < NT; ++u) b[u] = zrow[px * BN + u * 32];
+      const float* xp = xrow + px * is * WG_CI;
+#pragma unroll
+      for (int t = 0; t < TB; ++t) {
+        if (t < nt) {
+          const float a = xp[toff[t]];
+#pragma unroll
+          for (int u = 0; u < NT; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[u], acc[t][u], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- fold the four waves in LDS, write this workgroup's partial slab
+  __syncthreads();
+  float* red = smem;  // [TB][32 ci][BN]
+  for (int i = tid; i < TB * WG_CI * BN; i += 256) red[i] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < TB; ++t)
+#pragma unroll
+    for (int u = 0; u < NT; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ci = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        atomicAdd(&red[(t * WG_CI + ci) * BN + u * 32 + li], acc[t][u][r]);
+      }
+  __syncthreads();
+  float* part = d.partial + (size_t)split * d.ntaps * g.Ktot * g.Cout32;
+  for (int i = tid; i < nt * kc * BN; i += 256) {
+    const int co = i % BN, r = i / BN;
+    const int ci = r % kc, t = r / kc;
+    if (co0 + co < g.Cout32)
+      part[((size_t)(t0 + t) * g.Ktot + k0 + ci) * g.Cout32 + co0 + co] = red[(t * WG_CI + ci) * BN + co];
+  }
+}
+
+// stage 2: dw_oihw[(co*Cin_real + k)*KHW + widx[t]] (+)= sum_s partial[s][t][k][co]
+__global__ void wgrad_reduce_k(const pmf_wgrad_desc_t d, int Ktot, int Cout32) {
+  const int64_t total = (int64_t)d.ntaps * Ktot * Cout32;
+  const int64_t slab = total;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int co = (int)(i % Cout32);
+    const int64_t r = i / Cout32;
+    const int k = (int)(r % Ktot), t = (int)(r / Ktot);
+    if (co >= d.Cout || k >= d.Cin_real) continue;
+    float s = 0.f;
+    for (int sp = 0; sp < d.nsplit; ++sp) s += d.partial[sp * slab + i];
+    float* o = d.dw_oihw + ((size_t)co * d.Cin_real + k) * d.KHW + d.tap_widx[t];
+    *o = d.accumulate ? *o + s : s;
+  }
+}
+
+static int wg_geometry(const pmf_wgrad_desc_t* d, int TB, int BN, WgGeom* g, int* lds) {
+  int Ktot = 0, nchunks = 0;
+  for (int i = 0; i < d->nsrc; ++i) { Ktot += d->src[i].C; nchunks += cdiv(d->src[i].C, WG_CI); }
+  g->Ktot = Ktot; g->nchunks = nchunks;
+  g->Cout32 = round_up(d->Cout, 32);
+  g->tiles_x = cdiv(d->OW, 32); g->tiles_y = cdiv(d->OH, WG_ROWS);
+  g->total_tiles = g->tiles_x * g->tiles_y * d->N;
+  int dy_min = 127, dy_max = -127, dx_min = 127, dx_max = -127;
+  for (int t = 0; t < d->ntaps; ++t) {
+    dy_min = d->tdy[t] < dy_min ? d->tdy[t] : dy_min; dy_max = d->tdy[t] > dy_max ? d->tdy[t] : dy_max;
+    dx_min = d->tdx[t] < dx_min ? d->tdx[t] : dx_min; dx_max = d->tdx[t] > dx_max ? d->tdx[t] : dx_max;
+  }
+  g->dy_min = dy_min; g->dx_min = dx_min;
+  int rows = (WG_ROWS - 1) * d->in_stride + 1, cols = 31 * d->in_stride + 1;
+  if (!d->gather) { rows += dy_max - dy_min; cols += dx_max - dx_min; }
+  g->in_rows = rows; g->in_cols = cols;
+  g->x_floats = rows * cols * WG_CI;
+  g->co_tiles = cdiv(d->Cout, BN);
+  g->tap_batches = cdiv(d->ntaps, TB);
+  int stage = (g->x_floats + WG_ROWS * 32 * BN) * 4, fold = TB * WG_CI * BN * 4;
+  *lds = stage > fold ? stage : fold;
+  return 0;
+}
+
+// taps per workgroup / channel tile: 3x3 -> 9 taps x 32 co, 2x2 -> 4 x 64, everything per-tap -> 1 x 64
+static void wg_config(const pmf_wgrad_desc_t* d, int* TB, int* NT) {
+  if (d->gather || d->ntaps == 1) { *TB = 1; *NT = 2; }
+  else if (d->ntaps <= 4) { *TB = 4; *NT = 2; }
+  else { *TB = 9; *NT = 1; }
+  if (d->Cout <= 32) *NT = 1;
+}
+
+extern "C" int pmf_conv_wgrad_nsplit(const pmf_wgrad_desc_t* d) {
+  int TB, NT, lds;
+  WgGeom g;
+  wg_config(d, &TB, &NT);
+  wg_geometry(d, TB, NT * 32, &g, &lds);
+  int other = g.nchunks * g.co_tiles * g.tap_batches;
+  int ns = 768 / (other > 0 ? other : 1);
+  if (ns < 1) ns = 1;
+  if (ns > g.total_tiles) ns = g.total_tiles;
+  return ns;
+}
+
+extern "C" int64_t pmf_conv_wgrad_workspace(const pmf_wgrad_desc_t* d) {
+  int Ktot = 0;
+  for (int i = 0; i < d->nsrc; ++i) Ktot += d->src[i].C;
+  return (int64_t)d->nsplit * d->ntaps * Ktot * round_up(d->Cout, 32) * 4;
+}
+
+template <int TB, int NT>
+static int wg_launch(const pmf_wgrad_desc_t* d, hipStream_t s) {
+  WgGeom g;
+  int lds;
+  wg_geometry(d, TB, NT * 32, &g, &lds);
+  if (lds > 160 * 1024) return PMF_E_UNSUPPORTED;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_k<TB, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  dim3 grid(d->nsplit, g.nchunks, g.co_tiles * g.tap_batches);
+  hipLaunchKernelGGL((conv_wgrad_k<TB, NT>), grid, dim3(256), lds, s, *d, g);
+  PMF_LAUNCH_CHECK();
+  const int64_t total = (int64_t)d->ntaps * g.Ktot * g.Cout32;
+  int gb = (int)cdiv64(total, 256);
+  hipLaunchKernelGGL(wgrad_reduce_k, dim3(gb > 2048 ? 2048 : gb), dim3(256), 0, s, *d, g.Ktot, g.Cout32);
+  PMF_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pmf_conv_wgrad(const pmf_wgrad_desc_t* d, pmf_stream_t st) {
+  hipStream_t s = (hipStream_t)st;
+  if (!d || d->nsrc < 1 || d->nsrc > PMF_MAX_SRC || d->ntaps < 1 || d->ntaps > PMF_MAX_TAPS || d->nsplit < 1)
+    return PMF_E_ARG;
+  for (int i = 0; i < d->nsrc; ++i)
+    if (d->src[i].C % 8 || d->src[i].ldc % 4) return PMF_E_ARG;
+  if (d->gather && false) return PMF_E_ARG;
+  int TB, NT;
+  wg_config(d, &TB, &NT);
+  if (TB == 1) return NT == 2 ? wg_launch<1, 2>(d, s) : wg_launch<1, 1>(d, s);
+  if (TB == 4) return NT == 2 ? wg_launch<4, 2>(d, s) : wg_launch<4, 1>(d, s);
+  return wg_launch<9, 1>(d, s);
+}

@@ -1,0 +1,85 @@
+// KNN post-processing vote (pc_processor/postproc/knn.py:55-143) as one lane per point on gfx950.
+// The reference materialises two [1, S*S, H*W] unfolds and four [1, S*S, P] gathers; here each lane keeps its
+// S*S window (weighted |range difference| and neighbour labels) in registers, selects the k smallest by
+// repeated first-minimum (ties -> smaller window index, the rule the CPU oracle pins) and votes.
+// HBM-bound: algorithmic bytes 12*H*W + 28*P per call.
+#include "common.h"
+
+template <int S>
+__global__ __launch_bounds__(256) void knn_k(const float* __restrict__ pr, const float* __restrict__ ur,
+                                             const int64_t* __restrict__ am, const int64_t* __restrict__ px,
+                                             const int64_t* __restrict__ py, int H, int W, int64_t P, int knn,
+                                             const float* __restrict__ invg, float cutoff, int nclasses,
+                                             int64_t* __restrict__ labels) {
+  constexpr int S2 = S * S, PAD = (S - 1) / 2, CENTER = (S2 - 1) / 2;
+  __shared__ float wsh[S2];
+  if (threadIdx.x < S2) wsh[threadIdx.x] = invg[threadIdx.x];
+  __syncthreads();
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= P) return;
+  const int cx = (int)px[i], cy = (int)py[i];
+  const float r = ur[i];
+  float dist[S2];
+  int lab[S2];
+#pragma unroll
+  for (int t = 0; t < S2; ++t) {
+    const int y = cy + t / S - PAD, x = cx + t % S - PAD;
+    float v = 0.f;   // F.unfold zero padding: range 0, label 0
+    int l = 0;
+    if (y >= 0 && y < H && x >= 0 && x < W) {
+      v = pr[(size_t)y * W + x];
+      l = (int)am[(size_t)y * W + x];
+      if (v < 0.f) v = INFINITY;
+    }
+    if (t == CENTER) v = r;
+    dist[t] = __fmul_rn(fabsf(__fsub_rn(v, r)), wsh[t]);
+    lab[t] = l;
+  }
+  // k x first-minimum selection
+  unsigned long long used = 0ull;
+  int sel[S2 < 8 ? 8 : 8];
+  int nsel = knn < 8 ? knn : 8;
+  for (int k = 0; k < nsel; ++k) {
+    float best = 0.f;
+    int bi = -1;
+#pragma unroll
+    for (int t = 0; t < S2; ++t) {
+      const bool free_ = !((used >> t) & 1ull);
+      if (free_ && (bi < 0 || dist[t] < best)) { best = dist[t]; bi = t; }
+    }
+    used |= 1ull << bi;
+    int l = 0;
+#pragma unroll
+    for (int t = 0; t < S2; ++t) if (t == bi) l = lab[t];
+    if (cutoff > 0.f && best > cutoff) l = nclasses;
+    sel[k] = l;
+  }
+  int best_cnt = 0, best_cls = 1;
+  for (int a = 0; a < nsel; ++a) {
+    const int cls = sel[a];
+    if (cls < 1 || cls >= nclasses) continue;
+    int cnt = 0;
+    for (int b = 0; b < nsel; ++b) cnt += sel[b] == cls;
+    if (cnt > best_cnt || (cnt == best_cnt && cls < best_cls)) { best_cnt = cnt; best_cls = cls; }
+  }
+  labels[i] = best_cls;
+}
+
+extern "C" int pmf_knn_vote(const float* proj_range, const float* unproj_range, const int64_t* proj_argmax,
+                            const int64_t* px, const int64_t* py, int32_t H, int32_t W, int64_t P, int32_t knn,
+                            int32_t search, const float* inv_gauss, float cutoff, int32_t nclasses, int64_t* labels,
+                            pmf_stream_t s) {
+  if (search % 2 == 0) return PMF_E_ARG;  // knn.py:73-74 raises ValueError
+  if (knn < 1 || knn > 8 || knn > search * search) return PMF_E_UNSUPPORTED;
+  if (P <= 0) return 0;
+  dim3 grid((unsigned)cdiv64(P, 256)), block(256);
+  hipStream_t st = (hipStream_t)s;
+  switch (search) {
+    case 3: hipLaunchKernelGGL(knn_k<3>, grid, block, 0, st, proj_range, unproj_range, proj_argmax, px, py, H, W, P, knn, inv_gauss, cutoff, nclasses, labels); break;
+    case 5: hipLaunchKernelGGL(knn_k<5>, grid, block, 0, st, proj_range, unproj_range, proj_argmax, px, py, H, W, P, knn, inv_gauss, cutoff, nclasses, labels); break;
+    case 7: hipLaunchKernelGGL(knn_k<7>, grid, block, 0, st, proj_range, unproj_range, proj_argmax, px, py, H, W, P, knn, inv_gauss, cutoff, nclasses, labels); break;
+    default: return PMF_E_UNSUPPORTED;
+  }
+  PMF_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,58 @@
+// Weight re-layout: PyTorch OIHW parameters -> packed implicit-GEMM slabs [tap][k][n] (gfx950).
+// One batched launch re-packs every conv of the network (weights change every optimiser step), tiled through
+// LDS so both the OIHW reads and the packed writes are coalesced.
+#include "common.h"
+
+#define PACK_L 320  // floats of one co-row slice held in LDS
+
+__global__ __launch_bounds__(256) void pack_k(const pmf_pack_job_t* __restrict__ jobs, int njobs) {
+  __shared__ float T[32][PACK_L + 1];
+  // locate the job of this block (block_start is ascending)
+  int lo = 0, hi = njobs - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].block_start <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const pmf_pack_job_t& J = jobs[lo];
+  const int b = blockIdx.x - J.block_start;
+  const int tci = b % J.tiles_ci, tco = b / J.tiles_ci;
+  const int co0 = tco * 32, ci0 = tci * J.CT;
+  const int nco = min(32, J.Cout - co0), ct = min(J.CT, J.Cin - ci0);
+  const int L = ct * J.KHW;
+  for (int i = threadIdx.x; i < nco * L; i += 256) {
+    const int col = i / L, j = i - col * L;
+    T[col][j] = J.w[((size_t)(co0 + col) * J.Cin + ci0) * J.KHW + j];
+  }
+  __syncthreads();
+  if (!J.transpose) {
+    const int total = J.ntaps * ct * 32;
+    for (int i = threadIdx.x; i < total; i += 256) {
+      const int col = i & 31, r = i >> 5;
+      const int cil = r % ct, t = r / ct;
+      if (col < nco)
+        J.dst[((size_t)t * J.K_pad + ci0 + cil) * J.ldw + co0 + col] = T[col][cil * J.KHW + J.tap_idx[t]];
+    }
+  } else {
+    const int total = J.ntaps * nco * ct;
+    for (int i = threadIdx.x; i < total; i += 256) {
+      const int cil = i % ct, r = i / ct;
+      const int col = r % nco, t = r / nco;
+      J.dst[((size_t)t * J.K_pad + co0 + col) * J.ldw + ci0 + cil] = T[col][cil * J.KHW + J.tap_idx[t]];
+    }
+  }
+}
+
+extern "C" int pmf_pack_tile_ci(int32_t Cin, int32_t KHW) {
+  int ct = PACK_L / KHW;
+  if (ct < 1) ct = 1;
+  if (ct > Cin) ct = Cin;
+  return ct;
+}
+
+extern "C" int pmf_pack_weights_batched(const pmf_pack_job_t* jobs_dev, int32_t njobs, int32_t total_blocks,
+                                        pmf_stream_t s) {
+  if (njobs < 1 || total_blocks < 1) return PMF_E_ARG;
+  hipLaunchKernelGGL(pack_k, dim3(total_blocks), dim3(256), 0, (hipStream_t)s, jobs_dev, njobs);
+  PMF_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,117 @@
+// Plan executor: a whole forward or backward pass of the network is a flat array of pmf_op_t built once on the
+// host (static shapes, static buffers); running it is ONE C call that enqueues every kernel on the caller's
+// HIP stream -- no Python between launches, and the array can be captured into a hipGraph by the caller.
+#include <hip/hip_runtime.h>
+#include "../../include/pmf_amd.h"
+
+extern "C" int pmf_pack_weights_batched(const pmf_pack_job_t*, int32_t, int32_t, pmf_stream_t);
+
+static int run_one(const pmf_op_t& o, pmf_stream_t s) {
+  const pmf_small_args_t& a = o.u.sm;
+  const int32_t* i = a.i;
+  switch (o.kind) {
+    case PMF_OP_CONV: return pmf_conv_fwd(&o.u.conv, s);
+    case PMF_OP_WGRAD: return pmf_conv_wgrad(&o.u.wgrad, s);
+    case PMF_OP_PACK:  // p0 jobs(dev)  i0 njobs  i1 total_blocks
+      return pmf_pack_weights_batched((const pmf_pack_job_t*)a.p[0], i[0], i[1], s);
+    case PMF_OP_BN_FINALIZE:  // p: stats gamma beta rm rv scale shift save_mean save_invstd | f: count mom eps | i0 C
+      return pmf_bn_finalize((const float*)a.p[0], a.f[0], (const float*)a.p[1], (const float*)a.p[2], (float*)a.p[3],
+                             (float*)a.p[4], a.f[1], a.f[2], (float*)a.p[5], (float*)a.p[6], (float*)a.p[7],
+                             (float*)a.p[8], i[0], s);
+    case PMF_OP_BN_EVAL:  // p: gamma beta rm rv scale shift save_mean save_invstd | f0 eps | i0 C
+      return pmf_bn_eval_affine((const float*)a.p[0], (const float*)a.p[1], (const float*)a.p[2], (const float*)a.p[3],
+                                a.f[0], (float*)a.p[4], (float*)a.p[5], (float*)a.p[6], (float*)a.p[7], i[0], s);
+    case PMF_OP_BN_BWD_REDUCE:  // p: gy a red | i: gy_ldc a_ldc C | l0 npix
+      return pmf_bn_bwd_reduce((const float*)a.p[0], i[0], (const float*)a.p[1], i[1], a.l[0], i[2], (float*)a.p[2], s);
+    case PMF_OP_BN_BWD_APPLY:  // p: gy a red gamma mean invstd dz dgamma dbeta dbias | i: gy_ldc a_ldc C act train dz_ldc
+      return pmf_bn_bwd_apply((const float*)a.p[0], i[0], (const float*)a.p[1], i[1], a.l[0], i[2], (const float*)a.p[2],
+                              (const float*)a.p[3], (const float*)a.p[4], (const float*)a.p[5], i[3], i[4],
+                              (float*)a.p[6], i[5], (float*)a.p[7], (float*)a.p[8], (float*)a.p[9], s);
+    case PMF_OP_ADD_ACT:  // v0 a, v1 b | p0 out | i: act out_ldc HW has_b C | l0 npix
+      return pmf_add_act(&a.v[0], i[3] ? &a.v[1] : nullptr, i[0], (float*)a.p[0], i[1], a.l[0], i[2], i[4], s);
+    case PMF_OP_ADD_ACT_BWD:  // p: gout out ga gb | i: g_ldc out_ldc act ga_ldc ga_acc gb_ldc gb_acc C
+      return pmf_add_act_bwd((const float*)a.p[0], i[0], (const float*)a.p[1], i[1], i[2], (float*)a.p[2], i[3], i[4],
+                             (float*)a.p[3], i[5], i[6], a.l[0], i[7], s);
+    case PMF_OP_ACT_BWD:  // p: g a dbias | i: g_ldc a_ldc act C
+      return pmf_act_bwd((float*)a.p[0], i[0], (const float*)a.p[1], i[1], i[2], (float*)a.p[2], a.l[0], i[3], s);
+    case PMF_OP_AVGPOOL:  // v0 | p0 out | i: N H W C out_ldc
+      return pmf_avgpool3s2(&a.v[0], i[0], i[1], i[2], i[3], (float*)a.p[0], i[4], s);
+    case PMF_OP_AVGPOOL_BWD:  // p: gout cmul gin | i: g_ldc N H W C cmul_ld gin_ldc acc
+      return pmf_avgpool3s2_bwd((const float*)a.p[0], i[0], i[1], i[2], i[3], i[4], (const float*)a.p[1], i[5],
+                                (float*)a.p[2], i[6], i[7], s);
+    case PMF_OP_MAXPOOL:  // v0 | p: out idx | i: N H W C out_ldc
+      return pmf_maxpool3s2(&a.v[0], i[0], i[1], i[2], i[3], (float*)a.p[0], i[4], (uint8_t*)a.p[1], s);
+    case PMF_OP_MAXPOOL_BWD:  // v0 | p: gout idx gin | i: g_ldc N H W C gin_ldc acc
+      return pmf_maxpool3s2_bwd((const float*)a.p[0], i[0], (const uint8_t*)a.p[1], i[1], i[2], i[3], i[4], &a.v[0],
+                                (float*)a.p[2], i[5], i[6], s);
+    case PMF_OP_BILINEAR:  // v0 | p0 out | i: N H W C out_ldc
+      return pmf_bilinear2x(&a.v[0], i[0], i[1], i[2], i[3], (float*)a.p[0], i[4], s);
+    case PMF_OP_BILINEAR_BWD:  // p: gout gin | i: g_ldc N H W C gin_ldc acc
+      return pmf_bilinear2x_bwd((const float*)a.p[0], i[0], i[1], i[2], i[3], i[4], (float*)a.p[1], i[5], i[6], s);
+    case PMF_OP_PSHUFFLE:  // v0 | p: out_cmul out | i: N H W Cout out_cmul_ld out_ldc
+      return pmf_pixel_shuffle2(&a.v[0], i[0], i[1], i[2], i[3], (const float*)a.p[0], i[4], (float*)a.p[1], i[5], s);
+    case PMF_OP_PSHUFFLE_BWD:  // p: gout out_cmul in_cmul gin | i: g_ldc N H W Cout out_cmul_ld in_cmul_ld gin_ldc acc
+      return pmf_pixel_shuffle2_bwd((const float*)a.p[0], i[0], i[1], i[2], i[3], i[4], (const float*)a.p[1], i[5],
+                                    (const float*)a.p[2], i[6], (float*)a.p[3], i[7], i[8], s);
+    case PMF_OP_GATE:  // v0 f, v1 att | p: pcd out | i: pcd_ldc out_ldc C | l0 npix
+      return pmf_fusion_gate(&a.v[0], &a.v[1], (const float*)a.p[0], i[0], (float*)a.p[1], i[1], a.l[0], i[2], s);
+    case PMF_OP_GATE_BWD:  // v0 v1 | p: gout gf gatt gpcd | i: g_ldc gf_ldc gf_acc gatt_ldc gpcd_ldc gpcd_acc C
+      return pmf_fusion_gate_bwd((const float*)a.p[0], i[0], &a.v[0], &a.v[1], (float*)a.p[1], i[1], i[2],
+                                 (float*)a.p[2], i[3], (float*)a.p[3], i[4], i[5], a.l[0], i[6], s);
+    case PMF_OP_GMEAN:  // v0 | p0 out | i: N HW C
+      return pmf_global_mean(&a.v[0], i[0], i[1], i[2], (float*)a.p[0], s);
+    case PMF_OP_GMEAN_BWD:  // p: gout cmul gin | i: N HW C cmul_ld gin_ldc acc
+      return pmf_global_mean_bwd((const float*)a.p[0], i[0], i[1], i[2], (const float*)a.p[1], i[3], (float*)a.p[2],
+                                 i[4], i[5], s);
+    case PMF_OP_COLSUM:  // p: x out | i: ldc C nz | l0 npix
+      return pmf_colsum((const float*)a.p[0], i[0], a.l[0], i[1], (float*)a.p[1], i[2], s);
+    case PMF_OP_SOFTMAX:  // p: logits prob | i: ldc N HW C
+      return pmf_softmax_nhwc_to_nchw((const float*)a.p[0], i[0], i[1], i[2], i[3], (float*)a.p[1], s);
+    case PMF_OP_SOFTMAX_BWD:  // p: prob g dlogits | i: N HW C ldc
+      return pmf_softmax_bwd_nchw_to_nhwc((const float*)a.p[0], (const float*)a.p[1], i[0], i[1], i[2], (float*)a.p[2],
+                                          i[3], s);
+    case PMF_OP_NCHW2NHWC:  // p: x out | l: stride_n stride_c | i: N C HW out_ldc
+      return pmf_nchw_to_nhwc((const float*)a.p[0], a.l[0], a.l[1], i[0], i[1], i[2], (float*)a.p[1], i[3], s);
+    case PMF_OP_FILL:  // p0 | f0 value | l0 count
+      return pmf_fill((float*)a.p[0], a.f[0], a.l[0], s);
+    default: return PMF_E_ARG;
+  }
+}
+
+extern "C" int pmf_plan_run(const pmf_op_t* ops, int32_t n, pmf_stream_t s, int32_t* failed_at) {
+  for (int32_t k = 0; k < n; ++k) {
+    const int rc = run_one(ops[k], s);
+    if (rc != 0) {
+      if (failed_at) *failed_at = k;
+      return rc;
+    }
+  }
+  return 0;
+}
+
+extern "C" int pmf_plan_run_range(const pmf_op_t* ops, int32_t begin, int32_t end, pmf_stream_t s, int32_t* failed_at) {
+  for (int32_t k = begin; k < end; ++k) {
+    const int rc = run_one(ops[k], s);
+    if (rc != 0) {
+      if (failed_at) *failed_at = k;
+      return rc;
+    }
+  }
+  return 0;
+}
+
+// ABI self-check for language bindings: sizes of the structs a binding has to mirror
+extern "C" int pmf_sizeof(int which) {
+  switch (which) {
+    case 0: return (int)sizeof(pmf_src_t);
+    case 1: return (int)sizeof(pmf_conv_desc_t);
+    case 2: return (int)sizeof(pmf_wgrad_desc_t);
+    case 3: return (int)sizeof(pmf_view_t);
+    case 4: return (int)sizeof(pmf_small_args_t);
+    case 5: return (int)sizeof(pmf_op_t);
+    case 6: return (int)sizeof(pmf_pack_job_t);
+    default: return -1;
+  }
+}
+
+extern "C" const char* pmf_version(void) { return "pmf_amd 0.1 (gfx950)"; }

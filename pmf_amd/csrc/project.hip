@@ -1,0 +1,162 @@
+// Perspective projection + last-writer-wins scatter of a LiDAR sweep into the camera plane (gfx950).
+// Follows pc_processor/dataset/semantic_kitti/parser.py:209-227 and perspective_view_loader.py:89-131:
+//   keep = x > 0.5 ; (u,v,s) = P(3x4, float64) . [x y z 1] ; u/=s, v/=s ; keep &= 0<u<w & 0<v<h ;
+//   row = int32(v), col = int32(u) (truncation) ; duplicates: the LAST point in file order wins.
+// Order-preserving compaction (x_data / y_data) = block counts -> single-block scan -> ballot prefix.
+// The winner per pixel is an atomicMax over point indices, then one gather pass builds the [10,h,w] tensor.
+#include "common.h"
+
+#define PB 1024
+
+struct Proj { double m[12]; };
+
+__device__ __forceinline__ bool project_point(const float* __restrict__ pt, const double* __restrict__ m, int h, int w,
+                                              int& row, int& col) {
+  const float xf = pt[0];
+  if (!(xf > 0.5f)) return false;
+  const double x = (double)xf, y = (double)pt[1], z = (double)pt[2];
+  // k-ordered FMA chain, the order an FMA dgemm micro-kernel accumulates a length-4 dot product
+  const double a = fma(m[3], 1.0, fma(m[2], z, fma(m[1], y, m[0] * x)));
+  const double b = fma(m[7], 1.0, fma(m[6], z, fma(m[5], y, m[4] * x)));
+  const double c = fma(m[11], 1.0, fma(m[10], z, fma(m[9], y, m[8] * x)));
+  const double u = a / c, v = b / c;
+  if (!(u > 0.0 && u < (double)w && v > 0.0 && v < (double)h)) return false;
+  row = (int)v;
+  col = (int)u;
+  return true;
+}
+
+__global__ __launch_bounds__(PB) void proj_count_k(const float* __restrict__ pts, int64_t P,
+                                                   const double* __restrict__ m, int h, int w,
+                                                   uint8_t* __restrict__ keep, float* __restrict__ depth,
+                                                   int32_t* __restrict__ blk_cnt) {
+  const int64_t i = blockIdx.x * (int64_t)PB + threadIdx.x;
+  int k = 0;
+  if (i < P) {
+    int r, c;
+    k = project_point(pts + i * 4, m, h, w, r, c) ? 1 : 0;
+    keep[i] = (uint8_t)k;
+    const float x = pts[i * 4], y = pts[i * 4 + 1], z = pts[i * 4 + 2];
+    depth[i] = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z)));
+  }
+  const int cnt = __syncthreads_count(k);
+  if (threadIdx.x == 0) blk_cnt[blockIdx.x] = cnt;
+}
+
+__global__ __launch_bounds__(1024) void proj_scan_k(int32_t* __restrict__ blk_cnt, int nblk, int32_t* __restrict__ n_kept) {
+  // exclusive scan in place, nblk small (P / 1024)
+  __shared__ int sh[1024];
+  __shared__ int carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < nblk; base += 1024) {
+    const int i = base + threadIdx.x;
+    const int v = i < nblk ? blk_cnt[i] : 0;
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+      const int t = threadIdx.x >= off ? sh[threadIdx.x - off] : 0;
+      __syncthreads();
+      sh[threadIdx.x] += t;
+      __syncthreads();
+    }
+    if (i < nblk) blk_cnt[i] = carry + sh[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry += sh[1023];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *n_kept = carry;
+}
+
+__global__ __launch_bounds__(PB) void proj_scatter_k(const float* __restrict__ pts, int64_t P,
+                                                     const double* __restrict__ m, int h, int w,
+                                                     const int32_t* __restrict__ blk_off, int32_t* __restrict__ x_data,
+                                                     int32_t* __restrict__ y_data, int32_t* __restrict__ pix_idx) {
+  __shared__ int wave_cnt[PB / 64];
+  const int64_t i = blockIdx.x * (int64_t)PB + threadIdx.x;
+  int r = 0, c = 0;
+  const bool k = i < P && project_point(pts + i * 4, m, h, w, r, c);
+  const unsigned long long bal = __ballot(k);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int before = __popcll(bal & ((1ull << lane) - 1ull));
+  if (lane == 0) wave_cnt[wv] = __popcll(bal);
+  __syncthreads();
+  int woff = 0;
+  for (int j = 0; j < wv; ++j) woff += wave_cnt[j];
+  if (k) {
+    const int dst = blk_off[blockIdx.x] + woff + before;
+    x_data[dst] = r;
+    y_data[dst] = c;
+    atomicMax(pix_idx + (size_t)r * w + c, (int)i);
+  }
+}
+
+__global__ void proj_gather_k(const float* __restrict__ pts, const int32_t* __restrict__ sem,
+                              const float* __restrict__ depth, const uint8_t* __restrict__ img,
+                              const int32_t* __restrict__ lut, int nlut, const int32_t* __restrict__ pix_idx, int h, int w,
+                              float* __restrict__ out) {
+  const int64_t hw = (int64_t)h * w;
+  for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < hw; p += (int64_t)gridDim.x * blockDim.x) {
+    const int i = pix_idx[p];
+    float d = 0.f, x = 0.f, y = 0.f, z = 0.f, it = 0.f, mk = 0.f, lb = 0.f;
+    if (i >= 0) {
+      const f32x4 q = *(const f32x4*)(pts + (size_t)i * 4);
+      x = q.x; y = q.y; z = q.z; it = q.w;
+      d = depth[i];
+      mk = 1.f;
+      const int sl = sem[i];
+      lb = (float)((sl >= 0 && sl < nlut) ? lut[sl] : 0);
+    }
+    out[0 * hw + p] = d; out[1 * hw + p] = x; out[2 * hw + p] = y; out[3 * hw + p] = z; out[4 * hw + p] = it;
+    out[5 * hw + p] = __fdiv_rn((float)img[p * 3 + 0], 255.0f);
+    out[6 * hw + p] = __fdiv_rn((float)img[p * 3 + 1], 255.0f);
+    out[7 * hw + p] = __fdiv_rn((float)img[p * 3 + 2], 255.0f);
+    out[8 * hw + p] = mk;
+    out[9 * hw + p] = lb;
+  }
+}
+
+extern "C" int pmf_project_scatter(const float* points, const int32_t* sem, int64_t P, const uint8_t* image,
+                                   int32_t h, int32_t w, const double* proj, const int32_t* lut, int32_t nlut,
+                                   float* proj_out, uint8_t* keep, int32_t* x_data, int32_t* y_data, float* depth,
+                                   int32_t* n_kept, int32_t* pix_idx, int32_t* blk_cnt, pmf_stream_t s) {
+  hipStream_t st = (hipStream_t)s;
+  if (P < 0 || h < 1 || w < 1) return PMF_E_ARG;
+  hipError_t e = hipMemsetAsync(pix_idx, 0xFF, (size_t)h * w * 4, st);
+  if (e != hipSuccess) return (int)e;
+  const int nblk = (int)cdiv64(P > 0 ? P : 1, PB);
+  hipLaunchKernelGGL(proj_count_k, dim3(nblk), dim3(PB), 0, st, points, P, proj, h, w, keep, depth, blk_cnt);
+  hipLaunchKernelGGL(proj_scan_k, dim3(1), dim3(1024), 0, st, blk_cnt, nblk, n_kept);
+  hipLaunchKernelGGL(proj_scatter_k, dim3(nblk), dim3(PB), 0, st, points, P, proj, h, w, blk_cnt, x_data, y_data, pix_idx);
+  int64_t hw = (int64_t)h * w;
+  int g = (int)cdiv64(hw, 256);
+  hipLaunchKernelGGL(proj_gather_k, dim3(g > 2048 ? 2048 : g), dim3(256), 0, st, points, sem, depth, image, lut, nlut,
+                     pix_idx, h, w, proj_out);
+  PMF_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ void crop_pad_k(const float* __restrict__ src, int C, int h, int w, int top, int left, float* __restrict__ dst,
+                           int oh, int ow, int pad_top, int pad_left, int ch, int cw) {
+  const int64_t total = (int64_t)C * oh * ow;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int x = (int)(i % ow), y = (int)((i / ow) % oh), c = (int)(i / ((int64_t)ow * oh));
+    const int cy = y - pad_top, cx = x - pad_left;  // position inside the crop window
+    float v = 0.f;
+    if (cy >= 0 && cy < ch && cx >= 0 && cx < cw) {
+      const int sy = cy + top, sx = cx + left;
+      if (sy >= 0 && sy < h && sx >= 0 && sx < w) v = src[((size_t)c * h + sy) * w + sx];
+    }
+    dst[i] = v;
+  }
+}
+extern "C" int pmf_crop_pad(const float* src, int32_t C, int32_t h, int32_t w, int32_t top, int32_t left, float* dst,
+                            int32_t oh, int32_t ow, int32_t pad_top, int32_t pad_left, int32_t ch, int32_t cw,
+                            pmf_stream_t s) {
+  int64_t total = (int64_t)C * oh * ow;
+  int g = (int)cdiv64(total, 256);
+  hipLaunchKernelGGL(crop_pad_k, dim3(g > 4096 ? 4096 : g), dim3(256), 0, (hipStream_t)s, src, C, h, w, top, left, dst, oh,
+                     ow, pad_top, pad_left, ch, cw);
+  PMF_LAUNCH_CHECK();
+  return 0;
+}

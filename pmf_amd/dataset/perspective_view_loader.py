@@ -1,0 +1,112 @@
+"""Perspective-view loader on MI355X (pc_processor/dataset/perspective_view_loader.py:8-146).
+
+Same constructor / item contract as the reference.  The projection (float64 pinhole, parser.py:209-227), the
+last-writer-wins scatter of (depth,x,y,z,intensity,label,mask) and the stacking with RGB/255 run as HIP kernels
+(pmf_project_scatter); the validation CenterCrop+Pad runs as pmf_crop_pad.  ``dataset`` is the reference's
+duck type; only ``proj_matrix`` / ``class_map_lut`` are needed from it beyond the four load functions:
+    loadDataByIndex(i) -> (points f32[P,4], sem i32[P], inst)       loadImage(i) -> PIL / uint8[h,w,3]
+    parsePathInfoByIndex(i) -> (seq, frame)                          proj_matrix[seq] -> f64[3,4]
+    labelMapping LUT: class_map_lut i32[L]
+The training-time torchvision tensor transforms (RandomHorizontalFlip / RandomRotation(15) / RandomCrop,
+perspective_view_loader.py:63-69) are NOT built (torchvision is a third-party dependency that is absent here;
+no parity definition) -- is_train=True raises unless the caller passes ``aug_ops``.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+from torch.utils.data import Dataset
+
+from .. import _lib as L
+
+
+def project_frame_gpu(points, sem_label, image_u8, proj_matrix, label_lut, device="cuda"):
+    """-> (proj f32[10,h,w], x_data i32[K], y_data i32[K], depth f32[P], keep bool[P]) on `device`."""
+    lib = L.lib()
+    dev = torch.device(device)
+    pts = torch.as_tensor(np.ascontiguousarray(points, np.float32)).to(dev)
+    sem = torch.as_tensor(np.ascontiguousarray(sem_label, np.int32)).to(dev)
+    img = torch.as_tensor(np.ascontiguousarray(image_u8, np.uint8)).to(dev)
+    mat = torch.as_tensor(np.ascontiguousarray(proj_matrix, np.float64).reshape(12)).to(dev)
+    lut = torch.as_tensor(np.ascontiguousarray(label_lut, np.int32)).to(dev)
+    P = pts.shape[0]
+    h, w = img.shape[0], img.shape[1]
+    out = torch.empty((10, h, w), dtype=torch.float32, device=dev)
+    keep = torch.empty(max(P, 1), dtype=torch.uint8, device=dev)
+    xd = torch.empty(max(P, 1), dtype=torch.int32, device=dev)
+    yd = torch.empty(max(P, 1), dtype=torch.int32, device=dev)
+    depth = torch.empty(max(P, 1), dtype=torch.float32, device=dev)
+    nk = torch.zeros(1, dtype=torch.int32, device=dev)
+    pix = torch.empty(h * w, dtype=torch.int32, device=dev)
+    blk = torch.empty((P + 1023) // 1024 + 1, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    rc = lib.pmf_project_scatter(pts.data_ptr(), sem.data_ptr(), P, img.data_ptr(), h, w, mat.data_ptr(),
+                                 lut.data_ptr(), lut.shape[0], out.data_ptr(), keep.data_ptr(), xd.data_ptr(),
+                                 yd.data_ptr(), depth.data_ptr(), nk.data_ptr(), pix.data_ptr(), blk.data_ptr(),
+                                 C.c_void_p(stream))
+    L.check(rc, "pmf_project_scatter")
+    k = int(nk.item())
+    return out, xd[:k], yd[:k], depth[:P], keep[:P].bool()
+
+
+def center_crop_pad_gpu(proj, out_h, out_w, h_pad, w_pad):
+    """CenterCrop((out_h-2hp, out_w-2wp)) then Pad((wp, hp)) (perspective_view_loader.py:71-74,138-141)."""
+    lib = L.lib()
+    c, h, w = proj.shape
+    ch, cw = out_h - 2 * h_pad, out_w - 2 * w_pad
+    # torchvision CenterCrop: symmetric zero-pad first when the image is smaller than the crop
+    pl = (cw - w) // 2 if cw > w else 0
+    pt = (ch - h) // 2 if ch > h else 0
+    hh = max(h, ch) if ch > h else h
+    ww = max(w, cw) if cw > w else w
+    top = int(round((hh - ch) / 2.0)) - pt
+    left = int(round((ww - cw) / 2.0)) - pl
+    dst = torch.empty((c, out_h, out_w), dtype=torch.float32, device=proj.device)
+    stream = torch.cuda.current_stream(proj.device).cuda_stream
+    rc = lib.pmf_crop_pad(proj.contiguous().data_ptr(), c, h, w, top, left, dst.data_ptr(), out_h, out_w, h_pad,
+                          w_pad, ch, cw, C.c_void_p(stream))
+    L.check(rc, "pmf_crop_pad")
+    return dst
+
+
+class PerspectiveViewLoader(Dataset):
+    def __init__(self, dataset, config, data_len=-1, is_train=True, pcd_aug=False, img_aug=False,
+                 use_padding=False, return_uproj=False, device="cuda", aug_ops=None):
+        self.dataset, self.config = dataset, config
+        self.is_train, self.data_len = is_train, data_len
+        self.use_padding, self.return_uproj = use_padding, return_uproj
+        self.device = device
+        self.aug_ops = aug_ops
+        if pcd_aug or img_aug:
+            raise NotImplementedError("pcd_aug / img_aug (python-random point augmentation, torchvision "
+                                      "ColorJitter) are outside the accelerated path; PMF trains with both off "
+                                      "for the point cloud (tasks/pmf/trainer.py:142)")
+        s = config["sensor"]
+        self.h_pad = s["h_pad"] if use_padding else 0
+        self.w_pad = s["w_pad"] if use_padding else 0
+        self.out_h = s["proj_ht"] if is_train else s["proj_h"]
+        self.out_w = s["proj_wt"] if is_train else s["proj_w"]
+        if is_train and aug_ops is None and not return_uproj:
+            raise NotImplementedError("training-time flip/rotate/crop needs torchvision tensor transforms; pass "
+                                      "aug_ops=callable([10,h,w] tensor) or use is_train=False")
+
+    def __getitem__(self, index):
+        pointcloud, sem_label, _ = self.dataset.loadDataByIndex(index)
+        image = np.asarray(self.dataset.loadImage(index))
+        seq_id, _ = self.dataset.parsePathInfoByIndex(index)
+        proj, xd, yd, depth, _ = project_frame_gpu(pointcloud, sem_label, image, self.dataset.proj_matrix[seq_id],
+                                                   self.dataset.class_map_lut, self.device)
+        if self.return_uproj:
+            return proj[:8], proj[8], proj[9], xd, yd, depth
+        if self.is_train:
+            proj = self.aug_ops(proj)
+            if self.use_padding:
+                proj = torch.nn.functional.pad(proj, (self.w_pad, self.w_pad, self.h_pad, self.h_pad))
+        else:
+            proj = center_crop_pad_gpu(proj, self.out_h, self.out_w, self.h_pad, self.w_pad)
+        return proj[:8], proj[8], proj[9]
+
+    def __len__(self):
+        if 0 < self.data_len < len(self.dataset):
+            return self.data_len
+        return len(self.dataset)

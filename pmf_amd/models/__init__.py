@@ -1,0 +1,1 @@
+from .pmf_net import PMFNet, SalsaNext, SalsaNextFusion, ResNet, RGBDecoder, ASPP, ResidualBasedFusionBlock  # noqa: F401

@@ -1,0 +1,614 @@
+"""PMFNet / SalsaNext on MI355X: the reference's module tree as PARAMETER CONTAINERS + a static HIP plan.
+
+API surface mirrored from the reference:
+    PMFNet(pcd_channels=5, img_channels=3, nclasses=20, base_channels=32, imagenet_pretrained=True,
+           image_backbone="resnet34")                                    pc_processor/models/pmf_net.py:224-249
+    model(pcd[N,5,H,W], rgb[N,3,H,W]) -> (lidar_prob, camera_prob), each [N,nclasses,H,W] softmaxed
+    .lidar_stream / .camera_stream_encoder / .camera_stream_decoder; state_dict keys identical (654 for R34).
+
+The sub-modules (nn.Conv2d / nn.BatchNorm2d / nn.Sequential) only HOLD parameters and buffers -- their own
+``forward`` is never called.  ``PMFNet.forward`` runs libpmf_amd.so through a static plan (pmf_amd/plan.py);
+there is no PyTorch / CPU fallback: on a CPU tensor or without the shared library it raises.
+"""
+import warnings
+
+import torch
+import torch.nn as nn
+
+from .. import _lib as L
+from ..plan import Plan, V
+
+__all__ = ["PMFNet", "SalsaNext", "SalsaNextFusion", "ResNet", "RGBDecoder", "ASPP",
+           "ResidualBasedFusionBlock", "ResContextBlock", "ResBlock", "UpBlock"]
+
+
+class _Holder(nn.Module):
+    def forward(self, *a, **k):
+        raise RuntimeError("%s only holds parameters; call the top-level model (HIP plan) instead"
+                           % type(self).__name__)
+
+
+# ------------------------------------------------------------------------------------------------------
+# SalsaNext blocks (pc_processor/models/salsanext.py)
+# ------------------------------------------------------------------------------------------------------
+class ResContextBlock(_Holder):
+    """salsanext.py:9-36."""
+
+    def __init__(self, in_filters, out_filters):
+        super().__init__()
+        self.conv1 = nn.Conv2d(in_filters, out_filters, (1, 1))
+        self.act1 = nn.LeakyReLU()
+        self.conv2 = nn.Conv2d(out_filters, out_filters, (3, 3), padding=1)
+        self.act2 = nn.LeakyReLU()
+        self.bn1 = nn.BatchNorm2d(out_filters)
+        self.conv3 = nn.Conv2d(out_filters, out_filters, (3, 3), dilation=2, padding=2)
+        self.act3 = nn.LeakyReLU()
+        self.bn2 = nn.BatchNorm2d(out_filters)
+
+    def emit(self, P, x, name):
+        s = P.conv([x], self.conv1, L.ACT_LRELU, name=name + ".s")
+        a1 = P.conv([s], self.conv2, L.ACT_LRELU, self.bn1, name=name + ".a1")
+        a2 = P.conv([a1], self.conv3, L.ACT_LRELU, self.bn2, name=name + ".a2")
+        return V(P.add_act(s, a2, L.ACT_NONE, name=name + ".out"))
+
+
+class ResBlock(_Holder):
+    """salsanext.py:38-104."""
+
+    def __init__(self, in_filters, out_filters, dropout_rate, kernel_size=(3, 3), stride=1, pooling=True,
+                 drop_out=True):
+        super().__init__()
+        self.pooling, self.drop_out = pooling, drop_out
+        self.conv1 = nn.Conv2d(in_filters, out_filters, (1, 1), stride=stride)
+        self.act1 = nn.LeakyReLU()
+        self.conv2 = nn.Conv2d(in_filters, out_filters, (3, 3), padding=1)
+        self.act2 = nn.LeakyReLU()
+        self.bn1 = nn.BatchNorm2d(out_filters)
+        self.conv3 = nn.Conv2d(out_filters, out_filters, (3, 3), dilation=2, padding=2)
+        self.act3 = nn.LeakyReLU()
+        self.bn2 = nn.BatchNorm2d(out_filters)
+        self.conv4 = nn.Conv2d(out_filters, out_filters, (2, 2), dilation=2, padding=1)
+        self.act4 = nn.LeakyReLU()
+        self.bn3 = nn.BatchNorm2d(out_filters)
+        self.conv5 = nn.Conv2d(out_filters * 3, out_filters, (1, 1))
+        self.act5 = nn.LeakyReLU()
+        self.bn4 = nn.BatchNorm2d(out_filters)
+        self.dropout = nn.Dropout2d(p=dropout_rate)
+        if pooling:
+            self.pool = nn.AvgPool2d(kernel_size=kernel_size, stride=2, padding=1)
+
+    def emit(self, P, x, name, drop=None):
+        """returns (pooled T, skip T) when pooling else the (dropped) view."""
+        s = P.conv([x], self.conv1, L.ACT_LRELU, name=name + ".s")
+        r1 = P.conv([x], self.conv2, L.ACT_LRELU, self.bn1, name=name + ".r1")
+        r2 = P.conv([r1], self.conv3, L.ACT_LRELU, self.bn2, name=name + ".r2")
+        r3 = P.conv([r2], self.conv4, L.ACT_LRELU, self.bn3, name=name + ".r3")
+        r5 = P.conv([r1, r2, r3], self.conv5, L.ACT_LRELU, self.bn4, name=name + ".r5")
+        res_a = P.add_act(s, r5, L.ACT_NONE, name=name + ".resA")
+        vb = V(res_a)
+        if self.drop_out and drop is not None:
+            vb = vb.with_cmul(drop, res_a.C)
+        if self.pooling:
+            return P.avgpool(vb, name=name + ".pool"), res_a
+        return vb
+
+
+class UpBlock(_Holder):
+    """salsanext.py:107-164."""
+
+    def __init__(self, in_filters, out_filters, dropout_rate, drop_out=True):
+        super().__init__()
+        self.drop_out, self.in_filters, self.out_filters = drop_out, in_filters, out_filters
+        self.dropout1 = nn.Dropout2d(p=dropout_rate)
+        self.dropout2 = nn.Dropout2d(p=dropout_rate)
+        self.conv1 = nn.Conv2d(in_filters // 4 + 2 * out_filters, out_filters, (3, 3), padding=1)
+        self.act1 = nn.LeakyReLU()
+        self.bn1 = nn.BatchNorm2d(out_filters)
+        self.conv2 = nn.Conv2d(out_filters, out_filters, (3, 3), dilation=2, padding=2)
+        self.act2 = nn.LeakyReLU()
+        self.bn2 = nn.BatchNorm2d(out_filters)
+        self.conv3 = nn.Conv2d(out_filters, out_filters, (2, 2), dilation=2, padding=1)
+        self.act3 = nn.LeakyReLU()
+        self.bn3 = nn.BatchNorm2d(out_filters)
+        self.conv4 = nn.Conv2d(out_filters * 3, out_filters, (1, 1))
+        self.act4 = nn.LeakyReLU()
+        self.bn4 = nn.BatchNorm2d(out_filters)
+        self.dropout3 = nn.Dropout2d(p=dropout_rate)
+
+    def emit(self, P, x, skip, name, masks=None):
+        """masks: dict(comb=off, d2=off, d3=off) float offsets into the plan's multiplier tensor, or None."""
+        c4 = self.in_filters // 4
+        ld2 = c4 + 2 * self.out_filters
+        use = self.drop_out and masks is not None
+        up_a = P.pixel_shuffle(x, masks["comb"] if use else None, c4, name=name + ".upA")
+        sk = V(skip)
+        if use:
+            sk = sk.with_cmul(masks["d2"] + c4, ld2)
+        e1 = P.conv([V(up_a), sk], self.conv1, L.ACT_LRELU, self.bn1, name=name + ".e1")
+        e2 = P.conv([e1], self.conv2, L.ACT_LRELU, self.bn2, name=name + ".e2")
+        e3 = P.conv([e2], self.conv3, L.ACT_LRELU, self.bn3, name=name + ".e3")
+        e = P.conv([e1, e2, e3], self.conv4, L.ACT_LRELU, self.bn4, name=name + ".e")
+        if use:
+            e = e.with_cmul(masks["d3"], self.out_filters)
+        return e
+
+
+class ResidualBasedFusionBlock(_Holder):
+    """pmf_net.py:10-36."""
+
+    def __init__(self, pcd_channels, img_channels):
+        super().__init__()
+        p = pcd_channels
+        self.fuse_conv = nn.Sequential(nn.Conv2d(p + img_channels, p, 3, padding=1, stride=1), nn.LeakyReLU(),
+                                       nn.BatchNorm2d(p))
+        self.attention = nn.Sequential(nn.Conv2d(p, p, 3, padding=1, stride=1), nn.BatchNorm2d(p),
+                                       nn.ReLU(inplace=True), nn.Conv2d(p, p, 3, padding=1, stride=1),
+                                       nn.BatchNorm2d(p), nn.Sigmoid())
+
+    def emit(self, P, pcd, img, name):
+        f = P.conv([V(pcd), img], self.fuse_conv[0], L.ACT_LRELU, self.fuse_conv[2], name=name + ".f")
+        a1 = P.conv([f], self.attention[0], L.ACT_NONE, self.attention[1], "bn_act", True, name=name + ".a1")
+        a2 = P.conv([a1], self.attention[3], L.ACT_NONE, self.attention[4], "bn_act", False, name=name + ".a2")
+        return P.gate(f, a2, pcd, name=name + ".out")
+
+
+class ASPP(_Holder):
+    """pmf_net.py:103-138 (no BN, no activation)."""
+
+    def __init__(self, in_channel=512, depth=256):
+        super().__init__()
+        self.mean = nn.AdaptiveAvgPool2d((1, 1))
+        self.conv = nn.Conv2d(in_channel, depth, 1, 1)
+        self.atrous_block1 = nn.Conv2d(in_channel, depth, 1, 1)
+        self.atrous_block6 = nn.Conv2d(in_channel, depth, 3, 1, padding=6, dilation=6)
+        self.atrous_block12 = nn.Conv2d(in_channel, depth, 3, 1, padding=12, dilation=12)
+        self.atrous_block18 = nn.Conv2d(in_channel, depth, 3, 1, padding=18, dilation=18)
+        self.conv_1x1_output = nn.Conv2d(depth * 5, depth, 1, 1)
+
+    def emit(self, P, x, name):
+        gm = P.global_mean(x, name=name + ".mean")
+        g = P.conv([V(gm)], self.conv, name=name + ".imgfeat")
+        gb = V(g.t, bcast=True)
+        b1 = P.conv([x], self.atrous_block1, name=name + ".b1")
+        b6 = P.conv([x], self.atrous_block6, name=name + ".b6")
+        b12 = P.conv([x], self.atrous_block12, name=name + ".b12")
+        b18 = P.conv([x], self.atrous_block18, name=name + ".b18")
+        return P.conv([gb, b1, b6, b12, b18], self.conv_1x1_output, name=name + ".out")
+
+
+class SalsaNext(_Holder):
+    """salsanext.py:166-208.  Stand-alone LiDAR-only model (also the base of the fusion trunk)."""
+
+    def __init__(self, in_channels=8, nclasses=20, base_channels=32, softmax=True):
+        super().__init__()
+        c = base_channels
+        self.base_channels, self.dropout_ratio, self.softmax = c, 0.2, softmax
+        self.in_channels, self.nclasses = in_channels, nclasses
+        self.downCntx = ResContextBlock(in_channels, c)
+        self.downCntx2 = ResContextBlock(c, c)
+        self.downCntx3 = ResContextBlock(c, c)
+        self.resBlock1 = ResBlock(c, 2 * c, 0.2, pooling=True, drop_out=False)
+        self.resBlock2 = ResBlock(2 * c, 4 * c, 0.2, pooling=True)
+        self.resBlock3 = ResBlock(4 * c, 8 * c, 0.2, pooling=True)
+        self.resBlock4 = ResBlock(8 * c, 8 * c, 0.2, pooling=True)
+        self.resBlock5 = ResBlock(8 * c, 8 * c, 0.2, pooling=False)
+        self.upBlock1 = UpBlock(8 * c, 4 * c, 0.2)
+        self.upBlock2 = UpBlock(4 * c, 4 * c, 0.2)
+        self.upBlock3 = UpBlock(4 * c, 2 * c, 0.2)
+        self.upBlock4 = UpBlock(2 * c, c, 0.2, drop_out=False)
+        self.logits = nn.Conv2d(c, nclasses, kernel_size=(1, 1))
+        self._plans = {}
+
+    # hooks overridden by the fusion trunk
+    def _fuse(self, P, i, x, feats):
+        return x
+
+    def _bottleneck(self, P, x):
+        return x
+
+    def emit_trunk(self, P, x, feats, M):
+        """x: V of the [N,H,W,8] LiDAR input; feats: camera features (or None); M: mask offsets or None."""
+        m = (lambda k: M[k]) if M is not None else (lambda k: None)
+        d = self.downCntx.emit(P, x, "downCntx")
+        d = self.downCntx2.emit(P, d, "downCntx2")
+        d = self.downCntx3.emit(P, d, "downCntx3")
+        d0c, d0b = self.resBlock1.emit(P, d, "resBlock1")
+        d0c = self._fuse(P, 1, d0c, feats)
+        d1c, d1b = self.resBlock2.emit(P, V(d0c), "resBlock2", m("resBlock2"))
+        d1c = self._fuse(P, 2, d1c, feats)
+        d2c, d2b = self.resBlock3.emit(P, V(d1c), "resBlock3", m("resBlock3"))
+        d2c = self._fuse(P, 3, d2c, feats)
+        d3c, d3b = self.resBlock4.emit(P, V(d2c), "resBlock4", m("resBlock4"))
+        d3c = self._fuse(P, 4, d3c, feats)
+        d5c = self._bottleneck(P, self.resBlock5.emit(P, V(d3c), "resBlock5", m("resBlock5")))
+        um = (lambda i: dict(comb=M["upBlock%d.comb" % i], d2=M["upBlock%d.d2" % i], d3=M["upBlock%d.d3" % i])) \
+            if M is not None else (lambda i: None)
+        u = self.upBlock1.emit(P, d5c, d3b, "upBlock1", um(1))
+        u = self.upBlock2.emit(P, u, d2b, "upBlock2", um(2))
+        u = self.upBlock3.emit(P, u, d1b, "upBlock3", um(3))
+        u = self.upBlock4.emit(P, u, d0b, "upBlock4", None)
+        lg = P.conv([u], self.logits, name="logits")
+        P.softmax_out(lg.t, "lidar", "lidar")
+        return lg
+
+    # ---- stand-alone use -------------------------------------------------------------------------
+    def forward(self, x):
+        if not self.softmax:
+            raise NotImplementedError("SalsaNext(softmax=False) is not built for the HIP path")
+        return _run_model(self, (x,))[0]
+
+    def _build(self, N, H, W, training, device):
+        P = Plan(device, training)
+        M = _alloc_masks(P, self, N, device) if training else None
+        x = V(P.input_nchw("pcd", N, self.in_channels, H, W, "pcd"))
+        self.emit_trunk(P, x, None, M)
+        return P.finalise()
+
+    def _mask_sites(self):
+        return _salsa_sites(self)
+
+    def _apply(self, fn, *a, **k):
+        self._plans = {}
+        return super()._apply(fn, *a, **k)
+
+
+class SalsaNextFusion(SalsaNext):
+    """pmf_net.py:141-180."""
+
+    def __init__(self, in_channels=8, nclasses=20, base_channels=32, img_feature_channels=[]):
+        super().__init__(in_channels=in_channels, base_channels=base_channels, nclasses=nclasses, softmax=True)
+        c = self.base_channels
+        self.fusionblock_1 = ResidualBasedFusionBlock(c * 2, img_feature_channels[0])
+        self.fusionblock_2 = ResidualBasedFusionBlock(c * 4, img_feature_channels[1])
+        self.fusionblock_3 = ResidualBasedFusionBlock(c * 8, img_feature_channels[2])
+        self.fusionblock_4 = ResidualBasedFusionBlock(c * 8, img_feature_channels[3])
+        self.aspp = ASPP(c * 8, c * 8)
+
+    def _fuse(self, P, i, x, feats):
+        return getattr(self, "fusionblock_%d" % i).emit(P, x, feats[i - 1], "fusion%d" % i)
+
+    def _bottleneck(self, P, x):
+        return self.aspp.emit(P, x, "aspp")
+
+    def forward(self, *a, **k):
+        raise RuntimeError("SalsaNextFusion runs inside PMFNet's plan; call PMFNet")
+
+
+# ------------------------------------------------------------------------------------------------------
+# camera stream: torchvision-structured ResNet (third-party arithmetic, restated) + decoder
+# ------------------------------------------------------------------------------------------------------
+class BasicBlock(_Holder):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = downsample
+        self.stride = stride
+
+    def emit(self, P, x, name):
+        y = P.conv([x], self.conv1, L.ACT_NONE, self.bn1, "bn_act", True, name=name + ".c1")
+        y = P.conv([y], self.conv2, L.ACT_NONE, self.bn2, "bn_act", False, name=name + ".c2")
+        idt = x
+        if self.downsample is not None:
+            idt = P.conv([x], self.downsample[0], L.ACT_NONE, self.downsample[1], "bn_act", False, name=name + ".ds")
+        return V(P.add_act(y, idt, L.ACT_RELU, name=name + ".out"))
+
+
+class Bottleneck(_Holder):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+    def emit(self, P, x, name):
+        y = P.conv([x], self.conv1, L.ACT_NONE, self.bn1, "bn_act", True, name=name + ".c1")
+        y = P.conv([y], self.conv2, L.ACT_NONE, self.bn2, "bn_act", True, name=name + ".c2")
+        y = P.conv([y], self.conv3, L.ACT_NONE, self.bn3, "bn_act", False, name=name + ".c3")
+        idt = x
+        if self.downsample is not None:
+            idt = P.conv([x], self.downsample[0], L.ACT_NONE, self.downsample[1], "bn_act", False, name=name + ".ds")
+        return V(P.add_act(y, idt, L.ACT_RELU, name=name + ".out"))
+
+
+_RESNET_CFG = {"resnet34": (BasicBlock, (3, 4, 6, 3)), "resnet50": (Bottleneck, (3, 4, 6, 3)),
+               "resnet101": (Bottleneck, (3, 4, 23, 3)), "resnet152": (Bottleneck, (3, 8, 36, 3))}
+
+
+def _make_layer(block, inplanes, planes, blocks, stride):
+    ds = None
+    if stride != 1 or inplanes != planes * block.expansion:
+        ds = nn.Sequential(nn.Conv2d(inplanes, planes * block.expansion, 1, stride, bias=False),
+                           nn.BatchNorm2d(planes * block.expansion))
+    layers = [block(inplanes, planes, stride, ds)]
+    layers += [block(planes * block.expansion, planes) for _ in range(1, blocks)]
+    return nn.Sequential(*layers)
+
+
+class ResNet(_Holder):
+    """pmf_net.py:41-100: torchvision resnet{34,50,101,152} body, stride-1 7x7 stem, Dropout2d on layer3/4."""
+
+    def __init__(self, in_channels=3, backbone="resnet50", dropout_rate=0.2, pretrained=True):
+        super().__init__()
+        if backbone not in _RESNET_CFG:
+            raise NotImplementedError("invalid backbone: {}".format(backbone))
+        block, counts = _RESNET_CFG[backbone]
+        self.expansion = block.expansion
+        e = self.expansion
+        self.feature_channels = [64 * e, 128 * e, 256 * e, 512 * e]
+        self.backbone_name = backbone
+        self.in_channels = in_channels
+        self.conv1 = nn.Conv2d(in_channels, 64, kernel_size=7, stride=1, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        self.layer1 = _make_layer(block, 64, 64, counts[0], 1)
+        self.layer2 = _make_layer(block, 64 * e, 128, counts[1], 2)
+        self.layer3 = _make_layer(block, 128 * e, 256, counts[2], 2)
+        self.layer4 = _make_layer(block, 256 * e, 512, counts[3], 2)
+        self.dropout = nn.Dropout2d(p=dropout_rate)
+        for m in self.modules():   # torchvision's initialisation
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+        if pretrained:
+            _try_load_imagenet(self, backbone, in_channels)
+
+    def emit(self, P, x, M):
+        c1 = P.conv([x], self.conv1, L.ACT_NONE, self.bn1, "bn_act", True, name="enc.stem")
+        y = V(P.maxpool(c1, name="enc.maxpool"))
+        feats = []
+        for li, layer in enumerate((self.layer1, self.layer2, self.layer3, self.layer4)):
+            for bi, blk in enumerate(layer):
+                y = blk.emit(P, y, "enc.layer%d.%d" % (li + 1, bi))
+            if li >= 2 and M is not None:    # Dropout2d on layer3 / layer4 outputs (one module, two masks)
+                y = y.with_cmul(M["enc.f%d" % li], y.t.C)
+            feats.append(y)
+        return feats
+
+
+def _try_load_imagenet(net, backbone, in_channels):
+    try:
+        import torchvision.models.resnet as tvr   # noqa: WPS433 (optional dependency)
+        ref = getattr(tvr, backbone)(True)
+        sd = {k: v for k, v in ref.state_dict().items() if not k.startswith("fc.")}
+        if in_channels != 3:
+            sd.pop("conv1.weight")
+        net.load_state_dict(sd, strict=False)
+    except Exception as e:  # no torchvision / no network: keep the random init, say so
+        warnings.warn("imagenet_pretrained=True but ImageNet weights are unavailable (%s); "
+                      "camera backbone keeps its random initialisation" % type(e).__name__)
+
+
+class RGBDecoder(_Holder):
+    """pmf_net.py:183-222."""
+
+    def __init__(self, in_channels=[], nclasses=4, base_channels=64):
+        super().__init__()
+        b = base_channels
+
+        def up(cin, k):
+            return nn.Sequential(nn.Conv2d(cin, b, k, padding=k // 2), nn.LeakyReLU(), nn.BatchNorm2d(b),
+                                 nn.Upsample(scale_factor=2, mode="bilinear"))
+        self.up_4a = up(in_channels[3], 3)
+        self.up_3a = up(in_channels[2] + b, 3)
+        self.up_2a = up(in_channels[1] + b, 3)
+        self.up_1a = up(in_channels[0] + b, 1)
+        self.conv = nn.Conv2d(b, nclasses, kernel_size=3, padding=1)
+
+    def emit(self, P, feats):
+        def up(seq, srcs, name):
+            v = P.conv(srcs, seq[0], L.ACT_LRELU, seq[2], name=name)
+            return V(P.bilinear(v, name=name + ".up"))
+        u = up(self.up_4a, [feats[3]], "dec.up4")
+        u = up(self.up_3a, [u, feats[2]], "dec.up3")
+        u = up(self.up_2a, [u, feats[1]], "dec.up2")
+        u = up(self.up_1a, [u, feats[0]], "dec.up1")
+        lg = P.conv([u], self.conv, name="dec.logits")
+        P.softmax_out(lg.t, "camera", "camera")
+        return lg
+
+
+class PMFNet(nn.Module):
+    """pmf_net.py:224-249 -- dual-branch fusion network, executed as one static HIP plan per input shape."""
+
+    def __init__(self, pcd_channels=5, img_channels=3, nclasses=20, base_channels=32, imagenet_pretrained=True,
+                 image_backbone="resnet34"):
+        super().__init__()
+        self.camera_stream_encoder = ResNet(in_channels=img_channels, pretrained=imagenet_pretrained,
+                                            backbone=image_backbone)
+        self.camera_stream_decoder = RGBDecoder(self.camera_stream_encoder.feature_channels, nclasses=nclasses,
+                                                base_channels=self.camera_stream_encoder.expansion * 16)
+        self.lidar_stream = SalsaNextFusion(in_channels=pcd_channels, nclasses=nclasses,
+                                            base_channels=base_channels,
+                                            img_feature_channels=self.camera_stream_encoder.feature_channels)
+        self.pcd_channels, self.img_channels, self.nclasses = pcd_channels, img_channels, nclasses
+        self._plans = {}
+
+    def forward(self, pcd_feature, img_feature):
+        h, w = img_feature.shape[2], img_feature.shape[3]
+        if h % 16 != 0 or w % 16 != 0:   # pmf_net.py:85-88
+            assert False, "invalid input size: {}".format(img_feature.shape)
+        return _run_model(self, (pcd_feature, img_feature))
+
+    def _build(self, N, H, W, training, device):
+        P = Plan(device, training)
+        M = _alloc_masks(P, self, N, device) if training else None
+        pcd = V(P.input_nchw("pcd", N, self.pcd_channels, H, W, "pcd"))
+        rgb = V(P.input_nchw("rgb", N, self.img_channels, H, W, "rgb"))
+        feats = self.camera_stream_encoder.emit(P, rgb, M)
+        self.lidar_stream.emit_trunk(P, pcd, feats, M)
+        self.camera_stream_decoder.emit(P, feats)
+        return P.finalise()
+
+    def _mask_sites(self):
+        enc = self.camera_stream_encoder
+        return [("enc.f2", enc.feature_channels[2]), ("enc.f3", enc.feature_channels[3])] + \
+            _salsa_sites(self.lidar_stream)
+
+    def _apply(self, fn, *a, **k):
+        self._plans = {}
+        return super()._apply(fn, *a, **k)
+
+    # test / reproducibility hook: masks = {site: [N, C] tensor of 0 or 1/(1-p)}; None -> draw from torch RNG
+    def set_dropout_masks(self, masks):
+        self._forced_masks = masks
+
+
+# ------------------------------------------------------------------------------------------------------
+# Dropout2d multipliers: one float tensor per plan, [site0 | site1 | ... | derived], each [N, C] row-major
+# ------------------------------------------------------------------------------------------------------
+def _salsa_sites(ls):
+    c = ls.base_channels
+    sites = [("resBlock%d" % i, ch) for i, ch in ((2, 4 * c), (3, 8 * c), (4, 8 * c), (5, 8 * c))]
+    for i, (cin, cout) in ((1, (8 * c, 4 * c)), (2, (4 * c, 4 * c)), (3, (4 * c, 2 * c))):
+        sites += [("upBlock%d.d1" % i, cin // 4), ("upBlock%d.d2" % i, cin // 4 + 2 * cout),
+                  ("upBlock%d.d3" % i, cout)]
+    return sites
+
+
+def _alloc_masks(P, model, N, device):
+    sites = model._mask_sites()
+    off, table = 0, {}
+    for name, ch in sites:
+        table[name] = off
+        off += N * ch
+    n_sites = off
+    derived = []
+    for i in (1, 2, 3):
+        c4 = dict(sites)["upBlock%d.d1" % i]
+        table["upBlock%d.comb" % i] = off
+        derived.append((off, table["upBlock%d.d1" % i], table["upBlock%d.d2" % i], c4,
+                        dict(sites)["upBlock%d.d2" % i]))
+        off += N * c4
+    P.masks = torch.ones(max(off, 4), dtype=torch.float32, device=device)
+    P.mask_table, P.mask_sites, P.mask_n_sites, P.mask_derived, P.mask_N = table, sites, n_sites, derived, N
+    return table
+
+
+def _fill_masks(P, model, p=0.2):
+    forced = getattr(model, "_forced_masks", None)
+    N = P.mask_N
+    if forced is not None:
+        for name, ch in P.mask_sites:
+            o = P.mask_table[name]
+            P.masks[o:o + N * ch].copy_(forced[name].reshape(-1).to(P.masks))
+    else:
+        P.masks[:P.mask_n_sites].bernoulli_(1.0 - p).mul_(1.0 / (1.0 - p))
+    for (o, o1, o2, c4, ld2) in P.mask_derived:
+        d1 = P.masks[o1:o1 + N * c4].view(N, c4)
+        d2 = P.masks[o2:o2 + N * ld2].view(N, ld2)[:, :c4]
+        torch.mul(d1, d2, out=P.masks[o:o + N * c4].view(N, c4))
+
+
+# ------------------------------------------------------------------------------------------------------
+# execution: plan cache + autograd bridge
+# ------------------------------------------------------------------------------------------------------
+def _get_plan(model, N, H, W, training, device):
+    L.lib()   # raises loudly if libpmf_amd.so is missing -- no fallback
+    key = (N, H, W, bool(training), str(device))
+    plan = model._plans.get(key)
+    if plan is not None and plan.param_ptrs != [p.data_ptr() for p in plan.params]:
+        plan = None    # parameters were re-allocated (e.g. .to()/.cuda()): rebuild
+    if plan is None:
+        with torch.cuda.device(device):
+            plan = model._build(N, H, W, training, device)
+        plan.generation = 0
+        plan.bn_counters = [m.num_batches_tracked for m in plan.bn_modules if m.num_batches_tracked is not None]
+        model._plans[key] = plan
+    return plan
+
+
+def _patch_input(plan, slot, x):
+    if x.stride(3) != 1 or x.stride(2) != x.shape[3]:
+        x = x.contiguous()
+    a = plan.fwd_ops[plan.in_slots[slot] + plan.fwd_shift].u.sm
+    a.p[0] = x.data_ptr()
+    a.l[0], a.l[1] = x.stride(0), x.stride(1)
+    return x
+
+
+def _forward_impl(model, inputs):
+    x0 = inputs[0]
+    if not x0.is_cuda:
+        raise RuntimeError("pmf_amd: the model runs only on an AMD GPU through libpmf_amd.so "
+                           "(no CPU / PyTorch fallback); got a %s tensor" % x0.device)
+    N, _, H, W = x0.shape
+    plan = _get_plan(model, N, H, W, model.training, x0.device)
+    keep = []
+    names = ("pcd", "rgb")[:len(inputs)]
+    for nm, x in zip(names, inputs):
+        if x.dtype != torch.float32:
+            x = x.float()
+        keep.append(_patch_input(plan, nm, x))
+    outs = []
+    for slot in ("lidar", "camera"):
+        if slot in plan.out_slots:
+            o = torch.empty(plan.out_slots[slot]["shape"], dtype=torch.float32, device=x0.device)
+            plan.fwd_ops[plan.out_slots[slot]["fwd_index"] + plan.fwd_shift].u.sm.p[1] = o.data_ptr()
+            outs.append(o)
+    if model.training:
+        _fill_masks(plan, model)
+    plan.run(plan.fwd_ops, plan.n_fwd, "forward")
+    if model.training and plan.bn_counters:
+        torch._foreach_add_(plan.bn_counters, 1)
+    plan.generation += 1
+    return plan, outs, keep
+
+
+class _PlanFunction(torch.autograd.Function):
+    """One autograd node for the whole network: forward = forward plan, backward = backward plan.
+    Parameters are explicit inputs so their gradients reach the leaf tensors (and DDP's reducer hooks)."""
+
+    @staticmethod
+    def forward(ctx, model, n_inputs, *args):
+        inputs, params = args[:n_inputs], args[n_inputs:]
+        plan, outs, _keep = _forward_impl(model, inputs)
+        ctx.plan, ctx.generation, ctx.n_inputs, ctx.params = plan, plan.generation, n_inputs, params
+        ctx.save_for_backward(*outs)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        plan = ctx.plan
+        if plan.generation != ctx.generation:
+            raise RuntimeError("pmf_amd: backward() after a newer forward() on the same plan -- activations live "
+                               "in the plan's arena; run forward/backward pairs in order")
+        probs = ctx.saved_tensors
+        keep = []
+        slots = [s for s in ("lidar", "camera") if s in plan.out_slots]
+        for slot, prob, g in zip(slots, probs, gouts):
+            g = torch.zeros_like(prob) if g is None else g.contiguous().float()
+            keep.append(g)
+            a = plan.bwd_ops[plan.out_slots[slot]["bwd_index"] + plan.bwd_shift].u.sm
+            a.p[0], a.p[1] = prob.data_ptr(), g.data_ptr()
+        plan.run(plan.bwd_ops, plan.n_bwd, "backward")
+        flat = plan.pgrad_buf.tensor((plan.pgrad_floats,))
+        grads = []
+        for p in ctx.params:
+            ent = plan._pid.get(id(p))
+            if ent is None:
+                grads.append(None)
+            else:
+                grads.append(flat[ent[1]:ent[1] + p.numel()].view(p.shape).clone())
+        return (None, None) + (None,) * ctx.n_inputs + tuple(grads)
+
+
+def _run_model(model, inputs):
+    if not (torch.is_grad_enabled() and model.training):
+        _, outs, _ = _forward_impl(model, inputs)
+        return tuple(outs)
+    params = [p for p in model.parameters() if p.requires_grad]
+    return _PlanFunction.apply(model, len(inputs), *inputs, *params)

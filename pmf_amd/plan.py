@@ -1,0 +1,779 @@
+"""Static execution plans for the PMF network on MI355X.
+
+A plan is built once per (model, N, H, W, training) and holds
+  * arenas (one device allocation each) for activations, gradients, packed weights and BN scratch,
+  * a flat ctypes array of ``pmf_op_t`` for the forward pass and one for the backward pass.
+Running a pass is ONE call into libpmf_amd.so (``pmf_plan_run``) that enqueues every kernel on the
+current HIP stream.  There is no tracing compiler and no per-op Python at run time.
+
+Graph conventions
+  T  -- a materialised NHWC fp32 tensor.
+  V  -- a *view*: T seen through BatchNorm-apply (scale/shift), optional ReLU and an optional
+        Dropout2d (n,c) multiplier.  Consumers fold the view into their loads; nothing is materialised.
+  For a view with BatchNorm, gradients are delivered w.r.t. the BN OUTPUT y (``V.gy``); the BN entry on the
+  tape turns them into the gradient w.r.t. the conv pre-activation (``T.g``), which feeds dgrad / wgrad.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+_A = 256  # arena alignment (bytes)
+
+
+def _ru(a, b):
+    return (a + b - 1) // b * b
+
+
+class Buf:
+    __slots__ = ("arena", "off", "nbytes")
+
+    def __init__(self, arena, off, nbytes):
+        self.arena, self.off, self.nbytes = arena, off, nbytes
+
+    @property
+    def ptr(self):
+        return self.arena.base + self.off
+
+    def at(self, float_off):
+        return self.ptr + 4 * float_off
+
+    def tensor(self, shape, dtype=torch.float32):
+        n = 1
+        for s in shape:
+            n *= s
+        esz = torch.empty(0, dtype=dtype).element_size()
+        return self.arena.t[self.off:self.off + n * esz].view(dtype).view(shape)
+
+
+class Arena:
+    def __init__(self, name):
+        self.name, self.size, self.t, self.base = name, 0, None, 0
+
+    def alloc(self, nbytes):
+        off = self.size
+        self.size = _ru(off + max(int(nbytes), 4), _A)
+        return Buf(self, off, int(nbytes))
+
+    def materialise(self, device, zero=False):
+        n = max(self.size, _A)
+        self.t = (torch.zeros if zero else torch.empty)(n, dtype=torch.uint8, device=device)
+        self.base = self.t.data_ptr()
+
+
+class T:
+    """Materialised NHWC tensor [N,H,W,ldc] with C logical channels (ldc = C rounded up to 8)."""
+
+    def __init__(self, plan, N, H, W, C, name="", arena=None, ldc=None):
+        self.N, self.H, self.W, self.C = N, H, W, C
+        self.ldc = ldc or _ru(C, 8)
+        self.name = name
+        self.buf = (arena or plan.act).alloc(4 * N * H * W * self.ldc)
+        if name:
+            plan.tensors[name] = self
+        self.g = None            # gradient tensor (same geometry)
+        self.g_written = False
+        self.needs_grad = True
+
+    @property
+    def npix(self):
+        return self.N * self.H * self.W
+
+
+class V:
+    def __init__(self, t, scale=None, shift=None, cmul=None, cmul_ld=0, relu=False, bcast=False, bn=None):
+        self.t, self.scale, self.shift = t, scale, shift
+        self.cmul, self.cmul_ld = cmul, cmul_ld     # cmul: (Buf, float offset) or None
+        self.relu, self.bcast, self.bn = relu, bcast, bn
+        self.gy = None
+        self.gy_written = False
+
+    def with_cmul(self, cm, ld):
+        v = V(self.t, self.scale, self.shift, cm, ld, self.relu, self.bcast, self.bn)
+        v._parent = self
+        return v
+
+    def root(self):
+        return getattr(self, "_parent", self)
+
+
+class Plan:
+    def __init__(self, device, training):
+        self.device, self.training = device, training
+        self.act = Arena("act")
+        self.zero_fwd = Arena("zero_fwd")
+        self.zero_bwd = Arena("zero_bwd")
+        self.persist = Arena("persist")     # packed weights (padding zeroed once), BN scale/shift/saved stats
+        self.fwd, self.bwd = [], []         # deferred op builders: callables returning L.Op
+        self.tape = []
+        self.pack_jobs = []
+        self.wg_scratch = 0                 # bytes of the shared wgrad partial-sum workspace
+        self.params = []                    # (param, grad Buf float offset)
+        self.pgrad_floats = 0
+        self._pid = {}
+        self.masks = None                   # dropout multipliers (torch tensor), laid out by MaskLayout
+        self.masks_ptr = 0
+        self.bn_modules = []
+        self.in_slots, self.out_slots = {}, {}
+        self.tensors, self.views = {}, {}   # debug registry: name -> T / V
+
+    # ------------------------------------------------------------------ parameter bookkeeping
+    def pgrad(self, p):
+        """float offset of p's gradient inside the flat gradient buffer."""
+        if id(p) not in self._pid:
+            self._pid[id(p)] = (len(self.params), self.pgrad_floats)
+            self.params.append(p)
+            self.pgrad_floats += _ru(p.numel(), 64)
+        return self._pid[id(p)][1]
+
+    # ------------------------------------------------------------------ op emission helpers
+    def emit(self, lst, kind, fill):
+        """fill(op) populates a zeroed L.Op at finalise time (pointers are known only then)."""
+        lst.append((kind, fill))
+
+    def view_struct(self, v, dst):
+        dst.x = v.t.buf.ptr
+        dst.scale = v.scale.ptr if v.scale is not None else None
+        dst.shift = v.shift.ptr if v.shift is not None else None
+        if v.cmul is not None:
+            dst.cmul = self.masks_ptr + 4 * v.cmul
+            dst.cmul_ld = v.cmul_ld
+        else:
+            dst.cmul, dst.cmul_ld = None, 0
+        dst.ldc = v.t.ldc
+        dst.flags = (L.SRC_RELU if v.relu else 0) | (L.SRC_BCAST if v.bcast else 0)
+
+    def src_struct(self, v, dst, C_override=None):
+        self.view_struct(v, dst)
+        dst.C = C_override or _ru(v.t.C, 8)
+        dst.H, dst.W = v.t.H, v.t.W
+
+    # gradient targets ------------------------------------------------------------------
+    def grad_of(self, v):
+        """(tensor receiving dL/dy of view v, accumulate flag); allocates lazily."""
+        r = v.root()
+        if r.bn is not None:
+            if r.gy is None:
+                r.gy = T(self, r.t.N, r.t.H, r.t.W, r.t.C, r.t.name + ".gy", ldc=r.t.ldc)
+            acc = r.gy_written
+            r.gy_written = True
+            return r.gy, int(acc)
+        t = r.t
+        if t.g is None:
+            t.g = T(self, t.N, t.H, t.W, t.C, t.name + ".g", ldc=t.ldc)
+        acc = t.g_written
+        t.g_written = True
+        return t.g, int(acc)
+
+    def tgrad(self, t):
+        """the gradient tensor of a materialised T that this op is about to CONSUME."""
+        if t.g is None or not t.g_written:
+            raise RuntimeError("plan: gradient of %s consumed before any producer wrote it" % t.name)
+        return t.g
+
+    # ------------------------------------------------------------------ primitives
+    def fill(self, lst, buf, nfloats, value=0.0):
+        def f(op):
+            a = op.u.sm
+            a.p[0], a.f[0], a.l[0] = buf.ptr, value, nfloats
+        self.emit(lst, L.OP_FILL, f)
+
+    def taps(self, kh, kw, dil, pad):
+        out = []
+        for ky in range(kh):
+            for kx in range(kw):
+                out.append((ky * dil - pad, kx * dil - pad, ky * kw + kx))
+        return out
+
+    def add_pack(self, weight, taps_widx, transpose, K_pad, ldw):
+        """register a pack job; returns the Buf of the packed slab [ntaps][K_pad][ldw]."""
+        buf = self.persist.alloc(4 * len(taps_widx) * K_pad * ldw)
+        self.pack_jobs.append((weight, buf, list(taps_widx), transpose, K_pad, ldw))
+        return buf
+
+    def conv(self, srcs, conv, act=L.ACT_NONE, bn=None, order="act_bn", relu_view=False, name=""):
+        """Conv2d (+bias) -> act -> [BatchNorm]  (order 'act_bn', SalsaNext style) or
+        Conv2d -> BatchNorm -> [ReLU on the view]  (order 'bn_act', ResNet / attention style).
+        Returns a V.  Registers the backward (BN backward, input gradients, weight gradient)."""
+        kh, kw = conv.kernel_size
+        dil, pad, stride = conv.dilation[0], conv.padding[0], conv.stride[0]
+        Cout = conv.out_channels
+        t0 = srcs[0].t
+        N = t0.N
+        inH = max(s.t.H for s in srcs)
+        inW = max(s.t.W for s in srcs)
+        OH = (inH + 2 * pad - dil * (kh - 1) - 1) // stride + 1
+        OW = (inW + 2 * pad - dil * (kw - 1) - 1) // stride + 1
+        out = T(self, N, OH, OW, Cout, name)
+        taps = self.taps(kh, kw, dil, pad)
+        Ktot = sum(_ru(s.t.C, 8) for s in srcs)
+        ldw = _ru(Cout, 64)
+        wbuf = self.add_pack(conv.weight, [t[2] for t in taps], 0, Ktot, ldw)
+        # very large dilations: per-tap staging (the halo tile would not fit LDS)
+        span = dil * (kh - 1)
+        gather = 1 if (8 * stride + span) * (32 * stride + span) * 80 > 110 * 1024 else 0
+        train_bn = bn is not None and self.training
+        stats = self.zero_fwd.alloc(8 * Cout) if train_bn else None
+        has_bias = conv.bias is not None
+        k_act = act if order == "act_bn" else L.ACT_NONE
+
+        def f(op, srcs=srcs):
+            d = op.u.conv
+            d.N, d.OH, d.OW, d.Cout, d.nsrc = N, OH, OW, Cout, len(srcs)
+            for i, s in enumerate(srcs):
+                self.src_struct(s, d.src[i])
+            d.ntaps = len(taps)
+            for i, (dy, dx, _) in enumerate(taps):
+                d.tdy[i], d.tdx[i] = dy, dx
+            d.in_stride, d.gather = stride, gather
+            d.w, d.ldw = wbuf.ptr, ldw
+            d.bias = conv.bias.data_ptr() if has_bias else None
+            d.act = k_act
+            d.out, d.out_ldc, d.out_H, d.out_W = out.buf.ptr, out.ldc, OH, OW
+            d.out_sy = d.out_sx = 1
+            d.stats = stats.ptr if stats is not None else None
+        self.emit(self.fwd, L.OP_CONV, f)
+
+        view = V(out)
+        info = None
+        if bn is not None:
+            Cb = Cout
+            scale, shift = self.persist.alloc(4 * Cb), self.persist.alloc(4 * Cb)
+            smean, sinv = self.persist.alloc(4 * Cb), self.persist.alloc(4 * Cb)
+            count = float(N * OH * OW)
+            if train_bn:
+                def fb(op):
+                    a = op.u.sm
+                    for i, p in enumerate((stats.ptr, bn.weight.data_ptr(), bn.bias.data_ptr(),
+                                           bn.running_mean.data_ptr(), bn.running_var.data_ptr(), scale.ptr,
+                                           shift.ptr, smean.ptr, sinv.ptr)):
+                        a.p[i] = p
+                    a.f[0], a.f[1], a.f[2] = count, bn.momentum, bn.eps
+                    a.i[0] = Cb
+                self.emit(self.fwd, L.OP_BN_FINALIZE, fb)
+            else:
+                def fb(op):
+                    a = op.u.sm
+                    for i, p in enumerate((bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(),
+                                           bn.running_var.data_ptr(), scale.ptr, shift.ptr, smean.ptr, sinv.ptr)):
+                        a.p[i] = p
+                    a.f[0] = bn.eps
+                    a.i[0] = Cb
+                self.emit(self.fwd, L.OP_BN_EVAL, fb)
+            info = dict(mean=smean, invstd=sinv, module=bn)
+            view = V(out, scale, shift, relu=relu_view, bn=info)
+            self.bn_modules.append(bn)
+        if name:
+            self.views[name] = view
+        if not self.training:
+            return view
+
+        # ------------------------------------------------------------------ backward
+        def backward():
+            if bn is not None:
+                if view.gy is None:
+                    raise RuntimeError("plan: no gradient reached BN output of %s" % name)
+                if out.g is None:
+                    out.g = T(self, N, OH, OW, Cout, name + ".dz", ldc=out.ldc)
+                out.g_written = True
+                red = self.zero_bwd.alloc(8 * Cout)
+                dgam, dbet = self.pgrad(bn.weight), self.pgrad(bn.bias)
+                dbias = self.pgrad(conv.bias) if has_bias else None
+                gyt, dz = view.gy, out.g
+
+                def r1(op):
+                    a = op.u.sm
+                    a.p[0], a.p[1], a.p[2] = gyt.buf.ptr, out.buf.ptr, red.ptr
+                    a.i[0], a.i[1], a.i[2] = gyt.ldc, out.ldc, Cout
+                    a.l[0] = out.npix
+                self.emit(self.bwd, L.OP_BN_BWD_REDUCE, r1)
+
+                def r2(op):
+                    a = op.u.sm
+                    ps = (gyt.buf.ptr, out.buf.ptr, red.ptr, bn.weight.data_ptr(), info["mean"].ptr,
+                          info["invstd"].ptr, dz.buf.ptr, self.pgrad_buf.at(dgam), self.pgrad_buf.at(dbet),
+                          self.pgrad_buf.at(dbias) if dbias is not None else None)
+                    for i, p in enumerate(ps):
+                        a.p[i] = p
+                    a.i[0], a.i[1], a.i[2] = gyt.ldc, out.ldc, Cout
+                    a.i[3] = k_act
+                    a.i[4], a.i[5] = 1, dz.ldc
+                    a.l[0] = out.npix
+                self.emit(self.bwd, L.OP_BN_BWD_APPLY, r2)
+            else:
+                dz = self.tgrad(out)
+                dbias = self.pgrad(conv.bias) if has_bias else None
+                if k_act != L.ACT_NONE:
+                    def r3(op):
+                        a = op.u.sm
+                        a.p[0], a.p[1] = dz.buf.ptr, out.buf.ptr
+                        a.p[2] = self.pgrad_buf.at(dbias) if dbias is not None else None
+                        a.i[0], a.i[1], a.i[2], a.i[3] = dz.ldc, out.ldc, k_act, _ru(Cout, 4)
+                        a.l[0] = out.npix
+                    self.emit(self.bwd, L.OP_ACT_BWD, r3)
+                elif has_bias:
+                    def r4(op):
+                        a = op.u.sm
+                        a.p[0], a.p[1] = dz.buf.ptr, self.pgrad_buf.at(dbias)
+                        a.i[0], a.i[1], a.i[2] = dz.ldc, _ru(Cout, 4), 1
+                        a.l[0] = out.npix
+                    self.emit(self.bwd, L.OP_COLSUM, r4)
+            dz = out.g
+            self._dgrad(srcs, conv, dz, taps, stride, gather, name)
+            self._wgrad(srcs, conv, dz, taps, stride, gather, name)
+        self.tape.append(backward)
+        return view
+
+    def _dgrad(self, srcs, conv, dz, taps, stride, gather, name):
+        """input gradients: the same implicit-GEMM kernel run over dz with transposed weights.
+        stride 1:  dX[y] = sum_t dz[y - dy_t] W_t^T                      (one launch per operand)
+        stride 2:  y = 2m + py:  dX[y] = sum_{t: (py-dy_t) even} dz[m + (py-dy_t)/2] W_t^T   (one launch per parity)"""
+        Cout = conv.out_channels
+        Kd = _ru(Cout, 8)                       # K of the input-gradient GEMM (padded channels of dz are zero)
+        Cin_tot = sum(_ru(s.t.C, 8) for s in srcs)
+        if not any(s.t.needs_grad for s in srcs):
+            return
+        ldwT = _ru(Cin_tot, 64) + 64
+        if stride == 1:
+            classes = [(0, 0, [(-dy, -dx, wi) for (dy, dx, wi) in taps])]
+        else:
+            classes = []
+            for py in range(2):
+                for px in range(2):
+                    sub = [((py - dy) // 2, (px - dx) // 2, wi) for (dy, dx, wi) in taps
+                           if (py - dy) % 2 == 0 and (px - dx) % 2 == 0]
+                    if sub:
+                        classes.append((py, px, sub))
+        packs = [self.add_pack(conv.weight, [t[2] for t in sub], 1, Kd, ldwT) for (_, _, sub) in classes]
+        coloff = 0
+        for s in srcs:
+            Cs = _ru(s.t.C, 8)
+            if s.t.needs_grad:
+                r = s.root()
+                tmp = None
+                if s.bcast:
+                    # 1x1 map broadcast over the image: full-size gradient into a temp, then per-sample column sums
+                    tmp = T(self, dz.N, dz.H, dz.W, s.t.C, name + ".bcast_tmp")
+                    if r.t.g is None:
+                        r.t.g = T(self, r.t.N, 1, 1, r.t.C, r.t.name + ".g", arena=self.zero_bwd, ldc=r.t.ldc)
+                    r.t.g_written = True
+                    tgt, acc = tmp, 0
+                else:
+                    tgt, acc = self.grad_of(s)
+                    if stride != 1:
+                        # parity classes only touch their own pixels: zero first, then accumulate
+                        if not acc:
+                            self.fill(self.bwd, tgt.buf, tgt.npix * tgt.ldc)
+                        acc = 1
+                relu_x = r.t if r.relu else None
+                for (py, px, sub), wT in zip(classes, packs):
+                    def f(op, s=s, r=r, sub=sub, wT=wT, tgt=tgt, acc=acc, coloff=coloff, py=py, px=px,
+                          relu_x=relu_x):
+                        d = op.u.conv
+                        H, W = tgt.H, tgt.W
+                        d.N = dz.N
+                        d.OH, d.OW = (H, W) if stride == 1 else ((H - py + 1) // 2, (W - px + 1) // 2)
+                        d.Cout, d.nsrc = s.t.C, 1
+                        sv = d.src[0]
+                        sv.x, sv.C, sv.ldc, sv.H, sv.W = dz.buf.ptr, Kd, dz.ldc, dz.H, dz.W
+                        d.ntaps = len(sub)
+                        for i, (dy, dx, _) in enumerate(sub):
+                            d.tdy[i], d.tdx[i] = dy, dx
+                        d.in_stride, d.gather = 1, gather
+                        d.w, d.ldw = wT.at(coloff), ldwT
+                        d.act = L.ACT_NONE
+                        d.out, d.out_ldc, d.out_H, d.out_W = tgt.buf.ptr, tgt.ldc, H, W
+                        d.out_sy = d.out_sx = stride
+                        d.out_oy, d.out_ox = py, px
+                        d.accumulate = acc
+                        if s.cmul is not None:
+                            d.ep_cmul, d.ep_cmul_ld = self.masks_ptr + 4 * s.cmul, s.cmul_ld
+                        if relu_x is not None:
+                            d.ep_relu_x, d.ep_relu_ldc = relu_x.buf.ptr, relu_x.ldc
+                            d.ep_relu_scale = r.scale.ptr if r.scale is not None else None
+                            d.ep_relu_shift = r.shift.ptr if r.shift is not None else None
+                    self.emit(self.bwd, L.OP_CONV, f)
+                if tmp is not None:
+                    def fc(op, tmp=tmp, g=r.t.g):
+                        a = op.u.sm
+                        a.p[0], a.p[1] = tmp.buf.ptr, g.buf.ptr
+                        a.i[0], a.i[1], a.i[2] = tmp.ldc, g.ldc, tmp.N
+                        a.l[0] = tmp.H * tmp.W
+                    self.emit(self.bwd, L.OP_COLSUM, fc)
+            coloff += Cs
+
+    def _wgrad(self, srcs, conv, dz, taps, stride, gather, name):
+        Cout = conv.out_channels
+        goff = self.pgrad(conv.weight)
+        kh, kw = conv.kernel_size
+        span = conv.dilation[0] * (kh - 1)
+        wg_gather = 1 if (gather or (3 * stride + 1 + span) * (31 * stride + 1 + span) * 128 > 100 * 1024) else 0
+
+        def shape_fill(d):
+            d.N, d.OH, d.OW, d.Cout, d.nsrc = dz.N, dz.H, dz.W, Cout, len(srcs)
+            for i, s in enumerate(srcs):
+                d.src[i].C = _ru(s.t.C, 8)
+                d.src[i].ldc, d.src[i].H, d.src[i].W = s.t.ldc, s.t.H, s.t.W
+            d.ntaps = len(taps)
+            for i, (dy, dx, wi) in enumerate(taps):
+                d.tdy[i], d.tdx[i], d.tap_widx[i] = dy, dx, wi
+            d.in_stride, d.gather = stride, wg_gather
+            d.Cin_real, d.KHW = conv.in_channels, kh * kw
+        probe = L.WgradDesc()
+        shape_fill(probe)
+        probe.nsplit = 1
+        nsplit = L.lib().pmf_conv_wgrad_nsplit(C.byref(probe))
+        probe.nsplit = nsplit
+        self.wg_scratch = max(self.wg_scratch, L.lib().pmf_conv_wgrad_workspace(C.byref(probe)))
+
+        def f(op):
+            d = op.u.wgrad
+            shape_fill(d)
+            for i, s in enumerate(srcs):
+                self.src_struct(s, d.src[i])
+            d.dz, d.dz_ldc = dz.buf.ptr, dz.ldc
+            d.partial = self.wg_buf.ptr
+            d.nsplit = nsplit
+            d.dw_oihw = self.pgrad_buf.at(goff)
+            d.accumulate = 0
+        self.emit(self.bwd, L.OP_WGRAD, f)
+
+    # ---- element-wise primitives -----------------------------------------------------------------
+    def add_act(self, a, b, act, name=""):
+        t = a.t
+        if self.training and (a.cmul is not None or (b is not None and b.cmul is not None)):
+            raise NotImplementedError("add_act: (n,c) multipliers on residual operands have no backward here")
+        out = T(self, t.N, t.H, t.W, t.C, name)
+
+        def f(op):
+            s = op.u.sm
+            self.view_struct(a, s.v[0])
+            if b is not None:
+                self.view_struct(b, s.v[1])
+            s.p[0] = out.buf.ptr
+            s.i[0], s.i[1], s.i[2], s.i[3], s.i[4] = act, out.ldc, t.H * t.W, int(b is not None), _ru(t.C, 4)
+            s.l[0] = out.npix
+        self.emit(self.fwd, L.OP_ADD_ACT, f)
+        if self.training:
+            def backward():
+                g = self.tgrad(out)
+                ga, acca = self.grad_of(a) if a.t.needs_grad else (None, 0)
+                gb, accb = self.grad_of(b) if (b is not None and b.t.needs_grad) else (None, 0)
+
+                def fb(op):
+                    s = op.u.sm
+                    s.p[0], s.p[1] = g.buf.ptr, out.buf.ptr
+                    s.p[2] = ga.buf.ptr if ga is not None else None
+                    s.p[3] = gb.buf.ptr if gb is not None else None
+                    s.i[0], s.i[1], s.i[2] = g.ldc, out.ldc, act
+                    s.i[3], s.i[4] = (ga.ldc if ga is not None else 0), acca
+                    s.i[5], s.i[6] = (gb.ldc if gb is not None else 0), accb
+                    s.i[7] = _ru(t.C, 4)
+                    s.l[0] = out.npix
+                self.emit(self.bwd, L.OP_ADD_ACT_BWD, fb)
+            self.tape.append(backward)
+        return out
+
+    def _pool(self, v, kind_f, kind_b, name, with_idx=False):
+        t = v.t
+        OH, OW = (t.H - 1) // 2 + 1, (t.W - 1) // 2 + 1
+        out = T(self, t.N, OH, OW, t.C, name)
+        idx = self.act.alloc(t.N * OH * OW * out.ldc) if (with_idx and self.training) else None
+
+        def f(op):
+            s = op.u.sm
+            self.view_struct(v, s.v[0])
+            s.p[0] = out.buf.ptr
+            if with_idx:
+                s.p[1] = idx.ptr if idx is not None else None
+            s.i[0], s.i[1], s.i[2], s.i[3], s.i[4] = t.N, t.H, t.W, _ru(t.C, 4), out.ldc
+        self.emit(self.fwd, kind_f, f)
+        if self.training and t.needs_grad:
+            def backward():
+                g = self.tgrad(out)
+                gin, acc = self.grad_of(v)
+
+                def fb(op):
+                    s = op.u.sm
+                    if with_idx:
+                        self.view_struct(v, s.v[0])
+                        s.p[0], s.p[1], s.p[2] = g.buf.ptr, idx.ptr, gin.buf.ptr
+                        s.i[0], s.i[1], s.i[2], s.i[3], s.i[4] = g.ldc, t.N, t.H, t.W, _ru(t.C, 4)
+                        s.i[5], s.i[6] = gin.ldc, acc
+                    else:
+                        s.p[0], s.p[2] = g.buf.ptr, gin.buf.ptr
+                        s.p[1] = (self.masks_ptr + 4 * v.cmul) if v.cmul is not None else None
+                        s.i[0], s.i[1], s.i[2], s.i[3], s.i[4] = g.ldc, t.N, t.H, t.W, _ru(t.C, 4)
+                        s.i[5], s.i[6], s.i[7] = v.cmul_ld, gin.ldc, acc
+                self.emit(self.bwd, kind_b, fb)
+            self.tape.append(backward)
+        return out
+
+    def avgpool(self, v, name=""):
+        return self._pool(v, L.OP_AVGPOOL, L.OP_AVGPOOL_BWD, name)
+
+    def maxpool(self, v, name=""):
+        return self._pool(v, L.OP_MAXPOOL, L.OP_MAXPOOL_BWD, name, with_idx=True)
+
+    def bilinear(self, v, name=""):
+        t = v.t
+        out = T(self, t.N, 2 * t.H, 2 * t.W, t.C, name)
+
+        def f(op):
+            s = op.u.sm
+            self.view_struct(v, s.v[0])
+            s.p[0] = out.buf.ptr
+            s.i[0], s.i[1], s.i[2], s.i[3], s.i[4] = t.N, t.H, t.W, _ru(t.C, 4), out.ldc
+        self.emit(self.fwd, L.OP_BILINEAR, f)
+        if self.training:
+            def backward():
+                g = self.tgrad(out)
+                gin, acc = self.grad_of(v)
+
+                def fb(op):
+                    s = op.u.sm
+                    s.p[0], s.p[1] = g.buf.ptr, gin.buf.ptr
+                    s.i[0], s.i[1], s.i[2], s.i[3], s.i[4] = g.ldc, t.N, t.H, t.W, _ru(t.C, 4)
+                    s.i[5], s.i[6] = gin.ldc, acc
+                self.emit(self.bwd, L.OP_BILINEAR_BWD, fb)
+            self.tape.append(backward)
+        return out
+
+    def pixel_shuffle(self, v, out_cmul=None, out_cmul_ld=0, name=""):
+        t = v.t
+        Co = t.C // 4
+        out = T(self, t.N, 2 * t.H, 2 * t.W, Co, name)
+
+        def f(op):
+            s = op.u.sm
+            self.view_struct(v, s.v[0])
+            s.p[0] = (self.masks_ptr + 4 * out_cmul) if out_cmul is not None else None
+            s.p[1] = out.buf.ptr
+            s.i[0], s.i[1], s.i[2], s.i[3], s.i[4], s.i[5] = t.N, t.H, t.W, Co, out_cmul_ld, out.ldc
+        self.emit(self.fwd, L.OP_PSHUFFLE, f)
+        if self.training:
+            def backward():
+                g = self.tgrad(out)
+                gin, acc = self.grad_of(v)
+
+                def fb(op):
+                    s = op.u.sm
+                    s.p[0] = g.buf.ptr
+                    s.p[1] = (self.masks_ptr + 4 * out_cmul) if out_cmul is not None else None
+                    s.p[2] = (self.masks_ptr + 4 * v.cmul) if v.cmul is not None else None
+                    s.p[3] = gin.buf.ptr
+                    for i, x in enumerate((g.ldc, t.N, t.H, t.W, Co, out_cmul_ld, v.cmul_ld, gin.ldc, acc)):
+                        s.i[i] = x
+                self.emit(self.bwd, L.OP_PSHUFFLE_BWD, fb)
+            self.tape.append(backward)
+        return out
+
+    def gate(self, f_v, att_v, pcd, name=""):
+        t = pcd
+        out = T(self, t.N, t.H, t.W, t.C, name)
+
+        def f(op):
+            s = op.u.sm
+            self.view_struct(f_v, s.v[0])
+            self.view_struct(att_v, s.v[1])
+            s.p[0], s.p[1] = pcd.buf.ptr, out.buf.ptr
+            s.i[0], s.i[1], s.i[2] = pcd.ldc, out.ldc, _ru(t.C, 4)
+            s.l[0] = out.npix
+        self.emit(self.fwd, L.OP_GATE, f)
+        if self.training:
+            def backward():
+                g = self.tgrad(out)
+                gf, accf = self.grad_of(f_v)
+                gatt, _ = self.grad_of(att_v)
+                gp, accp = self.grad_of(V(pcd))
+
+                def fb(op):
+                    s = op.u.sm
+                    self.view_struct(f_v, s.v[0])
+                    self.view_struct(att_v, s.v[1])
+                    s.p[0], s.p[1], s.p[2], s.p[3] = g.buf.ptr, gf.buf.ptr, gatt.buf.ptr, gp.buf.ptr
+                    for i, x in enumerate((g.ldc, gf.ldc, accf, gatt.ldc, gp.ldc, accp, _ru(t.C, 4))):
+                        s.i[i] = x
+                    s.l[0] = out.npix
+                self.emit(self.bwd, L.OP_GATE_BWD, fb)
+            self.tape.append(backward)
+        return out
+
+    def global_mean(self, v, name=""):
+        t = v.t
+        out = T(self, t.N, 1, 1, t.C, name, arena=self.zero_fwd)
+
+        def f(op):
+            s = op.u.sm
+            self.view_struct(v, s.v[0])
+            s.p[0] = out.buf.ptr
+            s.i[0], s.i[1], s.i[2] = t.N, t.H * t.W, _ru(t.C, 4)
+        self.emit(self.fwd, L.OP_GMEAN, f)
+        if self.training:
+            def backward():
+                g = self.tgrad(out)
+                gin, acc = self.grad_of(v)
+
+                def fb(op):
+                    s = op.u.sm
+                    s.p[0], s.p[2] = g.buf.ptr, gin.buf.ptr
+                    s.p[1] = (self.masks_ptr + 4 * v.cmul) if v.cmul is not None else None
+                    for i, x in enumerate((t.N, t.H * t.W, _ru(t.C, 4), v.cmul_ld, gin.ldc, acc)):
+                        s.i[i] = x
+                self.emit(self.bwd, L.OP_GMEAN_BWD, fb)
+            self.tape.append(backward)
+        return out
+
+    def softmax_out(self, logits, slot, name=""):
+        """logits T -> NCHW probabilities written to an external tensor patched per call (slot index)."""
+        t = logits
+
+        def f(op):
+            s = op.u.sm
+            s.p[0] = t.buf.ptr
+            s.p[1] = None   # patched per call
+            s.i[0], s.i[1], s.i[2], s.i[3] = t.ldc, t.N, t.H * t.W, t.C
+        self.emit(self.fwd, L.OP_SOFTMAX, f)
+        self.out_slots[slot] = dict(fwd_index=len(self.fwd) - 1, shape=(t.N, t.C, t.H, t.W))
+        if self.training:
+            def backward():
+                if t.g is None:
+                    t.g = T(self, t.N, t.H, t.W, t.C, name + ".dlogits", ldc=t.ldc)
+                t.g_written = True
+
+                def fb(op):
+                    s = op.u.sm
+                    s.p[0] = s.p[1] = None   # prob / grad_output patched per call
+                    s.p[2] = t.g.buf.ptr
+                    s.i[0], s.i[1], s.i[2], s.i[3] = t.N, t.H * t.W, t.C, t.ldc
+                self.emit(self.bwd, L.OP_SOFTMAX_BWD, fb)
+                self.out_slots[slot]["bwd_index"] = len(self.bwd) - 1
+            self.tape.append(backward)
+
+    def input_nchw(self, slot, N, C, H, W, name):
+        t = T(self, N, H, W, C, name)
+        t.needs_grad = False
+
+        def f(op):
+            s = op.u.sm
+            s.p[0] = None   # patched per call
+            s.p[1] = t.buf.ptr
+            s.i[0], s.i[1], s.i[2], s.i[3] = N, C, H * W, t.ldc
+        self.emit(self.fwd, L.OP_NCHW2NHWC, f)
+        self.in_slots[slot] = len(self.fwd) - 1
+        return t
+
+    # ------------------------------------------------------------------ finalisation
+    def finalise(self):
+        dev = self.device
+        # backward ops are emitted by walking the tape in reverse; gradients of the flat parameter buffer and
+        # the BN reduction scratch live in zero_bwd (one fill at the start of the backward pass)
+        if self.training:
+            for fn in reversed(self.tape):
+                fn()
+        self.tape = None
+        self.pgrad_buf = self.zero_bwd.alloc(4 * max(self.pgrad_floats, 64)) if self.training else None
+        self.wg_buf = self.act.alloc(max(self.wg_scratch, 256)) if self.training else None
+        for a, zero in ((self.act, False), (self.zero_fwd, True), (self.zero_bwd, True), (self.persist, True)):
+            a.materialise(dev, zero)
+        self.masks_ptr = self.masks.data_ptr() if self.masks is not None else 0
+        lib = L.lib()
+        # pack job table (device) --------------------------------------------------------------
+        njobs = len(self.pack_jobs)
+        jobs = (L.PackJob * max(njobs, 1))()
+        blocks = 0
+        for j, (w, buf, tap_idx, transpose, K_pad, ldw) in enumerate(self.pack_jobs):
+            Cout, Cin, KHW = w.shape[0], w.shape[1], w.shape[2] * w.shape[3]
+            ct = lib.pmf_pack_tile_ci(Cin, KHW)
+            J = jobs[j]
+            J.w, J.dst = w.data_ptr(), buf.ptr
+            J.Cout, J.Cin, J.KHW, J.ntaps, J.transpose = Cout, Cin, KHW, len(tap_idx), transpose
+            J.K_pad, J.ldw, J.CT = K_pad, ldw, ct
+            J.tiles_ci = (Cin + ct - 1) // ct
+            J.block_start = blocks
+            for i, ti in enumerate(tap_idx):
+                J.tap_idx[i] = ti
+            blocks += J.tiles_ci * ((Cout + 31) // 32)
+        raw = bytes(jobs)
+        self.jobs_dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+        self.n_pack_jobs, self.n_pack_blocks = njobs, blocks
+        self.pack_is_bwd = [bool(j[3]) for j in self.pack_jobs]
+
+        def build(lst, prologue):
+            n = len(lst) + len(prologue)
+            arr = (L.Op * max(n, 1))()
+            k = 0
+            for kind, fill in prologue + lst:
+                arr[k].kind = kind
+                fill(arr[k])
+                k += 1
+            return arr, n
+
+        def pack_op(op):
+            a = op.u.sm
+            a.p[0] = self.jobs_dev.data_ptr()
+            a.i[0], a.i[1] = njobs, blocks
+
+        def zero_arena(arena):
+            def z(op):
+                a = op.u.sm
+                a.p[0], a.f[0], a.l[0] = arena.base, 0.0, arena.size // 4
+            return z
+
+        pro_f = [(L.OP_PACK, pack_op)]
+        if self.zero_fwd.size:
+            pro_f.append((L.OP_FILL, zero_arena(self.zero_fwd)))
+        self.fwd_shift = len(pro_f)
+        self.fwd_ops, self.n_fwd = build(self.fwd, pro_f)
+        if self.training:
+            pro_b = [(L.OP_FILL, zero_arena(self.zero_bwd))]
+            self.bwd_shift = len(pro_b)
+            self.bwd_ops, self.n_bwd = build(self.bwd, pro_b)
+        else:
+            self.bwd_ops, self.n_bwd, self.bwd_shift = None, 0, 0
+        self.fwd_kinds = [k for k, _ in pro_f + self.fwd]
+        self.bwd_kinds = [k for k, _ in (pro_b + self.bwd)] if self.training else []
+        self.fwd = self.bwd = None
+        self.param_ptrs = [p.data_ptr() for p in self.params]
+        return self
+
+    # ------------------------------------------------------------------ debug readers (tests / tools only)
+    def read(self, t):
+        """materialised tensor -> torch NCHW copy"""
+        x = t.buf.tensor((t.N, t.H, t.W, t.ldc))[..., :t.C]
+        return x.permute(0, 3, 1, 2).contiguous()
+
+    def read_view(self, v):
+        x = self.read(v.t)
+        if v.scale is not None:
+            sc = v.scale.tensor((v.t.C,)).view(1, -1, 1, 1)
+            sh = v.shift.tensor((v.t.C,)).view(1, -1, 1, 1)
+            x = x * sc + sh
+        if v.relu:
+            x = x.clamp_min(0)
+        if v.cmul is not None:
+            cm = self.masks[v.cmul:v.cmul + v.t.N * v.cmul_ld].view(v.t.N, v.cmul_ld)[:, :v.t.C]
+            x = x * cm[:, :, None, None]
+        return x
+
+    # ------------------------------------------------------------------ running
+    def run(self, ops, n, what, begin=0, end=None):
+        import os
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        failed = C.c_int32(-1)
+        end = n if end is None else end
+        if os.environ.get("PMF_DEBUG_STEP"):   # one op at a time with a sync: localises a faulting kernel
+            kinds = self.fwd_kinds if what == "forward" else self.bwd_kinds
+            for k in range(begin, end):
+                rc = L.lib().pmf_plan_run_range(C.addressof(ops), k, k + 1, C.c_void_p(stream), C.byref(failed))
+                torch.cuda.synchronize()
+                print("[pmf step] %s #%d %s rc=%d" % (what, k, L.OP_NAMES.get(kinds[k], "?"), rc), flush=True)
+                if rc != 0:
+                    raise RuntimeError("pmf_amd %s plan failed at op #%d: code %d" % (what, k, rc))
+            return
+        rc = L.lib().pmf_plan_run_range(C.addressof(ops), begin, end, C.c_void_p(stream), C.byref(failed))
+        if rc != 0:
+            kinds = self.fwd_kinds if what == "forward" else self.bwd_kinds
+            kname = L.OP_NAMES.get(kinds[failed.value], "?") if 0 <= failed.value < len(kinds) else "?"
+            raise RuntimeError("pmf_amd %s plan failed at op #%d (%s): code %d" % (what, failed.value, kname, rc))

@@ -1,0 +1,64 @@
+"""KNN post-processing on MI355X -- same call surface as pc_processor/postproc/knn.py:37-143.
+
+``KNN(params, nclasses)(proj_range[H,W] f32, unproj_range[P] f32, proj_argmax[H,W] i64, px[P] i64, py[P] i64)
+-> labels[P] i64``.  One HIP launch (pmf_knn_vote); the reference's two [1,S*S,H*W] unfolds and four
+[1,S*S,P] gathers are never materialised.  No CPU fallback: inputs must live on the GPU.
+"""
+import ctypes as C
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import _lib as L
+
+
+def inverse_gaussian_window(search, sigma):
+    """1 - normalised Gaussian (knn.py:12-34,103-105), evaluated with the reference's float32 torch ops on
+    the host so the S*S weights are bit-identical to the reference's."""
+    c = torch.arange(search)
+    xg = c.repeat(search).view(search, search)
+    xy = torch.stack([xg, xg.t()], dim=-1).float()
+    mean = (search - 1) / 2.
+    var = sigma ** 2.
+    g = (1. / (2. * math.pi * var)) * torch.exp(-torch.sum((xy - mean) ** 2., dim=-1) / (2 * var))
+    g = g / torch.sum(g)
+    return (1 - g).reshape(-1).contiguous()
+
+
+class KNN(nn.Module):
+    def __init__(self, params, nclasses):
+        super().__init__()
+        self.knn = params["knn"]
+        self.search = params["search"]
+        self.sigma = params["sigma"]
+        self.cutoff = params["cutoff"]
+        self.nclasses = nclasses
+        self._w = None
+
+    def forward(self, proj_range, unproj_range, proj_argmax, px, py):
+        if self.search % 2 == 0:
+            raise ValueError("Nearest neighbor kernel must be odd number")     # knn.py:73-74
+        if not proj_range.is_cuda:
+            raise RuntimeError("pmf_amd KNN runs on the GPU only (no CPU fallback)")
+        lib = L.lib()
+        dev = proj_range.device
+        H, W = proj_range.shape
+        P = unproj_range.shape[0]
+        if px.shape[0] != P or py.shape[0] != P:
+            raise ValueError("len(unproj_range) must equal len(px) == len(py): %d vs %d/%d"
+                             % (P, px.shape[0], py.shape[0]))
+        if self._w is None or self._w.device != dev:
+            self._w = inverse_gaussian_window(self.search, self.sigma).to(dev)
+        pr = proj_range.contiguous().float()
+        ur = unproj_range.contiguous().float()
+        am = proj_argmax.contiguous().long()
+        pxx, pyy = px.contiguous().long(), py.contiguous().long()
+        out = torch.empty(P, dtype=torch.int64, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        rc = lib.pmf_knn_vote(pr.data_ptr(), ur.data_ptr(), am.data_ptr(), pxx.data_ptr(), pyy.data_ptr(),
+                              H, W, P, int(self.knn), int(self.search), self._w.data_ptr(),
+                              C.c_float(float(self.cutoff)), int(self.nclasses), out.data_ptr(),
+                              C.c_void_p(stream))
+        L.check(rc, "pmf_knn_vote")
+        return out

@@ -1,0 +1,128 @@
+"""Helpers for the -m gpu parity tests: call single C-ABI entry points on torch CUDA tensors and
+compare whole plans against the CPU oracle tensor-by-tensor."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from pmf_amd import _lib as L
+
+
+def nhwc(x, ldc=None):
+    """NCHW cpu tensor -> contiguous NHWC cuda tensor with channel padding to ldc."""
+    n, c, h, w = x.shape
+    ldc = ldc or (c + 7) // 8 * 8
+    out = torch.zeros(n, h, w, ldc)
+    out[..., :c] = x.permute(0, 2, 3, 1)
+    return out.cuda().contiguous()
+
+
+def from_nhwc(t, c):
+    return t[..., :c].permute(0, 3, 1, 2).contiguous().cpu()
+
+
+def pack_fwd(w, k_pad, ldw):
+    """OIHW -> [taps][k_pad][ldw] (host-side reference packing for single-op tests)."""
+    co, ci, kh, kw = w.shape
+    p = torch.zeros(kh * kw, k_pad, ldw)
+    p[:, :ci, :co] = w.permute(2, 3, 1, 0).reshape(kh * kw, ci, co)
+    return p.cuda().contiguous()
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def conv_desc(srcs, wpk, ldw, bias, out, N, OH, OW, Cout, taps, stride=1, act=0, gather=0, stats=None):
+    """srcs: list of dict(x=tensor NHWC, C=int, scale=, shift=, cmul=, relu=bool, bcast=bool)."""
+    d = L.ConvDesc()
+    d.N, d.OH, d.OW, d.Cout, d.nsrc = N, OH, OW, Cout, len(srcs)
+    for i, s in enumerate(srcs):
+        x = s["x"]
+        d.src[i].x = x.data_ptr()
+        d.src[i].C = s["C"]
+        d.src[i].ldc = x.shape[-1]
+        d.src[i].H, d.src[i].W = x.shape[1], x.shape[2]
+        d.src[i].scale = s["scale"].data_ptr() if s.get("scale") is not None else None
+        d.src[i].shift = s["shift"].data_ptr() if s.get("shift") is not None else None
+        if s.get("cmul") is not None:
+            d.src[i].cmul = s["cmul"].data_ptr()
+            d.src[i].cmul_ld = s["cmul"].shape[1]
+        d.src[i].flags = (L.SRC_RELU if s.get("relu") else 0) | (L.SRC_BCAST if s.get("bcast") else 0)
+    d.ntaps = len(taps)
+    for i, (dy, dx) in enumerate(taps):
+        d.tdy[i], d.tdx[i] = dy, dx
+    d.in_stride, d.gather = stride, gather
+    d.w, d.ldw = wpk.data_ptr(), ldw
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.act = act
+    d.out, d.out_ldc, d.out_H, d.out_W = out.data_ptr(), out.shape[-1], OH, OW
+    d.out_sy = d.out_sx = 1
+    d.stats = stats.data_ptr() if stats is not None else None
+    return d
+
+
+def taps_of(kh, kw, dil, pad):
+    return [(ky * dil - pad, kx * dil - pad) for ky in range(kh) for kx in range(kw)]
+
+
+def rel_err(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float((np.abs(a - b) / np.maximum(np.abs(b), 1.0)).max())
+
+
+def capture_oracle(oracle):
+    """register forward hooks on the oracle PMFNet; returns (dict filled during forward, handles).
+    Keys are the plan's debug names (pmf_amd.plan.Plan.tensors / .views)."""
+    cap, hs = {}, []
+
+    def hook(name, fn=None):
+        def h(mod, inp, out):
+            cap[name] = (fn(out) if fn else out)
+        return h
+    enc, ls, dec = oracle.camera_stream_encoder, oracle.lidar_stream, oracle.camera_stream_decoder
+    hs.append(enc.bn1.register_forward_hook(hook("enc.stem", lambda o: o.clamp_min(0))))
+    for li in range(4):
+        for bi, blk in enumerate(getattr(enc, "layer%d" % (li + 1))):
+            hs.append(blk.register_forward_hook(hook("enc.layer%d.%d.out" % (li + 1, bi))))
+    for nm in ("downCntx", "downCntx2", "downCntx3"):
+        hs.append(getattr(ls, nm).register_forward_hook(hook(nm + ".out")))
+    for i in range(1, 5):
+        def h(mod, inp, out, i=i):
+            cap["resBlock%d.pool" % i], cap["resBlock%d.resA" % i] = out
+        hs.append(getattr(ls, "resBlock%d" % i).register_forward_hook(h))
+        if hasattr(ls, "fusionblock_%d" % i):
+            hs.append(getattr(ls, "fusionblock_%d" % i).register_forward_hook(hook("fusion%d.out" % i)))
+            fb = getattr(ls, "fusionblock_%d" % i)
+            hs.append(fb.fuse_conv.register_forward_hook(hook("fusion%d.f" % i)))
+    hs.append(ls.resBlock5.register_forward_hook(hook("resBlock5.resA")))
+    if hasattr(ls, "aspp"):
+        hs.append(ls.aspp.register_forward_hook(hook("aspp.out")))
+    for i in range(1, 5):
+        hs.append(getattr(ls, "upBlock%d" % i).register_forward_hook(hook("upBlock%d.e" % i)))
+    hs.append(ls.logits.register_forward_hook(hook("logits")))
+    for i, nm in ((4, "up_4a"), (3, "up_3a"), (2, "up_2a"), (1, "up_1a")):
+        hs.append(getattr(dec, nm).register_forward_hook(hook("dec.up%d.up" % i)))
+    hs.append(dec.conv.register_forward_hook(hook("dec.logits")))
+    return cap, hs
+
+
+def compare_plan_to_oracle(plan, cap, skip=()):
+    """[(name, rel_err)] in the oracle's execution order for every captured tensor the plan also holds."""
+    rows = []
+    for name, ref in cap.items():
+        if name in skip:
+            continue
+        if name in plan.views:
+            got = plan.read_view(plan.views[name]).cpu()
+        elif name in plan.tensors:
+            got = plan.read(plan.tensors[name]).cpu()
+        else:
+            continue
+        ref = ref.detach()
+        if got.shape != ref.shape:
+            rows.append((name, float("inf")))
+            continue
+        rows.append((name, rel_err(got.numpy(), ref.numpy())))
+    return rows

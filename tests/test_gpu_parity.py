@@ -1,0 +1,279 @@
+"""-m gpu: the HIP path (through the C ABI) against the CPU oracle and the committed golden fixtures.
+
+Tolerance (BASELINE.json north_star / SURVEY.md 7): |d| <= 1e-3 * max(|ref|, 1) on pre-softmax logits,
+abs <= 1e-4 on probabilities; integer outputs (KNN labels, loader indices / scatter) bit-exact.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from pmf_amd import _lib as L  # noqa: E402
+from pmf_amd.utils.detinit import deterministic_init, det_tensor, synthetic_batch  # noqa: E402
+from tests import gpu_helpers as G  # noqa: E402
+
+
+def _sync_check(rc, what):
+    L.check(rc, what)
+    torch.cuda.synchronize()
+
+
+# ---------------------------------------------------------------------------------------------- single ops
+CONV_CASES = [
+    # name, N, H, W, [Cin...], Cout, k, dil, pad, stride, act, transforms
+    ("3x3_32_32", 2, 16, 64, [32], 32, 3, 1, 1, 1, 1, False),
+    ("3x3d2_64_64_xf", 1, 24, 40, [64], 64, 3, 2, 2, 1, 1, True),
+    ("2x2d2_32", 2, 8, 32, [32], 32, 2, 2, 1, 1, 1, False),
+    ("1x1_cat3", 2, 16, 32, [64, 64, 64], 64, 1, 1, 0, 1, 1, True),
+    ("3x3_cat2_80_32", 1, 16, 96, [16, 64], 32, 3, 1, 1, 1, 1, True),
+    ("1x1_8_32", 2, 16, 32, [8], 32, 1, 1, 0, 1, 1, False),
+    ("7x7_8_64", 1, 16, 48, [8], 64, 7, 1, 3, 1, 0, False),
+    ("3x3s2_64_128", 2, 16, 32, [64], 128, 3, 1, 1, 2, 0, False),
+    ("1x1s2_64_128", 2, 16, 32, [64], 128, 1, 1, 0, 2, 0, False),
+    ("3x3d6_64_64", 1, 8, 40, [64], 64, 3, 6, 6, 1, 0, False),
+    ("3x3d18_64_64", 1, 8, 40, [64], 64, 3, 18, 18, 1, 0, False),
+    ("3x3_16_20", 1, 16, 32, [16], 20, 3, 1, 1, 1, 0, False),
+    ("3x3_256_256_small", 2, 4, 16, [256], 256, 3, 1, 1, 1, 1, False),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_fwd_vs_torch_cpu(case):
+    name, N, H, W, cins, Cout, k, dil, pad, stride, act, xf = case
+    lib = L.lib()
+    xs = [det_tensor("%s.x%d" % (name, i), (N, c, H, W)) for i, c in enumerate(cins)]
+    w = det_tensor(name + ".w", (Cout, sum(cins), k, k), -0.2, 0.2)
+    b = det_tensor(name + ".b", (Cout,))
+    srcs, ref_in = [], []
+    for i, (x, c) in enumerate(zip(xs, cins)):
+        s = dict(x=G.nhwc(x), C=c)
+        xr = x
+        if xf:
+            sc, sh = det_tensor("%s.sc%d" % (name, i), (c,), 0.5, 1.5), det_tensor("%s.sh%d" % (name, i), (c,))
+            cm = (det_tensor("%s.cm%d" % (name, i), (N, c)) > -0.6).float() * 1.25
+            s.update(scale=sc.cuda(), shift=sh.cuda(), cmul=cm.cuda().contiguous(), relu=(i % 2 == 0))
+            xr = x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+            if i % 2 == 0:
+                xr = xr.clamp_min(0)
+            xr = xr * cm[:, :, None, None]
+        srcs.append(s)
+        ref_in.append(xr)
+    ref = F.conv2d(torch.cat(ref_in, 1), w, b, stride=stride, padding=pad, dilation=dil)
+    if act == 1:
+        ref = F.leaky_relu(ref, 0.01)
+    OH, OW = ref.shape[2], ref.shape[3]
+    ldw = (Cout + 63) // 64 * 64
+    wpk = G.pack_fwd(w, sum(cins), ldw)
+    out = torch.zeros(N, OH, OW, (Cout + 7) // 8 * 8, device="cuda")
+    stats = torch.zeros(2 * Cout, device="cuda")
+    d = G.conv_desc(srcs, wpk, ldw, b.cuda(), out, N, OH, OW, Cout, G.taps_of(k, k, dil, pad), stride, act,
+                    stats=stats)
+    _sync_check(lib.pmf_conv_fwd(C.byref(d), G.stream()), "pmf_conv_fwd")
+    got = G.from_nhwc(out, Cout)
+    assert G.rel_err(got.numpy(), ref.numpy()) < 2e-5
+    st = stats.cpu().view(2, Cout)
+    assert G.rel_err(st[0].numpy() / ref[0, 0].numel(), (ref.sum((0, 2, 3)) / ref[0, 0].numel()).numpy()) < 1e-3
+    assert G.rel_err(st[1].numpy() / ref[0, 0].numel(), ((ref * ref).sum((0, 2, 3)) / ref[0, 0].numel()).numpy()) < 1e-3
+
+
+# ---------------------------------------------------------------------------------------------- whole network
+def _models(backbone="resnet34", ncls=20):
+    from pmf_amd.models import PMFNet
+    from oracle import pmf_torch as O
+    hip = deterministic_init(PMFNet(5, 3, ncls, 32, False, backbone)).cuda()
+    ref = deterministic_init(O.PMFNet(5, 3, ncls, 32, False, backbone))
+    return hip, ref
+
+
+def _report(rows, tol):
+    bad = [(n, e) for n, e in rows if not e <= tol]
+    txt = "\n".join("%-28s %.3e%s" % (n, e, "   <-- FAIL" if not e <= tol else "") for n, e in rows)
+    return bad, txt
+
+
+@pytest.mark.parametrize("backbone,ncls,n,h,w", [("resnet34", 20, 2, 32, 64), ("resnet34", 20, 1, 64, 512),
+                                                 ("resnet50", 17, 1, 32, 64)])
+def test_eval_forward_matches_oracle(backbone, ncls, n, h, w, golden):
+    hip, ref = _models(backbone, ncls)
+    hip.eval()
+    ref.eval()
+    pcd, rgb, _, _ = synthetic_batch(n, h, w, ncls, seed=1)
+    cap, hs = G.capture_oracle(ref)
+    with torch.no_grad():
+        rl, rc = ref(pcd, rgb)
+        # strided channel views of one [N,8,H,W] tensor, like tasks/pmf/trainer.py:296-297
+        both = torch.cat((pcd, rgb), 1).cuda()
+        lp, cp = hip(both[:, 0:5], both[:, 5:8])
+    torch.cuda.synchronize()
+    plan = next(iter(hip._plans.values()))
+    rows = G.compare_plan_to_oracle(plan, cap)
+    bad, txt = _report(rows, 1e-3)
+    assert not bad, "intermediate mismatch (rel err, oracle order):\n" + txt
+    assert (lp.cpu() - rl).abs().max() < 1e-4 and (cp.cpu() - rc).abs().max() < 1e-4
+    if (backbone, n, h, w) == ("resnet34", 2, 32, 64):      # also straight against the reference-run fixture
+        g = golden("g3_wholenet")
+        lg = plan.read(plan.tensors["logits"]).cpu().numpy()
+        assert G.rel_err(lg, g["r34.eval.lidar_logits"]) < 1e-3
+        assert np.abs(cp.cpu().numpy() - g["r34.eval.cam_prob"]).max() < 1e-4
+    if backbone == "resnet50":
+        g = golden("g3_wholenet")
+        lg = plan.read(plan.tensors["logits"]).cpu().numpy()
+        assert G.rel_err(lg, g["r50.eval.lidar_logits"]) < 1e-3
+
+
+def _masks(ref, n, seed=3):
+    from oracle import pmf_torch as O
+    g = torch.Generator().manual_seed(seed)
+    return {nm: (torch.rand(n, c, generator=g) > 0.2).float() / 0.8 for nm, _, c in O.dropout_sites(ref)}
+
+
+@pytest.mark.parametrize("n,h,w,drop", [(2, 32, 64, False), (2, 32, 64, True), (1, 64, 512, True)])
+def test_train_step_matches_oracle(n, h, w, drop):
+    """forward (batch-stat BN, Dropout2d masks), 5-term loss, backward: logits, running stats, every parameter
+    gradient against the oracle's autograd."""
+    from oracle import pmf_torch as O
+    from oracle import losses_ref
+    hip, ref = _models()
+    hip.train()
+    ref.train()
+    if drop:
+        m = _masks(ref, n)
+        O.set_dropout_masks(ref, m)
+        hip.set_dropout_masks({k: v.cuda() for k, v in m.items()})
+    else:
+        for x in ref.modules():
+            if isinstance(x, O.DropSite):
+                x.p = 0.0
+        hip.set_dropout_masks({nm: torch.ones(n, c).cuda() for nm, c in hip._mask_sites()})
+    pcd, rgb, label, _ = synthetic_batch(n, h, w, 20, seed=1)
+    alpha = torch.linspace(0.2, 1.0, 20)
+    alpha[0] = 0
+    cap, hs = G.capture_oracle(ref)
+    rl, rc = ref(pcd, rgb)
+    total_r, _ = losses_ref.pmf_total_loss(rl, rc, label, alpha)
+    total_r.backward()
+    lp, cp = hip(pcd.cuda(), rgb.cuda())
+    total_h, _ = losses_ref.pmf_total_loss(lp, cp, label.cuda(), alpha.cuda())   # same torch ops, on the GPU
+    total_h.backward()
+    torch.cuda.synchronize()
+    plan = next(iter(hip._plans.values()))
+    skip = [k for k in cap if drop and (k.startswith("upBlock") or k.startswith("resBlock5"))]
+    rows = G.compare_plan_to_oracle(plan, cap, skip)
+    bad, txt = _report(rows, 1e-3)
+    assert not bad, "train-mode forward mismatch:\n" + txt
+    assert abs(total_h.item() - total_r.item()) < 1e-4 * max(1.0, abs(total_r.item()))
+    # running statistics (momentum 0.1, unbiased variance)
+    rsd = ref.state_dict()
+    for k, v in hip.state_dict().items():
+        if "running_" in k:
+            assert G.rel_err(v.cpu().numpy(), rsd[k].numpy()) < 1e-4, k
+        if k.endswith("num_batches_tracked"):
+            assert int(v) == int(rsd[k]) == 1
+    # gradients: relative L2 error per parameter (absolute floor for the ~0 bias-before-BN gradients)
+    rp = dict(ref.named_parameters())
+    rows = []
+    for k, p in hip.named_parameters():
+        assert p.grad is not None, k
+        gr = rp[k].grad
+        e = ((p.grad.cpu() - gr).norm() / max(gr.norm().item(), 1e-4 * gr.numel() ** 0.5)).item()
+        rows.append((k, e))
+    bad, txt = _report(rows, 2e-3)
+    assert not bad, "gradient mismatch (rel L2):\n" + "\n".join(l for l in txt.splitlines() if "FAIL" in l)
+
+
+def test_salsanext_standalone_matches_golden(golden):
+    from pmf_amd.models import SalsaNext
+    m = deterministic_init(SalsaNext(5, 20, 32)).cuda().eval()
+    pcd, _, _, _ = synthetic_batch(1, 32, 64, 20, seed=2)
+    with torch.no_grad():
+        p = m(pcd.cuda())
+    assert np.abs(p.cpu().numpy() - golden("g3_wholenet")["salsanext.eval.prob"]).max() < 1e-4
+
+
+def test_invalid_size_and_cpu_tensor_raise():
+    from pmf_amd.models import PMFNet
+    m = PMFNet(imagenet_pretrained=False).cuda()
+    with pytest.raises(AssertionError):
+        m(torch.zeros(1, 5, 24, 32).cuda(), torch.zeros(1, 3, 24, 32).cuda())
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 5, 32, 32), torch.zeros(1, 3, 32, 32))
+
+
+def test_full_size_properties():
+    """BASELINE size (64x2048, bs 2): probabilities are a distribution, finite, and eval is deterministic."""
+    hip, _ = _models()
+    hip.eval()
+    pcd, rgb, _, _ = synthetic_batch(2, 64, 2048, 20, seed=7)
+    with torch.no_grad():
+        a = hip(pcd.cuda(), rgb.cuda())
+        b = hip(pcd.cuda(), rgb.cuda())
+    for x, y in zip(a, b):
+        assert torch.isfinite(x).all()
+        assert (x.sum(1) - 1).abs().max() < 1e-5
+        assert torch.equal(x, y)
+
+
+def test_full_size_eval_vs_oracle():
+    hip, ref = _models()
+    hip.eval()
+    ref.eval()
+    pcd, rgb, _, _ = synthetic_batch(1, 64, 2048, 20, seed=9)
+    with torch.no_grad():
+        rl, rc = ref(pcd, rgb)
+        lp, cp = hip(pcd.cuda(), rgb.cuda())
+    plan = next(iter(hip._plans.values()))
+    assert G.rel_err(plan.read(plan.tensors["logits"]).cpu().numpy(), ref.lidar_stream.last_logits.numpy()) < 1e-3
+    assert (lp.cpu() - rl).abs().max() < 1e-4 and (cp.cpu() - rc).abs().max() < 1e-4
+
+
+# ---------------------------------------------------------------------------------------------- KNN
+@pytest.mark.parametrize("tag,seed,h,w,npts,q", [("a", 11, 64, 512, 20000, False), ("b", 12, 48, 160, 6000, False),
+                                                 ("ties", 13, 32, 64, 3000, True), (None, 21, 384, 1232, 130000, False),
+                                                 (None, 22, 64, 2048, 40000, True)])
+def test_knn_labels_exact(tag, seed, h, w, npts, q, golden):
+    from pmf_amd.postproc import KNN
+    from oracle import knn_ref
+    from oracle.cases import knn_case
+    pr, ur, am, px, py = knn_case(seed, h, w, npts, q)
+    knn = KNN({"knn": 5, "search": 5, "sigma": 1.0, "cutoff": 1.0}, 20)
+    t = lambda a: torch.from_numpy(a).cuda()
+    got = knn(t(pr), t(ur), t(am), t(px), t(py)).cpu().numpy()
+    np.testing.assert_array_equal(got, knn_ref.knn_vote(pr, ur, am, px, py))
+    if tag is not None and not q:
+        np.testing.assert_array_equal(got, golden("g4_knn")["knn.%s.labels" % tag].astype(np.int64))
+
+
+def test_knn_errors():
+    from pmf_amd.postproc import KNN
+    z = torch.zeros(4, 4).cuda()
+    with pytest.raises(ValueError):
+        KNN({"knn": 5, "search": 4, "sigma": 1.0, "cutoff": 1.0}, 20)(z, z[0], z.long(), z[0].long(), z[0].long())
+    with pytest.raises(ValueError):
+        KNN({"knn": 5, "search": 5, "sigma": 1.0, "cutoff": 1.0}, 20)(z, z[0], z.long(), z[0, :2].long(), z[0].long())
+
+
+# ---------------------------------------------------------------------------------------------- loader
+@pytest.mark.parametrize("tag,seed,npts,h,w", [("a", 0, 5000, 96, 320), ("b", 5, 20000, 64, 208),
+                                               (None, 8, 120000, 376, 1241), (None, 9, 0, 32, 64)])
+def test_projection_scatter_exact(tag, seed, npts, h, w, golden):
+    from pmf_amd.dataset import project_frame_gpu, center_crop_pad_gpu
+    from oracle import loader_ref
+    M, pts, sem, img, lut = loader_ref.synthetic_frame(seed, max(npts, 20), h, w)
+    if npts == 0:
+        pts, sem = pts[:0], sem[:0]
+    proj, xd, yd, depth, keep = project_frame_gpu(pts, sem, img, M, lut)
+    rp, rx, ry, rd = loader_ref.project_frame(pts, sem, img, M, lut)
+    np.testing.assert_array_equal(xd.cpu().numpy(), rx)
+    np.testing.assert_array_equal(yd.cpu().numpy(), ry)
+    np.testing.assert_array_equal(depth.cpu().numpy(), rd)
+    np.testing.assert_array_equal(proj.cpu().numpy(), rp)
+    if tag:
+        np.testing.assert_array_equal(proj.cpu().numpy(), golden("g5_loader")["loader.%s.proj" % tag])
+    # validation crop + pad window (perspective_view_loader.py:71-74)
+    for (oh, ow, hp, wp) in ((h - 8, w - 16, 3, 5), (h + 14, w + 6, 7, 3)):
+        got = center_crop_pad_gpu(proj, oh, ow, hp, wp).cpu().numpy()
+        np.testing.assert_array_equal(got, loader_ref.center_crop_pad(rp, oh, ow, hp, wp))

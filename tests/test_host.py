@@ -1,0 +1,105 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every declared symbol, the binding's struct
+layout matches, the module tree reproduces the reference's state-dict, and plans build (graph logic only)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from pmf_amd import _lib as L
+from pmf_amd.models import PMFNet, SalsaNext
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_header_symbols():
+    lib = L.lib()
+    hdr = open(os.path.join(ROOT, "include", "pmf_amd.h")).read()
+    declared = set(re.findall(r"\b(pmf_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    for sym in sorted(declared):
+        assert hasattr(lib, sym), "libpmf_amd.so does not export %s" % sym
+    assert set(L.EXPORTS) <= declared | {"pmf_sizeof", "pmf_version"}
+    assert b"gfx950" in lib.pmf_version()
+
+
+def test_struct_sizes_match_binding():
+    lib = L.lib()
+    for which, st in enumerate((L.Src, L.ConvDesc, L.WgradDesc, L.View, L.SmallArgs, L.Op, L.PackJob)):
+        assert lib.pmf_sizeof(which) == C.sizeof(st)
+
+
+def test_argument_errors_without_gpu():
+    lib = L.lib()
+    d = L.ConvDesc()
+    assert lib.pmf_conv_fwd(C.byref(d), None) == -1            # nsrc = 0 -> PMF_E_ARG
+    assert lib.pmf_knn_vote(None, None, None, None, None, 4, 4, 10, 5, 4, None, C.c_float(1.0), 20, None, None) == -1
+
+
+def test_state_dict_matches_reference_keys(golden):
+    g = golden("g3_wholenet")
+    m = PMFNet(imagenet_pretrained=False)
+    assert sorted(m.state_dict().keys()) == list(g["r34.keys"])
+    assert sum(p.numel() for p in m.parameters()) == int(g["r34.nparams"][0])
+    m50 = PMFNet(5, 3, 17, 32, False, "resnet50")
+    assert sorted(m50.state_dict().keys()) == list(g["r50.keys"])
+    assert sum(p.numel() for p in m50.parameters()) == int(g["r50.nparams"][0])
+    with pytest.raises(NotImplementedError):
+        PMFNet(image_backbone="resnet18", imagenet_pretrained=False)
+    # trainer.py:82-89 groups
+    n_l = sum(p.numel() for p in m.lidar_stream.parameters())
+    n_c = sum(p.numel() for p in m.camera_stream_encoder.parameters()) + \
+        sum(p.numel() for p in m.camera_stream_decoder.parameters())
+    assert n_l + n_c == 36416040
+
+
+def test_no_cpu_fallback():
+    m = PMFNet(imagenet_pretrained=False)
+    with pytest.raises(RuntimeError, match="no CPU"):
+        m(torch.zeros(1, 5, 32, 64), torch.zeros(1, 3, 32, 64))
+    with pytest.raises(AssertionError):
+        m(torch.zeros(1, 5, 24, 64), torch.zeros(1, 3, 24, 64))
+    with pytest.raises(RuntimeError):
+        m.lidar_stream.downCntx(torch.zeros(1, 5, 8, 8))
+
+
+@pytest.mark.parametrize("training", [False, True])
+def test_plan_builds_and_is_consistent(training):
+    """graph-builder logic on CPU memory (never run): op counts, gradient coverage, descriptor sanity."""
+    m = PMFNet(imagenet_pretrained=False).train(training)
+    P = m._build(2, 32, 64, training, torch.device("cpu"))
+    kinds = [L.OP_NAMES[k] for k in P.fwd_kinds]
+    assert kinds.count("OP_CONV") == 110 and kinds.count("OP_SOFTMAX") == 2
+    assert kinds.count("OP_BN_FINALIZE" if training else "OP_BN_EVAL") == 94
+    for i, k in enumerate(P.fwd_kinds):
+        if k == L.OP_CONV:
+            d = P.fwd_ops[i].u.conv
+            assert d.w and d.out and d.nsrc >= 1 and d.ldw % 64 == 0
+            assert sum(d.src[j].C for j in range(d.nsrc)) % 8 == 0
+    if training:
+        bk = [L.OP_NAMES[k] for k in P.bwd_kinds]
+        assert bk.count("OP_WGRAD") == 110 and bk.count("OP_BN_BWD_APPLY") == 94
+        # every parameter has a slot in the flat gradient buffer
+        assert {id(p) for p in m.parameters()} == {id(p) for p in P.params}
+        offs = sorted((P._pid[id(p)][1], p.numel()) for p in P.params)
+        for (o1, n1), (o2, _) in zip(offs, offs[1:]):
+            assert o1 + n1 <= o2
+        # dropout multiplier table covers the 15 application sites + 3 derived products
+        assert len(P.mask_sites) == 15 and len(P.mask_derived) == 3
+
+
+def test_salsanext_plan_builds():
+    m = SalsaNext(5, 20, 32).eval()
+    P = m._build(1, 32, 64, False, torch.device("cpu"))
+    assert [L.OP_NAMES[k] for k in P.fwd_kinds].count("OP_CONV") == 51
+
+
+def test_center_crop_geometry_matches_oracle():
+    from oracle import loader_ref
+    rng = np.random.default_rng(0)
+    x = rng.random((3, 20, 30)).astype(np.float32)
+    for (oh, ow, hp, wp) in ((16, 24, 2, 3), (26, 40, 1, 2), (21, 31, 0, 0)):
+        ref = loader_ref.center_crop_pad(x, oh, ow, hp, wp)
+        assert ref.shape == (3, oh, ow)
