@@ -55,7 +55,7 @@ typedef struct {
  * where k runs over the concatenated operands.  ep(): optional multiply by ep_cmul[n][co], optional ReLU mask
  * (ep_relu_x*scale+shift > 0 at the output position), both used by the input-gradient form.
  * stats (optional): per-channel sum and sum of squares of the activated output, accumulated with atomics
- * into stats[0..Cout) / stats[Cout..2Cout) (train-mode BatchNorm that FOLLOWS the activation). */
+ * into the FLOAT64 array stats[0..Cout) / stats[Cout..2Cout) (train-mode BatchNorm after the activation). */
 typedef struct {
   int32_t N, OH, OW;      /* GEMM M-space: output positions computed */
   int32_t Cout;
@@ -78,7 +78,7 @@ typedef struct {
   const float* ep_relu_scale;
   const float* ep_relu_shift;
   int32_t ep_relu_ldc;
-  float* stats;
+  double* stats;
 } pmf_conv_desc_t;
 
 int pmf_conv_fwd(const pmf_conv_desc_t* d, pmf_stream_t s);
@@ -125,22 +125,22 @@ int pmf_pack_tile_ci(int32_t Cin, int32_t KHW);
 int pmf_pack_weights_batched(const pmf_pack_job_t* jobs_dev, int32_t njobs, int32_t total_blocks, pmf_stream_t s);
 
 /* ---- BatchNorm2d (eps 1e-5, momentum 0.1; salsanext.py:17,21,...; torchvision bn) ------------------------ */
-/* train: stats[2][C] (sum, sumsq over `count` elements) -> scale/shift for apply-on-load, saved mean/invstd,
+/* train: float64 stats[2][C] (sum, sumsq over `count` elements) -> scale/shift for apply-on-load, saved mean/invstd,
  * running_mean/var update (unbiased var), and zeroes nothing.  eval: running stats -> scale/shift. */
-int pmf_bn_finalize(const float* stats, float count, const float* gamma, const float* beta, float* running_mean,
+int pmf_bn_finalize(const double* stats, float count, const float* gamma, const float* beta, float* running_mean,
                     float* running_var, float momentum, float eps, float* scale, float* shift, float* save_mean,
                     float* save_invstd, int32_t C, pmf_stream_t s);
 int pmf_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                        float eps, float* scale, float* shift, float* save_mean, float* save_invstd, int32_t C,
                        pmf_stream_t s);
-/* backward, two passes over (gy, a):  red[0..C) = sum gy, red[C..2C) = sum gy*a   (must be zeroed by caller) */
+/* backward, two passes over (gy, a):  red[0..C) += sum gy, red[C..2C) += sum gy*(a - save_mean)  (zeroed by caller) */
 int pmf_bn_bwd_reduce(const float* gy, int32_t gy_ldc, const float* a, int32_t a_ldc, int64_t npix, int32_t C,
-                      float* red, pmf_stream_t s);
+                      const float* save_mean, double* red, pmf_stream_t s);
 /* dz = (gamma*invstd*(gy - sum_gy/M - ahat*sum_gy_ahat/M)) * act'(a);  dgamma, dbeta written; dbias (optional)
  * accumulated = sum dz.  act: PMF_ACT_LRELU (a = lrelu(z): slope from sign of a) or PMF_ACT_NONE.
  * train == 0 (eval-mode BN): dz = gamma*invstd_running * gy * act'. */
 int pmf_bn_bwd_apply(const float* gy, int32_t gy_ldc, const float* a, int32_t a_ldc, int64_t npix, int32_t C,
-                     const float* red, const float* gamma, const float* save_mean, const float* save_invstd,
+                     const double* red, const float* gamma, const float* save_mean, const float* save_invstd,
                      int32_t act, int32_t train, float* dz, int32_t dz_ldc, float* dgamma, float* dbeta,
                      float* dbias, pmf_stream_t s);
 

@@ -15,7 +15,7 @@ def focal_loss(prob, target, alpha, gamma=2.0, mask=None):
     p = prob.permute(0, 2, 3, 1).reshape(-1, c)
     t = target.reshape(-1)
     pt = p.gather(1, t[:, None]).squeeze(1)
-    loss = -(1 - pt).pow(gamma) * pt.clamp(1e-6).log() * alpha.to(prob.device)[t]
+    loss = -(1 - pt).pow(gamma) * pt.clamp(1e-6).log() * alpha.to(prob.device, prob.dtype)[t]
     if mask is None:
         return loss.mean()
     m = mask.reshape(-1).to(loss.dtype)
@@ -32,7 +32,7 @@ def lovasz_softmax(prob, target, ignore=0):
         return p * 0.
     terms = []
     for k in range(c):
-        fg = (t == k).float()
+        fg = (t == k).to(p.dtype)
         if fg.sum() == 0:
             continue
         err = (fg - p[:, k]).abs()
@@ -59,8 +59,8 @@ def perception_aware(pcd_prob, img_prob, tau=0.7):
     ie, ilog = entropy_norm(img_prob)
     pc, ic = 1 - pe, 1 - ie
     d = pc - ic
-    w_pcd = d.gt(0).float() * d.abs() * pc.ge(tau).float()
-    w_img = d.lt(0).float() * d.abs() * ic.ge(tau).float()
+    w_pcd = d.gt(0).to(d.dtype) * d.abs() * pc.ge(tau).to(d.dtype)
+    w_img = d.lt(0).to(d.dtype) * d.abs() * ic.ge(tau).to(d.dtype)
     kl = lambda logq, p: F.kl_div(logq, p, reduction="none")
     l_pcd = (kl(plog, img_prob) * w_img.unsqueeze(1)).mean()
     l_img = (kl(ilog, pcd_prob) * w_pcd.unsqueeze(1)).mean()

@@ -3,13 +3,13 @@
 // epilogue and consumers apply scale/shift on load (see conv_fwd.hip).
 #include "common.h"
 
-__global__ void bn_finalize_k(const float* __restrict__ stats, float count, const float* __restrict__ gamma,
+__global__ void bn_finalize_k(const double* __restrict__ stats, float count, const float* __restrict__ gamma,
                               const float* __restrict__ beta, float* running_mean, float* running_var, float momentum,
                               float eps, float* scale, float* shift, float* save_mean, float* save_invstd, int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  const double mean = (double)stats[c] / (double)count;
-  double var = (double)stats[C + c] / (double)count - mean * mean;
+  const double mean = stats[c] / (double)count;
+  double var = stats[C + c] / (double)count - mean * mean;
   if (var < 0.0) var = 0.0;
   const float invstd = (float)(1.0 / sqrt(var + (double)eps));
   const float sc = gamma[c] * invstd;
@@ -22,7 +22,7 @@ __global__ void bn_finalize_k(const float* __restrict__ stats, float count, cons
     running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
   }
 }
-extern "C" int pmf_bn_finalize(const float* stats, float count, const float* gamma, const float* beta,
+extern "C" int pmf_bn_finalize(const double* stats, float count, const float* gamma, const float* beta,
                                float* running_mean, float* running_var, float momentum, float eps, float* scale,
                                float* shift, float* save_mean, float* save_invstd, int32_t C, pmf_stream_t s) {
   hipLaunchKernelGGL(bn_finalize_k, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)s, stats, count, gamma, beta,
@@ -65,40 +65,44 @@ static ColL col_l(int64_t npix, int Q) {
 }
 
 __global__ void bn_bwd_reduce_k(const float* __restrict__ gy, int gy_ldc, const float* __restrict__ a, int a_ldc,
-                                int64_t npix, int Q, int C, float* red) {
-  __shared__ f32x4 sh[2][256];
+                                int64_t npix, int Q, int C, const float* __restrict__ save_mean, double* red) {
+  __shared__ double sh[2][256][4];
   const int Qm = qgmax(Q), Qg = min(Q - (int)blockIdx.y * 256, 256), rows = 256 / Qm;
   const int row = threadIdx.x / Qm, cql = threadIdx.x - row * Qm;
   const bool active = cql < Qg;
   const int c = ((int)blockIdx.y * 256 + cql) * 4;
-  f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
-  if (active)
+  double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};   // float64 accumulation (HBM-bound kernel: free)
+  if (active) {
+    const f32x4 mu = *(const f32x4*)(save_mean + c);   // centre first: sum g*(a - mean) has no cancellation
     for (int64_t p = (int64_t)blockIdx.x * rows + row; p < npix; p += (int64_t)gridDim.x * rows) {
       const f32x4 g = *(const f32x4*)(gy + p * gy_ldc + c);
-      const f32x4 x = *(const f32x4*)(a + p * a_ldc + c);
-      s1 += g;
-      s2 += g * x;
+      const f32x4 x = *(const f32x4*)(a + p * a_ldc + c) - mu;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { s1[k] += (double)g[k]; s2[k] += (double)g[k] * (double)x[k]; }
     }
-  sh[0][row * Qm + cql] = s1;
-  sh[1][row * Qm + cql] = s2;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { sh[0][row * Qm + cql][k] = s1[k]; sh[1][row * Qm + cql][k] = s2[k]; }
   __syncthreads();
   if (row == 0 && active) {
-    for (int r = 1; r < rows; ++r) { s1 += sh[0][r * Qm + cql]; s2 += sh[1][r * Qm + cql]; }
+    for (int r = 1; r < rows; ++r)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { s1[k] += sh[0][r * Qm + cql][k]; s2[k] += sh[1][r * Qm + cql][k]; }
 #pragma unroll
     for (int k = 0; k < 4; ++k) { atomicAdd(red + c + k, s1[k]); atomicAdd(red + C + c + k, s2[k]); }
   }
 }
 extern "C" int pmf_bn_bwd_reduce(const float* gy, int32_t gy_ldc, const float* a, int32_t a_ldc, int64_t npix,
-                                 int32_t C, float* red, pmf_stream_t s) {
+                                 int32_t C, const float* save_mean, double* red, pmf_stream_t s) {
   if (C % 4) return PMF_E_ARG;
   ColL L = col_l(npix, C / 4);
-  hipLaunchKernelGGL(bn_bwd_reduce_k, L.grid, L.block, 0, (hipStream_t)s, gy, gy_ldc, a, a_ldc, npix, C / 4, C, red);
+  hipLaunchKernelGGL(bn_bwd_reduce_k, L.grid, L.block, 0, (hipStream_t)s, gy, gy_ldc, a, a_ldc, npix, C / 4, C, save_mean, red);
   PMF_LAUNCH_CHECK();
   return 0;
 }
 
 __global__ void bn_bwd_apply_k(const float* __restrict__ gy, int gy_ldc, const float* __restrict__ a, int a_ldc,
-                               int64_t npix, int Q, int C, const float* __restrict__ red,
+                               int64_t npix, int Q, int C, const double* __restrict__ red,
                                const float* __restrict__ gamma, const float* __restrict__ save_mean,
                                const float* __restrict__ save_invstd, int act, int train, float* __restrict__ dz,
                                int dz_ldc, float* dgamma, float* dbeta, float* dbias) {
@@ -109,18 +113,20 @@ __global__ void bn_bwd_apply_k(const float* __restrict__ gy, int gy_ldc, const f
   const int c = ((int)blockIdx.y * 256 + cql) * 4;
   f32x4 part = {0.f, 0.f, 0.f, 0.f};
   if (active) {
-    // dz = A*gy + B*a + Cc  (per channel), then * act'(a)
-    f32x4 A, B, Cc;
+    // dz = A * ((gy - mean(gy)) - (a - mean) * K) * act'(a), K = invstd^2 * mean(gy*(a-mean)): differences of
+    // nearby float32 values first (exact), scaling last -- the same conditioning as PyTorch's CPU kernel
+    f32x4 A, B, Cc, MU;   // B = K, Cc = mean(gy)
     const float invM = 1.f / (float)npix;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const float g = gamma[c + k], r = save_invstd[c + k], mu = save_mean[c + k];
-      const float sg = red[c + k], sga = red[C + c + k];
-      const float dgam = r * (sga - mu * sg);
+      const float sg = (float)red[c + k], sgc = (float)red[C + c + k];
+      const float dgam = r * sgc;
+      MU[k] = mu;
       if (train) {
         A[k] = g * r;
-        B[k] = -g * r * r * dgam * invM;
-        Cc[k] = -g * r * sg * invM - B[k] * mu;
+        B[k] = r * dgam * invM;
+        Cc[k] = sg * invM;
       } else {
         A[k] = g * r; B[k] = 0.f; Cc[k] = 0.f;
       }
@@ -130,7 +136,7 @@ __global__ void bn_bwd_apply_k(const float* __restrict__ gy, int gy_ldc, const f
     for (int64_t p = (int64_t)blockIdx.x * rows + row; p < npix; p += (int64_t)gridDim.x * rows) {
       const f32x4 g = *(const f32x4*)(gy + p * gy_ldc + c);
       const f32x4 x = *(const f32x4*)(a + p * a_ldc + c);
-      f32x4 d = A * g + B * x + Cc;
+      f32x4 d = A * ((g - Cc) - (x - MU) * B);
       if (act != PMF_ACT_NONE) {
         d.x *= x.x > 0.f ? 1.f : sl; d.y *= x.y > 0.f ? 1.f : sl; d.z *= x.z > 0.f ? 1.f : sl; d.w *= x.w > 0.f ? 1.f : sl;
       }
@@ -149,7 +155,7 @@ __global__ void bn_bwd_apply_k(const float* __restrict__ gy, int gy_ldc, const f
   }
 }
 extern "C" int pmf_bn_bwd_apply(const float* gy, int32_t gy_ldc, const float* a, int32_t a_ldc, int64_t npix,
-                                int32_t C, const float* red, const float* gamma, const float* save_mean,
+                                int32_t C, const double* red, const float* gamma, const float* save_mean,
                                 const float* save_invstd, int32_t act, int32_t train, float* dz, int32_t dz_ldc,
                                 float* dgamma, float* dbeta, float* dbias, pmf_stream_t s) {
   if (C % 4) return PMF_E_ARG;

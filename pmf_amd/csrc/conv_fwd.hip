@@ -125,14 +125,16 @@ __global__ __launch_bounds__(256) void conv_fwd_k(const pmf_conv_desc_t d, const
           }
         }
       }
-      k_base += kc;
     }
+    k_base += sC;
   }
 
   // ---- epilogue
-  float ssum[NT], ssq[NT];
+  // BatchNorm statistics in float64: float*float is exact in double, so var = E[x^2] - mean^2 keeps full
+  // float32 accuracy even for nearly-constant channels (the classic cancellation), at ~2 DP ops per output
+  double ssum[NT], ssq[NT];
 #pragma unroll
-  for (int u = 0; u < NT; ++u) ssum[u] = ssq[u] = 0.f;
+  for (int u = 0; u < NT; ++u) ssum[u] = ssq[u] = 0.0;
 #pragma unroll
   for (int u = 0; u < NT; ++u) {
     const int co = n0 + u * 32 + li;
@@ -158,19 +160,21 @@ __global__ __launch_bounds__(256) void conv_fwd_k(const pmf_conv_desc_t d, const
           float* op = d.out + opix * d.out_ldc + co;
           if (d.accumulate) v += *op;
           *op = v;
-          ssum[u] += v;
-          ssq[u] += v * v;
+          if (d.stats) {
+            ssum[u] += (double)v;
+            ssq[u] += (double)v * (double)v;
+          }
         }
       }
     }
   }
   if (d.stats) {
     __syncthreads();
-    float* red = smem;  // [4 waves][NT][32][2]
+    double* red = (double*)smem;  // [4 waves][NT][32][2]
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
-      float a = ssum[u] + __shfl_xor(ssum[u], 32);
-      float b = ssq[u] + __shfl_xor(ssq[u], 32);
+      double a = ssum[u] + __shfl_xor(ssum[u], 32);
+      double b = ssq[u] + __shfl_xor(ssq[u], 32);
       if (lh == 0) {
         red[((wave * NT + u) * 32 + li) * 2 + 0] = a;
         red[((wave * NT + u) * 32 + li) * 2 + 1] = b;
@@ -180,13 +184,13 @@ __global__ __launch_bounds__(256) void conv_fwd_k(const pmf_conv_desc_t d, const
     if (tid < BN) {
       const int u = tid >> 5, l = tid & 31, co = n0 + tid;
       if (co < d.Cout) {
-        float a = 0.f, b = 0.f;
+        double a = 0.0, b = 0.0;
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
           a += red[((w * NT + u) * 32 + l) * 2 + 0];
           b += red[((w * NT + u) * 32 + l) * 2 + 1];
         }
-        atomicAdd(d.stats + co, a);
+        atomicAdd(d.stats + co, a);   // native global f64 atomics
         atomicAdd(d.stats + d.Cout + co, b);
       }
     }
@@ -223,7 +227,7 @@ int pmf_conv_geometry(int OH, int OW, int ntaps, const int8_t* tdy, const int8_t
     g->a_floats = round_up(rows * cols * APITCH, 4);
     g->tap_group = gather ? 1 : (ntaps < TAPG ? ntaps : TAPG);
     int lds = (g->a_floats + g->tap_group * kc_alloc * BN) * 4;
-    if (lds < 2 * 4 * 64 * 2 * 4) lds = 2 * 4 * 64 * 2 * 4;  // room for the stats reduction
+    if (lds < 2 * 4 * 64 * 2 * 8) lds = 2 * 4 * 64 * 2 * 8;  // room for the float64 stats reduction
     if (lds <= 150 * 1024 || gather) { *gather_out = gather; return lds; }
     gather = 1;
   }

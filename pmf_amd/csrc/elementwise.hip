@@ -158,22 +158,28 @@ extern "C" int pmf_colsum(const float* x, int32_t ldc, int64_t npix, int32_t C, 
   return 0;
 }
 
-// per-(n,c) mean of a view
+// per-(n,c) mean of a view.  One workgroup per (sample, 256-quad column group) walks all pixels in a fixed order
+// (the map is H/16 x W/16): deterministic, no atomics.
 __global__ void gmean_k(pmf_view_t v, int HW, int Q, float* out, int C) {
   __shared__ f32x4 sh[256];
   COL_SETUP(Q)
   const int n = blockIdx.z;
   f32x4 part = zero4();
   if (active_)
-    for (int64_t p = (int64_t)blockIdx.x * rows_ + row_; p < HW; p += (int64_t)gridDim.x * rows_)
-      part += ldv(v, (int64_t)n * HW + p, n, c);
-  part *= 1.f / (float)HW;
-  col_fold_atomic(part, out + (size_t)n * C, c, row_, cql_, rows_, Qg_max_(Q), active_, sh);
+    for (int64_t p = row_; p < HW; p += rows_) part += ldv(v, (int64_t)n * HW + p, n, c);
+  sh[row_ * Qg_max_(Q) + cql_] = part;
+  __syncthreads();
+  if (row_ == 0 && active_) {
+    for (int r = 1; r < rows_; ++r) part += sh[r * Qg_max_(Q) + cql_];
+    part *= 1.f / (float)HW;
+    *(f32x4*)(out + (size_t)n * C + c) = part;
+  }
 }
 extern "C" int pmf_global_mean(const pmf_view_t* in, int32_t N, int32_t HW, int32_t C, float* out, pmf_stream_t s) {
   if (C % 4) return PMF_E_ARG;
   ColLaunch L = col_launch(HW, C / 4, N);
-  hipLaunchKernelGGL(gmean_k, L.grid, L.block, 0, (hipStream_t)s, *in, HW, C / 4, out, C);  // out pre-zeroed
+  L.grid.x = 1;
+  hipLaunchKernelGGL(gmean_k, L.grid, L.block, 0, (hipStream_t)s, *in, HW, C / 4, out, C);
   PMF_LAUNCH_CHECK();
   return 0;
 }

@@ -4,6 +4,7 @@
 // repeated first-minimum (ties -> smaller window index, the rule the CPU oracle pins) and votes.
 // HBM-bound: algorithmic bytes 12*H*W + 28*P per call.
 #include "common.h"
+#pragma clang fp contract(off)
 
 template <int S>
 __global__ __launch_bounds__(256) void knn_k(const float* __restrict__ pr, const float* __restrict__ ur,
@@ -32,7 +33,7 @@ __global__ __launch_bounds__(256) void knn_k(const float* __restrict__ pr, const
       if (v < 0.f) v = INFINITY;
     }
     if (t == CENTER) v = r;
-    dist[t] = __fmul_rn(fabsf(__fsub_rn(v, r)), wsh[t]);
+    dist[t] = fabsf(v - r) * wsh[t];   // |neigh - range| * (1 - gauss), float32, knn.py:97-108
     lab[t] = l;
   }
   // k x first-minimum selection

@@ -6,6 +6,9 @@
 // The winner per pixel is an atomicMax over point indices, then one gather pass builds the [10,h,w] tensor.
 #include "common.h"
 
+// bit-exact float32 / float64 arithmetic: no fused contraction except the explicit fma() calls below
+#pragma clang fp contract(off)
+
 #define PB 1024
 
 struct Proj { double m[12]; };
@@ -37,7 +40,8 @@ __global__ __launch_bounds__(PB) void proj_count_k(const float* __restrict__ pts
     k = project_point(pts + i * 4, m, h, w, r, c) ? 1 : 0;
     keep[i] = (uint8_t)k;
     const float x = pts[i * 4], y = pts[i * 4 + 1], z = pts[i * 4 + 2];
-    depth[i] = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z)));
+    // numpy: sqrt(add.reduce(x*x)) in float32, left to right; sqrtf / '/' are correctly rounded (hipcc default)
+    depth[i] = sqrtf((x * x + y * y) + z * z);
   }
   const int cnt = __syncthreads_count(k);
   if (threadIdx.x == 0) blk_cnt[blockIdx.x] = cnt;
@@ -108,9 +112,9 @@ __global__ void proj_gather_k(const float* __restrict__ pts, const int32_t* __re
       lb = (float)((sl >= 0 && sl < nlut) ? lut[sl] : 0);
     }
     out[0 * hw + p] = d; out[1 * hw + p] = x; out[2 * hw + p] = y; out[3 * hw + p] = z; out[4 * hw + p] = it;
-    out[5 * hw + p] = __fdiv_rn((float)img[p * 3 + 0], 255.0f);
-    out[6 * hw + p] = __fdiv_rn((float)img[p * 3 + 1], 255.0f);
-    out[7 * hw + p] = __fdiv_rn((float)img[p * 3 + 2], 255.0f);
+    out[5 * hw + p] = (float)img[p * 3 + 0] / 255.0f;
+    out[6 * hw + p] = (float)img[p * 3 + 1] / 255.0f;
+    out[7 * hw + p] = (float)img[p * 3 + 2] / 255.0f;
     out[8 * hw + p] = mk;
     out[9 * hw + p] = lb;
   }

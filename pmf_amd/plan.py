@@ -214,7 +214,7 @@ class Plan:
         span = dil * (kh - 1)
         gather = 1 if (8 * stride + span) * (32 * stride + span) * 80 > 110 * 1024 else 0
         train_bn = bn is not None and self.training
-        stats = self.zero_fwd.alloc(8 * Cout) if train_bn else None
+        stats = self.zero_fwd.alloc(16 * Cout) if train_bn else None   # float64 [2][Cout]
         has_bias = conv.bias is not None
         k_act = act if order == "act_bn" else L.ACT_NONE
 
@@ -277,14 +277,14 @@ class Plan:
                 if out.g is None:
                     out.g = T(self, N, OH, OW, Cout, name + ".dz", ldc=out.ldc)
                 out.g_written = True
-                red = self.zero_bwd.alloc(8 * Cout)
+                red = self.zero_bwd.alloc(16 * Cout)   # float64 [2][Cout]
                 dgam, dbet = self.pgrad(bn.weight), self.pgrad(bn.bias)
                 dbias = self.pgrad(conv.bias) if has_bias else None
                 gyt, dz = view.gy, out.g
 
                 def r1(op):
                     a = op.u.sm
-                    a.p[0], a.p[1], a.p[2] = gyt.buf.ptr, out.buf.ptr, red.ptr
+                    a.p[0], a.p[1], a.p[2], a.p[3] = gyt.buf.ptr, out.buf.ptr, red.ptr, info["mean"].ptr
                     a.i[0], a.i[1], a.i[2] = gyt.ldc, out.ldc, Cout
                     a.l[0] = out.npix
                 self.emit(self.bwd, L.OP_BN_BWD_REDUCE, r1)
@@ -651,6 +651,11 @@ class Plan:
                 self.out_slots[slot]["bwd_index"] = len(self.bwd) - 1
             self.tape.append(backward)
 
+    def external_grad(self, v):
+        """tests: declare that dL/d(view) is supplied from outside (written into the returned T before backward)."""
+        g, _ = self.grad_of(v)
+        return g
+
     def input_nchw(self, slot, N, C, H, W, name):
         t = T(self, N, H, W, C, name)
         t.needs_grad = False
@@ -721,7 +726,7 @@ class Plan:
                 a.p[0], a.f[0], a.l[0] = arena.base, 0.0, arena.size // 4
             return z
 
-        pro_f = [(L.OP_PACK, pack_op)]
+        pro_f = [(L.OP_PACK, pack_op)] if njobs else []
         if self.zero_fwd.size:
             pro_f.append((L.OP_FILL, zero_arena(self.zero_fwd)))
         self.fwd_shift = len(pro_f)

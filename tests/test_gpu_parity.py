@@ -69,7 +69,7 @@ def test_conv_fwd_vs_torch_cpu(case):
     ldw = (Cout + 63) // 64 * 64
     wpk = G.pack_fwd(w, sum(cins), ldw)
     out = torch.zeros(N, OH, OW, (Cout + 7) // 8 * 8, device="cuda")
-    stats = torch.zeros(2 * Cout, device="cuda")
+    stats = torch.zeros(2 * Cout, device="cuda", dtype=torch.float64)
     d = G.conv_desc(srcs, wpk, ldw, b.cuda(), out, N, OH, OW, Cout, G.taps_of(k, k, dil, pad), stride, act,
                     stats=stats)
     _sync_check(lib.pmf_conv_fwd(C.byref(d), G.stream()), "pmf_conv_fwd")
@@ -111,6 +111,7 @@ def test_eval_forward_matches_oracle(backbone, ncls, n, h, w, golden):
     torch.cuda.synchronize()
     plan = next(iter(hip._plans.values()))
     rows = G.compare_plan_to_oracle(plan, cap)
+    _dump("eval_fwd_%s_%d_%d_%d.txt" % (backbone, n, h, w), rows)
     bad, txt = _report(rows, 1e-3)
     assert not bad, "intermediate mismatch (rel err, oracle order):\n" + txt
     assert (lp.cpu() - rl).abs().max() < 1e-4 and (cp.cpu() - rc).abs().max() < 1e-4
@@ -131,10 +132,20 @@ def _masks(ref, n, seed=3):
     return {nm: (torch.rand(n, c, generator=g) > 0.2).float() / 0.8 for nm, _, c in O.dropout_sites(ref)}
 
 
+def _dump(name, rows):
+    import os
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(os.path.join("gpurun_out", name), "w") as f:
+        for r in rows:
+            f.write("  ".join(("%-52s" % x) if isinstance(x, str) else ("%.3e" % x) for x in r) + "\n")
+
+
 @pytest.mark.parametrize("n,h,w,drop", [(2, 32, 64, False), (2, 32, 64, True), (1, 64, 512, True)])
 def test_train_step_matches_oracle(n, h, w, drop):
-    """forward (batch-stat BN, Dropout2d masks), 5-term loss, backward: logits, running stats, every parameter
-    gradient against the oracle's autograd."""
+    """forward (batch-stat BN, Dropout2d masks), 5-term loss, backward.  Ground truth = the oracle in FLOAT64;
+    the HIP fp32 gradients must be as close to it as the fp32 CPU oracle is (up to a small factor): tiny-batch
+    BatchNorm makes the backward pass ill-conditioned, so fp32-vs-fp32 differences are not a bug signal."""
+    import copy
     from oracle import pmf_torch as O
     from oracle import losses_ref
     hip, ref = _models()
@@ -142,13 +153,12 @@ def test_train_step_matches_oracle(n, h, w, drop):
     ref.train()
     if drop:
         m = _masks(ref, n)
-        O.set_dropout_masks(ref, m)
-        hip.set_dropout_masks({k: v.cuda() for k, v in m.items()})
     else:
-        for x in ref.modules():
-            if isinstance(x, O.DropSite):
-                x.p = 0.0
-        hip.set_dropout_masks({nm: torch.ones(n, c).cuda() for nm, c in hip._mask_sites()})
+        m = {nm: torch.ones(n, c) for nm, _, c in O.dropout_sites(ref)}
+    O.set_dropout_masks(ref, m)
+    hip.set_dropout_masks({k: v.cuda() for k, v in m.items()})
+    ref64 = copy.deepcopy(ref).double()
+    O.set_dropout_masks(ref64, {k: v.double() for k, v in m.items()})
     pcd, rgb, label, _ = synthetic_batch(n, h, w, 20, seed=1)
     alpha = torch.linspace(0.2, 1.0, 20)
     alpha[0] = 0
@@ -156,6 +166,9 @@ def test_train_step_matches_oracle(n, h, w, drop):
     rl, rc = ref(pcd, rgb)
     total_r, _ = losses_ref.pmf_total_loss(rl, rc, label, alpha)
     total_r.backward()
+    dl, dc = ref64(pcd.double(), rgb.double())
+    total_d, _ = losses_ref.pmf_total_loss(dl, dc, label, alpha.double())
+    total_d.backward()
     lp, cp = hip(pcd.cuda(), rgb.cuda())
     total_h, _ = losses_ref.pmf_total_loss(lp, cp, label.cuda(), alpha.cuda())   # same torch ops, on the GPU
     total_h.backward()
@@ -163,26 +176,33 @@ def test_train_step_matches_oracle(n, h, w, drop):
     plan = next(iter(hip._plans.values()))
     skip = [k for k in cap if drop and (k.startswith("upBlock") or k.startswith("resBlock5"))]
     rows = G.compare_plan_to_oracle(plan, cap, skip)
+    _dump("train_fwd_%d_%d_%d_%d.txt" % (n, h, w, drop), rows)
     bad, txt = _report(rows, 1e-3)
     assert not bad, "train-mode forward mismatch:\n" + txt
-    assert abs(total_h.item() - total_r.item()) < 1e-4 * max(1.0, abs(total_r.item()))
-    # running statistics (momentum 0.1, unbiased variance)
+    assert G.rel_err(plan.read(plan.tensors["logits"]).cpu().numpy(), dl.new_tensor(ref64.lidar_stream.last_logits).numpy()) < 1e-3
+    assert abs(total_h.item() - total_d.item()) < 1e-4 * max(1.0, abs(total_d.item()))
     rsd = ref.state_dict()
     for k, v in hip.state_dict().items():
         if "running_" in k:
-            assert G.rel_err(v.cpu().numpy(), rsd[k].numpy()) < 1e-4, k
+            assert G.scale_err(v.cpu().numpy(), rsd[k].numpy()) < 1e-4, k
         if k.endswith("num_batches_tracked"):
             assert int(v) == int(rsd[k]) == 1
-    # gradients: relative L2 error per parameter (absolute floor for the ~0 bias-before-BN gradients)
-    rp = dict(ref.named_parameters())
-    rows = []
+    rp, dp = dict(ref.named_parameters()), dict(ref64.named_parameters())
+    rows, bad = [], []
     for k, p in hip.named_parameters():
         assert p.grad is not None, k
-        gr = rp[k].grad
-        e = ((p.grad.cpu() - gr).norm() / max(gr.norm().item(), 1e-4 * gr.numel() ** 0.5)).item()
-        rows.append((k, e))
-    bad, txt = _report(rows, 2e-3)
-    assert not bad, "gradient mismatch (rel L2):\n" + "\n".join(l for l in txt.splitlines() if "FAIL" in l)
+        g64 = dp[k].grad
+        wk = k.rsplit(".", 1)[0] + ".weight"
+        floor = 1e-6 * dp[wk].grad.norm().item() if wk in dp else 0.0
+        den = max(g64.norm().item(), floor, 1e-30)
+        e_h = (p.grad.cpu().double() - g64).norm().item() / den
+        e_r = (rp[k].grad.double() - g64).norm().item() / den
+        rows.append((k, e_h, e_r))
+        if not e_h <= max(20 * e_r, 5e-4):
+            bad.append((k, e_h, e_r))
+    _dump("train_grads_%d_%d_%d_%d.txt" % (n, h, w, drop), rows)
+    assert not bad, "gradient error vs float64 oracle (name, HIP fp32, CPU fp32):\n" + "\n".join(
+        "%-50s %.3e %.3e" % b for b in bad[:40])
 
 
 def test_salsanext_standalone_matches_golden(golden):
@@ -204,7 +224,8 @@ def test_invalid_size_and_cpu_tensor_raise():
 
 
 def test_full_size_properties():
-    """BASELINE size (64x2048, bs 2): probabilities are a distribution, finite, and eval is deterministic."""
+    """BASELINE size (64x2048, bs 2): probabilities are a distribution, finite, and eval is deterministic
+    (no atomics on the inference path)."""
     hip, _ = _models()
     hip.eval()
     pcd, rgb, _, _ = synthetic_batch(2, 64, 2048, 20, seed=7)
