@@ -1,0 +1,103 @@
+"""One PMF optimisation step (tasks/pmf/trainer.py:289-341 of the reference) as a reusable engine.
+
+    normalise LiDAR channels * mask -> PMFNet (HIP plan) -> focal + Lovasz (both heads) + perception-aware loss
+    -> backward (HIP plan) -> AdamW(lidar_stream) + SGD-Nesterov(camera encoder+decoder) -> 2 x WarmupCosineLR.step
+    -> confusion-matrix update for both heads.
+
+Used by tasks/pmf/trainer.py (real loop) and bench.py (synthetic, device-resident batches) so the benchmark
+times exactly what the trainer runs.  Metrics are reduced across ranks every ``metrics_sync_every`` steps
+(the reference reduces 6x per iteration) -- epoch-end numbers are identical."""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .loss import FocalSoftmaxLoss, Lovasz_softmax, pmf_total_loss
+from .metrics import IOUEval
+from .utils import WarmupCosineLR
+
+
+def kitti_focal_alpha(cls_freq, learning_ignore):
+    """trainer.py:108-114,194-199: w = 1/(f+1e-3), 0 for ignored; alpha = log(1+w)/max, alpha[0] = 0."""
+    w = 1.0 / (np.asarray(cls_freq, np.float64) + 1e-3)
+    for c, ig in enumerate(learning_ignore):
+        if ig:
+            w[c] = 0
+    a = np.log(1 + w)
+    a = a / a.max()
+    a[0] = 0
+    return a.astype(np.float32), [c for c in range(len(w)) if w[c] < 1e-10]
+
+
+class TrainEngine:
+    def __init__(self, model, nclasses, lr=1e-3, momentum=0.9, weight_decay=1e-5, lambda_=1.0, gamma=0.5, tau=0.7,
+                 alpha=None, ignore_class=(0,), warmup_steps=1, max_steps=1, feature_mean=None, feature_std=None,
+                 distributed=False, device_ids=None, metrics_sync_every=0):
+        self.raw_model = model
+        dev = next(model.parameters()).device
+        self.device = dev
+        self.nclasses, self.lambda_, self.gamma, self.tau = nclasses, lambda_, gamma, tau
+        fused = dict(fused=True) if dev.type == "cuda" else {}
+        # trainer.py:80-98: AdamW over the LiDAR stream (torch defaults incl. weight_decay 0.01),
+        # SGD-Nesterov over camera encoder + decoder
+        self.optimizer = torch.optim.AdamW([{"params": model.lidar_stream.parameters()}], lr=lr, **fused)
+        self.aux_optimizer = torch.optim.SGD(
+            [{"params": model.camera_stream_encoder.parameters()}, {"params": model.camera_stream_decoder.parameters()}],
+            lr=lr, nesterov=True, momentum=momentum, weight_decay=weight_decay, **fused)
+        self.model = model
+        if distributed:
+            self.model = nn.parallel.DistributedDataParallel(
+                model, device_ids=device_ids, gradient_as_bucket_view=True)   # local-stat BN: see layers/sync_bn.py
+        if alpha is None:
+            alpha = np.ones(nclasses, np.float32)
+            alpha[0] = 0
+        self.focal = FocalSoftmaxLoss(nclasses, gamma=2, alpha=np.asarray(alpha, np.float32), softmax=False).to(dev)
+        self.lovasz = Lovasz_softmax(ignore=0)
+        self.metrics = IOUEval(nclasses, dev, ignore=list(ignore_class), is_distributed=distributed)
+        self.metrics_img = IOUEval(nclasses, dev, ignore=list(ignore_class), is_distributed=distributed)
+        self.scheduler = WarmupCosineLR(self.optimizer, lr, warmup_steps, momentum, max_steps)
+        self.aux_scheduler = WarmupCosineLR(self.aux_optimizer, lr, warmup_steps, momentum, max_steps)
+        self.mean = None if feature_mean is None else torch.tensor(feature_mean, device=dev).view(1, -1, 1, 1).float()
+        self.std = None if feature_std is None else torch.tensor(feature_std, device=dev).view(1, -1, 1, 1).float()
+        self.metrics_sync_every = metrics_sync_every
+        self.iteration = 0
+
+    def prepare(self, input_feature, input_mask):
+        """trainer.py:291-297: normalise the 5 LiDAR channels in place, return the two channel-slice views."""
+        if self.mean is not None:
+            input_feature[:, 0:5] = (input_feature[:, 0:5] - self.mean) / self.std * input_mask.unsqueeze(1)
+        return input_feature[:, 0:5], input_feature[:, 5:8]
+
+    def forward_loss(self, pcd, rgb, label):
+        lidar_pred, camera_pred = self.model(pcd, rgb)
+        total, terms = pmf_total_loss(lidar_pred, camera_pred, label, self.focal, self.lovasz,
+                                      self.lambda_, self.gamma, self.tau)
+        return total, terms, lidar_pred, camera_pred
+
+    def train_step(self, input_feature, input_mask, input_label):
+        """one full iteration; everything stays on the device (no .item())."""
+        self.model.train()
+        pcd, rgb = self.prepare(input_feature, input_mask)
+        label = input_label.long()
+        total, terms, lidar_pred, camera_pred = self.forward_loss(pcd, rgb, label)
+        self.optimizer.zero_grad(set_to_none=True)
+        self.aux_optimizer.zero_grad(set_to_none=True)
+        total.backward()
+        self.optimizer.step()
+        self.aux_optimizer.step()
+        self.scheduler.step()
+        self.aux_scheduler.step()
+        with torch.no_grad():
+            self.metrics.addBatch(lidar_pred.argmax(dim=1), label)
+            self.metrics_img.addBatch(camera_pred.argmax(dim=1), label)
+        self.iteration += 1
+        return total.detach(), terms
+
+    @torch.no_grad()
+    def eval_step(self, input_feature, input_mask, input_label):
+        self.model.eval()
+        pcd, rgb = self.prepare(input_feature, input_mask)
+        label = input_label.long()
+        total, terms, lidar_pred, camera_pred = self.forward_loss(pcd, rgb, label)
+        self.metrics.addBatch(lidar_pred.argmax(dim=1), label)
+        self.metrics_img.addBatch(camera_pred.argmax(dim=1), label)
+        return total, terms

@@ -594,6 +594,7 @@ class _PlanFunction(torch.autograd.Function):
             keep.append(g)
             a = plan.bwd_ops[plan.out_slots[slot]["bwd_index"] + plan.bwd_shift].u.sm
             a.p[0], a.p[1] = prob.data_ptr(), g.data_ptr()
+        plan._last_gouts = keep          # keeps the patched pointers valid for profiling re-runs
         plan.run(plan.bwd_ops, plan.n_bwd, "backward")
         flat = plan.pgrad_buf.tensor((plan.pgrad_floats,))
         grads = []

@@ -117,6 +117,7 @@ class Plan:
         self.bn_modules = []
         self.in_slots, self.out_slots = {}, {}
         self.tensors, self.views = {}, {}   # debug registry: name -> T / V
+        self.meta_fwd, self.meta_bwd = {}, {}   # op index (before prologue shift) -> dict(family, flops)
 
     # ------------------------------------------------------------------ parameter bookkeeping
     def pgrad(self, p):
@@ -234,6 +235,8 @@ class Plan:
             d.out_sy = d.out_sx = 1
             d.stats = stats.ptr if stats is not None else None
         self.emit(self.fwd, L.OP_CONV, f)
+        conv_flops = 2.0 * N * OH * OW * Cout * conv.in_channels * len(taps)   # algorithmic (SURVEY.md 8d rule)
+        self.meta_fwd[len(self.fwd) - 1] = dict(family="conv_fwd", flops=conv_flops, name=name)
 
         view = V(out)
         info = None
@@ -394,6 +397,10 @@ class Plan:
                             d.ep_relu_scale = r.scale.ptr if r.scale is not None else None
                             d.ep_relu_shift = r.shift.ptr if r.shift is not None else None
                     self.emit(self.bwd, L.OP_CONV, f)
+                    mh = tgt.H if stride == 1 else (tgt.H - py + 1) // 2
+                    mw = tgt.W if stride == 1 else (tgt.W - px + 1) // 2
+                    self.meta_bwd[len(self.bwd) - 1] = dict(
+                        family="conv_dgrad", flops=2.0 * dz.N * mh * mw * s.t.C * Cout * len(sub), name=name)
                 if tmp is not None:
                     def fc(op, tmp=tmp, g=r.t.g):
                         a = op.u.sm
@@ -438,6 +445,8 @@ class Plan:
             d.dw_oihw = self.pgrad_buf.at(goff)
             d.accumulate = 0
         self.emit(self.bwd, L.OP_WGRAD, f)
+        self.meta_bwd[len(self.bwd) - 1] = dict(
+            family="conv_wgrad", flops=2.0 * dz.N * dz.H * dz.W * Cout * conv.in_channels * len(taps), name=name)
 
     # ---- element-wise primitives -----------------------------------------------------------------
     def add_act(self, a, b, act, name=""):
@@ -761,6 +770,30 @@ class Plan:
             cm = self.masks[v.cmul:v.cmul + v.t.N * v.cmul_ld].view(v.t.N, v.cmul_ld)[:, :v.t.C]
             x = x * cm[:, :, None, None]
         return x
+
+    def run_profiled(self, what):
+        """run one pass op by op with a HIP event pair around every launch (on the stream the plan uses);
+        returns [(op kind name, family or None, algorithmic flops, milliseconds)].  Measurement only."""
+        ops, n = (self.fwd_ops, self.n_fwd) if what == "forward" else (self.bwd_ops, self.n_bwd)
+        kinds = self.fwd_kinds if what == "forward" else self.bwd_kinds
+        meta = self.meta_fwd if what == "forward" else self.meta_bwd
+        shift = self.fwd_shift if what == "forward" else self.bwd_shift
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        failed = C.c_int32(-1)
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+        for k in range(n):
+            evs[k][0].record()
+            rc = L.lib().pmf_plan_run_range(C.addressof(ops), k, k + 1, C.c_void_p(stream), C.byref(failed))
+            evs[k][1].record()
+            if rc != 0:
+                raise RuntimeError("pmf_amd %s plan failed at op #%d: code %d" % (what, k, rc))
+        torch.cuda.synchronize(self.device)
+        out = []
+        for k in range(n):
+            m = meta.get(k - shift, {})
+            out.append((L.OP_NAMES.get(kinds[k], "?"), m.get("family"), m.get("flops", 0.0), evs[k][0].elapsed_time(evs[k][1]),
+                        m.get("name", "")))
+        return out
 
     # ------------------------------------------------------------------ running
     def run(self, ops, n, what, begin=0, end=None):
