@@ -79,6 +79,8 @@ typedef struct {
   const float* ep_relu_shift;
   int32_t ep_relu_ldc;
   double* stats;
+  float* splitk_ws;          /* optional scratch for deterministic split-K on small maps (NULL = never split) */
+  int64_t splitk_ws_bytes;
 } pmf_conv_desc_t;
 
 int pmf_conv_fwd(const pmf_conv_desc_t* d, pmf_stream_t s);

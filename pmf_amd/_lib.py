@@ -37,7 +37,7 @@ class ConvDesc(C.Structure):
                 ("out_sx", C.c_int32), ("out_oy", C.c_int32), ("out_ox", C.c_int32), ("accumulate", C.c_int32),
                 ("ep_cmul", C.c_void_p), ("ep_cmul_ld", C.c_int32), ("ep_relu_x", C.c_void_p),
                 ("ep_relu_scale", C.c_void_p), ("ep_relu_shift", C.c_void_p), ("ep_relu_ldc", C.c_int32),
-                ("stats", C.c_void_p)]
+                ("stats", C.c_void_p), ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_int64)]
 
 
 class WgradDesc(C.Structure):

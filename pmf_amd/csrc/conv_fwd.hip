@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void conv_fwd_k(const pmf_conv_desc_t d, const
   const int li = lane & 31, lh = lane >> 5;
   const int tile = blockIdx.x;
   const int tx = tile % g.tiles_x, ty = tile / g.tiles_x;
-  const int n = blockIdx.z, n0 = blockIdx.y * BN;
+  const int n = blockIdx.z, n0 = ((int)blockIdx.y / g.ksplit) * BN, ks = (int)blockIdx.y % g.ksplit;
   const int oy0 = ty * g.th, ox0 = tx * g.tw;
   const int is = d.in_stride;
   const int in_cols = g.in_cols;
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void conv_fwd_k(const pmf_conv_desc_t d, const
   }
 
   const int ngroups = d.gather ? d.ntaps : 1;
-  int k_base = 0;
+  int k_base = 0, chunk_no = 0;
   for (int si = 0; si < d.nsrc; ++si) {
     const float* __restrict__ sx = d.src[si].x;
     const float* __restrict__ sscale = d.src[si].scale;
@@ -59,6 +59,7 @@ __global__ __launch_bounds__(256) void conv_fwd_k(const pmf_conv_desc_t d, const
     const bool bc = (sflags & PMF_SRC_BCAST) != 0;
     const int sH = bc ? d.OH * is : d.src[si].H, sW = bc ? d.OW * is : d.src[si].W;
     for (int c0 = 0; c0 < sC; c0 += KC) {
+      if ((chunk_no++ % g.ksplit) != ks) continue;   // split-K: chunks are dealt round-robin
       const int kc = min(KC, sC - c0);
       const int nql = kc == 16 ? 2 : 1;   // log2(float4 per pixel)
       const int kcl = kc == 16 ? 4 : 3;   // log2(kc)
@@ -130,6 +131,25 @@ __global__ __launch_bounds__(256) void conv_fwd_k(const pmf_conv_desc_t d, const
   }
 
   // ---- epilogue
+  if (g.ksplit > 1) {   // raw partial sums -> slab ks; bias / activation / statistics happen in conv_finish_k
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+      const int co = n0 + u * 32 + li;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const int oy = oy0 + segrow[m];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ox = ox0 + segcol[m] * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (co < g.ws_ld && oy < d.OH && ox < d.OW) {
+            const size_t pix = ((size_t)(ks * d.N + n) * d.OH + oy) * d.OW + ox;
+            g.ws[pix * g.ws_ld + co] = acc[m][u][r];
+          }
+        }
+      }
+    }
+    return;
+  }
   // BatchNorm statistics in float64: float*float is exact in double, so var = E[x^2] - mean^2 keeps full
   // float32 accuracy even for nearly-constant channels (the classic cancellation), at ~2 DP ops per output
   double ssum[NT], ssq[NT];
@@ -197,6 +217,58 @@ __global__ __launch_bounds__(256) void conv_fwd_k(const pmf_conv_desc_t d, const
   }
 }
 
+// Deterministic split-K tail: out = ep( act( sum_ks ws[ks] + bias ) ), optional BatchNorm statistics.
+__global__ void conv_finish_k(const pmf_conv_desc_t d, int ksplit, const float* __restrict__ ws, int ws_ld, int Q) {
+  __shared__ double sh[2][256][4];
+  const int Qm = Q < 256 ? Q : 256, Qg = min(Q - (int)blockIdx.y * 256, 256), rows = 256 / Qm;
+  const int row = threadIdx.x / Qm, cql = threadIdx.x - row * Qm;
+  const bool active = cql < Qg;
+  const int c = ((int)blockIdx.y * 256 + cql) * 4;
+  const int64_t npix = (int64_t)d.N * d.OH * d.OW, hw = (int64_t)d.OH * d.OW;
+  double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+  if (active) {
+    f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+    if (d.bias) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) if (c + k < d.Cout) bias[k] = d.bias[c + k];
+    }
+    for (int64_t p = (int64_t)blockIdx.x * rows + row; p < npix; p += (int64_t)gridDim.x * rows) {
+      f32x4 v = bias;
+      for (int s = 0; s < ksplit; ++s) v += *(const f32x4*)(ws + ((int64_t)s * npix + p) * ws_ld + c);
+      const int n = (int)(p / hw);
+      float* op = d.out + p * d.out_ldc + c;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (c + k >= d.Cout) continue;
+        float x = pmf_act(v[k], d.act);
+        if (d.ep_cmul) x *= d.ep_cmul[(size_t)n * d.ep_cmul_ld + c + k];
+        if (d.ep_relu_x) {
+          float xr = d.ep_relu_x[p * d.ep_relu_ldc + c + k];
+          if (d.ep_relu_scale) xr = xr * d.ep_relu_scale[c + k] + d.ep_relu_shift[c + k];
+          if (!(xr > 0.f)) x = 0.f;
+        }
+        if (d.accumulate) x += op[k];
+        op[k] = x;
+        s1[k] += (double)x;
+        s2[k] += (double)x * (double)x;
+      }
+    }
+  }
+  if (d.stats) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { sh[0][row * Qm + cql][k] = s1[k]; sh[1][row * Qm + cql][k] = s2[k]; }
+    __syncthreads();
+    if (row == 0 && active) {
+      for (int r = 1; r < rows; ++r)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { s1[k] += sh[0][r * Qm + cql][k]; s2[k] += sh[1][r * Qm + cql][k]; }
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (c + k < d.Cout) { atomicAdd(d.stats + c + k, s1[k]); atomicAdd(d.stats + d.Cout + c + k, s2[k]); }
+    }
+  }
+}
+
 static int floor_log2(int v) { int l = 0; while ((2 << l) <= v) ++l; return l; }
 
 // Chooses tile shape / staging mode; returns LDS bytes (or <0).
@@ -233,11 +305,24 @@ int pmf_conv_geometry(int OH, int OW, int ntaps, const int8_t* tdy, const int8_t
   }
 }
 
+// split-K factor: only when the M x N grid cannot fill the 256 CUs (low-resolution, many-channel layers)
+static int choose_ksplit(const pmf_conv_desc_t* d, int blocks_mn, int nchunks) {
+  if (!d->splitk_ws || d->out_sy != 1 || d->out_sx != 1 || blocks_mn >= 200 || nchunks < 4) return 1;
+  int k = 512 / (blocks_mn > 0 ? blocks_mn : 1);
+  if (k > nchunks / 2) k = nchunks / 2;
+  if (k > 32) k = 32;
+  const int64_t slab = (int64_t)d->N * d->OH * d->OW * round_up(d->Cout, 4) * 4;
+  while (k > 1 && slab * k > d->splitk_ws_bytes) --k;
+  return k < 2 ? 1 : k;
+}
+
 template <int BN, int MT>
 static int launch(const pmf_conv_desc_t* d, hipStream_t s) {
   ConvGeom g;
-  int Ktot = 0, cmax = 0;
-  for (int i = 0; i < d->nsrc; ++i) { Ktot += d->src[i].C; cmax = d->src[i].C > cmax ? d->src[i].C : cmax; }
+  int Ktot = 0, cmax = 0, nchunks = 0;
+  for (int i = 0; i < d->nsrc; ++i) {
+    Ktot += d->src[i].C; cmax = d->src[i].C > cmax ? d->src[i].C : cmax; nchunks += cdiv(d->src[i].C, KC);
+  }
   int gather;
   int lds = pmf_conv_geometry(d->OH, d->OW, d->ntaps, d->tdy, d->tdx, d->in_stride, d->gather, BN, MT,
                               cmax < KC ? cmax : KC, &g, &gather);
@@ -250,9 +335,21 @@ static int launch(const pmf_conv_desc_t* d, hipStream_t s) {
     (void)hipFuncSetAttribute((const void*)conv_fwd_k<BN, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  dim3 grid(g.tiles_x * g.tiles_y, cdiv(d->Cout, BN), d->N);
+  const int co_tiles = cdiv(d->Cout, BN);
+  g.ksplit = choose_ksplit(d, g.tiles_x * g.tiles_y * d->N * co_tiles, nchunks);
+  g.ws = d->splitk_ws;
+  g.ws_ld = round_up(d->Cout, 4);
+  dim3 grid(g.tiles_x * g.tiles_y, co_tiles * g.ksplit, d->N);
   hipLaunchKernelGGL((conv_fwd_k<BN, MT>), grid, dim3(256), lds, s, dd, g);
   PMF_LAUNCH_CHECK();
+  if (g.ksplit > 1) {
+    const int Q = g.ws_ld / 4, Qg = Q < 256 ? Q : 256, rows = 256 / Qg;
+    int64_t gx = cdiv64((int64_t)d->N * d->OH * d->OW, (int64_t)rows * 4);
+    gx = gx > 1024 ? 1024 : (gx < 1 ? 1 : gx);
+    hipLaunchKernelGGL(conv_finish_k, dim3((unsigned)gx, (unsigned)cdiv(Q, 256), 1), dim3(rows * Qg), 0, s, dd, g.ksplit,
+                       (const float*)g.ws, g.ws_ld, Q);
+    PMF_LAUNCH_CHECK();
+  }
   return 0;
 }
 

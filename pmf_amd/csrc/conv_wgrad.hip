@@ -2,14 +2,14 @@
 //
 // GEMM view per tap t:  dW_t[ci][co] = sum_pixels X_t[pixel][ci] * dz[pixel][co]   (M = 32 input channels,
 // N = BN output channels, K = pixels).  A workgroup owns one 32-channel chunk of the (virtually concatenated)
-// input, BN output channels and a batch of TB taps, and walks a strided list of 4x32-pixel tiles: per tile the
-// input chunk INCLUDING ITS HALO is staged once in LDS (BatchNorm-apply / ReLU / Dropout2d multiplier folded
-// into the load) next to the dz tile; wave w consumes row w of the tile, two pixels per v_mfma_f32_32x32x2_f32:
+// input, BN = 32/64/128 output channels and a batch of TB taps, and walks a strided list of 4x32-pixel tiles: per
+// tile the input chunk INCLUDING ITS HALO is staged once in LDS (BatchNorm-apply / ReLU / Dropout2d multiplier
+// folded into the load) next to the dz tile.  Two pixels per v_mfma_f32_32x32x2_f32:
 //   A[i=ci=lane&31][k=lane>>5] = ds_read_b32 X[pixel+tap offset][ci]   (32 consecutive banks)
 //   B[k][j=co=lane&31]         = ds_read_b32 dz[pixel][co]
-// One A read per tap and one B read per pixel pair feed TB * BN/32 MFMAs.  The four waves' accumulators are
-// folded with LDS float atomics and written as one partial slab per workgroup; stage 2 sums the slabs in a
-// fixed order and writes the gradient directly in PyTorch's OIHW layout.
+// The TB x BN/32 output tiles are dealt to the four waves (see conv_wgrad_k); each wave sees every pixel, so its
+// accumulators are complete and go straight to this workgroup's partial slab.  Stage 2 sums the slabs in a fixed
+// order (deterministic) and writes the gradient directly in PyTorch's OIHW layout.
 #include "common.h"
 
 #define WG_ROWS 4
@@ -24,10 +24,16 @@ struct WgGeom {
   int co_tiles, tap_batches;
 };
 
+// Work decomposition inside a workgroup: the output slab [TB taps][32 ci][NT*32 co] is TB*NT MFMA tiles ("units",
+// u = tap*NT + co_tile).  Wave w owns units w, w+4, w+8, ... and walks EVERY pixel of the staged tile, so its
+// accumulators are final for the pixels it saw: no cross-wave reduction, and one staged tile feeds
+// 64 pixel-pairs x UPW MFMAs per wave.  Because 4 % NT == 0 a wave's units share one co tile (one B read per
+// pixel pair) and differ only in the tap (one A read each).
 template <int TB, int NT>
 __global__ __launch_bounds__(256) void conv_wgrad_k(const pmf_wgrad_desc_t d, const WgGeom g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int BN = NT * 32;
+  constexpr int U = TB * NT, UPW = (U + 3) / 4;
   float* __restrict__ Xs = smem;
   float* __restrict__ Zs = smem + g.x_floats;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -58,21 +64,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_k(const pmf_wgrad_desc_t d, co
   const int kc = min(WG_CI, sC - c0);   // multiple of 8
   const int nq = kc >> 2;
 
-  f32x16 acc[TB][NT];
+  f32x16 acc[UPW];
 #pragma unroll
-  for (int t = 0; t < TB; ++t)
+  for (int j = 0; j < UPW; ++j)
 #pragma unroll
-    for (int u = 0; u < NT; ++u)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
   const int gy0 = d.gather ? (int)d.tdy[t0] : g.dy_min;
   const int gx0 = d.gather ? (int)d.tdx[t0] : g.dx_min;
-  int toff[TB];
+  // this wave's units
+  int toff[UPW];
+  bool uok[UPW];
+  const int myc = wave % NT;   // shared co tile of all units of this wave
 #pragma unroll
-  for (int t = 0; t < TB; ++t) {
-    const int tt = t0 + (t < nt ? t : 0);
-    toff[t] = (((int)d.tdy[tt] - gy0) * g.in_cols + ((int)d.tdx[tt] - gx0)) * WG_CI;
+  for (int j = 0; j < UPW; ++j) {
+    const int u = wave + 4 * j, t = u / NT;
+    uok[j] = u < U && t < nt;
+    const int tt = t0 + (uok[j] ? t : 0);
+    toff[j] = (((int)d.tdy[tt] - gy0) * g.in_cols + ((int)d.tdx[tt] - gx0)) * WG_CI;
   }
 
   for (int tile = split; tile < g.total_tiles; tile += d.nsplit) {
@@ -110,47 +119,39 @@ __global__ __launch_bounds__(256) void conv_wgrad_k(const pmf_wgrad_desc_t d, co
       }
     }
     __syncthreads();
-    const float* xrow = Xs + (wave * is * g.in_cols) * WG_CI + li;
-    const float* zrow = Zs + (wave * 32) * BN + li;
-#pragma unroll 2
-    for (int kp = 0; kp < 16; ++kp) {
-      const int px = 2 * kp + lh;
-      float b[NT];
+    const float* zbase = Zs + myc * 32 + li;
+#pragma unroll 1
+    for (int row = 0; row < WG_ROWS; ++row) {
+      const float* xrow = Xs + (row * is * g.in_cols) * WG_CI + li;
+      const float* zrow = zbase + (row * 32) * BN;
+#pragma unroll 4
+      for (int kp = 0; kp < 16; ++kp) {
+        const int px = 2 * kp + lh;
+        const float b = zrow[px * BN];
+        const float* xp = xrow + px * is * WG_CI;
 #pragma unroll
-      for (int u = 0; u < NT; ++u) b[u] = zrow[px * BN + u * 32];
-      const float* xp = xrow + px * is * WG_CI;
-#pragma unroll
-      for (int t = 0; t < TB; ++t) {
-        if (t < nt) {
-          const float a = xp[toff[t]];
-#pragma unroll
-          for (int u = 0; u < NT; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[u], acc[t][u], 0, 0, 0);
+        for (int j = 0; j < UPW; ++j) {
+          if (uok[j]) {
+            const float a = xp[toff[j]];
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j], 0, 0, 0);
+          }
         }
       }
     }
   }
 
-  // ---- fold the four waves in LDS, write this workgroup's partial slab
-  __syncthreads();
-  float* red = smem;  // [TB][32 ci][BN]
-  for (int i = tid; i < TB * WG_CI * BN; i += 256) red[i] = 0.f;
-  __syncthreads();
-#pragma unroll
-  for (int t = 0; t < TB; ++t)
-#pragma unroll
-    for (int u = 0; u < NT; ++u)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ci = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        atomicAdd(&red[(t * WG_CI + ci) * BN + u * 32 + li], acc[t][u][r]);
-      }
-  __syncthreads();
+  // ---- every wave owns complete sums for its units: write them straight into the partial slab
   float* part = d.partial + (size_t)split * d.ntaps * g.Ktot * g.Cout32;
-  for (int i = tid; i < nt * kc * BN; i += 256) {
-    const int co = i % BN, r = i / BN;
-    const int ci = r % kc, t = r / kc;
-    if (co0 + co < g.Cout32)
-      part[((size_t)(t0 + t) * g.Ktot + k0 + ci) * g.Cout32 + co0 + co] = red[(t * WG_CI + ci) * BN + co];
+  const int co = co0 + myc * 32 + li;
+#pragma unroll
+  for (int j = 0; j < UPW; ++j) {
+    if (!uok[j]) continue;
+    const int t = (wave + 4 * j) / NT;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ci = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (ci < kc && co < g.Cout32) part[((size_t)(t0 + t) * g.Ktot + k0 + ci) * g.Cout32 + co] = acc[j][r];
+    }
   }
 }
 
@@ -189,17 +190,17 @@ static int wg_geometry(const pmf_wgrad_desc_t* d, int TB, int BN, WgGeom* g, int
   g->x_floats = rows * cols * WG_CI;
   g->co_tiles = cdiv(d->Cout, BN);
   g->tap_batches = cdiv(d->ntaps, TB);
-  int stage = (g->x_floats + WG_ROWS * 32 * BN) * 4, fold = TB * WG_CI * BN * 4;
-  *lds = stage > fold ? stage : fold;
+  *lds = (g->x_floats + WG_ROWS * 32 * BN) * 4;
   return 0;
 }
 
-// taps per workgroup / channel tile: 3x3 -> 9 taps x 32 co, 2x2 -> 4 x 64, everything per-tap -> 1 x 64
+// taps per workgroup (TB) and output-channel tiles (NT): 3x3 -> 9 taps, 2x2 -> 4, per-tap staging -> 1;
+// NT*32 output channels per workgroup, as wide as Cout allows (wider = fewer re-reads of the input tile)
 static void wg_config(const pmf_wgrad_desc_t* d, int* TB, int* NT) {
-  if (d->gather || d->ntaps == 1) { *TB = 1; *NT = 2; }
-  else if (d->ntaps <= 4) { *TB = 4; *NT = 2; }
-  else { *TB = 9; *NT = 1; }
-  if (d->Cout <= 32) *NT = 1;
+  if (d->gather || d->ntaps == 1) *TB = 1;
+  else if (d->ntaps <= 4) *TB = 4;
+  else *TB = 9;
+  *NT = d->Cout > 64 ? 4 : (d->Cout > 32 ? 2 : 1);
 }
 
 extern "C" int pmf_conv_wgrad_nsplit(const pmf_wgrad_desc_t* d) {
@@ -208,7 +209,7 @@ extern "C" int pmf_conv_wgrad_nsplit(const pmf_wgrad_desc_t* d) {
   wg_config(d, &TB, &NT);
   wg_geometry(d, TB, NT * 32, &g, &lds);
   int other = g.nchunks * g.co_tiles * g.tap_batches;
-  int ns = 768 / (other > 0 ? other : 1);
+  int ns = 512 / (other > 0 ? other : 1);
   if (ns < 1) ns = 1;
   if (ns > g.total_tiles) ns = g.total_tiles;
   return ns;
@@ -250,7 +251,10 @@ extern "C" int pmf_conv_wgrad(const pmf_wgrad_desc_t* d, pmf_stream_t st) {
   if (d->gather && false) return PMF_E_ARG;
   int TB, NT;
   wg_config(d, &TB, &NT);
-  if (TB == 1) return NT == 2 ? wg_launch<1, 2>(d, s) : wg_launch<1, 1>(d, s);
-  if (TB == 4) return NT == 2 ? wg_launch<4, 2>(d, s) : wg_launch<4, 1>(d, s);
-  return wg_launch<9, 1>(d, s);
+#define WG_CASE(tb, nt) if (TB == tb && NT == nt) return wg_launch<tb, nt>(d, s)
+  WG_CASE(9, 1); WG_CASE(9, 2); WG_CASE(9, 4);
+  WG_CASE(4, 1); WG_CASE(4, 2); WG_CASE(4, 4);
+  WG_CASE(1, 1); WG_CASE(1, 2); WG_CASE(1, 4);
+#undef WG_CASE
+  return PMF_E_UNSUPPORTED;
 }

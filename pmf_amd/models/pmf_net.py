@@ -596,14 +596,15 @@ class _PlanFunction(torch.autograd.Function):
             a.p[0], a.p[1] = prob.data_ptr(), g.data_ptr()
         plan._last_gouts = keep          # keeps the patched pointers valid for profiling re-runs
         plan.run(plan.bwd_ops, plan.n_bwd, "backward")
-        flat = plan.pgrad_buf.tensor((plan.pgrad_floats,))
+        # ONE device copy of the flat gradient buffer (the plan reuses it next iteration), then per-parameter views
+        flat = plan.pgrad_buf.tensor((plan.pgrad_floats,)).clone()
         grads = []
         for p in ctx.params:
             ent = plan._pid.get(id(p))
             if ent is None:
                 grads.append(None)
             else:
-                grads.append(flat[ent[1]:ent[1] + p.numel()].view(p.shape).clone())
+                grads.append(flat[ent[1]:ent[1] + p.numel()].view(p.shape))
         return (None, None) + (None,) * ctx.n_inputs + tuple(grads)
 
 

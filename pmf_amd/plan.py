@@ -234,6 +234,7 @@ class Plan:
             d.out, d.out_ldc, d.out_H, d.out_W = out.buf.ptr, out.ldc, OH, OW
             d.out_sy = d.out_sx = 1
             d.stats = stats.ptr if stats is not None else None
+            d.splitk_ws, d.splitk_ws_bytes = self.sk_buf.ptr, self.sk_buf.nbytes
         self.emit(self.fwd, L.OP_CONV, f)
         conv_flops = 2.0 * N * OH * OW * Cout * conv.in_channels * len(taps)   # algorithmic (SURVEY.md 8d rule)
         self.meta_fwd[len(self.fwd) - 1] = dict(family="conv_fwd", flops=conv_flops, name=name)
@@ -390,6 +391,7 @@ class Plan:
                         d.out_sy = d.out_sx = stride
                         d.out_oy, d.out_ox = py, px
                         d.accumulate = acc
+                        d.splitk_ws, d.splitk_ws_bytes = self.sk_buf.ptr, self.sk_buf.nbytes
                         if s.cmul is not None:
                             d.ep_cmul, d.ep_cmul_ld = self.masks_ptr + 4 * s.cmul, s.cmul_ld
                         if relu_x is not None:
@@ -689,6 +691,7 @@ class Plan:
         self.tape = None
         self.pgrad_buf = self.zero_bwd.alloc(4 * max(self.pgrad_floats, 64)) if self.training else None
         self.wg_buf = self.act.alloc(max(self.wg_scratch, 256)) if self.training else None
+        self.sk_buf = self.act.alloc(32 << 20)    # shared split-K scratch (small maps only; ops run in stream order)
         for a, zero in ((self.act, False), (self.zero_fwd, True), (self.zero_bwd, True), (self.persist, True)):
             a.materialise(dev, zero)
         self.masks_ptr = self.masks.data_ptr() if self.masks is not None else 0
