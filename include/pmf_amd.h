@@ -106,6 +106,9 @@ typedef struct {
   float* dw_oihw;
   int32_t Cin_real, KHW;
   int32_t accumulate;     /* dw_oihw += (stride-2 parity classes share one weight) */
+  const float* dbias_rows; /* optional: partial column sums of dz [dbias_nrows][dbias_ld] (pmf_bn_bwd_apply / */
+  int32_t dbias_nrows, dbias_ld; /* pmf_act_bwd output); stage 2 folds them: dbias_out[co] += sum_r rows[r][co] */
+  float* dbias_out;
 } pmf_wgrad_desc_t;
 
 int pmf_conv_wgrad(const pmf_wgrad_desc_t* d, pmf_stream_t s);
@@ -126,25 +129,33 @@ typedef struct {
 int pmf_pack_tile_ci(int32_t Cin, int32_t KHW);
 int pmf_pack_weights_batched(const pmf_pack_job_t* jobs_dev, int32_t njobs, int32_t total_blocks, pmf_stream_t s);
 
-/* ---- BatchNorm2d (eps 1e-5, momentum 0.1; salsanext.py:17,21,...; torchvision bn) ------------------------ */
-/* train: float64 stats[2][C] (sum, sumsq over `count` elements) -> scale/shift for apply-on-load, saved mean/invstd,
- * running_mean/var update (unbiased var), and zeroes nothing.  eval: running stats -> scale/shift. */
-int pmf_bn_finalize(const double* stats, float count, const float* gamma, const float* beta, float* running_mean,
-                    float* running_var, float momentum, float eps, float* scale, float* shift, float* save_mean,
-                    float* save_invstd, int32_t C, pmf_stream_t s);
+/* ---- BatchNorm2d (eps 1e-5, momentum 0.1; salsanext.py:17,21,...; torchvision bn) ------------------------
+ * No atomics anywhere: producers write one partial row per workgroup, tiny fold kernels sum the rows in a fixed
+ * order (deterministic; contended float64 atomics cost ~80 us per launch on MI355X).
+ * train: stats = float64 [nrows][2][C] partial (sum, sumsq) rows from pmf_conv_fwd (nrows = pmf_conv_fwd_stat_rows)
+ *        -> scale/shift for apply-on-load, saved mean/invstd, running_mean/var update (unbiased var).
+ * eval:  running stats -> scale/shift. */
+int pmf_conv_fwd_stat_rows(const pmf_conv_desc_t* d);
+int pmf_bn_finalize(const double* stats, int32_t nrows, float count, const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, float momentum, float eps, float* scale, float* shift,
+                    float* save_mean, float* save_invstd, int32_t C, pmf_stream_t s);
 int pmf_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                        float eps, float* scale, float* shift, float* save_mean, float* save_invstd, int32_t C,
                        pmf_stream_t s);
-/* backward, two passes over (gy, a):  red[0..C) += sum gy, red[C..2C) += sum gy*(a - save_mean)  (zeroed by caller) */
+/* number of partial rows the column-reduction kernels (bn_bwd_reduce/apply, act_bwd) write for npix pixels, C channels */
+int pmf_col_rows(int64_t npix, int32_t C);
+/* backward pass 1 + fold: partial rows of sum gy, sum gy*(a-mean) into `part` (float64 [rows][2][C] scratch), then
+ * dgamma += invstd*sum gy*(a-mean), dbeta += sum gy, coef[3][C] = {gamma*invstd, invstd^2*mean(gy*(a-mean)), mean(gy)}
+ * (train == 0, eval-mode BN: coef[1] = coef[2] = 0). */
 int pmf_bn_bwd_reduce(const float* gy, int32_t gy_ldc, const float* a, int32_t a_ldc, int64_t npix, int32_t C,
-                      const float* save_mean, double* red, pmf_stream_t s);
-/* dz = (gamma*invstd*(gy - sum_gy/M - ahat*sum_gy_ahat/M)) * act'(a);  dgamma, dbeta written; dbias (optional)
- * accumulated = sum dz.  act: PMF_ACT_LRELU (a = lrelu(z): slope from sign of a) or PMF_ACT_NONE.
- * train == 0 (eval-mode BN): dz = gamma*invstd_running * gy * act'. */
+                      const float* save_mean, const float* gamma, const float* save_invstd, int32_t train,
+                      double* part, float* coef, float* dgamma, float* dbeta, pmf_stream_t s);
+/* backward pass 2: dz = coef0 * ((gy - coef2) - (a - mean) * coef1) * act'(a)   (act LRELU: slope from the sign of
+ * a = lrelu(z); NONE for conv -> BN -> ReLU ordering).  dbias_rows (optional): partial column sums of dz
+ * [pmf_col_rows(npix, C)][dbias_ld] for pmf_conv_wgrad to fold into the conv-bias gradient. */
 int pmf_bn_bwd_apply(const float* gy, int32_t gy_ldc, const float* a, int32_t a_ldc, int64_t npix, int32_t C,
-                     const double* red, const float* gamma, const float* save_mean, const float* save_invstd,
-                     int32_t act, int32_t train, float* dz, int32_t dz_ldc, float* dgamma, float* dbeta,
-                     float* dbias, pmf_stream_t s);
+                     const float* coef, const float* save_mean, int32_t act, float* dz, int32_t dz_ldc,
+                     float* dbias_rows, int32_t dbias_ld, pmf_stream_t s);
 
 /* ---- element-wise / resampling ops (all NHWC fp32) ----------------------------------------------------- */
 typedef struct { /* a tensor operand with optional affine-on-load */
@@ -163,9 +174,10 @@ int pmf_add_act(const pmf_view_t* a, const pmf_view_t* b, int32_t act, float* ou
 int pmf_add_act_bwd(const float* gout, int32_t g_ldc, const float* out, int32_t out_ldc, int32_t act, float* ga,
                     int32_t ga_ldc, int32_t ga_acc, float* gb, int32_t gb_ldc, int32_t gb_acc, int64_t npix,
                     int32_t C, pmf_stream_t s);
-/* g *= act'(a) in place (+ optional dbias[c] += sum) for convs not followed by BN (salsanext.py:24-25,70-71). */
-int pmf_act_bwd(float* g, int32_t g_ldc, const float* a, int32_t a_ldc, int32_t act, float* dbias, int64_t npix,
-                int32_t C, pmf_stream_t s);
+/* g *= act'(a) in place for convs not followed by BN (salsanext.py:24-25,70-71); act NONE leaves g untouched.
+ * dbias_rows (optional): partial column sums of the result, [pmf_col_rows(npix, C)][dbias_ld] (see pmf_conv_wgrad). */
+int pmf_act_bwd(float* g, int32_t g_ldc, const float* a, int32_t a_ldc, int32_t act, float* dbias_rows,
+                int32_t dbias_ld, int64_t npix, int32_t C, pmf_stream_t s);
 /* AvgPool2d(3, stride 2, pad 1, count_include_pad) of view (salsanext.py:65,96) and its gradient */
 int pmf_avgpool3s2(const pmf_view_t* in, int32_t N, int32_t H, int32_t W, int32_t C, float* out, int32_t out_ldc,
                    pmf_stream_t s);

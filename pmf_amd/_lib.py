@@ -47,7 +47,9 @@ class WgradDesc(C.Structure):
                 ("tap_widx", C.c_int8 * (MAX_TAPS + 3)),
                 ("in_stride", C.c_int32), ("gather", C.c_int32), ("dz", C.c_void_p), ("dz_ldc", C.c_int32),
                 ("partial", C.c_void_p), ("nsplit", C.c_int32), ("dw_oihw", C.c_void_p),
-                ("Cin_real", C.c_int32), ("KHW", C.c_int32), ("accumulate", C.c_int32)]
+                ("Cin_real", C.c_int32), ("KHW", C.c_int32), ("accumulate", C.c_int32),
+                ("dbias_rows", C.c_void_p), ("dbias_nrows", C.c_int32), ("dbias_ld", C.c_int32),
+                ("dbias_out", C.c_void_p)]
 
 
 class View(C.Structure):
@@ -111,6 +113,10 @@ def lib():
     L.pmf_conv_wgrad_nsplit.argtypes = [C.POINTER(WgradDesc)]
     L.pmf_conv_wgrad_workspace.restype = C.c_int64
     L.pmf_conv_wgrad_workspace.argtypes = [C.POINTER(WgradDesc)]
+    L.pmf_conv_fwd_stat_rows.restype = C.c_int
+    L.pmf_conv_fwd_stat_rows.argtypes = [C.POINTER(ConvDesc)]
+    L.pmf_col_rows.restype = C.c_int
+    L.pmf_col_rows.argtypes = [C.c_int64, C.c_int32]
     L.pmf_pack_tile_ci.restype = C.c_int
     L.pmf_pack_tile_ci.argtypes = [C.c_int32, C.c_int32]
     L.pmf_pack_weights_batched.restype = C.c_int
@@ -131,7 +137,7 @@ def lib():
 
 EXPORTS = [
     "pmf_conv_fwd", "pmf_conv_wgrad", "pmf_conv_wgrad_workspace", "pmf_conv_wgrad_nsplit", "pmf_pack_tile_ci",
-    "pmf_pack_weights_batched", "pmf_bn_finalize", "pmf_bn_eval_affine", "pmf_bn_bwd_reduce", "pmf_bn_bwd_apply",
+    "pmf_pack_weights_batched", "pmf_conv_fwd_stat_rows", "pmf_col_rows", "pmf_bn_finalize", "pmf_bn_eval_affine", "pmf_bn_bwd_reduce", "pmf_bn_bwd_apply",
     "pmf_add_act", "pmf_add_act_bwd", "pmf_act_bwd", "pmf_avgpool3s2", "pmf_avgpool3s2_bwd", "pmf_maxpool3s2",
     "pmf_maxpool3s2_bwd", "pmf_bilinear2x", "pmf_bilinear2x_bwd", "pmf_pixel_shuffle2", "pmf_pixel_shuffle2_bwd",
     "pmf_fusion_gate", "pmf_fusion_gate_bwd", "pmf_global_mean", "pmf_global_mean_bwd", "pmf_colsum",

@@ -2,14 +2,28 @@
 // The normalisation itself never runs as a kernel: producers emit per-channel sum / sum-of-squares from their
 // epilogue and consumers apply scale/shift on load (see conv_fwd.hip).
 #include "common.h"
+#include <stdlib.h>
 
-__global__ void bn_finalize_k(const double* __restrict__ stats, float count, const float* __restrict__ gamma,
+// grid = C workgroups: workgroup c folds the nrows partial (sum, sumsq) rows of channel c in a fixed order
+__global__ void bn_finalize_k(const double* __restrict__ stats, int nrows, float count, const float* __restrict__ gamma,
                               const float* __restrict__ beta, float* running_mean, float* running_var, float momentum,
                               float eps, float* scale, float* shift, float* save_mean, float* save_invstd, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const double mean = stats[c] / (double)count;
-  double var = stats[C + c] / (double)count - mean * mean;
+  __shared__ double sh[2][256];
+  const int c = blockIdx.x;
+  double s1 = 0.0, s2 = 0.0;
+  for (int r = threadIdx.x; r < nrows; r += 256) {
+    s1 += stats[(size_t)r * 2 * C + c];
+    s2 += stats[(size_t)r * 2 * C + C + c];
+  }
+  sh[0][threadIdx.x] = s1; sh[1][threadIdx.x] = s2;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) { sh[0][threadIdx.x] += sh[0][threadIdx.x + o]; sh[1][threadIdx.x] += sh[1][threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x) return;
+  const double mean = sh[0][0] / (double)count;
+  double var = sh[1][0] / (double)count - mean * mean;
   if (var < 0.0) var = 0.0;
   const float invstd = (float)(1.0 / sqrt(var + (double)eps));
   const float sc = gamma[c] * invstd;
@@ -22,10 +36,10 @@ __global__ void bn_finalize_k(const double* __restrict__ stats, float count, con
     running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
   }
 }
-extern "C" int pmf_bn_finalize(const double* stats, float count, const float* gamma, const float* beta,
+extern "C" int pmf_bn_finalize(const double* stats, int32_t nrows, float count, const float* gamma, const float* beta,
                                float* running_mean, float* running_var, float momentum, float eps, float* scale,
                                float* shift, float* save_mean, float* save_invstd, int32_t C, pmf_stream_t s) {
-  hipLaunchKernelGGL(bn_finalize_k, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)s, stats, count, gamma, beta,
+  hipLaunchKernelGGL(bn_finalize_k, dim3(C), dim3(256), 0, (hipStream_t)s, stats, nrows, count, gamma, beta,
                      running_mean, running_var, momentum, eps, scale, shift, save_mean, save_invstd, C);
   PMF_LAUNCH_CHECK();
   return 0;
@@ -52,20 +66,26 @@ extern "C" int pmf_bn_eval_affine(const float* gamma, const float* beta, const f
 }
 
 // ---- backward -------------------------------------------------------------------------------------------
+// pass 1 (bn_bwd_reduce): per-workgroup partial rows of  sum gy  and  sum gy*(a - mean)   (float64, no atomics)
+// fold  (bn_bwd_fold):    rows -> dgamma, dbeta (+= into the gradient buffer) and the per-channel coefficients
+//                         coef[0][c] = gamma*invstd, coef[1][c] = invstd^2 * mean(gy*(a-mean)), coef[2][c] = mean(gy)
+// pass 2 (bn_bwd_apply):  dz = coef0 * ((gy - coef2) - (a - mean) * coef1) * act'(a); per-workgroup partial rows of
+//                         sum dz (the conv-bias gradient) for the weight-gradient kernel to fold
 __device__ __forceinline__ int qgmax(int Q) { return Q < 256 ? Q : 256; }
 struct ColL { dim3 grid, block; };
 static ColL col_l(int64_t npix, int Q) {
   int Qg = Q < 256 ? Q : 256, rows = 256 / Qg;
-  int64_t gx = cdiv64(npix, (int64_t)rows * 8);
-  gx = gx > 1024 ? 1024 : (gx < 1 ? 1 : gx);
+  int64_t gx = cdiv64(npix, (int64_t)rows * 4);
+  gx = gx > PMF_COL_ROWS ? PMF_COL_ROWS : (gx < 1 ? 1 : gx);
   ColL L;
   L.grid = dim3((unsigned)gx, (unsigned)cdiv(Q, 256), 1);
   L.block = dim3(rows * Qg);
   return L;
 }
+extern "C" int pmf_col_rows(int64_t npix, int32_t C) { return (int)col_l(npix, C / 4).grid.x; }
 
 __global__ void bn_bwd_reduce_k(const float* __restrict__ gy, int gy_ldc, const float* __restrict__ a, int a_ldc,
-                                int64_t npix, int Q, int C, const float* __restrict__ save_mean, double* red) {
+                                int64_t npix, int Q, int C, const float* __restrict__ save_mean, double* part) {
   __shared__ double sh[2][256][4];
   const int Qm = qgmax(Q), Qg = min(Q - (int)blockIdx.y * 256, 256), rows = 256 / Qm;
   const int row = threadIdx.x / Qm, cql = threadIdx.x - row * Qm;
@@ -88,24 +108,53 @@ __global__ void bn_bwd_reduce_k(const float* __restrict__ gy, int gy_ldc, const 
     for (int r = 1; r < rows; ++r)
 #pragma unroll
       for (int k = 0; k < 4; ++k) { s1[k] += sh[0][r * Qm + cql][k]; s2[k] += sh[1][r * Qm + cql][k]; }
+    double* prow = part + (size_t)blockIdx.x * 2 * C;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { atomicAdd(red + c + k, s1[k]); atomicAdd(red + C + c + k, s2[k]); }
+    for (int k = 0; k < 4; ++k) { prow[c + k] = s1[k]; prow[C + c + k] = s2[k]; }
   }
 }
+
+__global__ void bn_bwd_fold_k(const double* __restrict__ part, int nrows, int C, float invM, int train,
+                              const float* __restrict__ gamma, const float* __restrict__ save_invstd, float* coef,
+                              float* dgamma, float* dbeta) {
+  __shared__ double sh[2][64];
+  const int c = blockIdx.x;
+  double s1 = 0.0, s2 = 0.0;
+  for (int r = threadIdx.x; r < nrows; r += 64) { s1 += part[(size_t)r * 2 * C + c]; s2 += part[(size_t)r * 2 * C + C + c]; }
+  sh[0][threadIdx.x] = s1; sh[1][threadIdx.x] = s2;
+  __syncthreads();
+  for (int o = 32; o > 0; o >>= 1) {
+    if (threadIdx.x < o) { sh[0][threadIdx.x] += sh[0][threadIdx.x + o]; sh[1][threadIdx.x] += sh[1][threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x) return;
+  const float sg = (float)sh[0][0], sgc = (float)sh[1][0], r = save_invstd[c], g = gamma[c];
+  const float dgam = r * sgc;
+  dgamma[c] += dgam;
+  dbeta[c] += sg;
+  coef[c] = g * r;
+  coef[C + c] = train ? r * dgam * invM : 0.f;
+  coef[2 * C + c] = train ? sg * invM : 0.f;
+}
+
 extern "C" int pmf_bn_bwd_reduce(const float* gy, int32_t gy_ldc, const float* a, int32_t a_ldc, int64_t npix,
-                                 int32_t C, const float* save_mean, double* red, pmf_stream_t s) {
+                                 int32_t C, const float* save_mean, const float* gamma, const float* save_invstd,
+                                 int32_t train, double* part, float* coef, float* dgamma, float* dbeta,
+                                 pmf_stream_t s) {
   if (C % 4) return PMF_E_ARG;
   ColL L = col_l(npix, C / 4);
-  hipLaunchKernelGGL(bn_bwd_reduce_k, L.grid, L.block, 0, (hipStream_t)s, gy, gy_ldc, a, a_ldc, npix, C / 4, C, save_mean, red);
+  hipLaunchKernelGGL(bn_bwd_reduce_k, L.grid, L.block, 0, (hipStream_t)s, gy, gy_ldc, a, a_ldc, npix, C / 4, C, save_mean,
+                     part);
+  hipLaunchKernelGGL(bn_bwd_fold_k, dim3(C), dim3(64), 0, (hipStream_t)s, (const double*)part, (int)L.grid.x, C,
+                     1.f / (float)npix, train, gamma, save_invstd, coef, dgamma, dbeta);
   PMF_LAUNCH_CHECK();
   return 0;
 }
 
 __global__ void bn_bwd_apply_k(const float* __restrict__ gy, int gy_ldc, const float* __restrict__ a, int a_ldc,
-                               int64_t npix, int Q, int C, const double* __restrict__ red,
-                               const float* __restrict__ gamma, const float* __restrict__ save_mean,
-                               const float* __restrict__ save_invstd, int act, int train, float* __restrict__ dz,
-                               int dz_ldc, float* dgamma, float* dbeta, float* dbias) {
+                               int64_t npix, int Q, int C, const float* __restrict__ coef,
+                               const float* __restrict__ save_mean, int act, float* __restrict__ dz, int dz_ldc,
+                               float* dbias_rows, int dbias_ld) {
   __shared__ f32x4 sh[256];
   const int Qm = qgmax(Q), Qg = min(Q - (int)blockIdx.y * 256, 256), rows = 256 / Qm;
   const int row = threadIdx.x / Qm, cql = threadIdx.x - row * Qm;
@@ -113,30 +162,14 @@ __global__ void bn_bwd_apply_k(const float* __restrict__ gy, int gy_ldc, const f
   const int c = ((int)blockIdx.y * 256 + cql) * 4;
   f32x4 part = {0.f, 0.f, 0.f, 0.f};
   if (active) {
-    // dz = A * ((gy - mean(gy)) - (a - mean) * K) * act'(a), K = invstd^2 * mean(gy*(a-mean)): differences of
-    // nearby float32 values first (exact), scaling last -- the same conditioning as PyTorch's CPU kernel
-    f32x4 A, B, Cc, MU;   // B = K, Cc = mean(gy)
-    const float invM = 1.f / (float)npix;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float g = gamma[c + k], r = save_invstd[c + k], mu = save_mean[c + k];
-      const float sg = (float)red[c + k], sgc = (float)red[C + c + k];
-      const float dgam = r * sgc;
-      MU[k] = mu;
-      if (train) {
-        A[k] = g * r;
-        B[k] = r * dgam * invM;
-        Cc[k] = sg * invM;
-      } else {
-        A[k] = g * r; B[k] = 0.f; Cc[k] = 0.f;
-      }
-      if (blockIdx.x == 0 && row == 0) { dgamma[c + k] += dgam; dbeta[c + k] += sg; }
-    }
+    // differences of nearby float32 values first (exact), scaling last -- PyTorch's conditioning
+    const f32x4 A = *(const f32x4*)(coef + c), K = *(const f32x4*)(coef + C + c), MG = *(const f32x4*)(coef + 2 * C + c);
+    const f32x4 MU = *(const f32x4*)(save_mean + c);
     const float sl = act == PMF_ACT_LRELU ? 0.01f : (act == PMF_ACT_RELU ? 0.f : 1.f);
     for (int64_t p = (int64_t)blockIdx.x * rows + row; p < npix; p += (int64_t)gridDim.x * rows) {
       const f32x4 g = *(const f32x4*)(gy + p * gy_ldc + c);
       const f32x4 x = *(const f32x4*)(a + p * a_ldc + c);
-      f32x4 d = A * ((g - Cc) - (x - MU) * B);
+      f32x4 d = A * ((g - MG) - (x - MU) * K);
       if (act != PMF_ACT_NONE) {
         d.x *= x.x > 0.f ? 1.f : sl; d.y *= x.y > 0.f ? 1.f : sl; d.z *= x.z > 0.f ? 1.f : sl; d.w *= x.w > 0.f ? 1.f : sl;
       }
@@ -144,24 +177,22 @@ __global__ void bn_bwd_apply_k(const float* __restrict__ gy, int gy_ldc, const f
       part += d;
     }
   }
-  if (dbias) {
+  if (dbias_rows) {
     sh[row * Qm + cql] = part;
     __syncthreads();
     if (row == 0 && active) {
       for (int r = 1; r < rows; ++r) part += sh[r * Qm + cql];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) atomicAdd(dbias + c + k, part[k]);
+      *(f32x4*)(dbias_rows + (size_t)blockIdx.x * dbias_ld + c) = part;
     }
   }
 }
 extern "C" int pmf_bn_bwd_apply(const float* gy, int32_t gy_ldc, const float* a, int32_t a_ldc, int64_t npix,
-                                int32_t C, const double* red, const float* gamma, const float* save_mean,
-                                const float* save_invstd, int32_t act, int32_t train, float* dz, int32_t dz_ldc,
-                                float* dgamma, float* dbeta, float* dbias, pmf_stream_t s) {
+                                int32_t C, const float* coef, const float* save_mean, int32_t act, float* dz,
+                                int32_t dz_ldc, float* dbias_rows, int32_t dbias_ld, pmf_stream_t s) {
   if (C % 4) return PMF_E_ARG;
   ColL L = col_l(npix, C / 4);
-  hipLaunchKernelGGL(bn_bwd_apply_k, L.grid, L.block, 0, (hipStream_t)s, gy, gy_ldc, a, a_ldc, npix, C / 4, C, red, gamma,
-                     save_mean, save_invstd, act, train, dz, dz_ldc, dgamma, dbeta, dbias);
+  hipLaunchKernelGGL(bn_bwd_apply_k, L.grid, L.block, 0, (hipStream_t)s, gy, gy_ldc, a, a_ldc, npix, C / 4, C, coef,
+                     save_mean, act, dz, dz_ldc, dbias_rows, dbias_ld);
   PMF_LAUNCH_CHECK();
   return 0;
 }

@@ -13,6 +13,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
     if (e_ != hipSuccess) return (int)e_;          \
   } while (0)
 
+#define PMF_COL_ROWS 512   // max partial rows written by the column-reduction kernels (one per workgroup)
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return cdiv(a, b) * b; }

@@ -210,8 +210,11 @@ __global__ __launch_bounds__(256) void conv_fwd_k(const pmf_conv_desc_t d, const
           a += red[((w * NT + u) * 32 + l) * 2 + 0];
           b += red[((w * NT + u) * 32 + l) * 2 + 1];
         }
-        atomicAdd(d.stats + co, a);   // native global f64 atomics
-        atomicAdd(d.stats + d.Cout + co, b);
+        // one partial row per (tile, sample): no atomics (contended f64 atomics cost ~80 us per launch); the
+        // BatchNorm finalize kernel folds the rows in a fixed order (deterministic)
+        double* row = d.stats + ((size_t)blockIdx.x + (size_t)gridDim.x * blockIdx.z) * 2 * d.Cout;
+        row[co] = a;
+        row[d.Cout + co] = b;
       }
     }
   }
@@ -262,9 +265,10 @@ __global__ void conv_finish_k(const pmf_conv_desc_t d, int ksplit, const float* 
       for (int r = 1; r < rows; ++r)
 #pragma unroll
         for (int k = 0; k < 4; ++k) { s1[k] += sh[0][r * Qm + cql][k]; s2[k] += sh[1][r * Qm + cql][k]; }
+      double* srow = d.stats + (size_t)blockIdx.x * 2 * d.Cout;
 #pragma unroll
       for (int k = 0; k < 4; ++k)
-        if (c + k < d.Cout) { atomicAdd(d.stats + c + k, s1[k]); atomicAdd(d.stats + d.Cout + c + k, s2[k]); }
+        if (c + k < d.Cout) { srow[c + k] = s1[k]; srow[d.Cout + c + k] = s2[k]; }
     }
   }
 }
@@ -303,6 +307,19 @@ int pmf_conv_geometry(int OH, int OW, int ntaps, const int8_t* tdy, const int8_t
     if (lds <= 150 * 1024 || gather) { *gather_out = gather; return lds; }
     gather = 1;
   }
+}
+
+static int finish_rows(const pmf_conv_desc_t* d) {
+  const int Q = round_up(d->Cout, 4) / 4, Qg = Q < 256 ? Q : 256, rows = 256 / Qg;
+  int64_t gx = cdiv64((int64_t)d->N * d->OH * d->OW, (int64_t)rows * 4);
+  return (int)(gx > 512 ? 512 : (gx < 1 ? 1 : gx));
+}
+
+static void conv_config(const pmf_conv_desc_t* d, int* BN, int* MT) {
+  *BN = d->Cout > 32 ? 64 : 32;
+  // enough workgroups to fill 256 CUs: fall back to 128-pixel tiles on small maps
+  const long px = (long)d->N * cdiv(d->OH, 8) * cdiv(d->OW, 32) * cdiv(d->Cout, *BN);
+  *MT = px >= 512 ? 2 : 1;
 }
 
 // split-K factor: only when the M x N grid cannot fill the 256 CUs (low-resolution, many-channel layers)
@@ -344,13 +361,27 @@ static int launch(const pmf_conv_desc_t* d, hipStream_t s) {
   PMF_LAUNCH_CHECK();
   if (g.ksplit > 1) {
     const int Q = g.ws_ld / 4, Qg = Q < 256 ? Q : 256, rows = 256 / Qg;
-    int64_t gx = cdiv64((int64_t)d->N * d->OH * d->OW, (int64_t)rows * 4);
-    gx = gx > 1024 ? 1024 : (gx < 1 ? 1 : gx);
+    const int gx = finish_rows(d);
     hipLaunchKernelGGL(conv_finish_k, dim3((unsigned)gx, (unsigned)cdiv(Q, 256), 1), dim3(rows * Qg), 0, s, dd, g.ksplit,
                        (const float*)g.ws, g.ws_ld, Q);
     PMF_LAUNCH_CHECK();
   }
   return 0;
+}
+
+// number of partial-statistics rows pmf_conv_fwd writes for this descriptor (stats must hold rows*2*Cout doubles)
+extern "C" int pmf_conv_fwd_stat_rows(const pmf_conv_desc_t* d) {
+  int BN, MT, gather, Ktot = 0, cmax = 0, nchunks = 0;
+  conv_config(d, &BN, &MT);
+  for (int i = 0; i < d->nsrc; ++i) {
+    Ktot += d->src[i].C; cmax = d->src[i].C > cmax ? d->src[i].C : cmax; nchunks += cdiv(d->src[i].C, KC);
+  }
+  ConvGeom g;
+  pmf_conv_geometry(d->OH, d->OW, d->ntaps, d->tdy, d->tdx, d->in_stride, d->gather, BN, MT, cmax < KC ? cmax : KC, &g,
+                    &gather);
+  const int tiles = g.tiles_x * g.tiles_y;
+  if (choose_ksplit(d, tiles * d->N * cdiv(d->Cout, BN), nchunks) > 1) return finish_rows(d);
+  return tiles * d->N;
 }
 
 extern "C" int pmf_conv_fwd(const pmf_conv_desc_t* d, pmf_stream_t st) {
@@ -359,10 +390,8 @@ extern "C" int pmf_conv_fwd(const pmf_conv_desc_t* d, pmf_stream_t st) {
   if (d->ldw % 4 || d->in_stride < 1 || d->in_stride > 2) return PMF_E_ARG;
   for (int i = 0; i < d->nsrc; ++i)
     if (d->src[i].C % 8 || d->src[i].ldc % 4) return PMF_E_ARG;
-  const int BN = d->Cout > 32 ? 64 : 32;
-  // enough workgroups to fill 256 CUs: fall back to 128-pixel tiles on small maps
-  const long px = (long)d->N * cdiv(d->OH, 8) * cdiv(d->OW, 32) * cdiv(d->Cout, BN);
-  const int MT = px >= 512 ? 2 : 1;
+  int BN, MT;
+  conv_config(d, &BN, &MT);
   if (BN == 64) return MT == 2 ? launch<64, 2>(d, s) : launch<64, 1>(d, s);
   return MT == 2 ? launch<32, 2>(d, s) : launch<32, 1>(d, s);
 }

@@ -169,6 +169,23 @@ __global__ void wgrad_reduce_k(const pmf_wgrad_desc_t d, int Ktot, int Cout32) {
     float* o = d.dw_oihw + ((size_t)co * d.Cin_real + k) * d.KHW + d.tap_widx[t];
     *o = d.accumulate ? *o + s : s;
   }
+  // conv-bias gradient: fold the partial column sums of dz left by the kernel that produced dz
+  // (one output channel per workgroup round, rows split over the threads, LDS tree)
+  if (d.dbias_rows) {
+    __shared__ float shb[256];
+    for (int co = blockIdx.x; co < d.Cout; co += gridDim.x) {
+      float s = 0.f;
+      for (int r = threadIdx.x; r < d.dbias_nrows; r += blockDim.x) s += d.dbias_rows[(size_t)r * d.dbias_ld + co];
+      shb[threadIdx.x] = s;
+      __syncthreads();
+      for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) shb[threadIdx.x] += shb[threadIdx.x + o];
+        __syncthreads();
+      }
+      if (threadIdx.x == 0) d.dbias_out[co] += shb[0];
+      __syncthreads();
+    }
+  }
 }
 
 static int wg_geometry(const pmf_wgrad_desc_t* d, int TB, int BN, WgGeom* g, int* lds) {

@@ -76,8 +76,8 @@ struct ColLaunch { dim3 grid, block; };
 static ColLaunch col_launch(int64_t npix, int Q, int nz) {
   int Qg = Q < 256 ? Q : 256;
   int rows = 256 / Qg;
-  int64_t gx = cdiv64(npix, (int64_t)rows * 8);
-  if (gx > 1024) gx = 1024;
+  int64_t gx = cdiv64(npix, (int64_t)rows * 4);   // same rule as bn.hip col_l / pmf_col_rows
+  if (gx > PMF_COL_ROWS) gx = PMF_COL_ROWS;
   if (gx < 1) gx = 1;
   ColLaunch L;
   L.grid = dim3((unsigned)gx, (unsigned)cdiv(Q, 256), (unsigned)nz);
@@ -105,9 +105,10 @@ __device__ __forceinline__ void col_fold_atomic(f32x4 part, float* dst, int c, i
   __syncthreads();
 }
 
-// g *= act'(a) in place, dbias += column sums
+// g *= act'(a) in place (act NONE: g untouched); per-workgroup partial column sums of the result go to
+// dbias_rows[blockIdx.x][*] (no atomics) for the weight-gradient kernel to fold into the conv-bias gradient
 __global__ void act_bwd_k(float* __restrict__ g, int g_ldc, const float* __restrict__ a, int a_ldc, int act,
-                          float* dbias, int64_t npix, int Q) {
+                          float* dbias_rows, int dbias_ld, int64_t npix, int Q) {
   __shared__ f32x4 sh[256];
   COL_SETUP(Q)
   f32x4 part = zero4();
@@ -122,13 +123,21 @@ __global__ void act_bwd_k(float* __restrict__ g, int g_ldc, const float* __restr
       }
       part += v;
     }
-  if (dbias) col_fold_atomic(part, dbias, c, row_, cql_, rows_, Qg_max_(Q), active_, sh);
+  if (dbias_rows) {
+    sh[row_ * Qg_max_(Q) + cql_] = part;
+    __syncthreads();
+    if (row_ == 0 && active_) {
+      for (int r = 1; r < rows_; ++r) part += sh[r * Qg_max_(Q) + cql_];
+      *(f32x4*)(dbias_rows + (size_t)blockIdx.x * dbias_ld + c) = part;
+    }
+  }
 }
-extern "C" int pmf_act_bwd(float* g, int32_t g_ldc, const float* a, int32_t a_ldc, int32_t act, float* dbias,
-                           int64_t npix, int32_t C, pmf_stream_t s) {
+extern "C" int pmf_act_bwd(float* g, int32_t g_ldc, const float* a, int32_t a_ldc, int32_t act, float* dbias_rows,
+                           int32_t dbias_ld, int64_t npix, int32_t C, pmf_stream_t s) {
   if (C % 4) return PMF_E_ARG;
   ColLaunch L = col_launch(npix, C / 4, 1);
-  hipLaunchKernelGGL(act_bwd_k, L.grid, L.block, 0, (hipStream_t)s, g, g_ldc, a, a_ldc, act, dbias, npix, C / 4);
+  hipLaunchKernelGGL(act_bwd_k, L.grid, L.block, 0, (hipStream_t)s, g, g_ldc, a, a_ldc, act, dbias_rows, dbias_ld, npix,
+                     C / 4);
   PMF_LAUNCH_CHECK();
   return 0;
 }

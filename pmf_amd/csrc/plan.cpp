@@ -14,27 +14,27 @@ static int run_one(const pmf_op_t& o, pmf_stream_t s) {
     case PMF_OP_WGRAD: return pmf_conv_wgrad(&o.u.wgrad, s);
     case PMF_OP_PACK:  // p0 jobs(dev)  i0 njobs  i1 total_blocks
       return pmf_pack_weights_batched((const pmf_pack_job_t*)a.p[0], i[0], i[1], s);
-    case PMF_OP_BN_FINALIZE:  // p: stats gamma beta rm rv scale shift save_mean save_invstd | f: count mom eps | i0 C
-      return pmf_bn_finalize((const double*)a.p[0], a.f[0], (const float*)a.p[1], (const float*)a.p[2], (float*)a.p[3],
-                             (float*)a.p[4], a.f[1], a.f[2], (float*)a.p[5], (float*)a.p[6], (float*)a.p[7],
-                             (float*)a.p[8], i[0], s);
+    case PMF_OP_BN_FINALIZE:  // p: stats gamma beta rm rv scale shift save_mean save_invstd | f: count mom eps | i: C nrows
+      return pmf_bn_finalize((const double*)a.p[0], i[1], a.f[0], (const float*)a.p[1], (const float*)a.p[2],
+                             (float*)a.p[3], (float*)a.p[4], a.f[1], a.f[2], (float*)a.p[5], (float*)a.p[6],
+                             (float*)a.p[7], (float*)a.p[8], i[0], s);
     case PMF_OP_BN_EVAL:  // p: gamma beta rm rv scale shift save_mean save_invstd | f0 eps | i0 C
       return pmf_bn_eval_affine((const float*)a.p[0], (const float*)a.p[1], (const float*)a.p[2], (const float*)a.p[3],
                                 a.f[0], (float*)a.p[4], (float*)a.p[5], (float*)a.p[6], (float*)a.p[7], i[0], s);
-    case PMF_OP_BN_BWD_REDUCE:  // p: gy a red save_mean | i: gy_ldc a_ldc C | l0 npix
+    case PMF_OP_BN_BWD_REDUCE:  // p: gy a save_mean gamma save_invstd part coef dgamma dbeta | i: gy_ldc a_ldc C train | l0 npix
       return pmf_bn_bwd_reduce((const float*)a.p[0], i[0], (const float*)a.p[1], i[1], a.l[0], i[2],
-                               (const float*)a.p[3], (double*)a.p[2], s);
-    case PMF_OP_BN_BWD_APPLY:  // p: gy a red gamma mean invstd dz dgamma dbeta dbias | i: gy_ldc a_ldc C act train dz_ldc
-      return pmf_bn_bwd_apply((const float*)a.p[0], i[0], (const float*)a.p[1], i[1], a.l[0], i[2], (const double*)a.p[2],
-                              (const float*)a.p[3], (const float*)a.p[4], (const float*)a.p[5], i[3], i[4],
-                              (float*)a.p[6], i[5], (float*)a.p[7], (float*)a.p[8], (float*)a.p[9], s);
+                               (const float*)a.p[2], (const float*)a.p[3], (const float*)a.p[4], i[3],
+                               (double*)a.p[5], (float*)a.p[6], (float*)a.p[7], (float*)a.p[8], s);
+    case PMF_OP_BN_BWD_APPLY:  // p: gy a coef save_mean dz dbias_rows | i: gy_ldc a_ldc C act dz_ldc dbias_ld | l0 npix
+      return pmf_bn_bwd_apply((const float*)a.p[0], i[0], (const float*)a.p[1], i[1], a.l[0], i[2], (const float*)a.p[2],
+                              (const float*)a.p[3], i[3], (float*)a.p[4], i[4], (float*)a.p[5], i[5], s);
     case PMF_OP_ADD_ACT:  // v0 a, v1 b | p0 out | i: act out_ldc HW has_b C | l0 npix
       return pmf_add_act(&a.v[0], i[3] ? &a.v[1] : nullptr, i[0], (float*)a.p[0], i[1], a.l[0], i[2], i[4], s);
     case PMF_OP_ADD_ACT_BWD:  // p: gout out ga gb | i: g_ldc out_ldc act ga_ldc ga_acc gb_ldc gb_acc C
       return pmf_add_act_bwd((const float*)a.p[0], i[0], (const float*)a.p[1], i[1], i[2], (float*)a.p[2], i[3], i[4],
                              (float*)a.p[3], i[5], i[6], a.l[0], i[7], s);
-    case PMF_OP_ACT_BWD:  // p: g a dbias | i: g_ldc a_ldc act C
-      return pmf_act_bwd((float*)a.p[0], i[0], (const float*)a.p[1], i[1], i[2], (float*)a.p[2], a.l[0], i[3], s);
+    case PMF_OP_ACT_BWD:  // p: g a dbias_rows | i: g_ldc a_ldc act C dbias_ld
+      return pmf_act_bwd((float*)a.p[0], i[0], (const float*)a.p[1], i[1], i[2], (float*)a.p[2], i[4], a.l[0], i[3], s);
     case PMF_OP_AVGPOOL:  // v0 | p0 out | i: N H W C out_ldc
       return pmf_avgpool3s2(&a.v[0], i[0], i[1], i[2], i[3], (float*)a.p[0], i[4], s);
     case PMF_OP_AVGPOOL_BWD:  // p: gout cmul gin | i: g_ldc N H W C cmul_ld gin_ldc acc

@@ -20,6 +20,9 @@ import torch
 from . import _lib as L
 
 _A = 256  # arena alignment (bytes)
+SPLITK_BYTES = 32 << 20      # shared split-K scratch
+DBIAS_LD = 2048              # floats per partial conv-bias-gradient row (max Cout)
+COL_ROWS = 512               # PMF_COL_ROWS in csrc/common.h
 
 
 def _ru(a, b):
@@ -118,6 +121,7 @@ class Plan:
         self.in_slots, self.out_slots = {}, {}
         self.tensors, self.views = {}, {}   # debug registry: name -> T / V
         self.meta_fwd, self.meta_bwd = {}, {}   # op index (before prologue shift) -> dict(family, flops)
+        self.colrows_max = 4
 
     # ------------------------------------------------------------------ parameter bookkeeping
     def pgrad(self, p):
@@ -215,19 +219,32 @@ class Plan:
         span = dil * (kh - 1)
         gather = 1 if (8 * stride + span) * (32 * stride + span) * 80 > 110 * 1024 else 0
         train_bn = bn is not None and self.training
-        stats = self.zero_fwd.alloc(16 * Cout) if train_bn else None   # float64 [2][Cout]
         has_bias = conv.bias is not None
         k_act = act if order == "act_bn" else L.ACT_NONE
 
-        def f(op, srcs=srcs):
-            d = op.u.conv
+        def shape_fill(d):
             d.N, d.OH, d.OW, d.Cout, d.nsrc = N, OH, OW, Cout, len(srcs)
             for i, s in enumerate(srcs):
-                self.src_struct(s, d.src[i])
+                d.src[i].C = _ru(s.t.C, 8)
+                d.src[i].ldc, d.src[i].H, d.src[i].W = s.t.ldc, s.t.H, s.t.W
             d.ntaps = len(taps)
             for i, (dy, dx, _) in enumerate(taps):
                 d.tdy[i], d.tdx[i] = dy, dx
             d.in_stride, d.gather = stride, gather
+            d.out_sy = d.out_sx = 1
+            d.splitk_ws, d.splitk_ws_bytes = 1, SPLITK_BYTES      # non-NULL: same split decision as the real launch
+        stat_rows = 0
+        if train_bn:
+            probe = L.ConvDesc()
+            shape_fill(probe)
+            stat_rows = L.lib().pmf_conv_fwd_stat_rows(C.byref(probe))
+        stats = self.act.alloc(16 * Cout * stat_rows) if train_bn else None   # float64 [rows][2][Cout] partials
+
+        def f(op, srcs=srcs):
+            d = op.u.conv
+            shape_fill(d)
+            for i, s in enumerate(srcs):
+                self.src_struct(s, d.src[i])
             d.w, d.ldw = wbuf.ptr, ldw
             d.bias = conv.bias.data_ptr() if has_bias else None
             d.act = k_act
@@ -254,7 +271,7 @@ class Plan:
                                            shift.ptr, smean.ptr, sinv.ptr)):
                         a.p[i] = p
                     a.f[0], a.f[1], a.f[2] = count, bn.momentum, bn.eps
-                    a.i[0] = Cb
+                    a.i[0], a.i[1] = Cb, stat_rows
                 self.emit(self.fwd, L.OP_BN_FINALIZE, fb)
             else:
                 def fb(op):
@@ -281,51 +298,46 @@ class Plan:
                 if out.g is None:
                     out.g = T(self, N, OH, OW, Cout, name + ".dz", ldc=out.ldc)
                 out.g_written = True
-                red = self.zero_bwd.alloc(16 * Cout)   # float64 [2][Cout]
+                coef = self.act.alloc(12 * Cout)                  # [3][Cout] per-channel backward coefficients
                 dgam, dbet = self.pgrad(bn.weight), self.pgrad(bn.bias)
-                dbias = self.pgrad(conv.bias) if has_bias else None
                 gyt, dz = view.gy, out.g
+                self.colrows_max = max(self.colrows_max, _ru(Cout, 4))
 
                 def r1(op):
                     a = op.u.sm
-                    a.p[0], a.p[1], a.p[2], a.p[3] = gyt.buf.ptr, out.buf.ptr, red.ptr, info["mean"].ptr
-                    a.i[0], a.i[1], a.i[2] = gyt.ldc, out.ldc, Cout
+                    ps = (gyt.buf.ptr, out.buf.ptr, info["mean"].ptr, bn.weight.data_ptr(), info["invstd"].ptr,
+                          self.bnpart_buf.ptr, coef.ptr, self.pgrad_buf.at(dgam), self.pgrad_buf.at(dbet))
+                    for i, p in enumerate(ps):
+                        a.p[i] = p
+                    a.i[0], a.i[1], a.i[2], a.i[3] = gyt.ldc, out.ldc, Cout, 1
                     a.l[0] = out.npix
                 self.emit(self.bwd, L.OP_BN_BWD_REDUCE, r1)
 
                 def r2(op):
                     a = op.u.sm
-                    ps = (gyt.buf.ptr, out.buf.ptr, red.ptr, bn.weight.data_ptr(), info["mean"].ptr,
-                          info["invstd"].ptr, dz.buf.ptr, self.pgrad_buf.at(dgam), self.pgrad_buf.at(dbet),
-                          self.pgrad_buf.at(dbias) if dbias is not None else None)
+                    ps = (gyt.buf.ptr, out.buf.ptr, coef.ptr, info["mean"].ptr, dz.buf.ptr,
+                          self.dbrows_buf.ptr if has_bias else None)
                     for i, p in enumerate(ps):
                         a.p[i] = p
-                    a.i[0], a.i[1], a.i[2] = gyt.ldc, out.ldc, Cout
-                    a.i[3] = k_act
-                    a.i[4], a.i[5] = 1, dz.ldc
+                    a.i[0], a.i[1], a.i[2], a.i[3], a.i[4], a.i[5] = gyt.ldc, out.ldc, Cout, k_act, dz.ldc, DBIAS_LD
                     a.l[0] = out.npix
                 self.emit(self.bwd, L.OP_BN_BWD_APPLY, r2)
+                dbias_rows = L.lib().pmf_col_rows(out.npix, Cout) if has_bias else 0
             else:
                 dz = self.tgrad(out)
-                dbias = self.pgrad(conv.bias) if has_bias else None
-                if k_act != L.ACT_NONE:
+                dbias_rows = 0
+                if k_act != L.ACT_NONE or has_bias:
                     def r3(op):
                         a = op.u.sm
                         a.p[0], a.p[1] = dz.buf.ptr, out.buf.ptr
-                        a.p[2] = self.pgrad_buf.at(dbias) if dbias is not None else None
-                        a.i[0], a.i[1], a.i[2], a.i[3] = dz.ldc, out.ldc, k_act, _ru(Cout, 4)
+                        a.p[2] = self.dbrows_buf.ptr if has_bias else None
+                        a.i[0], a.i[1], a.i[2], a.i[3], a.i[4] = dz.ldc, out.ldc, k_act, _ru(Cout, 4), DBIAS_LD
                         a.l[0] = out.npix
                     self.emit(self.bwd, L.OP_ACT_BWD, r3)
-                elif has_bias:
-                    def r4(op):
-                        a = op.u.sm
-                        a.p[0], a.p[1] = dz.buf.ptr, self.pgrad_buf.at(dbias)
-                        a.i[0], a.i[1], a.i[2] = dz.ldc, _ru(Cout, 4), 1
-                        a.l[0] = out.npix
-                    self.emit(self.bwd, L.OP_COLSUM, r4)
+                    dbias_rows = L.lib().pmf_col_rows(out.npix, _ru(Cout, 4)) if has_bias else 0
             dz = out.g
             self._dgrad(srcs, conv, dz, taps, stride, gather, name)
-            self._wgrad(srcs, conv, dz, taps, stride, gather, name)
+            self._wgrad(srcs, conv, dz, taps, stride, gather, name, dbias_rows)
         self.tape.append(backward)
         return view
 
@@ -412,7 +424,7 @@ class Plan:
                     self.emit(self.bwd, L.OP_COLSUM, fc)
             coloff += Cs
 
-    def _wgrad(self, srcs, conv, dz, taps, stride, gather, name):
+    def _wgrad(self, srcs, conv, dz, taps, stride, gather, name, dbias_rows=0):
         Cout = conv.out_channels
         goff = self.pgrad(conv.weight)
         kh, kw = conv.kernel_size
@@ -446,6 +458,10 @@ class Plan:
             d.nsplit = nsplit
             d.dw_oihw = self.pgrad_buf.at(goff)
             d.accumulate = 0
+            if dbias_rows:
+                d.dbias_rows, d.dbias_nrows, d.dbias_ld = self.dbrows_buf.ptr, dbias_rows, DBIAS_LD
+                d.dbias_out = self.pgrad_buf.at(boff)
+        boff = self.pgrad(conv.bias) if dbias_rows else None
         self.emit(self.bwd, L.OP_WGRAD, f)
         self.meta_bwd[len(self.bwd) - 1] = dict(
             family="conv_wgrad", flops=2.0 * dz.N * dz.H * dz.W * Cout * conv.in_channels * len(taps), name=name)
@@ -691,7 +707,9 @@ class Plan:
         self.tape = None
         self.pgrad_buf = self.zero_bwd.alloc(4 * max(self.pgrad_floats, 64)) if self.training else None
         self.wg_buf = self.act.alloc(max(self.wg_scratch, 256)) if self.training else None
-        self.sk_buf = self.act.alloc(32 << 20)    # shared split-K scratch (small maps only; ops run in stream order)
+        self.sk_buf = self.act.alloc(SPLITK_BYTES)   # shared split-K scratch (small maps only; ops run in stream order)
+        self.bnpart_buf = self.act.alloc(COL_ROWS * 2 * max(self.colrows_max, 4) * 8)   # float64 partial rows
+        self.dbrows_buf = self.act.alloc(COL_ROWS * DBIAS_LD * 4)
         for a, zero in ((self.act, False), (self.zero_fwd, True), (self.zero_bwd, True), (self.persist, True)):
             a.materialise(dev, zero)
         self.masks_ptr = self.masks.data_ptr() if self.masks is not None else 0

@@ -69,13 +69,16 @@ def test_conv_fwd_vs_torch_cpu(case):
     ldw = (Cout + 63) // 64 * 64
     wpk = G.pack_fwd(w, sum(cins), ldw)
     out = torch.zeros(N, OH, OW, (Cout + 7) // 8 * 8, device="cuda")
-    stats = torch.zeros(2 * Cout, device="cuda", dtype=torch.float64)
-    d = G.conv_desc(srcs, wpk, ldw, b.cuda(), out, N, OH, OW, Cout, G.taps_of(k, k, dil, pad), stride, act,
-                    stats=stats)
+    b_dev = b.cuda()   # keep alive: the descriptor only holds raw pointers
+    d = G.conv_desc(srcs, wpk, ldw, b_dev, out, N, OH, OW, Cout, G.taps_of(k, k, dil, pad), stride, act)
+    rows = lib.pmf_conv_fwd_stat_rows(C.byref(d))          # one partial (sum, sumsq) row per workgroup tile
+    stats = torch.full((rows, 2, Cout), float("nan"), device="cuda", dtype=torch.float64)
+    d.stats = stats.data_ptr()
     _sync_check(lib.pmf_conv_fwd(C.byref(d), G.stream()), "pmf_conv_fwd")
     got = G.from_nhwc(out, Cout)
     assert G.rel_err(got.numpy(), ref.numpy()) < 2e-5
-    st = stats.cpu().view(2, Cout)
+    st = stats.sum(0).cpu()
+    assert torch.isfinite(st).all()
     assert G.rel_err(st[0].numpy() / ref[0, 0].numel(), (ref.sum((0, 2, 3)) / ref[0, 0].numel()).numpy()) < 1e-3
     assert G.rel_err(st[1].numpy() / ref[0, 0].numel(), ((ref * ref).sum((0, 2, 3)) / ref[0, 0].numel()).numpy()) < 1e-3
 
