@@ -50,6 +50,13 @@ __global__ __launch_bounds__(256) void conv_fwd_k(const pmf_conv_desc_t d, const
 
   const int ngroups = d.gather ? d.ntaps : 1;
   int k_base = 0, chunk_no = 0;
+  // LDS offsets of the taps of one weight sub-stage, relative to the tile origin (gather mode: always 0).
+  // Read from the kernel arguments ONCE when all taps fit one sub-stage (every conv but the 7x7 stem).
+  int aoff[TAPG];
+  const bool aoff_static = !d.gather && d.ntaps <= TAPG;
+#pragma unroll
+  for (int t = 0; t < TAPG; ++t)
+    aoff[t] = (aoff_static && t < d.ntaps) ? (((int)d.tdy[t] - g.dy_min) * in_cols + ((int)d.tdx[t] - g.dx_min)) * APITCH : 0;
   for (int si = 0; si < d.nsrc; ++si) {
     const float* __restrict__ sx = d.src[si].x;
     const float* __restrict__ sscale = d.src[si].scale;
@@ -69,59 +76,110 @@ __global__ __launch_bounds__(256) void conv_fwd_k(const pmf_conv_desc_t d, const
         const int gy0 = d.gather ? (int)d.tdy[grp] : g.dy_min;
         const int gx0 = d.gather ? (int)d.tdx[grp] : g.dx_min;
         __syncthreads();
-        {  // ---- stage the input tile (with halo)
+        {  // ---- stage the input tile (with halo): issue a batch of independent global loads, then transform +
+           // write to LDS (a load -> wait -> store loop would expose one HBM round trip per 16 bytes)
+          constexpr int AB = 4;
           const int total = (g.in_rows * in_cols) << nql;
-          for (int f = tid; f < total; f += 256) {
-            const int pix = f >> nql, q = f & ((1 << nql) - 1);
-            const int r = pix / in_cols, c = pix - r * in_cols;
-            const int iy = oy0 * is + gy0 + r, ix = ox0 * is + gx0 + c;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (iy >= 0 && iy < sH && ix >= 0 && ix < sW) {
-              const size_t off = bc ? (size_t)n * sld + c0 + q * 4
-                                    : ((size_t)(n * sH + iy) * sW + ix) * sld + c0 + q * 4;
-              v = pmf_view_load4(sx, sscale, sshift, scm, sflags, off, c0 + q * 4);
+          const int q = tid & ((1 << nql) - 1);            // 256 % (float4 per pixel) == 0: q is loop-invariant
+          const int cch = c0 + q * 4;
+          f32x4 sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f}, cm4 = {1.f, 1.f, 1.f, 1.f};
+          if (sscale) { sc4 = *(const f32x4*)(sscale + cch); sh4 = *(const f32x4*)(sshift + cch); }
+          if (scm) cm4 = *(const f32x4*)(scm + cch);
+          for (int base = 0; base < total; base += 256 * AB) {
+            f32x4 v[AB];
+            bool ok[AB];
+#pragma unroll
+            for (int j = 0; j < AB; ++j) {
+              const int f = base + tid + 256 * j;
+              const int pix = f >> nql;
+              const int r = pix / in_cols, c = pix - r * in_cols;
+              const int iy = oy0 * is + gy0 + r, ix = ox0 * is + gx0 + c;
+              ok[j] = f < total && iy >= 0 && iy < sH && ix >= 0 && ix < sW;
+              if (ok[j]) {
+                const size_t off = bc ? (size_t)n * sld + cch : ((size_t)(n * sH + iy) * sW + ix) * sld + cch;
+                v[j] = *(const f32x4*)(sx + off);
+              }
             }
-            *(f32x4*)(As + pix * APITCH + q * 4) = v;
+#pragma unroll
+            for (int j = 0; j < AB; ++j) {
+              const int f = base + tid + 256 * j;
+              if (f < total) {
+                f32x4 t = {0.f, 0.f, 0.f, 0.f};
+                if (ok[j]) {
+                  t = v[j];
+                  if (sscale) t = t * sc4 + sh4;
+                  if (sflags & PMF_SRC_RELU) {
+                    t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f);
+                  }
+                  t = t * cm4;
+                }
+                *(f32x4*)(As + (f >> nql) * APITCH + q * 4) = t;
+              }
+            }
           }
         }
         for (int sub = 0; sub < gnt; sub += g.tap_group) {
           const int snt = min(g.tap_group, gnt - sub);
           if (sub) __syncthreads();
-          {  // ---- stage the weight slab [snt][kc][BN]
+          {  // ---- stage the weight slab [snt][kc][BN] (batched loads, as above)
             constexpr int rowq = BN / 4;
+            constexpr int BB = 5;
             const int totalB = snt * kc * rowq;
-            for (int f = tid; f < totalB; f += 256) {
-              const int row = f / rowq, q = f - row * rowq;
-              const int tl = row >> kcl, kk = row & (kc - 1);
-              const float* p = d.w + ((size_t)(gt0 + sub + tl) * g.Ktot + k_base + c0 + kk) * d.ldw + n0 + q * 4;
-              *(f32x4*)(Bs + (tl * kca + kk) * BN + q * 4) = *(const f32x4*)p;
+            for (int base = 0; base < totalB; base += 256 * BB) {
+              f32x4 v[BB];
+#pragma unroll
+              for (int j = 0; j < BB; ++j) {
+                const int f = base + tid + 256 * j;
+                if (f < totalB) {
+                  const int row = f / rowq, qq = f - row * rowq;
+                  const int tl = row >> kcl, kk = row & (kc - 1);
+                  v[j] = *(const f32x4*)(d.w + ((size_t)(gt0 + sub + tl) * g.Ktot + k_base + c0 + kk) * d.ldw + n0 + qq * 4);
+                }
+              }
+#pragma unroll
+              for (int j = 0; j < BB; ++j) {
+                const int f = base + tid + 256 * j;
+                if (f < totalB) {
+                  const int row = f / rowq, qq = f - row * rowq;
+                  const int tl = row >> kcl, kk = row & (kc - 1);
+                  *(f32x4*)(Bs + (tl * kca + kk) * BN + qq * 4) = v[j];
+                }
+              }
+            }
+          }
+          if (!aoff_static && !d.gather) {
+#pragma unroll
+            for (int t = 0; t < TAPG; ++t) {
+              const int tt = gt0 + sub + (t < snt ? t : 0);
+              aoff[t] = (((int)d.tdy[tt] - gy0) * in_cols + ((int)d.tdx[tt] - gx0)) * APITCH;
             }
           }
           __syncthreads();
-          for (int tl = 0; tl < snt; ++tl) {
-            const int t = gt0 + sub + tl;
-            const int ady = (int)d.tdy[t] - gy0, adx = (int)d.tdx[t] - gx0;
-            int abase[MT];
+          int abase[MT];
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
-              abase[m] = ((segrow[m] * is + ady) * in_cols + (segcol[m] * 32 + li) * is + adx) * APITCH + lh * 4;
-            const float* bp = Bs + (tl * kca + lh * 4) * BN + li;
-            for (int kg = 0; kg < kc; kg += 8) {
-              f32x4 a[MT];
+          for (int m = 0; m < MT; ++m)
+            abase[m] = ((segrow[m] * is) * in_cols + (segcol[m] * 32 + li) * is) * APITCH + lh * 4;
 #pragma unroll
-              for (int m = 0; m < MT; ++m) a[m] = *(const f32x4*)(As + abase[m] + kg);
-              float b[NT][4];
+          for (int tl = 0; tl < TAPG; ++tl) {
+            if (tl < snt) {
+              const float* bp = Bs + (tl * kca + lh * 4) * BN + li;
+              for (int kg = 0; kg < kc; kg += 8) {
+                f32x4 a[MT];
+                float b[NT][4];
 #pragma unroll
-              for (int u = 0; u < NT; ++u)
+                for (int m = 0; m < MT; ++m) a[m] = *(const f32x4*)(As + abase[m] + aoff[tl] + kg);
 #pragma unroll
-                for (int s = 0; s < 4; ++s) b[u][s] = bp[(kg + s) * BN + u * 32];
+                for (int u = 0; u < NT; ++u)
 #pragma unroll
-              for (int s = 0; s < 4; ++s)
+                  for (int s = 0; s < 4; ++s) b[u][s] = bp[(kg + s) * BN + u * 32];
 #pragma unroll
-                for (int m = 0; m < MT; ++m)
+                for (int s = 0; s < 4; ++s)
 #pragma unroll
-                  for (int u = 0; u < NT; ++u)
-                    acc[m][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][s], b[u][s], acc[m][u], 0, 0, 0);
+                  for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int u = 0; u < NT; ++u)
+                      acc[m][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][s], b[u][s], acc[m][u], 0, 0, 0);
+              }
             }
           }
         }

@@ -24,6 +24,61 @@ struct WgGeom {
   int co_tiles, tap_batches;
 };
 
+// one staged 4x32-pixel tile: NA accumulators (compile-time) share the B value of each pixel pair.
+// Operands of pixel pair kp+1 are fetched from LDS BEFORE the MFMAs of pair kp are issued (explicit double
+// buffer + sched_barrier), so the ~100-cycle ds_read latency hides under NA x 64 cycles of MFMA even with one
+// wave per SIMD; left alone, hipcc emits read -> wait -> mfma triplets through a single temporary register.
+template <int UPW, int NA, int BN>
+__device__ __forceinline__ void wg_tile(f32x16 (&acc)[UPW], const float* __restrict__ Xs, const float* __restrict__ zbase,
+                                        const int (&toff)[UPW], int li, int lh, int in_cols) {
+  constexpr int is = 1;                                  // stride-1 convolutions only (offsets fold into ds_read)
+  constexpr int xstep = 2 * is * WG_CI, zstep = 2 * BN;
+#pragma unroll 1
+  for (int row = 0; row < WG_ROWS; ++row) {
+    const float* xp = Xs + (row * is * in_cols) * WG_CI + li + lh * is * WG_CI;
+    const float* zp = zbase + (row * 32) * BN + lh * BN;
+    float ac[NA], an[NA], bc, bn;
+    bc = zp[0];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) ac[j] = xp[toff[j]];
+#pragma unroll
+    for (int kp = 0; kp < 16; ++kp) {
+      if (kp < 15) {
+        bn = zp[(kp + 1) * zstep];
+#pragma unroll
+        for (int j = 0; j < NA; ++j) an[j] = xp[(kp + 1) * xstep + toff[j]];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < NA; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[j], bc, acc[j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      bc = bn;
+#pragma unroll
+      for (int j = 0; j < NA; ++j) ac[j] = an[j];
+    }
+  }
+}
+// ragged tap batches (e.g. the last batch of the 49-tap stem): scalar guards
+template <int UPW>
+__device__ __forceinline__ void wg_tile_any(f32x16 (&acc)[UPW], const float* __restrict__ Xs,
+                                            const float* __restrict__ zbase, const int (&toff)[UPW], int nact, int li,
+                                            int lh, int is, int in_cols, int BN) {
+#pragma unroll 1
+  for (int row = 0; row < WG_ROWS; ++row) {
+    const float* xrow = Xs + (row * is * in_cols) * WG_CI + li;
+    const float* zrow = zbase + (row * 32) * BN;
+#pragma unroll 1
+    for (int kp = 0; kp < 16; ++kp) {
+      const int px = 2 * kp + lh;
+      const float b = zrow[px * BN];
+      const float* xp = xrow + px * is * WG_CI;
+#pragma unroll
+      for (int j = 0; j < UPW; ++j)
+        if (j < nact) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xp[toff[j]], b, acc[j], 0, 0, 0);
+    }
+  }
+}
+
 // Work decomposition inside a workgroup: the output slab [TB taps][32 ci][NT*32 co] is TB*NT MFMA tiles ("units",
 // u = tap*NT + co_tile).  Wave w owns units w, w+4, w+8, ... and walks EVERY pixel of the staged tile, so its
 // accumulators are final for the pixels it saw: no cross-wave reduction, and one staged tile feeds
@@ -36,7 +91,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_k(const pmf_wgrad_desc_t d, co
   constexpr int U = TB * NT, UPW = (U + 3) / 4;
   float* __restrict__ Xs = smem;
   float* __restrict__ Zs = smem + g.x_floats;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform (SGPR): unit bookkeeping stays scalar
   const int li = lane & 31, lh = lane >> 5;
   const int split = blockIdx.x, chunk = blockIdx.y;
   const int cot = blockIdx.z % g.co_tiles, tb = blockIdx.z / g.co_tiles;
@@ -74,13 +130,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_k(const pmf_wgrad_desc_t d, co
   const int gx0 = d.gather ? (int)d.tdx[t0] : g.dx_min;
   // this wave's units
   int toff[UPW];
-  bool uok[UPW];
+  int nact = 0;                // active units form a prefix j < nact (taps grow with j)
   const int myc = wave % NT;   // shared co tile of all units of this wave
 #pragma unroll
   for (int j = 0; j < UPW; ++j) {
     const int u = wave + 4 * j, t = u / NT;
-    uok[j] = u < U && t < nt;
-    const int tt = t0 + (uok[j] ? t : 0);
+    const bool ok = u < U && t < nt;
+    nact += ok ? 1 : 0;
+    const int tt = t0 + (ok ? t : 0);
     toff[j] = (((int)d.tdy[tt] - gy0) * g.in_cols + ((int)d.tdx[tt] - gx0)) * WG_CI;
   }
 
@@ -89,55 +146,82 @@ __global__ __launch_bounds__(256) void conv_wgrad_k(const pmf_wgrad_desc_t d, co
     const int oy0 = ty * WG_ROWS, ox0 = tx * 32;
     const float* __restrict__ scm = d.src[si].cmul ? d.src[si].cmul + (size_t)n * d.src[si].cmul_ld : nullptr;
     __syncthreads();
-    {  // stage X (zero-fill missing channels of a short chunk so stale LDS never reaches the MFMA)
+    {  // stage X: a batch of independent global loads first, transform + LDS write after (latency paid once per
+       // batch); missing channels of a short chunk are zero-filled so stale LDS never reaches the MFMA
+      constexpr int XB = 5;
       const int total = g.in_rows * g.in_cols * (WG_CI / 4);
-      for (int f = tid; f < total; f += 256) {
-        const int pix = f >> 3, q = f & 7;
-        const int r = pix / g.in_cols, c = pix - r * g.in_cols;
-        const int iy = oy0 * is + gy0 + r, ix = ox0 * is + gx0 + c;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (q < nq && iy >= 0 && iy < sH && ix >= 0 && ix < sW) {
-          const size_t off = bc ? (size_t)n * sld + c0 + q * 4 : ((size_t)(n * sH + iy) * sW + ix) * sld + c0 + q * 4;
-          v = pmf_view_load4(sx, sscale, sshift, scm, sflags, off, c0 + q * 4);
-        }
-        *(f32x4*)(Xs + pix * WG_CI + q * 4) = v;
-      }
-    }
-    {  // stage dz tile [4*32 pixels][BN]
-      constexpr int rq = BN / 4;
-      for (int f = tid; f < WG_ROWS * 32 * rq; f += 256) {
-        const int pix = f / rq, q = f - pix * rq;
-        const int oy = oy0 + (pix >> 5), ox = ox0 + (pix & 31);
-        const int co = co0 + q * 4;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (oy < d.OH && ox < d.OW && co < d.Cout) {
-          const float* p = d.dz + ((size_t)(n * d.OH + oy) * d.OW + ox) * d.dz_ldc + co;
-          if (co + 3 < d.Cout) v = *(const f32x4*)p;
-          else { v.x = p[0]; if (co + 1 < d.Cout) v.y = p[1]; if (co + 2 < d.Cout) v.z = p[2]; }
-        }
-        *(f32x4*)(Zs + pix * BN + q * 4) = v;
-      }
-    }
-    __syncthreads();
-    const float* zbase = Zs + myc * 32 + li;
-#pragma unroll 1
-    for (int row = 0; row < WG_ROWS; ++row) {
-      const float* xrow = Xs + (row * is * g.in_cols) * WG_CI + li;
-      const float* zrow = zbase + (row * 32) * BN;
-#pragma unroll 4
-      for (int kp = 0; kp < 16; ++kp) {
-        const int px = 2 * kp + lh;
-        const float b = zrow[px * BN];
-        const float* xp = xrow + px * is * WG_CI;
+      const int q = tid & 7, cch = c0 + q * 4;
+      const bool qok = q < nq;
+      f32x4 sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f}, cm4 = {1.f, 1.f, 1.f, 1.f};
+      if (qok && sscale) { sc4 = *(const f32x4*)(sscale + cch); sh4 = *(const f32x4*)(sshift + cch); }
+      if (qok && scm) cm4 = *(const f32x4*)(scm + cch);
+      for (int base = 0; base < total; base += 256 * XB) {
+        f32x4 v[XB];
+        bool ok[XB];
 #pragma unroll
-        for (int j = 0; j < UPW; ++j) {
-          if (uok[j]) {
-            const float a = xp[toff[j]];
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j], 0, 0, 0);
+        for (int j = 0; j < XB; ++j) {
+          const int f = base + tid + 256 * j;
+          const int pix = f >> 3;
+          const int r = pix / g.in_cols, c = pix - r * g.in_cols;
+          const int iy = oy0 * is + gy0 + r, ix = ox0 * is + gx0 + c;
+          ok[j] = f < total && qok && iy >= 0 && iy < sH && ix >= 0 && ix < sW;
+          if (ok[j]) {
+            const size_t off = bc ? (size_t)n * sld + cch : ((size_t)(n * sH + iy) * sW + ix) * sld + cch;
+            v[j] = *(const f32x4*)(sx + off);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < XB; ++j) {
+          const int f = base + tid + 256 * j;
+          if (f < total) {
+            f32x4 t = {0.f, 0.f, 0.f, 0.f};
+            if (ok[j]) {
+              t = v[j];
+              if (sscale) t = t * sc4 + sh4;
+              if (sflags & PMF_SRC_RELU) {
+                t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f);
+              }
+              t = t * cm4;
+            }
+            *(f32x4*)(Xs + (f >> 3) * WG_CI + q * 4) = t;
           }
         }
       }
     }
+    {  // stage dz tile [4*32 pixels][BN], batches of <= 8 independent loads
+      constexpr int rq = BN / 4;
+      constexpr int ZT = WG_ROWS * 32 * rq / 256, ZB = ZT < 4 ? ZT : 4;
+#pragma unroll
+      for (int zb = 0; zb < ZT; zb += ZB) {
+        f32x4 v[ZB];
+#pragma unroll
+        for (int j = 0; j < ZB; ++j) {
+          const int f = tid + 256 * (zb + j);
+          const int pix = f / rq, qq = f - pix * rq;
+          const int oy = oy0 + (pix >> 5), ox = ox0 + (pix & 31);
+          const int co = co0 + qq * 4;
+          f32x4 t = {0.f, 0.f, 0.f, 0.f};
+          if (oy < d.OH && ox < d.OW && co < d.Cout) {
+            const float* p = d.dz + ((size_t)(n * d.OH + oy) * d.OW + ox) * d.dz_ldc + co;
+            if (co + 3 < d.Cout) t = *(const f32x4*)p;
+            else { t.x = p[0]; if (co + 1 < d.Cout) t.y = p[1]; if (co + 2 < d.Cout) t.z = p[2]; }
+          }
+          v[j] = t;
+        }
+#pragma unroll
+        for (int j = 0; j < ZB; ++j) {
+          const int f = tid + 256 * (zb + j);
+          const int pix = f / rq, qq = f - pix * rq;
+          *(f32x4*)(Zs + pix * BN + qq * 4) = v[j];
+        }
+      }
+    }
+    __syncthreads();
+    const float* zbase = Zs + myc * 32 + li;
+    if (is == 1 && nact == UPW) wg_tile<UPW, UPW, BN>(acc, Xs, zbase, toff, li, lh, g.in_cols);
+    else if (is == 1 && nact == UPW - 1 && UPW > 1)
+      wg_tile<UPW, (UPW > 1 ? UPW - 1 : 1), BN>(acc, Xs, zbase, toff, li, lh, g.in_cols);
+    else wg_tile_any<UPW>(acc, Xs, zbase, toff, nact, li, lh, is, g.in_cols, BN);
   }
 
   // ---- every wave owns complete sums for its units: write them straight into the partial slab
@@ -145,7 +229,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_k(const pmf_wgrad_desc_t d, co
   const int co = co0 + myc * 32 + li;
 #pragma unroll
   for (int j = 0; j < UPW; ++j) {
-    if (!uok[j]) continue;
+    if (j >= nact) continue;
     const int t = (wave + 4 * j) / NT;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {

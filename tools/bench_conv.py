@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of single conv launches through the C ABI (forward kernel and weight gradient).
+usage: python tools/bench_conv.py [fwd|wgrad|all] [case-substring]"""
+import ctypes as C, sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from pmf_amd import _lib as L
+from tests import gpu_helpers as G
+lib = L.lib()
+CASES = [  # name, N, H, W, Cin, Cout, k, dil
+    ("full_32_32_3x3", 2, 64, 2048, 32, 32, 3, 1),
+    ("full_32_32_3x3d2", 2, 64, 2048, 32, 32, 3, 2),
+    ("full_64_64_3x3d2", 2, 64, 2048, 64, 64, 3, 2),
+    ("full_32_32_1x1", 2, 64, 2048, 32, 32, 1, 1),
+    ("half_64_64_3x3", 2, 32, 1024, 64, 64, 3, 1),
+    ("half_128_128_3x3d2", 2, 32, 1024, 128, 128, 3, 2),
+    ("quar_128_128_3x3", 2, 16, 512, 128, 128, 3, 1),
+    ("quar_256_256_3x3d2", 2, 16, 512, 256, 256, 3, 2),
+    ("8th_256_256_3x3", 2, 8, 256, 256, 256, 3, 1),
+    ("16th_512_512_3x3", 2, 4, 128, 512, 512, 3, 1),
+]
+def timeit(fn, n=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+def run(which, filt):
+    ws = torch.empty(32 << 20, dtype=torch.uint8, device="cuda")
+    for name, N, H, W, ci, co, k, dil in CASES:
+        if filt and filt not in name: continue
+        pad = dil * (k - 1) // 2
+        x = torch.randn(N, H, W, ci, device="cuda"); w = torch.randn(co, ci, k, k) * 0.05
+        ldw = (co + 63) // 64 * 64
+        wpk = G.pack_fwd(w, ci, ldw); out = torch.empty(N, H, W, co, device="cuda")
+        taps = G.taps_of(k, k, dil, pad)
+        gf = 2.0 * N * H * W * ci * co * k * k / 1e9
+        if which in ("fwd", "all"):
+            d = G.conv_desc([dict(x=x, C=ci)], wpk, ldw, None, out, N, H, W, co, taps, 1, 1)
+            d.splitk_ws, d.splitk_ws_bytes = ws.data_ptr(), ws.numel()
+            st = G.stream()
+            us = timeit(lambda: lib.pmf_conv_fwd(C.byref(d), st))
+            print("fwd   %-22s %8.1f us  %6.1f TF/s" % (name, us, gf / us * 1e3), flush=True)
+        if which in ("wgrad", "all"):
+            dz = torch.randn(N, H, W, co, device="cuda")
+            wd = L.WgradDesc()
+            wd.N, wd.OH, wd.OW, wd.Cout, wd.nsrc = N, H, W, co, 1
+            wd.src[0].x, wd.src[0].C, wd.src[0].ldc, wd.src[0].H, wd.src[0].W = x.data_ptr(), ci, ci, H, W
+            wd.ntaps = len(taps)
+            for i, (dy, dx) in enumerate(taps): wd.tdy[i], wd.tdx[i], wd.tap_widx[i] = dy, dx, i
+            wd.in_stride = 1; wd.dz, wd.dz_ldc = dz.data_ptr(), co
+            wd.nsplit = 1; wd.nsplit = lib.pmf_conv_wgrad_nsplit(C.byref(wd))
+            part = torch.empty(lib.pmf_conv_wgrad_workspace(C.byref(wd)), dtype=torch.uint8, device="cuda")
+            gw = torch.empty(co, ci, k, k, device="cuda")
+            wd.partial, wd.dw_oihw, wd.Cin_real, wd.KHW = part.data_ptr(), gw.data_ptr(), ci, k * k
+            st = G.stream()
+            us = timeit(lambda: lib.pmf_conv_wgrad(C.byref(wd), st))
+            print("wgrad %-22s %8.1f us  %6.1f TF/s  (nsplit %d)" % (name, us, gf / us * 1e3, wd.nsplit), flush=True)
+if __name__ == "__main__":
+    run(sys.argv[1] if len(sys.argv) > 1 else "all", sys.argv[2] if len(sys.argv) > 2 else "")
