@@ -240,18 +240,33 @@ __global__ __launch_bounds__(256) void conv_wgrad_k(const pmf_wgrad_desc_t d, co
 }
 
 // stage 2: dw_oihw[(co*Cin_real + k)*KHW + widx[t]] (+)= sum_s partial[s][t][k][co]
-__global__ void wgrad_reduce_k(const pmf_wgrad_desc_t d, int Ktot, int Cout32) {
+// 256 threads = 32 consecutive outputs x 8 split slices (independent, unrolled loads), folded through LDS in a
+// fixed order -> deterministic, and no thread walks hundreds of slabs serially.
+__global__ __launch_bounds__(256) void wgrad_reduce_k(const pmf_wgrad_desc_t d, int Ktot, int Cout32) {
+  __shared__ float shr[8][32];
   const int64_t total = (int64_t)d.ntaps * Ktot * Cout32;
   const int64_t slab = total;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int co = (int)(i % Cout32);
-    const int64_t r = i / Cout32;
-    const int k = (int)(r % Ktot), t = (int)(r / Ktot);
-    if (co >= d.Cout || k >= d.Cin_real) continue;
+  const int ol = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  for (int64_t base = (int64_t)blockIdx.x * 32; base < total; base += (int64_t)gridDim.x * 32) {
+    const int64_t i = base + ol;
     float s = 0.f;
-    for (int sp = 0; sp < d.nsplit; ++sp) s += d.partial[sp * slab + i];
-    float* o = d.dw_oihw + ((size_t)co * d.Cin_real + k) * d.KHW + d.tap_widx[t];
-    *o = d.accumulate ? *o + s : s;
+    if (i < total) {
+#pragma unroll 8
+      for (int sp = sl; sp < d.nsplit; sp += 8) s += d.partial[sp * slab + i];
+    }
+    shr[sl][ol] = s;
+    __syncthreads();
+    if (sl == 0 && i < total) {
+      s = ((shr[0][ol] + shr[1][ol]) + (shr[2][ol] + shr[3][ol])) + ((shr[4][ol] + shr[5][ol]) + (shr[6][ol] + shr[7][ol]));
+      const int co = (int)(i % Cout32);
+      const int64_t r = i / Cout32;
+      const int k = (int)(r % Ktot), t = (int)(r / Ktot);
+      if (co < d.Cout && k < d.Cin_real) {
+        float* o = d.dw_oihw + ((size_t)co * d.Cin_real + k) * d.KHW + d.tap_widx[t];
+        *o = d.accumulate ? *o + s : s;
+      }
+    }
+    __syncthreads();
   }
   // conv-bias gradient: fold the partial column sums of dz left by the kernel that produced dz
   // (one output channel per workgroup round, rows split over the threads, LDS tree)
@@ -337,8 +352,8 @@ static int wg_launch(const pmf_wgrad_desc_t* d, hipStream_t s) {
   hipLaunchKernelGGL((conv_wgrad_k<TB, NT>), grid, dim3(256), lds, s, *d, g);
   PMF_LAUNCH_CHECK();
   const int64_t total = (int64_t)d->ntaps * g.Ktot * g.Cout32;
-  int gb = (int)cdiv64(total, 256);
-  hipLaunchKernelGGL(wgrad_reduce_k, dim3(gb > 2048 ? 2048 : gb), dim3(256), 0, s, *d, g.Ktot, g.Cout32);
+  int gb = (int)cdiv64(total, 32);
+  hipLaunchKernelGGL(wgrad_reduce_k, dim3(gb > 4096 ? 4096 : gb), dim3(256), 0, s, *d, g.Ktot, g.Cout32);
   PMF_LAUNCH_CHECK();
   return 0;
 }
