@@ -32,3 +32,31 @@ def test_lovasz_edge_cases():
     assert out.item() == 0 and p.grad.abs().max() == 0
     lab = torch.full((1, 4, 4), 3, dtype=torch.long)              # single present class
     assert torch.isfinite(lov(p, lab))
+
+
+def test_engine_two_steps_match_reference_trace(golden):
+    """G7: TrainEngine (AdamW lidar / SGD-Nesterov camera grouping, loss weights) against two optimisation steps driven
+    with the reference's modules (tests/golden/g7_trace.npz); the CPU oracle network stands in for the HIP model."""
+    from oracle import pmf_torch as O
+    from pmf_amd.engine import TrainEngine
+    from pmf_amd.utils.detinit import deterministic_init
+    g = golden("g7_trace")
+    m = deterministic_init(O.PMFNet(5, 3, 20, 32, False, "resnet34"))
+    for x in m.modules():
+        if isinstance(x, O.DropSite):
+            x.p = 0.0
+    alpha = np.linspace(0.2, 1.0, 20).astype(np.float32)
+    alpha[0] = 0
+    eng = TrainEngine(m, 20, lr=1e-3, momentum=0.9, weight_decay=1e-5, alpha=alpha, warmup_steps=1, max_steps=10 ** 9)
+    pcd, rgb, label, mask = synthetic_batch(1, 64, 512, 20, seed=1)
+    feat = torch.cat((pcd, rgb), 1)
+    vals = []
+    for _ in range(2):
+        total, t = eng.train_step(feat.clone(), torch.ones_like(mask), label)
+        vals.append([total.item()] + [t[k].item() for k in ("foc", "lov", "foc_cam", "lov_cam", "per")])
+    assert np.abs(np.array(vals) - g["trace.losses"]).max() < 5e-4 * np.abs(g["trace.losses"]).max()
+    sd = m.state_dict()
+    for k in [k for k in g.files if k.startswith("trace.param.")]:
+        name = k[len("trace.param."):]
+        got = np.array([sd[name].double().sum().item(), sd[name].double().abs().sum().item()])
+        assert np.abs(got - g[k]).max() <= 1e-3 * max(np.abs(g[k]).max(), 1e-3), name
