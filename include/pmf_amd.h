@@ -244,6 +244,14 @@ int pmf_project_scatter(const float* points, const int32_t* sem, int64_t P, cons
 int pmf_crop_pad(const float* src, int32_t C, int32_t h, int32_t w, int32_t top, int32_t left, float* dst,
                  int32_t oh, int32_t ow, int32_t pad_top, int32_t pad_left, int32_t ch, int32_t cw, pmf_stream_t s);
 
+/* ---- loss-side kernels ------------------------------------------------------------------------------------ */
+/* Lovasz-softmax Jaccard gradient (pc_processor/loss/lovasz_softmax.py:56-68) for C class rows at once.
+ * fg_sorted f32[C][P]: 0/1 foreground indicator, each row ordered by DESCENDING error with ignored pixels last;
+ * n_valid: device int64, number of non-ignored pixels; bsum: f32[C][ceil(P/4096)] scratch.
+ * grad[c][i] = jaccard_i - jaccard_{i-1}, jaccard_i = 1 - (G - cumsum(fg)_i) / (G + cumsum(1-fg)_i); 0 for i >= n_valid. */
+int pmf_lovasz_grad(const float* fg_sorted, int32_t C, int64_t P, const int64_t* n_valid, float* bsum, float* grad,
+                    pmf_stream_t s);
+
 /* ---- plan executor: a whole forward (or backward) pass = one call --------------------------------------- */
 enum {
   PMF_OP_CONV = 1, PMF_OP_WGRAD, PMF_OP_PACK, PMF_OP_BN_FINALIZE, PMF_OP_BN_EVAL, PMF_OP_BN_BWD_REDUCE,

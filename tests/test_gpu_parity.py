@@ -309,3 +309,34 @@ def test_projection_scatter_exact(tag, seed, npts, h, w, golden):
     for (oh, ow, hp, wp) in ((h - 8, w - 16, 3, 5), (h + 14, w + 6, 7, 3)):
         got = center_crop_pad_gpu(proj, oh, ow, hp, wp).cpu().numpy()
         np.testing.assert_array_equal(got, loader_ref.center_crop_pad(rp, oh, ow, hp, wp))
+
+
+# ---------------------------------------------------------------------------------------------- losses
+def test_losses_gpu_match_cpu_and_fixture(golden):
+    """product loss modules on the GPU (incl. the HIP Lovasz Jaccard-gradient kernel) vs the same ops on CPU and the
+    reference-run fixture: values and gradients w.r.t. the logits."""
+    from pmf_amd.loss import FocalSoftmaxLoss, Lovasz_softmax, pmf_total_loss
+    g = golden("g6_losses")
+    n, c, h, w = 2, 20, 16, 32
+    a0, b0 = det_tensor("g6.logits", (n, c, h, w), -3, 3), det_tensor("g6.logits2", (n, c, h, w), -3, 3)
+    _, _, label, _ = synthetic_batch(n, h, w, c, seed=3, fill=0.4)
+    alpha = np.linspace(0.2, 1.0, c).astype(np.float32)
+    alpha[0] = 0
+    a, b = a0.cuda().requires_grad_(True), b0.cuda().requires_grad_(True)
+    foc, lov = FocalSoftmaxLoss(c, gamma=2, alpha=alpha, softmax=False).cuda(), Lovasz_softmax(ignore=0)
+    total, t = pmf_total_loss(torch.softmax(a, 1), torch.softmax(b, 1), label.cuda(), foc, lov)
+    total.backward()
+    vals = np.array([total.item()] + [t[k].item() for k in ("foc", "lov", "foc_cam", "lov_cam", "per")])
+    assert np.abs(vals - g["loss.values"]).max() < 5e-6
+    assert np.abs(a.grad.cpu().numpy() - g["loss.grad_a"]).max() < 5e-7
+    assert np.abs(b.grad.cpu().numpy() - g["loss.grad_b"]).max() < 5e-7
+    # bench-size row lengths (262144 pixels): HIP Jaccard gradient vs the torch formula
+    from pmf_amd.loss.lovasz_softmax import _jaccard_grad
+    torch.manual_seed(0)
+    fg = (torch.rand(20, 262144) < 0.07).float()
+    nvalid = 200000
+    nv = (torch.arange(262144) < nvalid).float()[None].expand(20, -1)
+    fg = fg * nv
+    ref = _jaccard_grad(fg, nv, torch.tensor(nvalid))
+    got = _jaccard_grad(fg.cuda(), nv.cuda(), torch.tensor(nvalid).cuda()).cpu()
+    assert (got - ref).abs().max() < 1e-6
