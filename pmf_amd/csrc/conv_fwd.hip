@@ -16,7 +16,158 @@
 #define APITCH 20
 #define TAPG 9
 
+// NTAPS taps x 16 channels of one staged chunk, fully unrolled and branch-free.  The LDS operands of step i+1 (one
+// ds_read_b128 per M tile + 4 ds_read_b32 per N tile) are issued BEFORE the 4*MT*NT MFMAs of step i (explicit double
+// buffer + sched_barrier): left alone hipcc emits read -> wait -> 2 mfma groups, four exposed LDS round trips per step.
+template <int BN, int MT, int NTAPS>
+__device__ __forceinline__ void conv_steps(f32x16 (&acc)[MT][BN / 32], const float* __restrict__ As,
+                                           const float* __restrict__ Bs, const int (&abase)[MT],
+                                           const int (&aoff)[TAPG], int kca, int li, int lh) {
+  constexpr int NT = BN / 32, NS = NTAPS * 2;
+  f32x4 a[2][MT];
+  float b[2][NT][4];
+  const float* bp0 = Bs + (lh * 4) * BN + li;
+#pragma unroll
+  for (int m = 0; m < MT; ++m) a[0][m] = *(const f32x4*)(As + abase[m] + aoff[0]);
+#pragma unroll
+  for (int u = 0; u < NT; ++u)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) b[0][u][q] = bp0[q * BN + u * 32];
+#pragma unroll
+  for (int st = 0; st < NS; ++st) {
+    const int cur = st & 1, nxt = cur ^ 1;
+    if (st + 1 < NS) {
+      const int tl = (st + 1) >> 1, kg = ((st + 1) & 1) * 8;
+      const float* bp = bp0 + (tl * kca + kg) * BN;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) a[nxt][m] = *(const f32x4*)(As + abase[m] + aoff[tl] + kg);
+#pragma unroll
+      for (int u = 0; u < NT; ++u)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) b[nxt][u][q] = bp[q * BN + u * 32];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int u = 0; u < NT; ++u)
+          acc[m][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][m][q], b[cur][u][q], acc[m][u], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Software-pipelined K loop for the common case (host-checked, ConvGeom::simple): one LDS tile with halo shared by
+// all taps, ntaps in {1,4,9}, stride 1, every operand a multiple of 16 channels with the same H x W, no broadcast.
+//   * per-thread slot tables (global pixel offset / validity of every float4 this thread stages) are computed ONCE
+//     per workgroup -- the index arithmetic (divisions) leaves the chunk loop;
+//   * the global loads of chunk i+1 are issued into registers right after the barrier that publishes chunk i, so HBM
+//     / L2 latency runs under the MFMAs of chunk i; the staging phase shrinks to transform + ds_write.
 template <int BN, int MT>
+__device__ __forceinline__ void conv_kloop_pipe(const pmf_conv_desc_t& d, const ConvGeom& g, f32x16 (&acc)[MT][BN / 32],
+                                                float* __restrict__ As, float* __restrict__ Bs, const int (&segrow)[MT],
+                                                const int (&segcol)[MT], int tid, int li, int lh, int n, int n0, int ks,
+                                                int oy0, int ox0) {
+  constexpr int ASL = MT == 2 ? 7 : 4;                    // float4 slots per thread for the input tile
+  constexpr int rowq = BN / 4;
+  constexpr int BSL = (TAPG * KC * rowq + 255) / 256;     // ... and for the weight slab
+  const int in_cols = g.in_cols;
+  const int sH = d.src[0].H, sW = d.src[0].W;
+  const int q = tid & 3;
+  const int totalA = g.in_rows * in_cols * 4, totalB = d.ntaps * KC * rowq;
+  int gA[ASL];
+  unsigned okA = 0u;
+#pragma unroll
+  for (int j = 0; j < ASL; ++j) {
+    const int f = tid + 256 * j, pix = f >> 2;
+    const int r = pix / in_cols, c = pix - r * in_cols;
+    const int iy = oy0 + g.dy_min + r, ix = ox0 + g.dx_min + c;
+    const bool ok = f < totalA && iy >= 0 && iy < sH && ix >= 0 && ix < sW;
+    gA[j] = ok ? (n * sH + iy) * sW + ix : 0;
+    okA |= ok ? (1u << j) : 0u;
+  }
+  int gB[BSL];
+#pragma unroll
+  for (int j = 0; j < BSL; ++j) {
+    const int f = tid + 256 * j, row = f / rowq, qq = f - row * rowq;
+    gB[j] = ((row >> 4) * g.Ktot + (row & 15)) * d.ldw + qq * 4;
+  }
+  int aoff[TAPG];
+#pragma unroll
+  for (int t = 0; t < TAPG; ++t)
+    aoff[t] = t < d.ntaps ? (((int)d.tdy[t] - g.dy_min) * in_cols + ((int)d.tdx[t] - g.dx_min)) * APITCH : 0;
+  int abase[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) abase[m] = (segrow[m] * in_cols + segcol[m] * 32 + li) * APITCH + lh * 4;
+
+  // stage iterator over (operand, 16-channel chunk), split-K chunks dealt round-robin
+  int si = 0, c0 = 0, kb = 0, cn = 0;
+  auto settle = [&]() {   // move (si, c0) forward to the next chunk owned by this workgroup; false at the end
+    for (;;) {
+      if (si >= d.nsrc) return false;
+      if (c0 >= d.src[si].C) { kb += d.src[si].C; ++si; c0 = 0; continue; }
+      if ((cn % g.ksplit) == ks) return true;
+      ++cn; c0 += KC;
+    }
+  };
+  f32x4 rA[ASL], rB[BSL], sc4, sh4, cm4;
+  int cur_flags = 0;
+  bool cur_aff = false;
+  auto issue = [&]() {     // global loads of stage (si, c0) -> registers
+    const float* __restrict__ sx = d.src[si].x;
+    const int sld = d.src[si].ldc, cch = c0 + q * 4;
+    cur_flags = d.src[si].flags;
+    cur_aff = d.src[si].scale != nullptr;
+    sc4 = f32x4{1.f, 1.f, 1.f, 1.f}; sh4 = f32x4{0.f, 0.f, 0.f, 0.f}; cm4 = f32x4{1.f, 1.f, 1.f, 1.f};
+    if (cur_aff) { sc4 = *(const f32x4*)(d.src[si].scale + cch); sh4 = *(const f32x4*)(d.src[si].shift + cch); }
+    if (d.src[si].cmul) cm4 = *(const f32x4*)(d.src[si].cmul + (size_t)n * d.src[si].cmul_ld + cch);
+#pragma unroll
+    for (int j = 0; j < ASL; ++j)
+      if ((okA >> j) & 1u) rA[j] = *(const f32x4*)(sx + (size_t)gA[j] * sld + cch);
+    const float* wb = d.w + (size_t)(kb + c0) * d.ldw + n0;
+#pragma unroll
+    for (int j = 0; j < BSL; ++j)
+      if (tid + 256 * j < totalB) rB[j] = *(const f32x4*)(wb + gB[j]);
+  };
+  bool have = settle();
+  if (have) issue();
+  while (have) {
+    __syncthreads();                       // everyone finished reading the previous stage
+#pragma unroll
+    for (int j = 0; j < ASL; ++j) {
+      const int f = tid + 256 * j;
+      if (f < totalA) {
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+        if ((okA >> j) & 1u) {
+          t = rA[j];
+          if (cur_aff) t = t * sc4 + sh4;
+          if (cur_flags & PMF_SRC_RELU) {
+            t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f);
+          }
+          t = t * cm4;
+        }
+        *(f32x4*)(As + (f >> 2) * APITCH + q * 4) = t;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < BSL; ++j) {
+      const int f = tid + 256 * j;
+      if (f < totalB) *(f32x4*)(Bs + f * 4) = rB[j];
+    }
+    __syncthreads();
+    ++cn; c0 += KC;
+    have = settle();
+    if (have) issue();                      // next stage's loads fly under this stage's MFMAs
+    __builtin_amdgcn_sched_barrier(0);
+    if (d.ntaps == 9) conv_steps<BN, MT, 9>(acc, As, Bs, abase, aoff, KC, li, lh);
+    else if (d.ntaps == 4) conv_steps<BN, MT, 4>(acc, As, Bs, abase, aoff, KC, li, lh);
+    else conv_steps<BN, MT, 1>(acc, As, Bs, abase, aoff, KC, li, lh);
+  }
+}
+
+template <int BN, int MT, bool PIPE>
 __global__ __launch_bounds__(256) void conv_fwd_k(const pmf_conv_desc_t d, const ConvGeom g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* __restrict__ As = smem;
@@ -48,6 +199,9 @@ __global__ __launch_bounds__(256) void conv_fwd_k(const pmf_conv_desc_t d, const
     segcol[m] = s & ((1 << g.segs_x_log2) - 1);
   }
 
+  if constexpr (PIPE) {
+    conv_kloop_pipe<BN, MT>(d, g, acc, As, Bs, segrow, segcol, tid, li, lh, n, n0, ks, oy0, ox0);
+  } else {
   const int ngroups = d.gather ? d.ntaps : 1;
   int k_base = 0, chunk_no = 0;
   // LDS offsets of the taps of one weight sub-stage, relative to the tile origin (gather mode: always 0).
@@ -159,26 +313,31 @@ __global__ __launch_bounds__(256) void conv_fwd_k(const pmf_conv_desc_t d, const
 #pragma unroll
           for (int m = 0; m < MT; ++m)
             abase[m] = ((segrow[m] * is) * in_cols + (segcol[m] * 32 + li) * is) * APITCH + lh * 4;
+          if (kc == 16 && snt == 9) conv_steps<BN, MT, 9>(acc, As, Bs, abase, aoff, kca, li, lh);
+          else if (kc == 16 && snt == 4) conv_steps<BN, MT, 4>(acc, As, Bs, abase, aoff, kca, li, lh);
+          else if (kc == 16 && snt == 1) conv_steps<BN, MT, 1>(acc, As, Bs, abase, aoff, kca, li, lh);
+          else {   // ragged chunks (8 channels) / tap groups: plain loop
 #pragma unroll
-          for (int tl = 0; tl < TAPG; ++tl) {
-            if (tl < snt) {
-              const float* bp = Bs + (tl * kca + lh * 4) * BN + li;
-              for (int kg = 0; kg < kc; kg += 8) {
-                f32x4 a[MT];
-                float b[NT][4];
+            for (int tl = 0; tl < TAPG; ++tl) {
+              if (tl < snt) {
+                const float* bp = Bs + (tl * kca + lh * 4) * BN + li;
+                for (int kg = 0; kg < kc; kg += 8) {
+                  f32x4 a[MT];
+                  float b[NT][4];
 #pragma unroll
-                for (int m = 0; m < MT; ++m) a[m] = *(const f32x4*)(As + abase[m] + aoff[tl] + kg);
+                  for (int m = 0; m < MT; ++m) a[m] = *(const f32x4*)(As + abase[m] + aoff[tl] + kg);
 #pragma unroll
-                for (int u = 0; u < NT; ++u)
+                  for (int u = 0; u < NT; ++u)
 #pragma unroll
-                  for (int s = 0; s < 4; ++s) b[u][s] = bp[(kg + s) * BN + u * 32];
+                    for (int q4 = 0; q4 < 4; ++q4) b[u][q4] = bp[(kg + q4) * BN + u * 32];
 #pragma unroll
-                for (int s = 0; s < 4; ++s)
+                  for (int q4 = 0; q4 < 4; ++q4)
 #pragma unroll
-                  for (int m = 0; m < MT; ++m)
+                    for (int m = 0; m < MT; ++m)
 #pragma unroll
-                    for (int u = 0; u < NT; ++u)
-                      acc[m][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][s], b[u][s], acc[m][u], 0, 0, 0);
+                      for (int u = 0; u < NT; ++u)
+                        acc[m][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][q4], b[u][q4], acc[m][u], 0, 0, 0);
+                }
               }
             }
           }
@@ -187,6 +346,7 @@ __global__ __launch_bounds__(256) void conv_fwd_k(const pmf_conv_desc_t d, const
     }
     k_base += sC;
   }
+  }  // !PIPE
 
   // ---- epilogue
   if (g.ksplit > 1) {   // raw partial sums -> slab ks; bias / activation / statistics happen in conv_finish_k
@@ -391,6 +551,17 @@ static int choose_ksplit(const pmf_conv_desc_t* d, int blocks_mn, int nchunks) {
   return k < 2 ? 1 : k;
 }
 
+// the software-pipelined K loop applies when ...
+static bool conv_simple(const pmf_conv_desc_t* d, const ConvGeom& g, int gather, int MT) {
+  if (gather || d->in_stride != 1) return false;
+  if (d->ntaps != 1 && d->ntaps != 4 && d->ntaps != 9) return false;
+  for (int i = 0; i < d->nsrc; ++i) {
+    if (d->src[i].C % 16 || (d->src[i].flags & PMF_SRC_BCAST)) return false;
+    if (d->src[i].H != d->src[0].H || d->src[i].W != d->src[0].W) return false;
+  }
+  return g.in_rows * g.in_cols * 4 <= 256 * (MT == 2 ? 7 : 4);
+}
+
 template <int BN, int MT>
 static int launch(const pmf_conv_desc_t* d, hipStream_t s) {
   ConvGeom g;
@@ -407,7 +578,8 @@ static int launch(const pmf_conv_desc_t* d, hipStream_t s) {
   dd.gather = gather;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv_fwd_k<BN, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_fwd_k<BN, MT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_fwd_k<BN, MT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   const int co_tiles = cdiv(d->Cout, BN);
@@ -415,7 +587,12 @@ static int launch(const pmf_conv_desc_t* d, hipStream_t s) {
   g.ws = d->splitk_ws;
   g.ws_ld = round_up(d->Cout, 4);
   dim3 grid(g.tiles_x * g.tiles_y, co_tiles * g.ksplit, d->N);
-  hipLaunchKernelGGL((conv_fwd_k<BN, MT>), grid, dim3(256), lds, s, dd, g);
+  if (conv_simple(d, g, gather, MT)) {
+    g.kc_alloc = KC;   // the pipelined loop lays the weight slab out as [tap][16][BN]
+    hipLaunchKernelGGL((conv_fwd_k<BN, MT, true>), grid, dim3(256), lds, s, dd, g);
+  } else {
+    hipLaunchKernelGGL((conv_fwd_k<BN, MT, false>), grid, dim3(256), lds, s, dd, g);
+  }
   PMF_LAUNCH_CHECK();
   if (g.ksplit > 1) {
     const int Q = g.ws_ld / 4, Qg = Q < 256 ? Q : 256, rows = 256 / Qg;
