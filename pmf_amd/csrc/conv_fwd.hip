@@ -16,13 +16,44 @@
 #define APITCH 20
 #define TAPG 9
 
+// Phase tracing (tools/trace_conv.py builds a private copy of this file with -DPMF_CONV_TRACE): thread 0 of every
+// workgroup stamps s_memtime at phase boundaries.  Compiled out of libpmf_amd.so.
+#ifdef PMF_CONV_TRACE
+__device__ unsigned long long* pmf_trace_buf = nullptr;
+extern "C" int pmf_conv_trace_set(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(pmf_trace_buf), &p, sizeof(p)); }
+#define TR()                                                                                            \
+  do {                                                                                                  \
+    if (threadIdx.x == 0 && pmf_trace_buf && tri_ < 60)                                                 \
+      pmf_trace_buf[(size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 64 + tri_++] = \
+          __builtin_amdgcn_s_memtime();                                                                 \
+  } while (0)
+#define TR_END()                                                                                        \
+  do {                                                                                                  \
+    if (threadIdx.x == 0 && pmf_trace_buf) {                                                            \
+      unsigned long long* t_ = pmf_trace_buf + (size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 64; \
+      t_[59] = tr_w0_;                                                                                  \
+      t_[60] = wall_clock64();                                                                          \
+      t_[61] = __builtin_amdgcn_s_getreg(63508);                                                        \
+      t_[62] = __builtin_amdgcn_s_getreg(63492);                                                        \
+      t_[63] = tri_;                                                                                    \
+    }                                                                                                   \
+  } while (0)
+#define TR_START() const unsigned long long tr_w0_ = wall_clock64()
+#else
+#define TR_START() do { } while (0)
+#define TR() do { } while (0)
+#define TR_END() do { } while (0)
+#endif
+
 // NTAPS taps x 16 channels of one staged chunk, fully unrolled and branch-free.  The LDS operands of step i+1 (one
 // ds_read_b128 per M tile + 4 ds_read_b32 per N tile) are issued BEFORE the 4*MT*NT MFMAs of step i (explicit double
 // buffer + sched_barrier): left alone hipcc emits read -> wait -> 2 mfma groups, four exposed LDS round trips per step.
-template <int BN, int MT, int NTAPS>
+struct NoFill { __device__ __forceinline__ void operator()(int, int) const {} };
+
+template <int BN, int MT, int NTAPS, class Fill = NoFill>
 __device__ __forceinline__ void conv_steps(f32x16 (&acc)[MT][BN / 32], const float* __restrict__ As,
                                            const float* __restrict__ Bs, const int (&abase)[MT],
-                                           const int (&aoff)[TAPG], int kca, int li, int lh) {
+                                           const int (&aoff)[TAPG], int kca, int li, int lh, Fill fill = Fill()) {
   constexpr int NT = BN / 32, NS = NTAPS * 2;
   f32x4 a[2][MT];
   float b[2][NT][4];
@@ -46,6 +77,7 @@ __device__ __forceinline__ void conv_steps(f32x16 (&acc)[MT][BN / 32], const flo
 #pragma unroll
         for (int q = 0; q < 4; ++q) b[nxt][u][q] = bp[q * BN + u * 32];
     }
+    fill(st, NS);   // a slice of the NEXT chunk's global loads rides along with every step
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int q = 0; q < 4; ++q)
@@ -59,24 +91,72 @@ __device__ __forceinline__ void conv_steps(f32x16 (&acc)[MT][BN / 32], const flo
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// Software-pipelined K loop for the common case (host-checked, ConvGeom::simple): one LDS tile with halo shared by
-// all taps, ntaps in {1,4,9}, stride 1, every operand a multiple of 16 channels with the same H x W, no broadcast.
-//   * per-thread slot tables (global pixel offset / validity of every float4 this thread stages) are computed ONCE
-//     per workgroup -- the index arithmetic (divisions) leaves the chunk loop;
-//   * the global loads of chunk i+1 are issued into registers right after the barrier that publishes chunk i, so HBM
-//     / L2 latency runs under the MFMAs of chunk i; the staging phase shrinks to transform + ds_write.
+// Software-pipelined K loop for the common case (host-checked, conv_simple()): one LDS tile with halo shared by all
+// taps, ntaps in {1,4,9}, stride 1, every operand a multiple of 16 channels with the same H x W, no broadcast.
+//   * input tile: per-thread slot tables (pixel offset / validity of every float4 this thread stages) are computed
+//     ONCE per workgroup; the loads of chunk i+1 (buffer_load_dwordx4, 32-bit offsets) are issued into registers during
+//     the first MFMA steps of chunk i, so HBM / L2 latency runs under MFMAs; the staging phase between chunks is only
+//     BatchNorm-apply / ReLU / mask + ds_write_b128;
+//   * weights need no transform: they go global -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave
+//     instruction, no VGPRs, no ds_write).  The [taps][16][BN] slab is split into two 8-channel halves that ping-pong:
+//     while the MFMAs read half h, the DMA fills the other half.
+// One chunk = barrier X | store A | barrier Y | DMA B(h1), loads A(next), MFMA(h0) | barrier Z | DMA B(next,h0), MFMA(h1).
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+template <int BN, int MT, int NTAPS, class Fill = NoFill>
+__device__ __forceinline__ void conv_half(f32x16 (&acc)[MT][BN / 32], const float* __restrict__ As,
+                                          const float* __restrict__ Bh, const int (&abase)[MT], const int (&aoff)[TAPG],
+                                          int kg, int li, int lh, Fill fill = Fill()) {
+  constexpr int NT = BN / 32;
+  f32x4 a[2][MT];
+  float b[2][NT][4];
+  const float* bp0 = Bh + (lh * 4) * BN + li;
+#pragma unroll
+  for (int m = 0; m < MT; ++m) a[0][m] = *(const f32x4*)(As + abase[m] + aoff[0] + kg);
+#pragma unroll
+  for (int u = 0; u < NT; ++u)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) b[0][u][q] = bp0[q * BN + u * 32];
+#pragma unroll
+  for (int st = 0; st < NTAPS; ++st) {
+    const int cur = st & 1, nxt = cur ^ 1;
+    if (st + 1 < NTAPS) {
+      const float* bp = bp0 + (st + 1) * 8 * BN;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) a[nxt][m] = *(const f32x4*)(As + abase[m] + aoff[st + 1] + kg);
+#pragma unroll
+      for (int u = 0; u < NT; ++u)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) b[nxt][u][q] = bp[q * BN + u * 32];
+    }
+    fill(st, NTAPS);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int u = 0; u < NT; ++u)
+          acc[m][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][m][q], b[cur][u][q], acc[m][u], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 template <int BN, int MT>
 __device__ __forceinline__ void conv_kloop_pipe(const pmf_conv_desc_t& d, const ConvGeom& g, f32x16 (&acc)[MT][BN / 32],
                                                 float* __restrict__ As, float* __restrict__ Bs, const int (&segrow)[MT],
                                                 const int (&segcol)[MT], int tid, int li, int lh, int n, int n0, int ks,
-                                                int oy0, int ox0) {
-  constexpr int ASL = MT == 2 ? 7 : 4;                    // float4 slots per thread for the input tile
-  constexpr int rowq = BN / 4;
-  constexpr int BSL = (TAPG * KC * rowq + 255) / 256;     // ... and for the weight slab
+                                                int oy0, int ox0, int& tri_) {
+  constexpr int ASL = MT == 2 ? 7 : 4;            // float4 slots per thread for the input tile
+  constexpr int RPI = 256 / BN;                   // weight rows one 1-KiB DMA wave-instruction covers
+  constexpr int NDMA = (TAPG * 8 / RPI + 3) / 4;  // DMA instructions per wave per half slab
   const int in_cols = g.in_cols;
   const int sH = d.src[0].H, sW = d.src[0].W;
   const int q = tid & 3;
-  const int totalA = g.in_rows * in_cols * 4, totalB = d.ntaps * KC * rowq;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int totalA = g.in_rows * in_cols * 4;
+  const int hrows = d.ntaps * 8;                  // rows of one half slab
+  float* __restrict__ Bh1 = Bs + hrows * BN;
   int gA[ASL];
   unsigned okA = 0u;
 #pragma unroll
@@ -85,14 +165,14 @@ __device__ __forceinline__ void conv_kloop_pipe(const pmf_conv_desc_t& d, const 
     const int r = pix / in_cols, c = pix - r * in_cols;
     const int iy = oy0 + g.dy_min + r, ix = ox0 + g.dx_min + c;
     const bool ok = f < totalA && iy >= 0 && iy < sH && ix >= 0 && ix < sW;
-    gA[j] = ok ? (n * sH + iy) * sW + ix : 0;
+    gA[j] = ok ? (n * sH + iy) * sW + ix : -1;   // -1: negative byte offset = out of range = the buffer load returns 0
     okA |= ok ? (1u << j) : 0u;
   }
-  int gB[BSL];
+  int offB[NDMA];   // per-lane source offset (floats) of DMA instruction wave + 4*jj, relative to the half's first row
 #pragma unroll
-  for (int j = 0; j < BSL; ++j) {
-    const int f = tid + 256 * j, row = f / rowq, qq = f - row * rowq;
-    gB[j] = ((row >> 4) * g.Ktot + (row & 15)) * d.ldw + qq * 4;
+  for (int jj = 0; jj < NDMA; ++jj) {
+    const int row = (wave + 4 * jj) * RPI + lane / (BN / 4);
+    offB[jj] = ((row >> 3) * g.Ktot + (row & 7)) * d.ldw + (lane % (BN / 4)) * 4;
   }
   int aoff[TAPG];
 #pragma unroll
@@ -112,29 +192,45 @@ __device__ __forceinline__ void conv_kloop_pipe(const pmf_conv_desc_t& d, const 
       ++cn; c0 += KC;
     }
   };
-  f32x4 rA[ASL], rB[BSL], sc4, sh4, cm4;
+  f32x4 rA[ASL], sc4, sh4, cm4;
   int cur_flags = 0;
   bool cur_aff = false;
-  auto issue = [&]() {     // global loads of stage (si, c0) -> registers
-    const float* __restrict__ sx = d.src[si].x;
-    const int sld = d.src[si].ldc, cch = c0 + q * 4;
+  __amdgpu_buffer_rsrc_t nrs;           // operand of the stage being fetched
+  int nld = 0, ncch = 0;
+  const float* __restrict__ nw = nullptr;   // first weight row of the stage being fetched (uniform)
+  auto head = [&]() {   // per-stage scalars + the channel transform of stage (si, c0)
+    nrs = __builtin_amdgcn_make_buffer_rsrc((void*)d.src[si].x, 0, d.N * sH * sW * d.src[si].ldc * 4, 0x00020000);
+    nld = d.src[si].ldc; ncch = c0 + q * 4;
     cur_flags = d.src[si].flags;
     cur_aff = d.src[si].scale != nullptr;
     sc4 = f32x4{1.f, 1.f, 1.f, 1.f}; sh4 = f32x4{0.f, 0.f, 0.f, 0.f}; cm4 = f32x4{1.f, 1.f, 1.f, 1.f};
-    if (cur_aff) { sc4 = *(const f32x4*)(d.src[si].scale + cch); sh4 = *(const f32x4*)(d.src[si].shift + cch); }
-    if (d.src[si].cmul) cm4 = *(const f32x4*)(d.src[si].cmul + (size_t)n * d.src[si].cmul_ld + cch);
+    if (cur_aff) { sc4 = *(const f32x4*)(d.src[si].scale + ncch); sh4 = *(const f32x4*)(d.src[si].shift + ncch); }
+    if (d.src[si].cmul) cm4 = *(const f32x4*)(d.src[si].cmul + (size_t)n * d.src[si].cmul_ld + ncch);
+    nw = d.w + (size_t)(kb + c0) * d.ldw + n0;
+  };
+  auto loadA = [&](int j) {   // j is a compile-time constant after unrolling; branch-free (see gA)
+    rA[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(nrs, (gA[j] * nld + ncch) * 4, 0, 0));
+  };
+  auto dma_half = [&](const float* __restrict__ wsrc, float* __restrict__ dst) {
 #pragma unroll
-    for (int j = 0; j < ASL; ++j)
-      if ((okA >> j) & 1u) rA[j] = *(const f32x4*)(sx + (size_t)gA[j] * sld + cch);
-    const float* wb = d.w + (size_t)(kb + c0) * d.ldw + n0;
-#pragma unroll
-    for (int j = 0; j < BSL; ++j)
-      if (tid + 256 * j < totalB) rB[j] = *(const f32x4*)(wb + gB[j]);
+    for (int jj = 0; jj < NDMA; ++jj) {
+      const int i = wave + 4 * jj;                 // wave-uniform
+      if (i * RPI < hrows)
+        __builtin_amdgcn_global_load_lds(wsrc + offB[jj], (lds_ptr_t)(dst + i * 256), 16, 0, 0);
+    }
   };
   bool have = settle();
-  if (have) issue();
+  const float* __restrict__ wcur = nullptr;
+  if (have) {
+    head();
+#pragma unroll
+    for (int j = 0; j < ASL; ++j) loadA(j);
+    dma_half(nw, Bs);
+  }
+  TR();
   while (have) {
-    __syncthreads();                       // everyone finished reading the previous stage
+    __syncthreads();                       // X: everyone finished the MFMAs of the previous chunk
+    TR();
 #pragma unroll
     for (int j = 0; j < ASL; ++j) {
       const int f = tid + 256 * j;
@@ -151,19 +247,45 @@ __device__ __forceinline__ void conv_kloop_pipe(const pmf_conv_desc_t& d, const 
         *(f32x4*)(As + (f >> 2) * APITCH + q * 4) = t;
       }
     }
-#pragma unroll
-    for (int j = 0; j < BSL; ++j) {
-      const int f = tid + 256 * j;
-      if (f < totalB) *(f32x4*)(Bs + f * 4) = rB[j];
-    }
-    __syncthreads();
+    wcur = nw;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of B(h0) has landed in LDS
+    __syncthreads();                       // Y: input tile + half 0 visible
+    TR();
     ++cn; c0 += KC;
     have = settle();
-    if (have) issue();                      // next stage's loads fly under this stage's MFMAs
+    if (have) head();
+    else nrs = __builtin_amdgcn_make_buffer_rsrc((void*)d.src[0].x, 0, 0, 0x00020000);   // last chunk: loads fetch nothing
+    dma_half(wcur + (size_t)8 * d.ldw, Bh1);
+    auto fill = [&](int st, int ns) {      // the next chunk's input loads ride along with the first MFMA steps
+      constexpr int per = 2;
+#pragma unroll
+      for (int j = 0; j < ASL; ++j)
+        if (j >= st * per && j < (st + 1) * per) loadA(j);
+      if (st == ns - 1) {
+#pragma unroll
+        for (int j = 0; j < ASL; ++j)
+          if (j >= ns * per) loadA(j);
+      }
+    };
+    // hipcc would hoist all taps x MT LDS addresses (abase + aoff) out of the chunk loop and keep them in VGPRs for
+    // the whole kernel; an opaque copy per half keeps the adds next to their ds_reads
+#pragma unroll
+    for (int m = 0; m < MT; ++m) asm volatile("" : "+v"(abase[m]));
     __builtin_amdgcn_sched_barrier(0);
-    if (d.ntaps == 9) conv_steps<BN, MT, 9>(acc, As, Bs, abase, aoff, KC, li, lh);
-    else if (d.ntaps == 4) conv_steps<BN, MT, 4>(acc, As, Bs, abase, aoff, KC, li, lh);
-    else conv_steps<BN, MT, 1>(acc, As, Bs, abase, aoff, KC, li, lh);
+    if (d.ntaps == 9) conv_half<BN, MT, 9>(acc, As, Bs, abase, aoff, 0, li, lh, fill);
+    else if (d.ntaps == 4) conv_half<BN, MT, 4>(acc, As, Bs, abase, aoff, 0, li, lh, fill);
+    else conv_half<BN, MT, 1>(acc, As, Bs, abase, aoff, 0, li, lh, fill);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // B(h1) (and the next input tile) landed
+    __syncthreads();                       // Z: everyone finished reading half 0
+    TR();
+    if (have) dma_half(nw, Bs);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) asm volatile("" : "+v"(abase[m]));
+    __builtin_amdgcn_sched_barrier(0);
+    if (d.ntaps == 9) conv_half<BN, MT, 9>(acc, As, Bh1, abase, aoff, 8, li, lh);
+    else if (d.ntaps == 4) conv_half<BN, MT, 4>(acc, As, Bh1, abase, aoff, 8, li, lh);
+    else conv_half<BN, MT, 1>(acc, As, Bh1, abase, aoff, 8, li, lh);
+    TR();
   }
 }
 
@@ -182,6 +304,9 @@ __global__ __launch_bounds__(256) void conv_fwd_k(const pmf_conv_desc_t d, const
   const int is = d.in_stride;
   const int in_cols = g.in_cols;
   const int kca = g.kc_alloc;
+  int tri_ = 0;
+  TR_START();
+  TR();
 
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -200,7 +325,7 @@ __global__ __launch_bounds__(256) void conv_fwd_k(const pmf_conv_desc_t d, const
   }
 
   if constexpr (PIPE) {
-    conv_kloop_pipe<BN, MT>(d, g, acc, As, Bs, segrow, segcol, tid, li, lh, n, n0, ks, oy0, ox0);
+    conv_kloop_pipe<BN, MT>(d, g, acc, As, Bs, segrow, segcol, tid, li, lh, n, n0, ks, oy0, ox0, tri_);
   } else {
   const int ngroups = d.gather ? d.ntaps : 1;
   int k_base = 0, chunk_no = 0;
@@ -348,24 +473,30 @@ __global__ __launch_bounds__(256) void conv_fwd_k(const pmf_conv_desc_t d, const
   }
   }  // !PIPE
 
-  // ---- epilogue
+  // ---- epilogue: branch-free.  Every element is one buffer store (buffer loads for the ReLU mask / accumulate) at
+  // a 32-bit byte offset; masked-off elements get offset 0xffffffff, which the hardware range check drops (host
+  // guarantees all tensors < 2 GiB).  The loads of a 16-row group are issued together, not load -> wait -> store.
+  TR();
   if (g.ksplit > 1) {   // raw partial sums -> slab ks; bias / activation / statistics happen in conv_finish_k
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)g.ws, 0, 0x7fffffff, 0x00020000);
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
       const int co = n0 + u * 32 + li;
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
-        const int oy = oy0 + segrow[m];
+        const int oy = oy0 + segrow[m], oxb = ox0 + segcol[m] * 32 + 4 * lh;
+        const bool rok = co < g.ws_ld && oy < d.OH;
+        const int base = ((((ks * d.N + n) * d.OH + oy) * d.OW + oxb) * g.ws_ld + co) * 4, estep = g.ws_ld * 4;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int ox = ox0 + segcol[m] * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (co < g.ws_ld && oy < d.OH && ox < d.OW) {
-            const size_t pix = ((size_t)(ks * d.N + n) * d.OH + oy) * d.OW + ox;
-            g.ws[pix * g.ws_ld + co] = acc[m][u][r];
-          }
+          const int dx = (r & 3) + 8 * (r >> 2);
+          const unsigned off = (rok && oxb + dx < d.OW) ? (unsigned)(base + dx * estep) : 0xffffffffu;
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[m][u][r]), wr, off, 0, 0);
         }
       }
     }
+    TR();
+    TR_END();
     return;
   }
   // BatchNorm statistics in float64: float*float is exact in double, so var = E[x^2] - mean^2 keeps full
@@ -373,32 +504,60 @@ __global__ __launch_bounds__(256) void conv_fwd_k(const pmf_conv_desc_t d, const
   double ssum[NT], ssq[NT];
 #pragma unroll
   for (int u = 0; u < NT; ++u) ssum[u] = ssq[u] = 0.0;
+  {
+    const __amdgpu_buffer_rsrc_t orr = __builtin_amdgcn_make_buffer_rsrc((void*)d.out, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xrr =
+        __builtin_amdgcn_make_buffer_rsrc((void*)d.ep_relu_x, 0, d.ep_relu_x ? 0x7fffffff : 0, 0x00020000);
+    const float slope = d.act == PMF_ACT_LRELU ? 0.01f : (d.act == PMF_ACT_RELU ? 0.f : 1.f);
+    const bool sig = d.act == PMF_ACT_SIGMOID, has_rx = d.ep_relu_x != nullptr, accum = d.accumulate != 0;
+    const bool want_stats = d.stats != nullptr;
 #pragma unroll
-  for (int u = 0; u < NT; ++u) {
-    const int co = n0 + u * 32 + li;
-    const bool cok = co < d.Cout;
-    const float bias = (cok && d.bias) ? d.bias[co] : 0.f;
-    const float ecm = (cok && d.ep_cmul) ? d.ep_cmul[(size_t)n * d.ep_cmul_ld + co] : 1.f;
-    float rs = 1.f, rt = 0.f;
-    if (cok && d.ep_relu_x && d.ep_relu_scale) { rs = d.ep_relu_scale[co]; rt = d.ep_relu_shift[co]; }
+    for (int u = 0; u < NT; ++u) {
+      const int co = n0 + u * 32 + li;
+      const bool cok = co < d.Cout;
+      const float bias = (cok && d.bias) ? d.bias[co] : 0.f;
+      const float ecm = (cok && d.ep_cmul) ? d.ep_cmul[(size_t)n * d.ep_cmul_ld + co] : 1.f;
+      float rs = 1.f, rt = 0.f;
+      if (cok && has_rx && d.ep_relu_scale) { rs = d.ep_relu_scale[co]; rt = d.ep_relu_shift[co]; }
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      const int oy = oy0 + segrow[m];
+      for (int m = 0; m < MT; ++m) {
+        const int oy = oy0 + segrow[m], oxb = ox0 + segcol[m] * 32 + 4 * lh;
+        const bool rok = cok && oy < d.OH;
+        const int pix0 = (n * d.out_H + oy * d.out_sy + d.out_oy) * d.out_W + oxb * d.out_sx + d.out_ox;
+        const int obase = (pix0 * d.out_ldc + co) * 4, ostep = d.out_sx * d.out_ldc * 4;
+        const int xbase = (pix0 * d.ep_relu_ldc + co) * 4, xstep = d.out_sx * d.ep_relu_ldc * 4;
+        unsigned off[16];
+        float xr[16], old[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ox = ox0 + segcol[m] * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (cok && oy < d.OH && ox < d.OW) {
-          float v = pmf_act(acc[m][u][r] + bias, d.act);
-          const size_t opix = (size_t)(n * d.out_H + oy * d.out_sy + d.out_oy) * d.out_W + ox * d.out_sx + d.out_ox;
-          v *= ecm;
-          if (d.ep_relu_x) {
-            const float xr = d.ep_relu_x[opix * d.ep_relu_ldc + co] * rs + rt;
-            if (!(xr > 0.f)) v = 0.f;
+        for (int r = 0; r < 16; ++r) {
+          const int dx = (r & 3) + 8 * (r >> 2);
+          const bool ok = rok && oxb + dx < d.OW;
+          off[r] = ok ? (unsigned)(obase + dx * ostep) : 0xffffffffu;
+          xr[r] = 1.f; old[r] = 0.f;
+        }
+        if (has_rx) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int dx = (r & 3) + 8 * (r >> 2);
+            const unsigned xo = off[r] == 0xffffffffu ? 0xffffffffu : (unsigned)(xbase + dx * xstep);
+            xr[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrr, xo, 0, 0)) * rs + rt;
           }
-          float* op = d.out + opix * d.out_ldc + co;
-          if (d.accumulate) v += *op;
-          *op = v;
-          if (d.stats) {
+        }
+        if (accum) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            old[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(orr, off[r], 0, 0));
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[m][u][r] + bias;
+          if (sig) v = 1.f / (1.f + __expf(-v));
+          else v = v > 0.f ? v : v * slope;
+          v *= ecm;
+          if (!(xr[r] > 0.f)) v = 0.f;
+          v += old[r];
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), orr, off[r], 0, 0);
+          if (want_stats && off[r] != 0xffffffffu) {
             ssum[u] += (double)v;
             ssq[u] += (double)v * (double)v;
           }
@@ -406,6 +565,7 @@ __global__ __launch_bounds__(256) void conv_fwd_k(const pmf_conv_desc_t d, const
       }
     }
   }
+  TR();
   if (d.stats) {
     __syncthreads();
     double* red = (double*)smem;  // [4 waves][NT][32][2]
@@ -436,6 +596,8 @@ __global__ __launch_bounds__(256) void conv_fwd_k(const pmf_conv_desc_t d, const
       }
     }
   }
+  TR();
+  TR_END();
 }
 
 // Deterministic split-K tail: out = ep( act( sum_ks ws[ks] + bias ) ), optional BatchNorm statistics.
@@ -558,6 +720,7 @@ static bool conv_simple(const pmf_conv_desc_t* d, const ConvGeom& g, int gather,
   for (int i = 0; i < d->nsrc; ++i) {
     if (d->src[i].C % 16 || (d->src[i].flags & PMF_SRC_BCAST)) return false;
     if (d->src[i].H != d->src[0].H || d->src[i].W != d->src[0].W) return false;
+    if ((int64_t)d->N * d->src[i].H * d->src[i].W * d->src[i].ldc * 4 >= (1ll << 31)) return false;
   }
   return g.in_rows * g.in_cols * 4 <= 256 * (MT == 2 ? 7 : 4);
 }
@@ -573,6 +736,9 @@ static int launch(const pmf_conv_desc_t* d, hipStream_t s) {
   int lds = pmf_conv_geometry(d->OH, d->OW, d->ntaps, d->tdy, d->tdx, d->in_stride, d->gather, BN, MT,
                               cmax < KC ? cmax : KC, &g, &gather);
   if (lds > 160 * 1024) return PMF_E_UNSUPPORTED;
+  // 32-bit byte offsets in the epilogue (buffer stores): every tensor it touches must stay below 2 GiB
+  if ((int64_t)d->N * d->out_H * d->out_W * d->out_ldc * 4 >= (1ll << 31)) return PMF_E_UNSUPPORTED;
+  if (d->ep_relu_x && (int64_t)d->N * d->out_H * d->out_W * d->ep_relu_ldc * 4 >= (1ll << 31)) return PMF_E_UNSUPPORTED;
   g.Ktot = Ktot;
   pmf_conv_desc_t dd = *d;
   dd.gather = gather;

@@ -254,7 +254,8 @@ class Plan:
             d.splitk_ws, d.splitk_ws_bytes = self.sk_buf.ptr, self.sk_buf.nbytes
         self.emit(self.fwd, L.OP_CONV, f)
         conv_flops = 2.0 * N * OH * OW * Cout * conv.in_channels * len(taps)   # algorithmic (SURVEY.md 8d rule)
-        self.meta_fwd[len(self.fwd) - 1] = dict(family="conv_fwd", flops=conv_flops, name=name)
+        self.meta_fwd[len(self.fwd) - 1] = dict(family="conv_fwd", flops=conv_flops, name=name, shape="%dx%dx%d %d->%d t%d s%d" % (
+            N, OH, OW, conv.in_channels, Cout, len(taps), stride))
 
         view = V(out)
         info = None
@@ -414,7 +415,8 @@ class Plan:
                     mh = tgt.H if stride == 1 else (tgt.H - py + 1) // 2
                     mw = tgt.W if stride == 1 else (tgt.W - px + 1) // 2
                     self.meta_bwd[len(self.bwd) - 1] = dict(
-                        family="conv_dgrad", flops=2.0 * dz.N * mh * mw * s.t.C * Cout * len(sub), name=name)
+                        family="conv_dgrad", flops=2.0 * dz.N * mh * mw * s.t.C * Cout * len(sub), name=name,
+                        shape="%dx%dx%d %d->%d t%d s%d" % (dz.N, mh, mw, Cout, s.t.C, len(sub), stride))
                 if tmp is not None:
                     def fc(op, tmp=tmp, g=r.t.g):
                         a = op.u.sm
@@ -464,7 +466,8 @@ class Plan:
         boff = self.pgrad(conv.bias) if dbias_rows else None
         self.emit(self.bwd, L.OP_WGRAD, f)
         self.meta_bwd[len(self.bwd) - 1] = dict(
-            family="conv_wgrad", flops=2.0 * dz.N * dz.H * dz.W * Cout * conv.in_channels * len(taps), name=name)
+            family="conv_wgrad", flops=2.0 * dz.N * dz.H * dz.W * Cout * conv.in_channels * len(taps), name=name,
+            shape="%dx%dx%d %d->%d t%d" % (dz.N, dz.H, dz.W, conv.in_channels, Cout, len(taps)))
 
     # ---- element-wise primitives -----------------------------------------------------------------
     def add_act(self, a, b, act, name=""):
@@ -813,7 +816,7 @@ class Plan:
         for k in range(n):
             m = meta.get(k - shift, {})
             out.append((L.OP_NAMES.get(kinds[k], "?"), m.get("family"), m.get("flops", 0.0), evs[k][0].elapsed_time(evs[k][1]),
-                        m.get("name", "")))
+                        m.get("name", "") + ("  [" + m["shape"] + "]" if "shape" in m else "")))
         return out
 
     # ------------------------------------------------------------------ running

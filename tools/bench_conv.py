@@ -19,8 +19,9 @@ CASES = [  # name, N, H, W, Cin, Cout, k, dil
     ("8th_256_256_3x3", 2, 8, 256, 256, 256, 3, 1),
     ("16th_512_512_3x3", 2, 4, 128, 512, 512, 3, 1),
 ]
-def timeit(fn, n=20):
-    for _ in range(3): fn()
+def timeit(fn, n=200):
+    # the shader clock needs tens of milliseconds of load to ramp from idle: warm up long enough, then time
+    for _ in range(400): fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
