@@ -491,7 +491,9 @@ __global__ __launch_bounds__(256) void conv_fwd_k(const pmf_conv_desc_t d, const
         for (int r = 0; r < 16; ++r) {
           const int dx = (r & 3) + 8 * (r >> 2);
           const unsigned off = (rok && oxb + dx < d.OW) ? (unsigned)(base + dx * estep) : 0xffffffffu;
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[m][u][r]), wr, off, 0, 0);
+          float v = acc[m][u][r];
+          asm volatile("" : "+v"(v));   // hipcc (ROCm 7.2) otherwise stores element 0 of each accumulator quad 4x
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), wr, off, 0, 0);
         }
       }
     }

@@ -11,6 +11,7 @@
 // accumulators are complete and go straight to this workgroup's partial slab.  Stage 2 sums the slabs in a fixed
 // order (deterministic) and writes the gradient directly in PyTorch's OIHW layout.
 #include "common.h"
+#include <stdlib.h>
 
 #define WG_ROWS 4
 #define WG_CI 32
@@ -239,6 +240,218 @@ __global__ __launch_bounds__(256) void conv_wgrad_k(const pmf_wgrad_desc_t d, co
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Software-pipelined variant for the common case (host-checked, wg_simple()): stride 1, halo staging, one tap batch
+// (ntaps == TB), every operand a multiple of 32 channels with the gradient's H x W, OH % 4 == 0, OW % 32 == 0,
+// Cout % BN == 0.
+//   * dz needs no transform: it goes global -> LDS by LDS-DMA (1 KiB per wave instruction), in two 2-row halves
+//     that ping-pong: while the MFMAs read half h the DMA fills the other half (of this tile or the next one);
+//   * the input tile of the NEXT 4x32-pixel tile is fetched into registers (buffer loads, out-of-image pixels get a
+//     negative offset = hardware zero fill) while this tile is multiplied; BatchNorm-apply / ReLU / mask + ds_write
+//     happen between tiles;
+//   * work split: wave w owns output-channel tile w % NT for ALL TB taps and every (4/NT)-th pixel pair, so the four
+//     waves always carry TB accumulators each (the unit-dealing kernel above leaves 9 units on 4 waves as 3/2/2/2);
+//     pixel groups are summed through LDS once, after the tile loop, in a fixed order.
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+template <int TB, int NT, int XSL>   // XSL: float4 slots per thread of the input tile (7: 6 x 34 pixels x 8, 9: 8 x 36)
+__device__ __forceinline__ void conv_wgrad_pipe_body(const pmf_wgrad_desc_t& d, const WgGeom& g, float* __restrict__ smem) {
+  constexpr int BN = NT * 32, PG = 4 / NT;
+  constexpr int HPX = 64;                   // pixels of a half tile
+  constexpr int ZPW = HPX * BN / 256 / 4;   // DMA instructions per wave per half (2, 4, 8)
+  constexpr int PPI = 256 / BN;             // pixels one DMA instruction covers
+  float* __restrict__ Xs = smem;
+  float* __restrict__ Z0 = smem + g.x_floats;
+  float* __restrict__ Z1 = Z0 + HPX * BN;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int split = blockIdx.x, chunk = blockIdx.y;
+  const int co0 = (int)blockIdx.z * BN;
+  const int in_cols = g.in_cols;
+
+  int si = 0, c0 = 0, k0 = 0;
+  {
+    int rem = chunk;
+    for (;;) {
+      const int nch = d.src[si].C / WG_CI;
+      if (rem < nch) { c0 = rem * WG_CI; k0 += c0; break; }
+      rem -= nch; k0 += d.src[si].C; ++si;
+    }
+  }
+  const int sld = d.src[si].ldc, sflags = d.src[si].flags;
+  const int sH = d.OH, sW = d.OW;
+  const bool aff = d.src[si].scale != nullptr;
+  const int q = tid & 7, cch = c0 + q * 4;
+  const int totalX = g.in_rows * in_cols * 8;
+  int rc[XSL];   // tile-relative (row << 8 | col) of every slot, -1 = unused
+#pragma unroll
+  for (int j = 0; j < XSL; ++j) {
+    const int f = tid + 256 * j, pix = f >> 3;
+    const int r = pix / in_cols, c = pix - r * in_cols;
+    rc[j] = f < totalX ? (r << 8 | c) : -1;
+  }
+  int offZ[ZPW];   // per-lane source offset (floats) of DMA instruction wave + 4*jj relative to the half's first pixel
+#pragma unroll
+  for (int jj = 0; jj < ZPW; ++jj) {
+    const int p = (wave + 4 * jj) * PPI + lane / (BN / 4);
+    offZ[jj] = ((p >> 5) * d.OW + (p & 31)) * d.dz_ldc + (lane % (BN / 4)) * 4;
+  }
+  const int cot = wave % NT, pg = wave / NT;
+  int toff[TB];
+#pragma unroll
+  for (int j = 0; j < TB; ++j)
+    toff[j] = (((int)d.tdy[j] - g.dy_min) * in_cols + ((int)d.tdx[j] - g.dx_min)) * WG_CI;
+
+  f32x16 acc[TB];
+#pragma unroll
+  for (int j = 0; j < TB; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  const __amdgpu_buffer_rsrc_t xrs_on =
+      __builtin_amdgcn_make_buffer_rsrc((void*)d.src[si].x, 0, d.N * sH * sW * sld * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t xrs_off = __builtin_amdgcn_make_buffer_rsrc((void*)d.src[si].x, 0, 0, 0x00020000);
+  f32x4 rX[XSL];
+  unsigned okX = 0u;
+  int ncur = 0;   // sample index of the tile held in rX
+  const int tiles_per_n = g.tiles_x * g.tiles_y;
+  auto fetch = [&](int tile, bool on) {   // input tile of `tile` -> registers; validity mask + (n,c) multiplier
+    const int n = tile / tiles_per_n, rem = tile - n * tiles_per_n;
+    const int ty = rem / g.tiles_x, tx = rem - ty * g.tiles_x;
+    const int by = ty * WG_ROWS + g.dy_min, bx = tx * 32 + g.dx_min;
+    const __amdgpu_buffer_rsrc_t rs = on ? xrs_on : xrs_off;
+    okX = 0u;
+#pragma unroll
+    for (int j = 0; j < XSL; ++j) {
+      const int iy = by + (rc[j] >> 8), ix = bx + (rc[j] & 255);
+      const bool ok = rc[j] >= 0 && iy >= 0 && iy < sH && ix >= 0 && ix < sW;
+      const int gp = ok ? (n * sH + iy) * sW + ix : -1;   // negative byte offset -> out of range -> reads 0
+      okX |= ok ? (1u << j) : 0u;
+      rX[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (gp * sld + cch) * 4, 0, 0));
+    }
+    ncur = n;
+  };
+  auto zsrc = [&](int tile, int half) -> const float* {   // first dz element of a half tile (wave-uniform)
+    const int n = tile / tiles_per_n, rem = tile - n * tiles_per_n;
+    const int ty = rem / g.tiles_x, tx = rem - ty * g.tiles_x;
+    return d.dz + ((size_t)(n * d.OH + ty * WG_ROWS + 2 * half) * d.OW + tx * 32) * d.dz_ldc + co0;
+  };
+  auto dma = [&](const float* __restrict__ src, float* __restrict__ dst) {
+#pragma unroll
+    for (int jj = 0; jj < ZPW; ++jj)
+      __builtin_amdgcn_global_load_lds(src + offZ[jj], (lds_ptr_t)(dst + (wave + 4 * jj) * 256), 16, 0, 0);
+  };
+  // one half tile: this wave's pixel pairs of two rows, TB MFMAs per pair, operands of the next pair prefetched
+  auto half = [&](const float* __restrict__ Zh, int h) {
+#pragma unroll 1
+    for (int rr = 0; rr < 2; ++rr) {
+      const float* xp = Xs + ((2 * h + rr) * in_cols + lh) * WG_CI + li;
+      const float* zp = Zh + (rr * 32 + lh) * BN + cot * 32 + li;
+      constexpr int NP = 16 / PG;
+      float ac[TB], an[TB], bc, bn;
+      bc = zp[2 * pg * BN];
+#pragma unroll
+      for (int j = 0; j < TB; ++j) ac[j] = xp[2 * pg * WG_CI + toff[j]];
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        if (i + 1 < NP) {
+          const int kp = pg + (i + 1) * PG;
+          bn = zp[2 * kp * BN];
+#pragma unroll
+          for (int j = 0; j < TB; ++j) an[j] = xp[2 * kp * WG_CI + toff[j]];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < TB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[j], bc, acc[j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        bc = bn;
+#pragma unroll
+        for (int j = 0; j < TB; ++j) ac[j] = an[j];
+      }
+    }
+  };
+
+  int tile = split;
+  if (tile < g.total_tiles) {
+    fetch(tile, true);
+    dma(zsrc(tile, 0), Z0);
+  }
+  while (tile < g.total_tiles) {
+    __syncthreads();                       // X: everyone finished the previous tile
+    // channel transform of this operand: re-read here (L1/L2 hits) instead of pinning 12 VGPRs across the MFMAs
+    f32x4 sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f}, cm4 = {1.f, 1.f, 1.f, 1.f};
+    if (aff) { sc4 = *(const f32x4*)(d.src[si].scale + cch); sh4 = *(const f32x4*)(d.src[si].shift + cch); }
+    if (d.src[si].cmul) cm4 = *(const f32x4*)(d.src[si].cmul + (size_t)ncur * d.src[si].cmul_ld + cch);
+#pragma unroll
+    for (int j = 0; j < XSL; ++j) {
+      if (rc[j] >= 0) {
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+        if ((okX >> j) & 1u) {
+          t = rX[j];
+          if (aff) t = t * sc4 + sh4;
+          if (sflags & PMF_SRC_RELU) {
+            t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f);
+          }
+          t = t * cm4;
+        }
+        *(f32x4*)(Xs + ((tid + 256 * j) >> 3) * WG_CI + q * 4) = t;
+      }
+    }
+    const int next = tile + d.nsplit;
+    const bool have = next < g.total_tiles;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of dz half 0 is in LDS
+    __syncthreads();                       // Y: input tile + half 0 visible
+    dma(zsrc(tile, 1), Z1);
+    fetch(have ? next : tile, have);       // next input tile -> registers, lands under the MFMAs
+    __builtin_amdgcn_sched_barrier(0);
+    half(Z0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                       // Z: everyone finished half 0
+    if (have) dma(zsrc(next, 0), Z0);
+    __builtin_amdgcn_sched_barrier(0);
+    half(Z1, 1);
+    tile = next;
+  }
+
+  // ---- sum the pixel groups (fixed order) and write this workgroup's partial slab
+  if (PG > 1) {
+    float* red = smem;   // [4 waves][16][64]
+#pragma unroll
+    for (int j = 0; j < TB; ++j) {
+      __syncthreads();
+      if (pg > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[j][r];
+      }
+      __syncthreads();
+      if (pg == 0) {
+#pragma unroll
+        for (int p = 1; p < PG; ++p)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[j][r] += red[((wave + NT * p) * 16 + r) * 64 + lane];
+      }
+    }
+  }
+  if (pg == 0) {
+    float* part = d.partial + (size_t)split * d.ntaps * g.Ktot * g.Cout32;
+    const int co = co0 + cot * 32 + li;
+#pragma unroll
+    for (int j = 0; j < TB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ci = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        part[((size_t)j * g.Ktot + k0 + ci) * g.Cout32 + co] = acc[j][r];
+      }
+  }
+}
+
+template <int TB, int NT, int XSL>
+__global__ __launch_bounds__(256) void conv_wgrad_pipe_k(const pmf_wgrad_desc_t d, const WgGeom g) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  conv_wgrad_pipe_body<TB, NT, XSL>(d, g, smem);
+}
+
 // stage 2: dw_oihw[(co*Cin_real + k)*KHW + widx[t]] (+)= sum_s partial[s][t][k][co]
 // 256 threads = 32 consecutive outputs x 8 split slices (independent, unrolled loads), folded through LDS in a
 // fixed order -> deterministic, and no thread walks hundreds of slabs serially.
@@ -310,13 +523,32 @@ static int wg_geometry(const pmf_wgrad_desc_t* d, int TB, int BN, WgGeom* g, int
   return 0;
 }
 
-// taps per workgroup (TB) and output-channel tiles (NT): 3x3 -> 9 taps, 2x2 -> 4, per-tap staging -> 1;
-// NT*32 output channels per workgroup, as wide as Cout allows (wider = fewer re-reads of the input tile)
+// conditions of the software-pipelined kernel
+static bool wg_simple(const pmf_wgrad_desc_t* d, const WgGeom& g, int TB, int BN) {
+  if (d->gather || d->in_stride != 1 || d->ntaps != TB) return false;
+  if (d->OH % WG_ROWS || d->OW % 32 || d->Cout % BN) return false;
+  if (g.in_rows * g.in_cols * 8 > 256 * 9 || g.in_cols > 255) return false;
+  for (int i = 0; i < d->nsrc; ++i) {
+    if (d->src[i].C % WG_CI || (d->src[i].flags & PMF_SRC_BCAST)) return false;
+    if (d->src[i].H != d->OH || d->src[i].W != d->OW) return false;
+    if ((int64_t)d->N * d->OH * d->OW * d->src[i].ldc * 4 >= (1ll << 31)) return false;
+  }
+  return true;
+}
+
+// taps per workgroup (TB) and output-channel tiles (NT): 3x3 -> 9 taps, 2x2 -> 4, per-tap staging -> 1.
+// Pipelined kernel (when its conditions hold): NT = 1 -- every wave carries all TB taps of one 32-channel tile, the
+// narrow tile keeps the split count (hence the partial-slab traffic) low and measured fastest at every resolution.
+// Unit-dealing kernel: 64 output channels per workgroup (2 waves/SIMD fit; 128 measured slower).
 static void wg_config(const pmf_wgrad_desc_t* d, int* TB, int* NT) {
   if (d->gather || d->ntaps == 1) *TB = 1;
   else if (d->ntaps <= 4) *TB = 4;
   else *TB = 9;
-  *NT = d->Cout > 64 ? 4 : (d->Cout > 32 ? 2 : 1);
+  WgGeom g;
+  int lds;
+  wg_geometry(d, *TB, 32, &g, &lds);
+  if (wg_simple(d, g, *TB, 32) && !getenv("PMF_WGRAD_NOPIPE")) { *NT = 1; return; }
+  *NT = d->Cout > 32 ? 2 : 1;
 }
 
 extern "C" int pmf_conv_wgrad_nsplit(const pmf_wgrad_desc_t* d) {
@@ -346,10 +578,23 @@ static int wg_launch(const pmf_wgrad_desc_t* d, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)conv_wgrad_k<TB, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if constexpr (NT == 1) {
+      (void)hipFuncSetAttribute((const void*)conv_wgrad_pipe_k<TB, 1, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)conv_wgrad_pipe_k<TB, 1, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }
     attr_set = true;
   }
   dim3 grid(d->nsplit, g.nchunks, g.co_tiles * g.tap_batches);
-  hipLaunchKernelGGL((conv_wgrad_k<TB, NT>), grid, dim3(256), lds, s, *d, g);
+  bool piped = false;
+  if constexpr (NT == 1) {
+    if (wg_simple(d, g, TB, 32) && !getenv("PMF_WGRAD_NOPIPE")) {
+      const int lds2 = lds < 16 * 1024 ? 16 * 1024 : lds;   // room for the pixel-group reduction
+      if (g.in_rows * g.in_cols * 8 <= 256 * 7) hipLaunchKernelGGL((conv_wgrad_pipe_k<TB, 1, 7>), grid, dim3(256), lds2, s, *d, g);
+      else hipLaunchKernelGGL((conv_wgrad_pipe_k<TB, 1, 9>), grid, dim3(256), lds2, s, *d, g);
+      piped = true;
+    }
+  }
+  if (!piped) hipLaunchKernelGGL((conv_wgrad_k<TB, NT>), grid, dim3(256), lds, s, *d, g);
   PMF_LAUNCH_CHECK();
   const int64_t total = (int64_t)d->ntaps * g.Ktot * g.Cout32;
   int gb = (int)cdiv64(total, 32);
@@ -368,9 +613,9 @@ extern "C" int pmf_conv_wgrad(const pmf_wgrad_desc_t* d, pmf_stream_t st) {
   int TB, NT;
   wg_config(d, &TB, &NT);
 #define WG_CASE(tb, nt) if (TB == tb && NT == nt) return wg_launch<tb, nt>(d, s)
-  WG_CASE(9, 1); WG_CASE(9, 2); WG_CASE(9, 4);
-  WG_CASE(4, 1); WG_CASE(4, 2); WG_CASE(4, 4);
-  WG_CASE(1, 1); WG_CASE(1, 2); WG_CASE(1, 4);
+  WG_CASE(9, 1); WG_CASE(9, 2);
+  WG_CASE(4, 1); WG_CASE(4, 2);
+  WG_CASE(1, 1); WG_CASE(1, 2);
 #undef WG_CASE
   return PMF_E_UNSUPPORTED;
 }
