@@ -273,6 +273,7 @@ __device__ __forceinline__ void conv_kloop_pipe(const pmf_conv_desc_t& d, const 
     for (int m = 0; m < MT; ++m) asm volatile("" : "+v"(abase[m]));
     __builtin_amdgcn_sched_barrier(0);
     if (d.ntaps == 9) conv_half<BN, MT, 9>(acc, As, Bs, abase, aoff, 0, li, lh, fill);
+    else if (d.ntaps == 3) conv_half<BN, MT, 3>(acc, As, Bs, abase, aoff, 0, li, lh, fill);
     else if (d.ntaps == 4) conv_half<BN, MT, 4>(acc, As, Bs, abase, aoff, 0, li, lh, fill);
     else conv_half<BN, MT, 1>(acc, As, Bs, abase, aoff, 0, li, lh, fill);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // B(h1) (and the next input tile) landed
@@ -283,6 +284,7 @@ __device__ __forceinline__ void conv_kloop_pipe(const pmf_conv_desc_t& d, const 
     for (int m = 0; m < MT; ++m) asm volatile("" : "+v"(abase[m]));
     __builtin_amdgcn_sched_barrier(0);
     if (d.ntaps == 9) conv_half<BN, MT, 9>(acc, As, Bh1, abase, aoff, 8, li, lh);
+    else if (d.ntaps == 3) conv_half<BN, MT, 3>(acc, As, Bh1, abase, aoff, 8, li, lh);
     else if (d.ntaps == 4) conv_half<BN, MT, 4>(acc, As, Bh1, abase, aoff, 8, li, lh);
     else conv_half<BN, MT, 1>(acc, As, Bh1, abase, aoff, 8, li, lh);
     TR();
@@ -297,9 +299,20 @@ __global__ __launch_bounds__(256) void conv_fwd_k(const pmf_conv_desc_t d, const
   constexpr int NT = BN / 32;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
-  const int tile = blockIdx.x;
+  // XCD-aware tile order: the dispatcher deals consecutive workgroup ids round-robin to the 8 XCDs (each with its own
+  // L2).  Re-number so that one XCD gets a CONTIGUOUS range of (tile, sample) for a fixed (output-channel tile, K
+  // split): neighbouring tiles share their halo and all of them share one weight slab in that XCD's L2, instead of
+  // every L2 holding every slab (matters for the low-resolution layers, whose weights are 2-20 MB).
+  unsigned lin = blockIdx.x + gridDim.x * (blockIdx.z + gridDim.z * blockIdx.y);
+  {
+    const unsigned total = gridDim.x * gridDim.y * gridDim.z;
+    if ((total & 7u) == 0u) lin = (lin & 7u) * (total >> 3) + (lin >> 3);
+  }
+  const int tile = lin % gridDim.x;
+  const unsigned lin_r = lin / gridDim.x;
+  const int bz = lin_r % gridDim.z, by = lin_r / gridDim.z;
   const int tx = tile % g.tiles_x, ty = tile / g.tiles_x;
-  const int n = blockIdx.z, n0 = ((int)blockIdx.y / g.ksplit) * BN, ks = (int)blockIdx.y % g.ksplit;
+  const int n = bz, n0 = (by / g.ksplit) * BN, ks = by % g.ksplit;
   const int oy0 = ty * g.th, ox0 = tx * g.tw;
   const int is = d.in_stride;
   const int in_cols = g.in_cols;
@@ -592,7 +605,7 @@ __global__ __launch_bounds__(256) void conv_fwd_k(const pmf_conv_desc_t d, const
         }
         // one partial row per (tile, sample): no atomics (contended f64 atomics cost ~80 us per launch); the
         // BatchNorm finalize kernel folds the rows in a fixed order (deterministic)
-        double* row = d.stats + ((size_t)blockIdx.x + (size_t)gridDim.x * blockIdx.z) * 2 * d.Cout;
+        double* row = d.stats + ((size_t)tile + (size_t)gridDim.x * n) * 2 * d.Cout;
         row[co] = a;
         row[d.Cout + co] = b;
       }
@@ -705,10 +718,11 @@ static void conv_config(const pmf_conv_desc_t* d, int* BN, int* MT) {
 }
 
 // split-K factor: only when the M x N grid cannot fill the 256 CUs (low-resolution, many-channel layers)
-static int choose_ksplit(const pmf_conv_desc_t* d, int blocks_mn, int nchunks) {
+static int choose_ksplit(const pmf_conv_desc_t* d, int blocks_mn, int nchunks, int mfma_per_chunk) {
   if (!d->splitk_ws || d->out_sy != 1 || d->out_sx != 1 || blocks_mn >= 200 || nchunks < 4) return 1;
   int k = 512 / (blocks_mn > 0 ? blocks_mn : 1);
   if (k > nchunks / 2) k = nchunks / 2;
+  (void)mfma_per_chunk;   // (a floor on the MFMA work per split was tried: the serial K loop of 1x1 layers is slower)
   if (k > 32) k = 32;
   const int64_t slab = (int64_t)d->N * d->OH * d->OW * round_up(d->Cout, 4) * 4;
   while (k > 1 && slab * k > d->splitk_ws_bytes) --k;
@@ -718,7 +732,7 @@ static int choose_ksplit(const pmf_conv_desc_t* d, int blocks_mn, int nchunks) {
 // the software-pipelined K loop applies when ...
 static bool conv_simple(const pmf_conv_desc_t* d, const ConvGeom& g, int gather, int MT) {
   if (gather || d->in_stride != 1) return false;
-  if (d->ntaps != 1 && d->ntaps != 4 && d->ntaps != 9) return false;
+  if (d->ntaps != 1 && d->ntaps != 3 && d->ntaps != 4 && d->ntaps != 9) return false;
   for (int i = 0; i < d->nsrc; ++i) {
     if (d->src[i].C % 16 || (d->src[i].flags & PMF_SRC_BCAST)) return false;
     if (d->src[i].H != d->src[0].H || d->src[i].W != d->src[0].W) return false;
@@ -751,7 +765,7 @@ static int launch(const pmf_conv_desc_t* d, hipStream_t s) {
     attr_set = true;
   }
   const int co_tiles = cdiv(d->Cout, BN);
-  g.ksplit = choose_ksplit(d, g.tiles_x * g.tiles_y * d->N * co_tiles, nchunks);
+  g.ksplit = choose_ksplit(d, g.tiles_x * g.tiles_y * d->N * co_tiles, nchunks, d->ntaps * 8 * MT * (BN / 32));
   g.ws = d->splitk_ws;
   g.ws_ld = round_up(d->Cout, 4);
   dim3 grid(g.tiles_x * g.tiles_y, co_tiles * g.ksplit, d->N);
@@ -783,7 +797,7 @@ extern "C" int pmf_conv_fwd_stat_rows(const pmf_conv_desc_t* d) {
   pmf_conv_geometry(d->OH, d->OW, d->ntaps, d->tdy, d->tdx, d->in_stride, d->gather, BN, MT, cmax < KC ? cmax : KC, &g,
                     &gather);
   const int tiles = g.tiles_x * g.tiles_y;
-  if (choose_ksplit(d, tiles * d->N * cdiv(d->Cout, BN), nchunks) > 1) return finish_rows(d);
+  if (choose_ksplit(d, tiles * d->N * cdiv(d->Cout, BN), nchunks, d->ntaps * 8 * MT * (BN / 32)) > 1) return finish_rows(d);
   return tiles * d->N;
 }
 

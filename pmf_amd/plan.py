@@ -211,12 +211,16 @@ class Plan:
         OH = (inH + 2 * pad - dil * (kh - 1) - 1) // stride + 1
         OW = (inW + 2 * pad - dil * (kw - 1) - 1) // stride + 1
         out = T(self, N, OH, OW, Cout, name)
-        taps = self.taps(kh, kw, dil, pad)
+        # taps that can only ever read zero padding (|offset| beyond the map: the dilation-12/18 ASPP branches on a
+        # 4-row map keep 3 of 9 taps) are dropped from forward, input gradient and weight gradient alike; their weight
+        # gradient is exactly zero and stays at the zero the backward prologue writes
+        taps = [(dy, dx, wi) for (dy, dx, wi) in self.taps(kh, kw, dil, pad)
+                if dy < inH and dy + (OH - 1) * stride >= 0 and dx < inW and dx + (OW - 1) * stride >= 0]
         Ktot = sum(_ru(s.t.C, 8) for s in srcs)
         ldw = _ru(Cout, 64)
         wbuf = self.add_pack(conv.weight, [t[2] for t in taps], 0, Ktot, ldw)
         # very large dilations: per-tap staging (the halo tile would not fit LDS)
-        span = dil * (kh - 1)
+        span = max(max(t[0] for t in taps) - min(t[0] for t in taps), max(t[1] for t in taps) - min(t[1] for t in taps))
         gather = 1 if (8 * stride + span) * (32 * stride + span) * 80 > 110 * 1024 else 0
         train_bn = bn is not None and self.training
         has_bias = conv.bias is not None
@@ -430,7 +434,7 @@ class Plan:
         Cout = conv.out_channels
         goff = self.pgrad(conv.weight)
         kh, kw = conv.kernel_size
-        span = conv.dilation[0] * (kh - 1)
+        span = max(max(t[0] for t in taps) - min(t[0] for t in taps), max(t[1] for t in taps) - min(t[1] for t in taps))
         wg_gather = 1 if (gather or (3 * stride + 1 + span) * (31 * stride + 1 + span) * 128 > 100 * 1024) else 0
 
         def shape_fill(d):
