@@ -634,14 +634,17 @@ __global__ void conv_finish_k(const pmf_conv_desc_t d, int ksplit, const float* 
       f32x4 v = bias;
       for (int s = 0; s < ksplit; ++s) v += *(const f32x4*)(ws + ((int64_t)s * npix + p) * ws_ld + c);
       const int n = (int)(p / hw);
-      float* op = d.out + p * d.out_ldc + c;
+      const int rem = (int)(p - (int64_t)n * hw), oy = rem / d.OW, ox = rem - oy * d.OW;
+      // strided / offset outputs (stride-2 input-gradient parity classes, pixel-shuffle style scatter)
+      const int64_t opix = (int64_t)(n * d.out_H + oy * d.out_sy + d.out_oy) * d.out_W + ox * d.out_sx + d.out_ox;
+      float* op = d.out + opix * d.out_ldc + c;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         if (c + k >= d.Cout) continue;
         float x = pmf_act(v[k], d.act);
         if (d.ep_cmul) x *= d.ep_cmul[(size_t)n * d.ep_cmul_ld + c + k];
         if (d.ep_relu_x) {
-          float xr = d.ep_relu_x[p * d.ep_relu_ldc + c + k];
+          float xr = d.ep_relu_x[opix * d.ep_relu_ldc + c + k];
           if (d.ep_relu_scale) xr = xr * d.ep_relu_scale[c + k] + d.ep_relu_shift[c + k];
           if (!(xr > 0.f)) x = 0.f;
         }
@@ -719,7 +722,7 @@ static void conv_config(const pmf_conv_desc_t* d, int* BN, int* MT) {
 
 // split-K factor: only when the M x N grid cannot fill the 256 CUs (low-resolution, many-channel layers)
 static int choose_ksplit(const pmf_conv_desc_t* d, int blocks_mn, int nchunks, int mfma_per_chunk) {
-  if (!d->splitk_ws || d->out_sy != 1 || d->out_sx != 1 || blocks_mn >= 200 || nchunks < 4) return 1;
+  if (!d->splitk_ws || blocks_mn >= 200 || nchunks < 4) return 1;
   int k = 512 / (blocks_mn > 0 ? blocks_mn : 1);
   if (k > nchunks / 2) k = nchunks / 2;
   (void)mfma_per_chunk;   // (a floor on the MFMA work per split was tried: the serial K loop of 1x1 layers is slower)
