@@ -136,7 +136,7 @@ def main():
         plan = next(iter(model._plans.values()))
         eng.model.train()
         pcd, rgb = eng.prepare(feat0.clone(), mask)
-        total, _, _, _ = eng.forward_loss(pcd, rgb, label.long())
+        total = eng.forward_loss(pcd, rgb, label.long())[0]
         prof_f = plan.run_profiled("forward")       # re-runs the forward plan op by op (same inputs)
         total.backward()                             # normal backward (needed to patch gradient pointers) ...
         prof_b = plan.run_profiled("backward")      # ... then the backward plan again, op by op

@@ -252,6 +252,28 @@ int pmf_crop_pad(const float* src, int32_t C, int32_t h, int32_t w, int32_t top,
 int pmf_lovasz_grad(const float* fg_sorted, int32_t C, int64_t P, const int64_t* n_valid, float* bsum, float* grad,
                     pmf_stream_t s);
 
+/* PMF training objective for both heads, value AND gradient w.r.t. the two probability maps (tasks/pmf/trainer.py:
+ * 231-252 perception-aware loss, 303-332 total; pc_processor/loss/focal_softmax.py:37-63; lovasz_softmax.py:132-160,
+ * classes='present', ignore=0):   total = foc + foc_cam + lambda * (lov + lov_cam) + gamma_per * per.
+ * Step 1, pmf_loss_pixel: label histogram cnt u64[C]; per pixel the entropies, focal terms, perception-aware KL terms
+ *   and their analytic gradients (weights NOT detached, as in the reference) -> grad_lidar / grad_camera f32[N][C][HW];
+ *   Lovasz sort keys key f32[2C][N*HW] (|fg - p|, -1 for ignored pixels; rows C.. = camera head); partial sums
+ *   rows f64[pmf_loss_rows(P)][4]; optional confusion matrices conf_*[pred][label] += 1 (u64[C][C], argmax vs label).
+ * Caller: ONE descending sort of the 2C key rows (values + permutation; rocprim via torch.sort).
+ * Step 2, pmf_loss_lovasz: Jaccard first differences along the permutation, value = dot(sorted errors, grad) per
+ *   class, gradient lambda / n_present * grad * d|fg-p|/dp added to grad_* through the permutation (no atomics);
+ *   bsum f32[2C][pmf_loss_chunks(P)], dots f64[2C][pmf_loss_chunks(P)] scratch;
+ *   out6 = {total, foc, lov, foc_cam, lov_cam, per}.  Deterministic (fixed summation order). */
+int pmf_loss_rows(int64_t P);
+int pmf_loss_chunks(int64_t P);
+int pmf_loss_pixel(const float* lidar_prob, const float* camera_prob, const int64_t* label, const float* alpha,
+                   int32_t N, int32_t C, int64_t HW, float focal_gamma, float tau, float gamma_per,
+                   unsigned long long* cnt, float* grad_lidar, float* grad_camera, float* key, double* rows,
+                   unsigned long long* conf_lidar, unsigned long long* conf_camera, pmf_stream_t s);
+int pmf_loss_lovasz(const int64_t* perm, const float* key_sorted, const int64_t* label, int32_t N, int32_t C, int64_t HW,
+                    const unsigned long long* cnt, float lambda, float gamma_per, float* bsum, double* dots,
+                    const double* rows, float* grad_lidar, float* grad_camera, float* out6, pmf_stream_t s);
+
 /* ---- plan executor: a whole forward (or backward) pass = one call --------------------------------------- */
 enum {
   PMF_OP_CONV = 1, PMF_OP_WGRAD, PMF_OP_PACK, PMF_OP_BN_FINALIZE, PMF_OP_BN_EVAL, PMF_OP_BN_BWD_REDUCE,

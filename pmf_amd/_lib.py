@@ -131,6 +131,16 @@ def lib():
     L.pmf_crop_pad.argtypes = [C.c_void_p] + [C.c_int32] * 5 + [C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p]
     L.pmf_lovasz_grad.restype = C.c_int
     L.pmf_lovasz_grad.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.pmf_loss_rows.restype = C.c_int
+    L.pmf_loss_rows.argtypes = [C.c_int64]
+    L.pmf_loss_chunks.restype = C.c_int
+    L.pmf_loss_chunks.argtypes = [C.c_int64]
+    L.pmf_loss_pixel.restype = C.c_int
+    L.pmf_loss_pixel.argtypes = [C.c_void_p] * 4 + [C.c_int32, C.c_int32, C.c_int64, C.c_float, C.c_float, C.c_float] + \
+        [C.c_void_p] * 8
+    L.pmf_loss_lovasz.restype = C.c_int
+    L.pmf_loss_lovasz.argtypes = [C.c_void_p] * 3 + [C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_float, C.c_float] + \
+        [C.c_void_p] * 7
     L.pmf_fill.restype = C.c_int
     L.pmf_fill.argtypes = [C.c_void_p, C.c_float, C.c_int64, C.c_void_p]
     _lib = L
@@ -144,7 +154,7 @@ EXPORTS = [
     "pmf_maxpool3s2_bwd", "pmf_bilinear2x", "pmf_bilinear2x_bwd", "pmf_pixel_shuffle2", "pmf_pixel_shuffle2_bwd",
     "pmf_fusion_gate", "pmf_fusion_gate_bwd", "pmf_global_mean", "pmf_global_mean_bwd", "pmf_colsum",
     "pmf_softmax_nhwc_to_nchw", "pmf_softmax_bwd_nchw_to_nhwc", "pmf_nchw_to_nhwc", "pmf_fill", "pmf_knn_vote",
-    "pmf_project_scatter", "pmf_crop_pad", "pmf_lovasz_grad", "pmf_plan_run", "pmf_plan_run_range", "pmf_sizeof", "pmf_version",
+    "pmf_project_scatter", "pmf_crop_pad", "pmf_lovasz_grad", "pmf_loss_rows", "pmf_loss_chunks", "pmf_loss_pixel", "pmf_loss_lovasz", "pmf_plan_run", "pmf_plan_run_range", "pmf_sizeof", "pmf_version",
 ]
 
 

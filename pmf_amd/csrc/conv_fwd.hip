@@ -11,6 +11,7 @@
 // Epilogue: + bias, activation, optional (n,c) multiplier / ReLU mask (input-gradient form), optional
 // per-channel sum / sum-of-squares for the BatchNorm that follows, coalesced 128-B row stores.
 #include "common.h"
+#include <stdlib.h>
 
 #define KC 16
 #define APITCH 20

@@ -93,3 +93,326 @@ extern "C" int pmf_lovasz_grad(const float* fg_sorted, int32_t C, int64_t P, con
   PMF_LAUNCH_CHECK();
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// PMF training objective, both heads, value AND gradient in one pass (tasks/pmf/trainer.py:231-252, 303-332;
+// pc_processor/loss/focal_softmax.py:37-63; lovasz_softmax.py:132-160).  Replaces ~250 element-wise torch launches
+// per iteration by:  label histogram -> per-pixel kernel -> [caller: one batched descending sort of the 2C Lovasz key
+// rows] -> Jaccard kernels (value + gradient scattered back through the permutation) -> fold.
+//   total = foc_l + foc_c + lambda * (lov_l + lov_c) + gamma * per
+// Analytic gradients (p = LiDAR probabilities, q = camera probabilities of one pixel, logC = ln C):
+//   plog_c = ln max(p_c, 1e-8),  e_p = -sum p_c plog_c / logC,  de_p/dp_c = -(plog_c + [p_c >= 1e-8]) / logC
+//   d = e_q - e_p (= confidence difference),  w_pcd = [d>0] |d| [1-e_p >= tau],  w_img = [d<0] |d| [1-e_q >= tau]
+//   Lp = sum_c xlogy(q_c,q_c) - q_c plog_c  (KL(q || p), weighted by w_img),  Lq the mirror image (weighted by w_pcd)
+//   per = mean over N*C*H*W of  w_img Lp + w_pcd Lq;  the weights are NOT detached in the reference, so
+//   d(per M)/dp_c = -w_img q_c [p_c>=1e-8]/p_c + w_pcd (ln p_c + 1 - qlog_c) + (Lq [d>0][pc>=tau] - Lp [d<0][ic>=tau]) dd_c,
+//   dd_c = (plog_c + [p_c >= 1e-8]) / logC, and symmetrically for q.
+//   focal: f = -(1-pt)^g ln max(pt,1e-6) alpha_t,  df/dpt = alpha_t (g (1-pt)^(g-1) ln max(pt,1e-6) - (1-pt)^g [pt>=1e-6]/pt)
+#define LP_BLOCK 256
+#define LP_MAXC 32
+
+__global__ __launch_bounds__(256) void loss_count_k(const int64_t* __restrict__ label, int64_t P, int C,
+                                                    unsigned long long* __restrict__ cnt) {
+  __shared__ unsigned int h[LP_MAXC];
+  if (threadIdx.x < LP_MAXC) h[threadIdx.x] = 0u;
+  __syncthreads();
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
+    const int t = (int)label[i];
+    if (t >= 0 && t < C) atomicAdd(&h[t], 1u);
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < C && h[threadIdx.x]) atomicAdd(&cnt[threadIdx.x], (unsigned long long)h[threadIdx.x]);
+}
+
+struct LossPixelArgs {
+  const float* pl; const float* pc;          // probabilities [N][C][HW]
+  const int64_t* label;                      // [N][HW]
+  const float* alpha;                        // [C]
+  const unsigned long long* cnt;             // label histogram [C]
+  float* gl; float* gc;                      // gradients (focal + perception part), same layout as pl / pc
+  float* key;                                // [2C][P] Lovasz sort keys
+  double* rows;                              // [nblocks][4] partial sums: focal lidar, focal camera, perception
+  unsigned long long* conf_l; unsigned long long* conf_c;   // [C][C] confusion matrices (pred, label), may be null
+  int64_t HW, P;
+  int C;
+  float fgamma, tau, gamma_per;
+};
+
+__global__ __launch_bounds__(LP_BLOCK) void loss_pixel_k(const LossPixelArgs a) {
+  __shared__ double red[3][LP_BLOCK];
+  __shared__ unsigned int hist[2][LP_MAXC * LP_MAXC];
+  const int C = a.C;
+  const bool want_conf = a.conf_l != nullptr;
+  if (want_conf) {
+    for (int k = threadIdx.x; k < C * C; k += LP_BLOCK) { hist[0][k] = 0u; hist[1][k] = 0u; }
+    __syncthreads();
+  }
+  const int64_t i = (int64_t)blockIdx.x * LP_BLOCK + threadIdx.x;
+  double s_fl = 0.0, s_fc = 0.0, s_per = 0.0;
+  if (i < a.P) {
+    const int64_t n = i / a.HW, hw = i - n * a.HW;
+    const float* pl = a.pl + n * C * a.HW + hw;
+    const float* pc = a.pc + n * C * a.HW + hw;
+    const int t = (int)a.label[i];
+    const float logC = logf((float)C), ilogC = 1.f / logC;
+    float p[LP_MAXC], q[LP_MAXC];
+    float ep = 0.f, eq = 0.f, Lp = 0.f, Lq = 0.f;
+    int am_l = 0, am_c = 0;
+    float mx_l = -1.f, mx_c = -1.f;
+#pragma unroll 4
+    for (int c = 0; c < C; ++c) {
+      const float pv = pl[c * a.HW], qv = pc[c * a.HW];
+      p[c] = pv; q[c] = qv;
+      const float plog = logf(fmaxf(pv, 1e-8f)), qlog = logf(fmaxf(qv, 1e-8f));
+      ep -= pv * plog; eq -= qv * qlog;
+      Lp += (qv > 0.f ? qv * logf(qv) : 0.f) - qv * plog;     // F.kl_div(plog, q): xlogy(q,q) - q*plog
+      Lq += (pv > 0.f ? pv * logf(pv) : 0.f) - pv * qlog;
+      if (pv > mx_l) { mx_l = pv; am_l = c; }
+      if (qv > mx_c) { mx_c = qv; am_c = c; }
+    }
+    ep *= ilogC; eq *= ilogC;
+    const float conf_p = 1.f - ep, conf_q = 1.f - eq;
+    const float d = conf_p - conf_q;
+    const float gate_p = (d > 0.f && conf_p >= a.tau) ? 1.f : 0.f;   // w_pcd = gate_p * |d|
+    const float gate_q = (d < 0.f && conf_q >= a.tau) ? 1.f : 0.f;   // w_img = gate_q * |d|
+    const float w_pcd = gate_p * fabsf(d), w_img = gate_q * fabsf(d);
+    const double M = (double)a.P * C;
+    s_per = ((double)w_img * Lp + (double)w_pcd * Lq) / M;
+    const float sper = a.gamma_per / (float)M;
+    // focal
+    const bool valid = t > 0 && t < C;
+    const double msum = (double)a.P - (double)a.cnt[0];
+    float dfl = 0.f, dfc = 0.f;
+    if (valid) {
+      const float al = a.alpha[t];
+      const float ptl = p[t], ptc = q[t];
+      const float ll = logf(fmaxf(ptl, 1e-6f)), lc = logf(fmaxf(ptc, 1e-6f));
+      const float ol = 1.f - ptl, oc = 1.f - ptc;
+      const float pwl = powf(ol, a.fgamma), pwc = powf(oc, a.fgamma);
+      s_fl = (double)(-pwl * ll * al) / msum;
+      s_fc = (double)(-pwc * lc * al) / msum;
+      const float pwl1 = a.fgamma == 1.f ? 1.f : powf(ol, a.fgamma - 1.f), pwc1 = a.fgamma == 1.f ? 1.f : powf(oc, a.fgamma - 1.f);
+      dfl = al * (a.fgamma * pwl1 * ll - (ptl >= 1e-6f ? pwl / ptl : 0.f)) / (float)msum;
+      dfc = al * (a.fgamma * pwc1 * lc - (ptc >= 1e-6f ? pwc / ptc : 0.f)) / (float)msum;
+    }
+    float* gl = a.gl + n * C * a.HW + hw;
+    float* gc = a.gc + n * C * a.HW + hw;
+    const float cw = Lq * gate_p - Lp * gate_q;    // d(w_pcd Lq + w_img Lp)/dd through the weights: sign folded in
+    const bool lov_valid = t != 0;                  // Lovasz ignore label 0
+#pragma unroll 4
+    for (int c = 0; c < C; ++c) {
+      const float pv = p[c], qv = q[c];
+      const float plog = logf(fmaxf(pv, 1e-8f)), qlog = logf(fmaxf(qv, 1e-8f));
+      const float ip = pv >= 1e-8f ? 1.f : 0.f, iq = qv >= 1e-8f ? 1.f : 0.f;
+      const float ddp = (plog + ip) * ilogC;       // dd/dp_c
+      const float ddq = -(qlog + iq) * ilogC;      // dd/dq_c
+      float g1 = -w_img * qv * (ip > 0.f ? 1.f / pv : 0.f) + w_pcd * (logf(fmaxf(pv, 1e-38f)) + 1.f - qlog) + cw * ddp;
+      float g2 = -w_pcd * pv * (iq > 0.f ? 1.f / qv : 0.f) + w_img * (logf(fmaxf(qv, 1e-38f)) + 1.f - plog) + cw * ddq;
+      g1 *= sper; g2 *= sper;
+      if (c == t) { g1 += dfl; g2 += dfc; }
+      gl[c * a.HW] = g1;
+      gc[c * a.HW] = g2;
+      const float fg = (lov_valid && c == t) ? 1.f : 0.f;
+      a.key[(int64_t)c * a.P + i] = lov_valid ? fabsf(fg - pv) : -1.f;
+      a.key[(int64_t)(C + c) * a.P + i] = lov_valid ? fabsf(fg - qv) : -1.f;
+    }
+    if (want_conf && t >= 0 && t < C) {
+      atomicAdd(&hist[0][am_l * C + t], 1u);
+      atomicAdd(&hist[1][am_c * C + t], 1u);
+    }
+  }
+  red[0][threadIdx.x] = s_fl; red[1][threadIdx.x] = s_fc; red[2][threadIdx.x] = s_per;
+  __syncthreads();
+  for (int o = LP_BLOCK / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + o];
+      red[1][threadIdx.x] += red[1][threadIdx.x + o];
+      red[2][threadIdx.x] += red[2][threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    double* r = a.rows + (size_t)blockIdx.x * 4;
+    r[0] = red[0][0]; r[1] = red[1][0]; r[2] = red[2][0]; r[3] = 0.0;
+  }
+  if (want_conf) {
+    for (int k = threadIdx.x; k < C * C; k += LP_BLOCK) {
+      if (hist[0][k]) atomicAdd(&a.conf_l[k], (unsigned long long)hist[0][k]);
+      if (hist[1][k]) atomicAdd(&a.conf_c[k], (unsigned long long)hist[1][k]);
+    }
+  }
+}
+
+// Lovasz stage (rows r = head * C + class, sorted descending by error; perm[r][k] = pixel of rank k):
+// per-chunk sums of the foreground indicator along the permutation ...
+__global__ __launch_bounds__(LV_BLOCK) void lovasz2_sums_k(const int64_t* __restrict__ perm, const int64_t* __restrict__ label,
+                                                           int64_t P, int C, int nb, float* __restrict__ bsum) {
+  __shared__ float sh[LV_BLOCK];
+  const int r = blockIdx.y, b = blockIdx.x, cls = r % C;
+  const int64_t base = (int64_t)b * LV_CHUNK + (int64_t)threadIdx.x * LV_PER_THREAD;
+  const int64_t* row = perm + (int64_t)r * P;
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < LV_PER_THREAD; ++k)
+    if (base + k < P) s += (cls != 0 && label[row[base + k]] == cls) ? 1.f : 0.f;
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = LV_BLOCK / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) bsum[r * nb + b] = sh[0];
+}
+
+// ... then the Jaccard first differences, the dot product with the sorted errors (value) and the gradient
+// lambda * [class present] / n_present * grad * d|fg - p|/dp, scattered back through the permutation (every (class, pixel)
+// pair occurs exactly once per row: plain read-modify-write, no atomics).
+__global__ __launch_bounds__(LV_BLOCK) void lovasz2_grad_k(const int64_t* __restrict__ perm, const float* __restrict__ key_sorted,
+                                                           const int64_t* __restrict__ label, int64_t P, int64_t HW, int C,
+                                                           int nb, const float* __restrict__ bsum,
+                                                           const unsigned long long* __restrict__ cnt, float lambda,
+                                                           float* __restrict__ gl, float* __restrict__ gc,
+                                                           double* __restrict__ dots) {
+  __shared__ float sh[LV_BLOCK];
+  __shared__ double shd[LV_BLOCK];
+  __shared__ float carry_s, total_s;
+  const int r = blockIdx.y, b = blockIdx.x, cls = r % C, head = r / C;
+  const int64_t nvalid = P - (int64_t)cnt[0];
+  if (threadIdx.x == 0) {
+    float pre = 0.f, tot = 0.f;
+    for (int j = 0; j < nb; ++j) { const float v = bsum[r * nb + j]; if (j < b) pre += v; tot += v; }
+    carry_s = pre; total_s = tot;
+  }
+  int npresent = 0;
+  for (int c = 1; c < C; ++c) npresent += cnt[c] > 0 ? 1 : 0;
+  const float wcls = (cls != 0 && cnt[cls] > 0) ? lambda / (float)(npresent > 0 ? npresent : 1) : 0.f;
+  const int64_t base = (int64_t)b * LV_CHUNK + (int64_t)threadIdx.x * LV_PER_THREAD;
+  const int64_t* row = perm + (int64_t)r * P;
+  const float* krow = key_sorted + (int64_t)r * P;
+  float v[LV_PER_THREAD];
+  int64_t pix[LV_PER_THREAD];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < LV_PER_THREAD; ++k) {
+    pix[k] = base + k < P ? row[base + k] : 0;
+    v[k] = (base + k < P && cls != 0 && label[pix[k]] == cls) ? 1.f : 0.f;
+    s += v[k];
+  }
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 1; o < LV_BLOCK; o <<= 1) {
+    const float t = (int)threadIdx.x >= o ? sh[threadIdx.x - o] : 0.f;
+    __syncthreads();
+    sh[threadIdx.x] += t;
+    __syncthreads();
+  }
+  float run = carry_s + sh[threadIdx.x] - s;
+  const float G = total_s;
+  float jprev;
+  {
+    const int64_t i = base - 1;
+    if (i < 0) jprev = 0.f;
+    else {
+      const float uni = G + ((float)(i + 1) - run);
+      jprev = 1.f - (G - run) / fmaxf(uni, 1e-12f);
+    }
+  }
+  float* g = head == 0 ? gl : gc;
+  double dot = 0.0;
+#pragma unroll
+  for (int k = 0; k < LV_PER_THREAD; ++k) {
+    const int64_t i = base + k;
+    if (i >= P) break;
+    run += v[k];
+    const float uni = G + ((float)(i + 1) - run);
+    const float j = 1.f - (G - run) / fmaxf(uni, 1e-12f);
+    const float gr = i < nvalid ? (i == 0 ? j : j - jprev) : 0.f;
+    jprev = j;
+    if (i < nvalid) {
+      const float e = krow[i];
+      dot += (double)e * (double)gr;
+      if (wcls != 0.f && e != 0.f) {
+        const int64_t n = pix[k] / HW, hw = pix[k] - n * HW;
+        float* gp = g + (n * C + cls) * HW + hw;
+        *gp += wcls * gr * (v[k] > 0.f ? -1.f : 1.f);
+      }
+    }
+  }
+  shd[threadIdx.x] = dot;
+  __syncthreads();
+  for (int o = LV_BLOCK / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) shd[threadIdx.x] += shd[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) dots[r * nb + b] = shd[0];
+}
+
+// out[6] = {total, foc, lov, foc_cam, lov_cam, per}; single workgroup, fixed summation order
+__global__ __launch_bounds__(256) void loss_fold_k(const double* __restrict__ rows, int nrows, const double* __restrict__ dots,
+                                                   int C, int nb, const unsigned long long* __restrict__ cnt, float lambda,
+                                                   float gamma_per, float* __restrict__ out) {
+  __shared__ double sh[5][256];
+  double a0 = 0, a1 = 0, a2 = 0;
+  for (int i = threadIdx.x; i < nrows; i += 256) { a0 += rows[(size_t)i * 4]; a1 += rows[(size_t)i * 4 + 1]; a2 += rows[(size_t)i * 4 + 2]; }
+  // Lovasz: per-class dot products, classes present only
+  double l0 = 0, l1 = 0;
+  for (int idx = threadIdx.x; idx < 2 * C * nb; idx += 256) {
+    const int r = idx / nb, cls = r % C;
+    if (cls != 0 && cnt[cls] > 0) { if (r < C) l0 += dots[idx]; else l1 += dots[idx]; }
+  }
+  sh[0][threadIdx.x] = a0; sh[1][threadIdx.x] = a1; sh[2][threadIdx.x] = a2; sh[3][threadIdx.x] = l0; sh[4][threadIdx.x] = l1;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o)
+      for (int k = 0; k < 5; ++k) sh[k][threadIdx.x] += sh[k][threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    int npresent = 0;
+    for (int c = 1; c < C; ++c) npresent += cnt[c] > 0 ? 1 : 0;
+    const double np = npresent > 0 ? npresent : 1;
+    const double foc = sh[0][0], focc = sh[1][0], per = sh[2][0], lov = sh[3][0] / np, lovc = sh[4][0] / np;
+    out[1] = (float)foc; out[2] = (float)lov; out[3] = (float)focc; out[4] = (float)lovc; out[5] = (float)per;
+    out[0] = (float)(foc + focc + lambda * (lov + lovc) + gamma_per * per);
+  }
+}
+
+extern "C" int pmf_loss_rows(int64_t P) { return (int)cdiv64(P, LP_BLOCK); }
+extern "C" int pmf_loss_chunks(int64_t P) { return (int)cdiv64(P, LV_CHUNK); }
+
+extern "C" int pmf_loss_pixel(const float* lidar_prob, const float* camera_prob, const int64_t* label, const float* alpha,
+                              int32_t N, int32_t C, int64_t HW, float focal_gamma, float tau, float gamma_per,
+                              unsigned long long* cnt, float* grad_lidar, float* grad_camera, float* key, double* rows,
+                              unsigned long long* conf_lidar, unsigned long long* conf_camera, pmf_stream_t s) {
+  if (C < 2 || C > LP_MAXC || N < 1 || HW < 1) return PMF_E_ARG;
+  const int64_t P = (int64_t)N * HW;
+  hipStream_t st = (hipStream_t)s;
+  hipError_t e = hipMemsetAsync(cnt, 0, sizeof(unsigned long long) * C, st);
+  if (e != hipSuccess) return (int)e;
+  int gb = (int)cdiv64(P, 256 * 8);
+  hipLaunchKernelGGL(loss_count_k, dim3(gb > 1024 ? 1024 : gb), dim3(256), 0, st, label, P, C, cnt);
+  LossPixelArgs a;
+  a.pl = lidar_prob; a.pc = camera_prob; a.label = label; a.alpha = alpha; a.cnt = cnt;
+  a.gl = grad_lidar; a.gc = grad_camera; a.key = key; a.rows = rows; a.conf_l = conf_lidar; a.conf_c = conf_camera;
+  a.HW = HW; a.P = P; a.C = C; a.fgamma = focal_gamma; a.tau = tau; a.gamma_per = gamma_per;
+  hipLaunchKernelGGL(loss_pixel_k, dim3((unsigned)cdiv64(P, LP_BLOCK)), dim3(LP_BLOCK), 0, st, a);
+  PMF_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pmf_loss_lovasz(const int64_t* perm, const float* key_sorted, const int64_t* label, int32_t N, int32_t C,
+                               int64_t HW, const unsigned long long* cnt, float lambda, float gamma_per, float* bsum,
+                               double* dots, const double* rows, float* grad_lidar, float* grad_camera, float* out6,
+                               pmf_stream_t s) {
+  if (C < 2 || C > LP_MAXC || N < 1 || HW < 1) return PMF_E_ARG;
+  const int64_t P = (int64_t)N * HW;
+  const int nb = (int)cdiv64(P, LV_CHUNK);
+  hipStream_t st = (hipStream_t)s;
+  hipLaunchKernelGGL(lovasz2_sums_k, dim3(nb, 2 * C), dim3(LV_BLOCK), 0, st, perm, label, P, C, nb, bsum);
+  hipLaunchKernelGGL(lovasz2_grad_k, dim3(nb, 2 * C), dim3(LV_BLOCK), 0, st, perm, key_sorted, label, P, HW, C, nb,
+                     (const float*)bsum, cnt, lambda, grad_lidar, grad_camera, dots);
+  hipLaunchKernelGGL(loss_fold_k, dim3(1), dim3(256), 0, st, rows, (int)cdiv64(P, LP_BLOCK), (const double*)dots, C, nb, cnt,
+                     lambda, gamma_per, out6);
+  PMF_LAUNCH_CHECK();
+  return 0;
+}

@@ -11,7 +11,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .loss import FocalSoftmaxLoss, Lovasz_softmax, pmf_total_loss
+from .loss import FocalSoftmaxLoss, Lovasz_softmax, pmf_total_loss, pmf_total_loss_fused
 from .metrics import IOUEval
 from .utils import WarmupCosineLR
 
@@ -68,17 +68,30 @@ class TrainEngine:
         return input_feature[:, 0:5], input_feature[:, 5:8]
 
     def forward_loss(self, pcd, rgb, label):
+        """returns (total, terms, lidar_pred, camera_pred, metrics_done).  On the GPU the objective, its gradient and
+        the confusion-matrix update of both heads are one fused HIP pass (loss/fused.py); the torch-op version
+        (loss/perception.py) serves CPU host tests."""
         lidar_pred, camera_pred = self.model(pcd, rgb)
+        if lidar_pred.is_cuda:
+            for m in (self.metrics, self.metrics_img):
+                if m.conf_matrix.device != lidar_pred.device:
+                    m.conf_matrix = m.conf_matrix.to(lidar_pred.device)
+            total, terms = pmf_total_loss_fused(lidar_pred, camera_pred, label, self.focal.alpha, self.lambda_,
+                                                self.gamma, self.tau, self.focal.gamma, self.metrics.conf_matrix,
+                                                self.metrics_img.conf_matrix)
+            self.metrics.external_update()
+            self.metrics_img.external_update()
+            return total, terms, lidar_pred, camera_pred, True
         total, terms = pmf_total_loss(lidar_pred, camera_pred, label, self.focal, self.lovasz,
                                       self.lambda_, self.gamma, self.tau)
-        return total, terms, lidar_pred, camera_pred
+        return total, terms, lidar_pred, camera_pred, False
 
     def train_step(self, input_feature, input_mask, input_label):
         """one full iteration; everything stays on the device (no .item())."""
         self.model.train()
         pcd, rgb = self.prepare(input_feature, input_mask)
         label = input_label.long()
-        total, terms, lidar_pred, camera_pred = self.forward_loss(pcd, rgb, label)
+        total, terms, lidar_pred, camera_pred, metrics_done = self.forward_loss(pcd, rgb, label)
         self.optimizer.zero_grad(set_to_none=True)
         self.aux_optimizer.zero_grad(set_to_none=True)
         total.backward()
@@ -86,9 +99,10 @@ class TrainEngine:
         self.aux_optimizer.step()
         self.scheduler.step()
         self.aux_scheduler.step()
-        with torch.no_grad():
-            self.metrics.addBatch(lidar_pred.argmax(dim=1), label)
-            self.metrics_img.addBatch(camera_pred.argmax(dim=1), label)
+        if not metrics_done:
+            with torch.no_grad():
+                self.metrics.addBatch(lidar_pred.argmax(dim=1), label)
+                self.metrics_img.addBatch(camera_pred.argmax(dim=1), label)
         self.iteration += 1
         return total.detach(), terms
 
@@ -97,7 +111,8 @@ class TrainEngine:
         self.model.eval()
         pcd, rgb = self.prepare(input_feature, input_mask)
         label = input_label.long()
-        total, terms, lidar_pred, camera_pred = self.forward_loss(pcd, rgb, label)
-        self.metrics.addBatch(lidar_pred.argmax(dim=1), label)
-        self.metrics_img.addBatch(camera_pred.argmax(dim=1), label)
+        total, terms, lidar_pred, camera_pred, metrics_done = self.forward_loss(pcd, rgb, label)
+        if not metrics_done:
+            self.metrics.addBatch(lidar_pred.argmax(dim=1), label)
+            self.metrics_img.addBatch(camera_pred.argmax(dim=1), label)
         return total, terms

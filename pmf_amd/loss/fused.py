@@ -1,0 +1,64 @@
+"""The PMF training objective as ONE autograd node on the GPU (value + analytic gradient in HIP, include/pmf_amd.h
+``pmf_loss_pixel`` / ``pmf_loss_lovasz``).
+
+    total = foc + foc_cam + lambda * (lov + lov_cam) + gamma * per          (tasks/pmf/trainer.py:303-332)
+
+``pmf_total_loss`` (perception.py) is the same objective written with torch ops, term by term like the reference; it
+is what the CPU host tests and the float64 parity tests differentiate with autograd.  This module is what the
+training engine runs on the GPU: ~250 element-wise launches per iteration become 6 kernels + one batched sort, and the
+confusion matrices of both heads (argmax vs label) are updated in the same pass."""
+import ctypes as C
+
+import torch
+
+from .. import _lib as L
+
+
+class _FusedPMFLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, lidar_prob, camera_prob, label, alpha, lambda_, gamma_per, tau, focal_gamma, conf_l, conf_c):
+        lib = L.lib()
+        if not (lidar_prob.is_cuda and camera_prob.is_cuda and label.is_cuda):
+            raise RuntimeError("pmf_amd fused loss: tensors must live on the GPU (no CPU fallback)")
+        pl, pc = lidar_prob.detach().contiguous().float(), camera_prob.detach().contiguous().float()
+        lab = label.contiguous().long()
+        n, c, h, w = pl.shape
+        hw, p = h * w, n * h * w
+        dev = pl.device
+        gl, gc = torch.empty_like(pl), torch.empty_like(pc)
+        key = torch.empty((2 * c, p), dtype=torch.float32, device=dev)
+        rows = torch.empty((lib.pmf_loss_rows(p), 4), dtype=torch.float64, device=dev)
+        cnt = torch.empty(c, dtype=torch.int64, device=dev)
+        nb = lib.pmf_loss_chunks(p)
+        bsum = torch.empty((2 * c, nb), dtype=torch.float32, device=dev)
+        dots = torch.empty((2 * c, nb), dtype=torch.float64, device=dev)
+        out6 = torch.empty(6, dtype=torch.float32, device=dev)
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        a = alpha.to(dev, torch.float32).contiguous()
+        L.check(lib.pmf_loss_pixel(pl.data_ptr(), pc.data_ptr(), lab.data_ptr(), a.data_ptr(), n, c, hw,
+                                   float(focal_gamma), float(tau), float(gamma_per), cnt.data_ptr(), gl.data_ptr(),
+                                   gc.data_ptr(), key.data_ptr(), rows.data_ptr(),
+                                   conf_l.data_ptr() if conf_l is not None else None,
+                                   conf_c.data_ptr() if conf_c is not None else None, st), "pmf_loss_pixel")
+        vals, perm = torch.sort(key, dim=1, descending=True)
+        L.check(lib.pmf_loss_lovasz(perm.data_ptr(), vals.data_ptr(), lab.data_ptr(), n, c, hw, cnt.data_ptr(),
+                                    float(lambda_), float(gamma_per), bsum.data_ptr(), dots.data_ptr(), rows.data_ptr(),
+                                    gl.data_ptr(), gc.data_ptr(), out6.data_ptr(), st), "pmf_loss_lovasz")
+        ctx.save_for_backward(gl, gc)
+        ctx.mark_non_differentiable(out6)
+        return out6[0].clone(), out6
+
+    @staticmethod
+    def backward(ctx, g_total, _g_terms):
+        gl, gc = ctx.saved_tensors
+        return gl * g_total, gc * g_total, None, None, None, None, None, None, None, None
+
+
+def pmf_total_loss_fused(lidar_prob, camera_prob, label, alpha, lambda_=1.0, gamma_=0.5, tau=0.7, focal_gamma=2.0,
+                         conf_lidar=None, conf_camera=None):
+    """returns (total, {"foc","lov","foc_cam","lov_cam","per"}); conf_* (int64 [C,C], rows = prediction) are updated
+    in place when given (same counts as IOUEval.addBatch(argmax, label))."""
+    total, out6 = _FusedPMFLoss.apply(lidar_prob, camera_prob, label, alpha, lambda_, gamma_, tau, focal_gamma,
+                                      conf_lidar, conf_camera)
+    t = {"foc": out6[1], "lov": out6[2], "foc_cam": out6[3], "lov_cam": out6[4], "per": out6[5]}
+    return total, t

@@ -36,6 +36,10 @@ class IOUEval:
         self.conf_matrix += torch.bincount(idx, minlength=self.n_classes ** 2).view(self.n_classes, self.n_classes)
         self._cache = None
 
+    def external_update(self):
+        """the fused GPU loss (pmf_loss_pixel) added a batch to conf_matrix in place: drop cached statistics."""
+        self._cache = None
+
     def getStats(self, sync=True):
         if self._cache is not None and self._cache[0] == sync:
             return self._cache[1]

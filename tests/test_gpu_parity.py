@@ -340,3 +340,51 @@ def test_losses_gpu_match_cpu_and_fixture(golden):
     ref = _jaccard_grad(fg, nv, torch.tensor(nvalid))
     got = _jaccard_grad(fg.cuda(), nv.cuda(), torch.tensor(nvalid).cuda()).cpu()
     assert (got - ref).abs().max() < 1e-6
+
+
+@pytest.mark.gpu
+def test_fused_loss_matches_reference_objective(golden):
+    """the fused HIP objective (value, analytic gradient w.r.t. both probability maps, confusion matrices) against
+    (1) the reference-run fixture g6_losses and (2) float64 autograd of the torch-op restatement, incl. a bench-size
+    map with ignored pixels and a class that is absent."""
+    from pmf_amd.loss import FocalSoftmaxLoss, Lovasz_softmax, pmf_total_loss, pmf_total_loss_fused
+    from pmf_amd.metrics import IOUEval
+    g = golden("g6_losses")
+    n, c, h, w = 2, 20, 16, 32
+    a0, b0 = det_tensor("g6.logits", (n, c, h, w), -3, 3), det_tensor("g6.logits2", (n, c, h, w), -3, 3)
+    _, _, label, _ = synthetic_batch(n, h, w, c, seed=3, fill=0.4)
+    alpha = np.linspace(0.2, 1.0, c).astype(np.float32)
+    alpha[0] = 0
+    a, b = a0.cuda().requires_grad_(True), b0.cuda().requires_grad_(True)
+    total, t = pmf_total_loss_fused(torch.softmax(a, 1), torch.softmax(b, 1), label.cuda(), torch.from_numpy(alpha))
+    total.backward()
+    vals = np.array([total.item()] + [t[k].item() for k in ("foc", "lov", "foc_cam", "lov_cam", "per")])
+    assert np.abs(vals - g["loss.values"]).max() < 5e-6, (vals, g["loss.values"])
+    assert np.abs(a.grad.cpu().numpy() - g["loss.grad_a"]).max() < 5e-7
+    assert np.abs(b.grad.cpu().numpy() - g["loss.grad_b"]).max() < 5e-7
+
+    for (n, h, w, fill, drop_cls) in ((1, 8, 32, 0.7, None), (2, 64, 2048, 0.25, 7)):
+        la, lb = det_tensor("fl.a", (n, c, h, w), -4, 4), det_tensor("fl.b", (n, c, h, w), -4, 4)
+        _, _, label, _ = synthetic_batch(n, h, w, c, seed=5, fill=fill)
+        if drop_cls is not None:
+            label = torch.where(label == drop_cls, torch.zeros_like(label), label)
+        pa = torch.softmax(la.double(), 1).requires_grad_(True)
+        pb = torch.softmax(lb.double(), 1).requires_grad_(True)
+        foc, lov = FocalSoftmaxLoss(c, gamma=2, alpha=alpha, softmax=False).double(), Lovasz_softmax(ignore=0)
+        ref, rt = pmf_total_loss(pa, pb, label.long(), foc, lov, 1.0, 0.5, 0.7)
+        ref.backward()
+        ga, gb = pa.detach().float().cuda().requires_grad_(True), pb.detach().float().cuda().requires_grad_(True)
+        ml, mc = IOUEval(c, "cuda", ignore=[0]), IOUEval(c, "cuda", ignore=[0])
+        tot, tt = pmf_total_loss_fused(ga, gb, label.cuda(), torch.from_numpy(alpha), 1.0, 0.5, 0.7, 2.0,
+                                       ml.conf_matrix, mc.conf_matrix)
+        tot.backward()
+        assert abs(tot.item() - ref.item()) < 2e-6 * max(1.0, abs(ref.item()))
+        for k in ("foc", "lov", "foc_cam", "lov_cam", "per"):
+            assert abs(tt[k].item() - rt[k].item()) < 2e-6 * max(1.0, abs(rt[k].item())), k
+        for got, want in ((ga.grad, pa.grad), (gb.grad, pb.grad)):
+            err = (got.cpu().double() - want).abs().max().item()
+            assert err < 1e-6 * max(want.abs().max().item(), 1e-3) + 1e-9, err
+        rl, rc = IOUEval(c, "cpu", ignore=[0]), IOUEval(c, "cpu", ignore=[0])
+        rl.addBatch(pa.argmax(1), label)
+        rc.addBatch(pb.argmax(1), label)
+        assert torch.equal(ml.conf_matrix.cpu(), rl.conf_matrix) and torch.equal(mc.conf_matrix.cpu(), rc.conf_matrix)
