@@ -31,22 +31,39 @@ def kitti_focal_alpha(cls_freq, learning_ignore):
 class TrainEngine:
     def __init__(self, model, nclasses, lr=1e-3, momentum=0.9, weight_decay=1e-5, lambda_=1.0, gamma=0.5, tau=0.7,
                  alpha=None, ignore_class=(0,), warmup_steps=1, max_steps=1, feature_mean=None, feature_std=None,
-                 distributed=False, device_ids=None, metrics_sync_every=0):
+                 distributed=False, device_ids=None, metrics_sync_every=0, flat_state=True):
         self.raw_model = model
         dev = next(model.parameters()).device
         self.device = dev
         self.nclasses, self.lambda_, self.gamma, self.tau = nclasses, lambda_, gamma, tau
         fused = dict(fused=True) if dev.type == "cuda" else {}
+        self.model = model
+        self.flat = None
+        self.distributed = distributed
+        if dev.type == "cuda" and flat_state:
+            # GPU: parameters + gradients re-homed in two flat buffers (models/pmf_net.py FlatState): the backward plan
+            # writes p.grad in place, each optimiser is ONE fused launch over one tensor, and data parallelism is a
+            # few large all-reduces over contiguous gradient ranges overlapped with the rest of the backward plan
+            # (the reference wraps the model in DistributedDataParallel, trainer.py:62-71; same averaged gradients).
+            from .models.pmf_net import flatten_training_state
+            groups = [list(model.lidar_stream.parameters()),
+                      list(model.camera_stream_encoder.parameters()) + list(model.camera_stream_decoder.parameters())]
+            self.flat = flatten_training_state(model, groups, dev)
+            lidar_params, camera_params = [self.flat.group_params[0]], [self.flat.group_params[1]]
+            if distributed:
+                self._pending, self._frontier = [], None
+                model._bwd_segment_hook = self._allreduce_ready_ranges
+        else:
+            lidar_params = list(model.lidar_stream.parameters())
+            camera_params = list(model.camera_stream_encoder.parameters()) + list(model.camera_stream_decoder.parameters())
+            if distributed:
+                self.model = nn.parallel.DistributedDataParallel(
+                    model, device_ids=device_ids, gradient_as_bucket_view=True)   # local-stat BN: layers/sync_bn.py
         # trainer.py:80-98: AdamW over the LiDAR stream (torch defaults incl. weight_decay 0.01),
         # SGD-Nesterov over camera encoder + decoder
-        self.optimizer = torch.optim.AdamW([{"params": model.lidar_stream.parameters()}], lr=lr, **fused)
-        self.aux_optimizer = torch.optim.SGD(
-            [{"params": model.camera_stream_encoder.parameters()}, {"params": model.camera_stream_decoder.parameters()}],
-            lr=lr, nesterov=True, momentum=momentum, weight_decay=weight_decay, **fused)
-        self.model = model
-        if distributed:
-            self.model = nn.parallel.DistributedDataParallel(
-                model, device_ids=device_ids, gradient_as_bucket_view=True)   # local-stat BN: see layers/sync_bn.py
+        self.optimizer = torch.optim.AdamW([{"params": lidar_params}], lr=lr, **fused)
+        self.aux_optimizer = torch.optim.SGD([{"params": camera_params}], lr=lr, nesterov=True, momentum=momentum,
+                                             weight_decay=weight_decay, **fused)
         if alpha is None:
             alpha = np.ones(nclasses, np.float32)
             alpha[0] = 0
@@ -60,6 +77,27 @@ class TrainEngine:
         self.std = None if feature_std is None else torch.tensor(feature_std, device=dev).view(1, -1, 1, 1).float()
         self.metrics_sync_every = metrics_sync_every
         self.iteration = 0
+
+    # ---- data parallel over the flat gradient buffer ---------------------------------------------------------
+    def _allreduce_ready_ranges(self, plan, op_end):
+        """called between segments of the backward plan: all-reduce the gradient ranges that are final by now.
+        The collective is asynchronous (RCCL stream): it overlaps with the remaining segments."""
+        import torch.distributed as dist
+        front = plan.grad_frontier(op_end)
+        if self._frontier is None:
+            self._frontier = [a for (a, _) in self.flat.ranges]
+        for g, f in enumerate(front):
+            a = self._frontier[g]
+            if f > a:
+                self._pending.append(dist.all_reduce(self.flat.grad[a:f], async_op=True))
+                self._frontier[g] = f
+
+    def _finish_allreduce(self):
+        import torch.distributed as dist
+        for h in self._pending:
+            h.wait()
+        self._pending, self._frontier = [], None
+        self.flat.grad.mul_(1.0 / dist.get_world_size())      # DDP averages; one pass over the flat buffer
 
     def prepare(self, input_feature, input_mask):
         """trainer.py:291-297: normalise the 5 LiDAR channels in place, return the two channel-slice views."""
@@ -92,9 +130,12 @@ class TrainEngine:
         pcd, rgb = self.prepare(input_feature, input_mask)
         label = input_label.long()
         total, terms, lidar_pred, camera_pred, metrics_done = self.forward_loss(pcd, rgb, label)
-        self.optimizer.zero_grad(set_to_none=True)
-        self.aux_optimizer.zero_grad(set_to_none=True)
-        total.backward()
+        if self.flat is None:
+            self.optimizer.zero_grad(set_to_none=True)
+            self.aux_optimizer.zero_grad(set_to_none=True)
+        total.backward()            # flat state: the plan zero-fills and rewrites the gradient buffer itself
+        if self.flat is not None and self.distributed:
+            self._finish_allreduce()
         self.optimizer.step()
         self.aux_optimizer.step()
         self.scheduler.step()

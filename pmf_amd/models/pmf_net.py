@@ -237,8 +237,8 @@ class SalsaNext(_Holder):
             raise NotImplementedError("SalsaNext(softmax=False) is not built for the HIP path")
         return _run_model(self, (x,))[0]
 
-    def _build(self, N, H, W, training, device):
-        P = Plan(device, training)
+    def _build(self, N, H, W, training, device, dry=False):
+        P = Plan(device, training, getattr(self, "_flat", None), dry)
         M = _alloc_masks(P, self, N, device) if training else None
         x = V(P.input_nchw("pcd", N, self.in_channels, H, W, "pcd"))
         self.emit_trunk(P, x, None, M)
@@ -249,6 +249,7 @@ class SalsaNext(_Holder):
 
     def _apply(self, fn, *a, **k):
         self._plans = {}
+        self._flat = None          # storage is about to move: a FlatState must be re-created afterwards
         return super()._apply(fn, *a, **k)
 
 
@@ -441,10 +442,14 @@ class PMFNet(nn.Module):
         h, w = img_feature.shape[2], img_feature.shape[3]
         if h % 16 != 0 or w % 16 != 0:   # pmf_net.py:85-88
             assert False, "invalid input size: {}".format(img_feature.shape)
+        if pcd_feature.shape[1] != self.pcd_channels or img_feature.shape[1] != self.img_channels or \
+                pcd_feature.shape[0] != img_feature.shape[0] or pcd_feature.shape[2:] != img_feature.shape[2:]:
+            raise ValueError("PMFNet: expected [N,%d,H,W] and [N,%d,H,W] inputs, got %s and %s" % (
+                self.pcd_channels, self.img_channels, tuple(pcd_feature.shape), tuple(img_feature.shape)))
         return _run_model(self, (pcd_feature, img_feature))
 
-    def _build(self, N, H, W, training, device):
-        P = Plan(device, training)
+    def _build(self, N, H, W, training, device, dry=False):
+        P = Plan(device, training, getattr(self, "_flat", None), dry)
         M = _alloc_masks(P, self, N, device) if training else None
         pcd = V(P.input_nchw("pcd", N, self.pcd_channels, H, W, "pcd"))
         rgb = V(P.input_nchw("rgb", N, self.img_channels, H, W, "rgb"))
@@ -460,6 +465,7 @@ class PMFNet(nn.Module):
 
     def _apply(self, fn, *a, **k):
         self._plans = {}
+        self._flat = None          # storage is about to move: a FlatState must be re-created afterwards
         return super()._apply(fn, *a, **k)
 
     # test / reproducibility hook: masks = {site: [N, C] tensor of 0 or 1/(1-p)}; None -> draw from torch RNG
@@ -511,6 +517,70 @@ def _fill_masks(P, model, p=0.2):
         d1 = P.masks[o1:o1 + N * c4].view(N, c4)
         d2 = P.masks[o2:o2 + N * ld2].view(N, ld2)[:, :c4]
         torch.mul(d1, d2, out=P.masks[o:o + N * c4].view(N, c4))
+
+
+# ------------------------------------------------------------------------------------------------------
+# flat training state: parameters and gradients of the whole network in two contiguous buffers
+# ------------------------------------------------------------------------------------------------------
+class FlatState:
+    """All trainable parameters re-homed as views of ONE flat buffer (``param``) with their gradients as views of a
+    second one (``grad``), group by group (e.g. [LiDAR stream | camera stream]) and, inside a group, in the order the
+    backward plan produces the gradients.  What it buys:
+      * the backward plan writes weight gradients straight into ``p.grad`` -- no flat copy, no 654 views per step;
+      * an optimiser step is one fused launch per group over one tensor (AdamW / SGD over 654 tensors cost ~1.5 ms of
+        host time per iteration during which the GPU idled);
+      * a data-parallel all-reduce is a handful of large contiguous collectives whose ranges complete front to back
+        while the backward plan is still running (ranges[g] = (start, end) floats; done_after[op index] frontier)."""
+
+    def __init__(self, model, groups, device):
+        plan = model._build(1, 64, 64, True, device, dry=True)     # records the backward emission order only
+        order = list(plan.params)
+        seen = {id(p) for p in order}
+        for p in model.parameters():
+            if p.requires_grad and id(p) not in seen:
+                order.append(p)
+                seen.add(id(p))
+        gid = {}
+        for g, ps in enumerate(groups):
+            for p in ps:
+                gid[id(p)] = g
+        self.offset, self.ranges, self.members = {}, [], []
+        off = 0
+        for g in range(len(groups)):
+            start = off
+            mem = [p for p in order if gid.get(id(p)) == g and p.requires_grad]
+            for p in mem:
+                self.offset[id(p)] = off
+                off += (p.numel() + 63) // 64 * 64
+            self.ranges.append((start, off))
+            self.members.append(mem)
+        missing = [p for p in order if id(p) not in self.offset]
+        if missing:
+            raise ValueError("FlatState: %d trainable parameters belong to no group" % len(missing))
+        self.param = torch.zeros(max(off, 64), dtype=torch.float32, device=device)
+        self.grad = torch.zeros(max(off, 64), dtype=torch.float32, device=device)
+        with torch.no_grad():
+            for mem in self.members:
+                for p in mem:
+                    o = self.offset[id(p)]
+                    v = self.param[o:o + p.numel()].view(p.shape)
+                    v.copy_(p.data)
+                    p.data = v
+                    p.grad = self.grad[o:o + p.numel()].view(p.shape)
+        self.group_params = []
+        for (a, b) in self.ranges:       # one leaf tensor per group for the optimisers
+            fp = torch.nn.Parameter(self.param[a:b], requires_grad=True)
+            fp.grad = self.grad[a:b]
+            self.group_params.append(fp)
+
+
+def flatten_training_state(model, groups, device):
+    """attach a FlatState to ``model`` (plans are rebuilt on the next call: parameter storage moved)."""
+    model._flat = None
+    model._plans = {}
+    model._flat = FlatState(model, groups, device)
+    model._plans = {}
+    return model._flat
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -577,6 +647,7 @@ class _PlanFunction(torch.autograd.Function):
         inputs, params = args[:n_inputs], args[n_inputs:]
         plan, outs, _keep = _forward_impl(model, inputs)
         ctx.plan, ctx.generation, ctx.n_inputs, ctx.params = plan, plan.generation, n_inputs, params
+        ctx.model = model
         ctx.save_for_backward(*outs)
         return tuple(outs)
 
@@ -595,7 +666,17 @@ class _PlanFunction(torch.autograd.Function):
             a = plan.bwd_ops[plan.out_slots[slot]["bwd_index"] + plan.bwd_shift].u.sm
             a.p[0], a.p[1] = prob.data_ptr(), g.data_ptr()
         plan._last_gouts = keep          # keeps the patched pointers valid for profiling re-runs
-        plan.run(plan.bwd_ops, plan.n_bwd, "backward")
+        hook = getattr(ctx.model, "_bwd_segment_hook", None) if plan.flat is not None else None
+        if hook is None:
+            plan.run(plan.bwd_ops, plan.n_bwd, "backward")
+        else:       # data parallel: the backward plan in a few segments, finished gradient ranges handed to the hook
+            cuts = plan.segment_cuts(4)
+            for k in range(len(cuts) - 1):
+                plan.run(plan.bwd_ops, plan.n_bwd, "backward", cuts[k], cuts[k + 1])
+                hook(plan, cuts[k + 1])
+        if plan.flat is not None:
+            # gradients were written in place into the FlatState buffer that every p.grad is a view of
+            return (None, None) + (None,) * ctx.n_inputs + (None,) * len(ctx.params)
         # ONE device copy of the flat gradient buffer (the plan reuses it next iteration), then per-parameter views
         flat = plan.pgrad_buf.tensor((plan.pgrad_floats,)).clone()
         grads = []

@@ -50,6 +50,27 @@ class Buf:
         return self.arena.t[self.off:self.off + n * esz].view(dtype).view(shape)
 
 
+class ExternalBuf:
+    """a caller-owned device tensor seen through the Buf interface (the flat gradient buffer of FlatState)."""
+
+    def __init__(self, t):
+        self.t = t
+        self.nbytes = t.numel() * t.element_size()
+
+    @property
+    def ptr(self):
+        return self.t.data_ptr()
+
+    def at(self, float_off):
+        return self.ptr + 4 * float_off
+
+    def tensor(self, shape, dtype=torch.float32):
+        n = 1
+        for s in shape:
+            n *= s
+        return self.t.view(-1)[:n].view(shape)
+
+
 class Arena:
     def __init__(self, name):
         self.name, self.size, self.t, self.base = name, 0, None, 0
@@ -102,8 +123,10 @@ class V:
 
 
 class Plan:
-    def __init__(self, device, training):
+    def __init__(self, device, training, flat=None, dry=False):
         self.device, self.training = device, training
+        self.flat = flat                    # FlatState: parameter gradients go to its buffer at its offsets
+        self.dry = dry                      # dry run: walk the tape (records the backward parameter order), no memory
         self.act = Arena("act")
         self.zero_fwd = Arena("zero_fwd")
         self.zero_bwd = Arena("zero_bwd")
@@ -113,6 +136,7 @@ class Plan:
         self.pack_jobs = []
         self.wg_scratch = 0                 # bytes of the shared wgrad partial-sum workspace
         self.params = []                    # (param, grad Buf float offset)
+        self.grad_done = {}                 # id(param) -> index (in self.bwd) of the last op writing its gradient
         self.pgrad_floats = 0
         self._pid = {}
         self.masks = None                   # dropout multipliers (torch tensor), laid out by MaskLayout
@@ -127,9 +151,12 @@ class Plan:
     def pgrad(self, p):
         """float offset of p's gradient inside the flat gradient buffer."""
         if id(p) not in self._pid:
-            self._pid[id(p)] = (len(self.params), self.pgrad_floats)
+            if self.flat is not None:
+                self._pid[id(p)] = (len(self.params), self.flat.offset[id(p)])
+            else:
+                self._pid[id(p)] = (len(self.params), self.pgrad_floats)
+                self.pgrad_floats += _ru(p.numel(), 64)
             self.params.append(p)
-            self.pgrad_floats += _ru(p.numel(), 64)
         return self._pid[id(p)][1]
 
     # ------------------------------------------------------------------ op emission helpers
@@ -214,8 +241,9 @@ class Plan:
         # taps that can only ever read zero padding (|offset| beyond the map: the dilation-12/18 ASPP branches on a
         # 4-row map keep 3 of 9 taps) are dropped from forward, input gradient and weight gradient alike; their weight
         # gradient is exactly zero and stays at the zero the backward prologue writes
-        taps = [(dy, dx, wi) for (dy, dx, wi) in self.taps(kh, kw, dil, pad)
-                if dy < inH and dy + (OH - 1) * stride >= 0 and dx < inW and dx + (OW - 1) * stride >= 0]
+        all_taps = self.taps(kh, kw, dil, pad)
+        taps = [(dy, dx, wi) for (dy, dx, wi) in all_taps
+                if dy < inH and dy + (OH - 1) * stride >= 0 and dx < inW and dx + (OW - 1) * stride >= 0] or all_taps[:1]
         Ktot = sum(_ru(s.t.C, 8) for s in srcs)
         ldw = _ru(Cout, 64)
         wbuf = self.add_pack(conv.weight, [t[2] for t in taps], 0, Ktot, ldw)
@@ -317,6 +345,7 @@ class Plan:
                     a.i[0], a.i[1], a.i[2], a.i[3] = gyt.ldc, out.ldc, Cout, 1
                     a.l[0] = out.npix
                 self.emit(self.bwd, L.OP_BN_BWD_REDUCE, r1)
+                self.grad_done[id(bn.weight)] = self.grad_done[id(bn.bias)] = len(self.bwd) - 1
 
                 def r2(op):
                     a = op.u.sm
@@ -469,6 +498,9 @@ class Plan:
                 d.dbias_out = self.pgrad_buf.at(boff)
         boff = self.pgrad(conv.bias) if dbias_rows else None
         self.emit(self.bwd, L.OP_WGRAD, f)
+        self.grad_done[id(conv.weight)] = len(self.bwd) - 1
+        if dbias_rows:
+            self.grad_done[id(conv.bias)] = len(self.bwd) - 1
         self.meta_bwd[len(self.bwd) - 1] = dict(
             family="conv_wgrad", flops=2.0 * dz.N * dz.H * dz.W * Cout * conv.in_channels * len(taps), name=name,
             shape="%dx%dx%d %d->%d t%d" % (dz.N, dz.H, dz.W, conv.in_channels, Cout, len(taps)))
@@ -712,7 +744,13 @@ class Plan:
             for fn in reversed(self.tape):
                 fn()
         self.tape = None
-        self.pgrad_buf = self.zero_bwd.alloc(4 * max(self.pgrad_floats, 64)) if self.training else None
+        if self.dry:
+            return self
+        if self.flat is not None and self.training:
+            self.pgrad_buf = ExternalBuf(self.flat.grad)
+            self.pgrad_floats = self.flat.grad.numel()
+        else:
+            self.pgrad_buf = self.zero_bwd.alloc(4 * max(self.pgrad_floats, 64)) if self.training else None
         self.wg_buf = self.act.alloc(max(self.wg_scratch, 256)) if self.training else None
         self.sk_buf = self.act.alloc(SPLITK_BYTES)   # shared split-K scratch (small maps only; ops run in stream order)
         self.bnpart_buf = self.act.alloc(COL_ROWS * 2 * max(self.colrows_max, 4) * 8)   # float64 partial rows
@@ -770,6 +808,11 @@ class Plan:
         self.fwd_ops, self.n_fwd = build(self.fwd, pro_f)
         if self.training:
             pro_b = [(L.OP_FILL, zero_arena(self.zero_bwd))]
+            if self.flat is not None:
+                def zero_flat(op, g=self.flat.grad):
+                    a = op.u.sm
+                    a.p[0], a.f[0], a.l[0] = g.data_ptr(), 0.0, g.numel()
+                pro_b.append((L.OP_FILL, zero_flat))
             self.bwd_shift = len(pro_b)
             self.bwd_ops, self.n_bwd = build(self.bwd, pro_b)
         else:
@@ -798,6 +841,34 @@ class Plan:
             cm = self.masks[v.cmul:v.cmul + v.t.N * v.cmul_ld].view(v.t.N, v.cmul_ld)[:, :v.t.C]
             x = x * cm[:, :, None, None]
         return x
+
+    def segment_cuts(self, k):
+        """op indices that split the backward plan into k segments of similar algorithmic work (by op count where no
+        flop estimate exists)."""
+        n = self.n_bwd
+        w = [1.0 + self.meta_bwd.get(i - self.bwd_shift, {}).get("flops", 0.0) / 2e9 for i in range(n)]
+        tot, acc, cuts = sum(w), 0.0, [0]
+        for i in range(n):
+            acc += w[i]
+            if len(cuts) < k and acc >= tot * len(cuts) / k:
+                cuts.append(i + 1)
+        if cuts[-1] != n:
+            cuts.append(n)
+        return cuts
+
+    def grad_frontier(self, op_end):
+        """per FlatState group: float offset up to which the gradient buffer is final once ops [0, op_end) have run
+        (members are laid out in backward order, so the finished part of a group is a prefix of its range)."""
+        out = []
+        for (a, b), mem in zip(self.flat.ranges, self.flat.members):
+            f = a
+            for p in mem:
+                d = self.grad_done.get(id(p))
+                if d is None or d + self.bwd_shift >= op_end:
+                    break
+                f = self.flat.offset[id(p)] + (p.numel() + 63) // 64 * 64
+            out.append(b if op_end >= self.n_bwd else f)
+        return out
 
     def run_profiled(self, what):
         """run one pass op by op with a HIP event pair around every launch (on the stream the plan uses);

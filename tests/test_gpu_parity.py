@@ -388,3 +388,36 @@ def test_fused_loss_matches_reference_objective(golden):
         rl.addBatch(pa.argmax(1), label)
         rc.addBatch(pb.argmax(1), label)
         assert torch.equal(ml.conf_matrix.cpu(), rl.conf_matrix) and torch.equal(mc.conf_matrix.cpu(), rc.conf_matrix)
+
+
+@pytest.mark.gpu
+def test_flat_training_state_matches_per_tensor_path():
+    """FlatState (parameters / gradients as views of two flat buffers, one fused optimiser launch per group, gradients
+    written in place by the backward plan) must produce bit-identical parameters to the per-tensor path."""
+    from pmf_amd.engine import TrainEngine
+    from pmf_amd.models import PMFNet
+    from pmf_amd.utils.detinit import deterministic_init
+
+    def run(flat):
+        torch.manual_seed(0)
+        m = PMFNet(5, 3, 20, 32, imagenet_pretrained=False, image_backbone="resnet34")
+        deterministic_init(m)
+        m = m.cuda()
+        eng = TrainEngine(m, 20, lr=1e-3, warmup_steps=2, max_steps=10, flat_state=flat)
+        pcd, rgb, label, mask = synthetic_batch(2, 32, 64, 20, seed=11, fill=0.5)
+        feat = torch.cat((pcd, rgb), 1)
+        torch.manual_seed(123)                       # same dropout masks in both runs
+        torch.cuda.manual_seed(123)
+        losses = []
+        for _ in range(3):
+            tot, _ = eng.train_step(feat.cuda().clone(), mask.cuda(), label.cuda())
+            losses.append(tot.item())
+        conf = eng.metrics.conf_matrix.clone()
+        return losses, {k: v.detach().clone() for k, v in m.state_dict().items()}, conf
+
+    l0, s0, c0 = run(False)
+    l1, s1, c1 = run(True)
+    assert l0 == l1, (l0, l1)
+    assert torch.equal(c0, c1)
+    for k in s0:
+        assert torch.equal(s0[k], s1[k]), k
