@@ -305,6 +305,12 @@ typedef struct {
 /* runs ops[0..n) in order on stream s; returns 0 or the first error (index in *failed_at if non-NULL) */
 int pmf_plan_run(const pmf_op_t* ops, int32_t n, pmf_stream_t s, int32_t* failed_at);
 int pmf_plan_run_range(const pmf_op_t* ops, int32_t begin, int32_t end, pmf_stream_t s, int32_t* failed_at);
+/* hipGraph capture of ops[begin..end): one hipGraphLaunch replays the whole range (the plan allocates nothing, copies
+ * nothing, never synchronises, and all its pointers are fixed).  Run the range eagerly once before capturing.  The
+ * executable graph is bound to the pointer values inside `ops` at capture time. */
+int pmf_plan_capture(const pmf_op_t* ops, int32_t begin, int32_t end, void** graph_exec, int32_t* failed_at);
+int pmf_graph_launch(void* graph_exec, pmf_stream_t s);
+int pmf_graph_destroy(void* graph_exec);
 /* pixel splits pmf_conv_wgrad will use for this descriptor (sizes `partial`) */
 int pmf_conv_wgrad_nsplit(const pmf_wgrad_desc_t* d);
 /* sizeof() of the structs above, for bindings to self-check: 0 src, 1 conv, 2 wgrad, 3 view, 4 small, 5 op, 6 pack job */

@@ -101,6 +101,52 @@ extern "C" int pmf_plan_run_range(const pmf_op_t* ops, int32_t begin, int32_t en
   return 0;
 }
 
+// ---- hipGraph capture of a plan range --------------------------------------------------------------------------
+// A plan performs no allocation, memcpy or synchronisation and every pointer it uses is fixed at build time, so a
+// range of ops can be captured ONCE (on a private capture stream: the legacy default stream cannot capture) and
+// replayed with a single hipGraphLaunch.  Issuing the ~1200 kernels of one training iteration one by one costs
+// ~19 ms of host time per step on this stack -- about as much as the GPU needs to run them -- so without the graph the
+// GPU starves whenever the host thread does anything else (optimiser, loss, next batch).
+// The caller must have run the range eagerly once before (kernel attributes are set on first launch, which is not
+// allowed inside a capture).
+extern "C" int pmf_plan_capture(const pmf_op_t* ops, int32_t begin, int32_t end, void** graph_exec, int32_t* failed_at) {
+  static hipStream_t cap = nullptr;
+  if (!graph_exec) return PMF_E_ARG;
+  *graph_exec = nullptr;
+  hipError_t e;
+  if (!cap) {
+    e = hipStreamCreateWithFlags(&cap, hipStreamNonBlocking);
+    if (e != hipSuccess) return (int)e;
+  }
+  e = hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal);
+  if (e != hipSuccess) return (int)e;
+  int rc = 0;
+  for (int32_t k = begin; k < end && rc == 0; ++k) {
+    rc = run_one(ops[k], (pmf_stream_t)cap);
+    if (rc != 0 && failed_at) *failed_at = k;
+  }
+  hipGraph_t graph = nullptr;
+  e = hipStreamEndCapture(cap, &graph);
+  if (rc != 0) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+  if (e != hipSuccess) return (int)e;
+  hipGraphExec_t exec = nullptr;
+  e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (e != hipSuccess) return (int)e;
+  *graph_exec = (void*)exec;
+  return 0;
+}
+
+extern "C" int pmf_graph_launch(void* graph_exec, pmf_stream_t s) {
+  if (!graph_exec) return PMF_E_ARG;
+  return (int)hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)s);
+}
+
+extern "C" int pmf_graph_destroy(void* graph_exec) {
+  if (!graph_exec) return 0;
+  return (int)hipGraphExecDestroy((hipGraphExec_t)graph_exec);
+}
+
 // ABI self-check for language bindings: sizes of the structs a binding has to mirror
 extern "C" int pmf_sizeof(int which) {
   switch (which) {

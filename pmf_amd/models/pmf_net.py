@@ -617,21 +617,24 @@ def _forward_impl(model, inputs):
                            "(no CPU / PyTorch fallback); got a %s tensor" % x0.device)
     N, _, H, W = x0.shape
     plan = _get_plan(model, N, H, W, model.training, x0.device)
-    keep = []
+    keep, sig = [], []
     names = ("pcd", "rgb")[:len(inputs)]
     for nm, x in zip(names, inputs):
         if x.dtype != torch.float32:
             x = x.float()
-        keep.append(_patch_input(plan, nm, x))
+        x = _patch_input(plan, nm, x)
+        keep.append(x)
+        sig += [x.data_ptr(), x.stride(0), x.stride(1)]
     outs = []
     for slot in ("lidar", "camera"):
         if slot in plan.out_slots:
             o = torch.empty(plan.out_slots[slot]["shape"], dtype=torch.float32, device=x0.device)
             plan.fwd_ops[plan.out_slots[slot]["fwd_index"] + plan.fwd_shift].u.sm.p[1] = o.data_ptr()
             outs.append(o)
+            sig.append(o.data_ptr())
     if model.training:
         _fill_masks(plan, model)
-    plan.run(plan.fwd_ops, plan.n_fwd, "forward")
+    plan.run(plan.fwd_ops, plan.n_fwd, "forward", sig=tuple(sig))
     if model.training and plan.bn_counters:
         torch._foreach_add_(plan.bn_counters, 1)
     plan.generation += 1
@@ -658,21 +661,23 @@ class _PlanFunction(torch.autograd.Function):
             raise RuntimeError("pmf_amd: backward() after a newer forward() on the same plan -- activations live "
                                "in the plan's arena; run forward/backward pairs in order")
         probs = ctx.saved_tensors
-        keep = []
+        keep, sig = [], []
         slots = [s for s in ("lidar", "camera") if s in plan.out_slots]
         for slot, prob, g in zip(slots, probs, gouts):
             g = torch.zeros_like(prob) if g is None else g.contiguous().float()
             keep.append(g)
             a = plan.bwd_ops[plan.out_slots[slot]["bwd_index"] + plan.bwd_shift].u.sm
             a.p[0], a.p[1] = prob.data_ptr(), g.data_ptr()
+            sig += [prob.data_ptr(), g.data_ptr()]
+        sig = tuple(sig)
         plan._last_gouts = keep          # keeps the patched pointers valid for profiling re-runs
         hook = getattr(ctx.model, "_bwd_segment_hook", None) if plan.flat is not None else None
         if hook is None:
-            plan.run(plan.bwd_ops, plan.n_bwd, "backward")
+            plan.run(plan.bwd_ops, plan.n_bwd, "backward", sig=sig)
         else:       # data parallel: the backward plan in a few segments, finished gradient ranges handed to the hook
             cuts = plan.segment_cuts(4)
             for k in range(len(cuts) - 1):
-                plan.run(plan.bwd_ops, plan.n_bwd, "backward", cuts[k], cuts[k + 1])
+                plan.run(plan.bwd_ops, plan.n_bwd, "backward", cuts[k], cuts[k + 1], sig=sig)
                 hook(plan, cuts[k + 1])
         if plan.flat is not None:
             # gradients were written in place into the FlatState buffer that every p.grad is a view of
