@@ -452,6 +452,157 @@ __global__ __launch_bounds__(256) void conv_wgrad_pipe_k(const pmf_wgrad_desc_t 
   conv_wgrad_pipe_body<TB, NT, XSL>(d, g, smem);
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Few-input-channel convolutions (the 7x7x3 ResNet stem): GEMM rows = (tap, channel) pairs, k = tap * Cin + c, so the
+// 147 products of the stem fill 5 MFMA row tiles instead of 49 taps x one 32-row tile that is 29/32 padding.
+// The input tile is kept PACKED in LDS ([row][col][Cin]); lane i of row tile g reads its own (tap, channel) through a
+// per-lane offset  koff = (dy * in_cols + dx) * Cin + c  -- an im2col view without materialising the im2col matrix.
+// Rows k >= ntaps*Cin read a zeroed word.  dz halves arrive by LDS-DMA exactly as in conv_wgrad_pipe_k; wave w owns
+// output tile w % 2 and every other pixel pair; the partial slab keeps the [tap][Ktot][Cout32] layout of stage 2.
+template <int KG>   // row tiles of 32 (tap, channel) pairs
+__device__ __forceinline__ void wgrad_fewc_body(const pmf_wgrad_desc_t& d, const WgGeom& g, float* __restrict__ smem) {
+  constexpr int BN = 64, NT = 2, PG = 2, HPX = 64, ZPW = HPX * BN / 256 / 4, PPI = 256 / BN;
+  const int cin = d.Cin_real;                           // packed channels per pixel in LDS
+  const int in_cols = g.in_cols, in_rows = g.in_rows;
+  const int xfl = (in_rows * in_cols * cin + 4 + 3) & ~3;   // + one zero word for the padding rows
+  float* __restrict__ Xs = smem;
+  float* __restrict__ Z0 = smem + xfl;
+  float* __restrict__ Z1 = Z0 + HPX * BN;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int split = blockIdx.x;
+  const int co0 = (int)blockIdx.z * BN;
+  const int sld = d.src[0].ldc, sH = d.OH, sW = d.OW;
+  const int kreal = d.ntaps * cin;
+  const int zero_word = in_rows * in_cols * cin;       // index of the zeroed word
+  int koff[KG];
+#pragma unroll
+  for (int j = 0; j < KG; ++j) {
+    const int k = j * 32 + li;
+    if (k < kreal) {
+      const int t = k / cin, c = k - t * cin;
+      koff[j] = (((int)d.tdy[t] - g.dy_min) * in_cols + ((int)d.tdx[t] - g.dx_min)) * cin + c;
+    } else koff[j] = -1;
+  }
+  int offZ[ZPW];
+#pragma unroll
+  for (int jj = 0; jj < ZPW; ++jj) {
+    const int p = (wave + 4 * jj) * PPI + lane / (BN / 4);
+    offZ[jj] = ((p >> 5) * d.OW + (p & 31)) * d.dz_ldc + (lane % (BN / 4)) * 4;
+  }
+  const int cot = wave % NT, pg = wave / NT;
+  f32x16 acc[KG];
+#pragma unroll
+  for (int j = 0; j < KG; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  const int tiles_per_n = g.tiles_x * g.tiles_y;
+  const int npixX = in_rows * in_cols;
+  auto zsrc = [&](int tile, int half) -> const float* {
+    const int n = tile / tiles_per_n, rem = tile - n * tiles_per_n;
+    const int ty = rem / g.tiles_x, tx = rem - ty * g.tiles_x;
+    return d.dz + ((size_t)(n * d.OH + ty * WG_ROWS + 2 * half) * d.OW + tx * 32) * d.dz_ldc + co0;
+  };
+  auto dma = [&](const float* __restrict__ src, float* __restrict__ dst) {
+#pragma unroll
+    for (int jj = 0; jj < ZPW; ++jj)
+      __builtin_amdgcn_global_load_lds(src + offZ[jj], (lds_ptr_t)(dst + (wave + 4 * jj) * 256), 16, 0, 0);
+  };
+  auto half = [&](const float* __restrict__ Zh, int h) {
+#pragma unroll 1
+    for (int rr = 0; rr < 2; ++rr) {
+      const int xrow = ((2 * h + rr) * in_cols + lh) * cin;
+      const float* zp = Zh + (rr * 32 + lh) * BN + cot * 32 + li;
+      constexpr int NP = 16 / PG;
+      float ac[KG], an[KG], bc, bn;
+      bc = zp[2 * pg * BN];
+#pragma unroll
+      for (int j = 0; j < KG; ++j) ac[j] = Xs[koff[j] < 0 ? zero_word : xrow + 2 * pg * cin + koff[j]];
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        if (i + 1 < NP) {
+          const int kp = pg + (i + 1) * PG;
+          bn = zp[2 * kp * BN];
+#pragma unroll
+          for (int j = 0; j < KG; ++j) an[j] = Xs[koff[j] < 0 ? zero_word : xrow + 2 * kp * cin + koff[j]];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < KG; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[j], bc, acc[j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        bc = bn;
+#pragma unroll
+        for (int j = 0; j < KG; ++j) ac[j] = an[j];
+      }
+    }
+  };
+  if (tid == 0) Xs[zero_word] = 0.f;
+  int tile = split;
+  if (tile < g.total_tiles) dma(zsrc(tile, 0), Z0);
+  while (tile < g.total_tiles) {
+    const int n = tile / tiles_per_n, rem = tile - n * tiles_per_n;
+    const int ty = rem / g.tiles_x, tx = rem - ty * g.tiles_x;
+    const int by = ty * WG_ROWS + g.dy_min, bx = tx * 32 + g.dx_min;
+    __syncthreads();                       // X: everyone finished the previous tile
+    for (int p = tid; p < npixX; p += 256) {     // packed input tile (zero padding; the raw image has no view)
+      const int r = p / in_cols, c = p - r * in_cols;
+      const int iy = by + r, ix = bx + c;
+      const bool ok = iy >= 0 && iy < sH && ix >= 0 && ix < sW;
+      const float* px = d.src[0].x + ((size_t)(n * sH + iy) * sW + ix) * sld;
+      for (int ch = 0; ch < cin; ++ch) Xs[p * cin + ch] = ok ? px[ch] : 0.f;
+    }
+    const int next = tile + d.nsplit;
+    const bool have = next < g.total_tiles;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                       // Y
+    dma(zsrc(tile, 1), Z1);
+    __builtin_amdgcn_sched_barrier(0);
+    half(Z0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                       // Z
+    if (have) dma(zsrc(next, 0), Z0);
+    __builtin_amdgcn_sched_barrier(0);
+    half(Z1, 1);
+    tile = next;
+  }
+  // sum the two pixel groups, then write [tap][c][co] rows of this workgroup's partial slab
+  float* red = smem;
+#pragma unroll
+  for (int j = 0; j < KG; ++j) {
+    __syncthreads();
+    if (pg > 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[j][r];
+    }
+    __syncthreads();
+    if (pg == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] += red[((wave + NT) * 16 + r) * 64 + lane];
+    }
+  }
+  if (pg == 0) {
+    float* part = d.partial + (size_t)split * d.ntaps * g.Ktot * g.Cout32;
+    const int co = co0 + cot * 32 + li;
+#pragma unroll
+    for (int j = 0; j < KG; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int k = j * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (k < kreal) {
+          const int t = k / cin, c = k - t * cin;
+          part[((size_t)t * g.Ktot + c) * g.Cout32 + co] = acc[j][r];
+        }
+      }
+  }
+}
+
+template <int KG>
+__global__ __launch_bounds__(256) void wgrad_fewc_k(const pmf_wgrad_desc_t d, const WgGeom g) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  wgrad_fewc_body<KG>(d, g, smem);
+}
+
 // stage 2: dw_oihw[(co*Cin_real + k)*KHW + widx[t]] (+)= sum_s partial[s][t][k][co]
 // 256 threads = 32 consecutive outputs x 8 split slices (independent, unrolled loads), folded through LDS in a
 // fixed order -> deterministic, and no thread walks hundreds of slabs serially.
@@ -554,7 +705,12 @@ static void wg_config(const pmf_wgrad_desc_t* d, int* TB, int* NT) {
   *NT = wide_1x1 ? 4 : (d->Cout > 32 ? 2 : 1);
 }
 
+static bool wg_fewc(const pmf_wgrad_desc_t* d);
 extern "C" int pmf_conv_wgrad_nsplit(const pmf_wgrad_desc_t* d) {
+  if (wg_fewc(d)) {   // one output-channel tile pair per workgroup: split the pixel tiles 256 ways
+    const int tiles = cdiv(d->OW, 32) * cdiv(d->OH, WG_ROWS) * d->N, ns = 256 / cdiv(d->Cout, 64);
+    return tiles < ns ? tiles : (ns < 1 ? 1 : ns);
+  }
   int TB, NT, lds;
   WgGeom g;
   wg_config(d, &TB, &NT);
@@ -606,6 +762,58 @@ static int wg_launch(const pmf_wgrad_desc_t* d, hipStream_t s) {
   return 0;
 }
 
+// few-input-channel path (ResNet stem): conditions
+static bool wg_fewc(const pmf_wgrad_desc_t* d) {
+  if (getenv("PMF_WGRAD_NOFEWC")) return false;
+  if (d->nsrc != 1 || d->in_stride != 1 || d->Cin_real > 4 || d->ntaps < 9) return false;
+  if (d->ntaps * d->Cin_real > 160 || d->Cout % 64 || d->OH % WG_ROWS || d->OW % 32) return false;
+  if (d->src[0].flags || d->src[0].scale || d->src[0].cmul) return false;        // raw input only
+  if (d->src[0].H != d->OH || d->src[0].W != d->OW) return false;
+  return true;
+}
+
+static void wg_geometry_fewc(const pmf_wgrad_desc_t* d, WgGeom* g, int* lds) {
+  int l0;
+  wg_geometry(d, 1, 64, g, &l0);
+  int dy_min = 127, dy_max = -127, dx_min = 127, dx_max = -127;
+  for (int t = 0; t < d->ntaps; ++t) {
+    dy_min = d->tdy[t] < dy_min ? d->tdy[t] : dy_min; dy_max = d->tdy[t] > dy_max ? d->tdy[t] : dy_max;
+    dx_min = d->tdx[t] < dx_min ? d->tdx[t] : dx_min; dx_max = d->tdx[t] > dx_max ? d->tdx[t] : dx_max;
+  }
+  g->in_rows = WG_ROWS + dy_max - dy_min; g->in_cols = 32 + dx_max - dx_min;   // always a halo tile here
+  g->dy_min = dy_min; g->dx_min = dx_min;
+  g->co_tiles = d->Cout / 64; g->tap_batches = 1;
+  const int xfl = (g->in_rows * g->in_cols * d->Cin_real + 4 + 3) & ~3;
+  *lds = (xfl + 2 * 64 * 64) * 4;
+  if (*lds < 16 * 1024) *lds = 16 * 1024;
+}
+
+static int wg_launch_fewc(const pmf_wgrad_desc_t* d, hipStream_t s) {
+  WgGeom g;
+  int lds;
+  wg_geometry_fewc(d, &g, &lds);
+  const int KGn = cdiv(d->ntaps * d->Cin_real, 32);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)wgrad_fewc_k<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)wgrad_fewc_k<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)wgrad_fewc_k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)wgrad_fewc_k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  dim3 grid(d->nsplit, 1, g.co_tiles);
+  if (KGn <= 1) hipLaunchKernelGGL((wgrad_fewc_k<1>), grid, dim3(256), lds, s, *d, g);
+  else if (KGn == 2) hipLaunchKernelGGL((wgrad_fewc_k<2>), grid, dim3(256), lds, s, *d, g);
+  else if (KGn == 3) hipLaunchKernelGGL((wgrad_fewc_k<3>), grid, dim3(256), lds, s, *d, g);
+  else hipLaunchKernelGGL((wgrad_fewc_k<5>), grid, dim3(256), lds, s, *d, g);
+  PMF_LAUNCH_CHECK();
+  const int64_t total = (int64_t)d->ntaps * g.Ktot * g.Cout32;
+  int gb = (int)cdiv64(total, 32);
+  hipLaunchKernelGGL(wgrad_reduce_k, dim3(gb > 4096 ? 4096 : gb), dim3(256), 0, s, *d, g.Ktot, g.Cout32);
+  PMF_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int pmf_conv_wgrad(const pmf_wgrad_desc_t* d, pmf_stream_t st) {
   hipStream_t s = (hipStream_t)st;
   if (!d || d->nsrc < 1 || d->nsrc > PMF_MAX_SRC || d->ntaps < 1 || d->ntaps > PMF_MAX_TAPS || d->nsplit < 1)
@@ -613,6 +821,7 @@ extern "C" int pmf_conv_wgrad(const pmf_wgrad_desc_t* d, pmf_stream_t st) {
   for (int i = 0; i < d->nsrc; ++i)
     if (d->src[i].C % 8 || d->src[i].ldc % 4) return PMF_E_ARG;
   if (d->gather && false) return PMF_E_ARG;
+  if (wg_fewc(d)) return wg_launch_fewc(d, s);
   int TB, NT;
   wg_config(d, &TB, &NT);
 #define WG_CASE(tb, nt) if (TB == tb && NT == nt) return wg_launch<tb, nt>(d, s)
