@@ -4,6 +4,7 @@ Tolerance (BASELINE.json north_star / SURVEY.md 7): |d| <= 1e-3 * max(|ref|, 1) 
 abs <= 1e-4 on probabilities; integer outputs (KNN labels, loader indices / scatter) bit-exact.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -421,3 +422,44 @@ def test_flat_training_state_matches_per_tensor_path():
     assert torch.equal(c0, c1)
     for k in s0:
         assert torch.equal(s0[k], s1[k]), k
+
+
+@pytest.mark.gpu
+def test_data_parallel_range_allreduce_world1():
+    """distributed=True on one rank (RCCL, world 1): the backward plan runs in segments, finished gradient ranges are
+    all-reduced between them (identity here) -- the parameters after 3 steps must equal the single-process run."""
+    import torch.distributed as dist
+    from pmf_amd.engine import TrainEngine
+    from pmf_amd.models import PMFNet
+    from pmf_amd.utils.detinit import deterministic_init
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1)
+        created = True
+    try:
+        def run(distributed):
+            m = PMFNet(5, 3, 20, 32, imagenet_pretrained=False, image_backbone="resnet34")
+            deterministic_init(m)
+            m = m.cuda()
+            eng = TrainEngine(m, 20, lr=1e-3, warmup_steps=2, max_steps=10, distributed=distributed, device_ids=[0])
+            pcd, rgb, label, mask = synthetic_batch(2, 32, 64, 20, seed=11, fill=0.5)
+            feat = torch.cat((pcd, rgb), 1)
+            torch.manual_seed(7)
+            torch.cuda.manual_seed(7)
+            for _ in range(3):
+                eng.train_step(feat.cuda().clone(), mask.cuda(), label.cuda())
+            plan = next(iter(m._plans.values()))
+            cuts = plan.segment_cuts(4)
+            assert cuts[0] == 0 and cuts[-1] == plan.n_bwd and all(a < b for a, b in zip(cuts, cuts[1:]))
+            fr = [plan.grad_frontier(c) for c in cuts[1:]]
+            assert fr[-1] == [b for (_, b) in plan.flat.ranges]           # everything final at the end
+            assert all(x <= y for f0, f1 in zip(fr, fr[1:]) for x, y in zip(f0, f1))   # frontiers only advance
+            return {k: v.detach().clone() for k, v in m.state_dict().items()}
+        a, b = run(False), run(True)
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
+    finally:
+        if created:
+            dist.destroy_process_group()
