@@ -79,6 +79,8 @@ typedef struct {
   const float* ep_relu_shift;
   int32_t ep_relu_ldc;
   double* stats;
+  const float* ep_pmask;     /* optional per-pixel multiplier [N*out_H*out_W] applied after the activation and before the
+                              * statistics (EPMF SparseVariantConv: output * dilated mask, epmf_net.py:44-49) */
   float* splitk_ws;          /* optional scratch for deterministic split-K on small maps (NULL = never split) */
   int64_t splitk_ws_bytes;
 } pmf_conv_desc_t;
@@ -212,6 +214,18 @@ int pmf_global_mean_bwd(const float* gout, int32_t N, int32_t HW, int32_t C, con
 /* column sums: out[z][c] += sum over the npix pixels of sample z of x[z][p][c], z < nz (x advances npix*ldc,
  * out advances C per sample).  Bias gradients (nz = 1) and broadcast-operand gradients (nz = N). */
 int pmf_colsum(const float* x, int32_t ldc, int64_t npix, int32_t C, float* out, int32_t nz, pmf_stream_t s);
+/* per-pixel validity masks of EPMF's SparseVariantConv / ResContextBlock (epmf_net.py:30-50, 66-80):
+ * mask[p] = (sum_c |x[p][c]| != 0); dilated mask = max-pool of the zero-padded mask with the conv's kernel/stride/
+ * dilation; y = view(x) * mask and its gradient gx (+)= gy * mask (gx == gy, acc = 0: in place); out = a + b (b may be
+ * NULL) for the layer's two bias vectors. */
+int pmf_pmask_from(const pmf_view_t* in, int64_t npix, int32_t HW, int32_t C, float* mask, pmf_stream_t s);
+int pmf_pmask_pool(const float* mask, int32_t N, int32_t H, int32_t W, int32_t kh, int32_t kw, int32_t dil, int32_t pad,
+                   int32_t stride, float* out, int32_t OH, int32_t OW, pmf_stream_t s);
+int pmf_pmask_mul(const pmf_view_t* in, const float* mask, int64_t npix, int32_t HW, int32_t C, float* out,
+                  int32_t out_ldc, pmf_stream_t s);
+int pmf_pmask_mul_bwd(const float* gy, int32_t gy_ldc, const float* mask, int64_t npix, int32_t C, float* gx,
+                      int32_t gx_ldc, int32_t acc, pmf_stream_t s);
+int pmf_vec_add(const float* a, const float* b, float* out, int32_t n, pmf_stream_t s);
 /* softmax over channels of NHWC logits -> NCHW probabilities (pmf_net.py:176-178,221) and gradient
  * dlogit[n,y,x,c] = p*(g - sum_k g_k p_k) from NCHW p, g. */
 int pmf_softmax_nhwc_to_nchw(const float* logits, int32_t ldc, int32_t N, int32_t HW, int32_t C, float* prob_nchw,
@@ -280,7 +294,8 @@ enum {
   PMF_OP_BN_BWD_APPLY, PMF_OP_ADD_ACT, PMF_OP_ADD_ACT_BWD, PMF_OP_ACT_BWD, PMF_OP_AVGPOOL, PMF_OP_AVGPOOL_BWD,
   PMF_OP_MAXPOOL, PMF_OP_MAXPOOL_BWD, PMF_OP_BILINEAR, PMF_OP_BILINEAR_BWD, PMF_OP_PSHUFFLE, PMF_OP_PSHUFFLE_BWD,
   PMF_OP_GATE, PMF_OP_GATE_BWD, PMF_OP_GMEAN, PMF_OP_GMEAN_BWD, PMF_OP_COLSUM, PMF_OP_SOFTMAX, PMF_OP_SOFTMAX_BWD,
-  PMF_OP_NCHW2NHWC, PMF_OP_FILL
+  PMF_OP_NCHW2NHWC, PMF_OP_FILL, PMF_OP_PMASK_FROM, PMF_OP_PMASK_POOL, PMF_OP_PMASK_MUL, PMF_OP_PMASK_MUL_BWD,
+  PMF_OP_VEC_ADD
 };
 
 /* generic argument record for the small ops (slot meaning documented next to each dispatcher case in plan.cpp) */

@@ -315,6 +315,67 @@ def loader(R):
     print("g5_loader: %d arrays" % len(out))
 
 
+def epmf(R):
+    """G8: the reference's EPMFNet (epmf_net.py) -- SparseVariantConv + stride-2 ResContextBlock at block level, whole
+    net eval/train (dropout p=0) at 64x128: logits, probabilities, gradient digest, running stats; MultiTaskLoss."""
+    out = {}
+    E = _load("refpc.models.epmf_net", "pc_processor/models/epmf_net.py")
+    mt = _load("refpc_mtloss", "pc_processor/loss/multi_task_loss.py")
+    # block level: ResContextBlock(8->32, stride 2) on a sparse input, train mode, input + parameter gradients
+    blk = deterministic_init(E.ResContextBlock(8, 32, stride=2))
+    blk.train()
+    pcd, _, _, mask = synthetic_batch(2, 16, 32, 20, seed=4, fill=0.3)
+    x = torch.cat((pcd, torch.zeros(2, 3, 16, 32)), 1).requires_grad_(True)
+    y = blk(x)
+    gy = det_tensor("g8.blk.gy", tuple(y.shape))
+    (y * gy).sum().backward()
+    out["blk.out"] = f32(y)
+    out["blk.gin"] = f32(x.grad)
+    for k, v in grad_digest(blk).items():
+        out["blk.gdig." + k] = v
+    out["blk.bn1.running_mean"] = f32(blk.bn1.running_mean)
+    out["blk.bn2.running_var"] = f32(blk.bn2.running_var)
+    # whole net
+    m = deterministic_init(E.EPMFNet(pcd_channels=5, img_channels=3, nclasses=20, base_channels=32,
+                                     imagenet_pretrained=False, image_backbone="resnet34"))
+    set_p0(m)
+    hooks = {}
+    m.lidar_stream.logits.register_forward_hook(lambda mod, i, o: hooks.__setitem__("lidar", o))
+    m.camera_stream_decoder.conv.register_forward_hook(lambda mod, i, o: hooks.__setitem__("cam", o))
+    pcd, rgb, label, _ = synthetic_batch(2, 64, 128, 20, seed=1, fill=0.3)
+    m.eval()
+    with torch.no_grad():
+        lp, cp = m(pcd, rgb)
+    out["eval.lidar_logits"], out["eval.cam_logits"] = f32(hooks["lidar"]), f32(hooks["cam"])
+    out["nparams"] = np.array([sum(p.numel() for p in m.parameters())])
+    out["keys"] = np.array(sorted(m.state_dict().keys()))
+    m.train()
+    lp, cp = m(pcd, rgb)
+    out["train.lidar_logits"] = f32(hooks["lidar"])
+    alpha = torch.linspace(0.2, 1.0, 20)
+    alpha[0] = 0
+    lov = R.lovasz.Lovasz_softmax(ignore=0)
+    foc = R.focal.FocalSoftmaxLoss(20, gamma=2, alpha=alpha.numpy(), softmax=False)
+    total, terms = reference_loss(lov, foc, lp, cp, label)
+    total.backward()
+    out["train.losses"] = np.array([total.item()] + [terms[k].item() for k in ("foc", "lov", "foc_cam", "lov_cam", "per")])
+    for k, v in grad_digest(m).items():
+        out["train.gdig." + k] = v
+    for k, b in m.named_buffers():
+        if k.endswith("running_mean") and ("downCntx3.bn2" in k or "extraUpSample" in k):
+            out["train.buf." + k] = f32(b)
+    # MultiTaskLoss (multi_task_loss.py:14-19)
+    mtl = mt.MultiTaskLoss(6)
+    ls = [torch.tensor(v, requires_grad=True) for v in (0.7, 1.3, 0.2, 2.1, 0.9, 0.05)]
+    tot = mtl(ls)
+    tot.backward()
+    out["mtl.total"] = np.array([tot.item()])
+    out["mtl.gsigma"] = f32(mtl.sigma.grad)
+    out["mtl.gloss"] = np.array([l.grad.item() for l in ls])
+    np.savez_compressed(os.path.join(OUT, "g8_epmf.npz"), **out)
+    print("g8_epmf: %d arrays" % len(out))
+
+
 def trainer_trace(R):
     """G7: two consecutive optimisation steps (AdamW lidar / SGD-Nesterov camera, trainer.py:80-98,214-219)
     on config-1 shapes (64x512, bs 1), dropout p=0."""
@@ -357,6 +418,6 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     R = import_reference()
-    which = sys.argv[1:] or ["blocks", "whole_net", "losses_metrics", "knn", "loader", "trainer_trace"]
+    which = sys.argv[1:] or ["blocks", "whole_net", "losses_metrics", "knn", "loader", "trainer_trace", "epmf"]
     for name in which:
         globals()[name](R)

@@ -16,7 +16,8 @@ SRC_RELU, SRC_BCAST = 1, 2
 (OP_CONV, OP_WGRAD, OP_PACK, OP_BN_FINALIZE, OP_BN_EVAL, OP_BN_BWD_REDUCE, OP_BN_BWD_APPLY, OP_ADD_ACT,
  OP_ADD_ACT_BWD, OP_ACT_BWD, OP_AVGPOOL, OP_AVGPOOL_BWD, OP_MAXPOOL, OP_MAXPOOL_BWD, OP_BILINEAR,
  OP_BILINEAR_BWD, OP_PSHUFFLE, OP_PSHUFFLE_BWD, OP_GATE, OP_GATE_BWD, OP_GMEAN, OP_GMEAN_BWD, OP_COLSUM,
- OP_SOFTMAX, OP_SOFTMAX_BWD, OP_NCHW2NHWC, OP_FILL) = range(1, 28)
+ OP_SOFTMAX, OP_SOFTMAX_BWD, OP_NCHW2NHWC, OP_FILL, OP_PMASK_FROM, OP_PMASK_POOL, OP_PMASK_MUL, OP_PMASK_MUL_BWD,
+ OP_VEC_ADD) = range(1, 33)
 
 OP_NAMES = {v: k for k, v in list(globals().items()) if k.startswith("OP_")}
 
@@ -37,7 +38,8 @@ class ConvDesc(C.Structure):
                 ("out_sx", C.c_int32), ("out_oy", C.c_int32), ("out_ox", C.c_int32), ("accumulate", C.c_int32),
                 ("ep_cmul", C.c_void_p), ("ep_cmul_ld", C.c_int32), ("ep_relu_x", C.c_void_p),
                 ("ep_relu_scale", C.c_void_p), ("ep_relu_shift", C.c_void_p), ("ep_relu_ldc", C.c_int32),
-                ("stats", C.c_void_p), ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_int64)]
+                ("stats", C.c_void_p), ("ep_pmask", C.c_void_p), ("splitk_ws", C.c_void_p),
+                ("splitk_ws_bytes", C.c_int64)]
 
 
 class WgradDesc(C.Structure):
@@ -159,7 +161,7 @@ EXPORTS = [
     "pmf_add_act", "pmf_add_act_bwd", "pmf_act_bwd", "pmf_avgpool3s2", "pmf_avgpool3s2_bwd", "pmf_maxpool3s2",
     "pmf_maxpool3s2_bwd", "pmf_bilinear2x", "pmf_bilinear2x_bwd", "pmf_pixel_shuffle2", "pmf_pixel_shuffle2_bwd",
     "pmf_fusion_gate", "pmf_fusion_gate_bwd", "pmf_global_mean", "pmf_global_mean_bwd", "pmf_colsum",
-    "pmf_softmax_nhwc_to_nchw", "pmf_softmax_bwd_nchw_to_nhwc", "pmf_nchw_to_nhwc", "pmf_fill", "pmf_knn_vote",
+    "pmf_pmask_from", "pmf_pmask_pool", "pmf_pmask_mul", "pmf_pmask_mul_bwd", "pmf_vec_add", "pmf_softmax_nhwc_to_nchw", "pmf_softmax_bwd_nchw_to_nhwc", "pmf_nchw_to_nhwc", "pmf_fill", "pmf_knn_vote",
     "pmf_project_scatter", "pmf_crop_pad", "pmf_lovasz_grad", "pmf_loss_rows", "pmf_loss_chunks", "pmf_loss_pixel", "pmf_loss_lovasz", "pmf_plan_run", "pmf_plan_run_range", "pmf_plan_capture", "pmf_graph_launch", "pmf_graph_destroy", "pmf_sizeof", "pmf_version",
 ]
 

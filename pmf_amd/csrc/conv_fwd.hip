@@ -543,13 +543,20 @@ __global__ __launch_bounds__(256) void conv_fwd_k(const pmf_conv_desc_t d, const
         const int obase = (pix0 * d.out_ldc + co) * 4, ostep = d.out_sx * d.out_ldc * 4;
         const int xbase = (pix0 * d.ep_relu_ldc + co) * 4, xstep = d.out_sx * d.ep_relu_ldc * 4;
         unsigned off[16];
-        float xr[16], old[16];
+        float xr[16], old[16], pm[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int dx = (r & 3) + 8 * (r >> 2);
           const bool ok = rok && oxb + dx < d.OW;
           off[r] = ok ? (unsigned)(obase + dx * ostep) : 0xffffffffu;
-          xr[r] = 1.f; old[r] = 0.f;
+          xr[r] = 1.f; old[r] = 0.f; pm[r] = 1.f;
+        }
+        if (d.ep_pmask) {   // per-pixel multiplier (EPMF dilated validity mask): one value per output pixel
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int dx = (r & 3) + 8 * (r >> 2);
+            if (off[r] != 0xffffffffu) pm[r] = d.ep_pmask[pix0 + dx * d.out_sx];
+          }
         }
         if (has_rx) {
 #pragma unroll
@@ -569,7 +576,7 @@ __global__ __launch_bounds__(256) void conv_fwd_k(const pmf_conv_desc_t d, const
           float v = acc[m][u][r] + bias;
           if (sig) v = 1.f / (1.f + __expf(-v));
           else v = v > 0.f ? v : v * slope;
-          v *= ecm;
+          v *= ecm * pm[r];
           if (!(xr[r] > 0.f)) v = 0.f;
           v += old[r];
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), orr, off[r], 0, 0);
@@ -644,6 +651,7 @@ __global__ void conv_finish_k(const pmf_conv_desc_t d, int ksplit, const float* 
         if (c + k >= d.Cout) continue;
         float x = pmf_act(v[k], d.act);
         if (d.ep_cmul) x *= d.ep_cmul[(size_t)n * d.ep_cmul_ld + c + k];
+        if (d.ep_pmask) x *= d.ep_pmask[opix];
         if (d.ep_relu_x) {
           float xr = d.ep_relu_x[opix * d.ep_relu_ldc + c + k];
           if (d.ep_relu_scale) xr = xr * d.ep_relu_scale[c + k] + d.ep_relu_shift[c + k];

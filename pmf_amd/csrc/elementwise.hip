@@ -636,3 +636,97 @@ extern "C" int pmf_fill(float* p, float v, int64_t n, pmf_stream_t s) {
   PMF_LAUNCH_CHECK();
   return 0;
 }
+
+// ---- per-pixel validity masks: EPMF SparseVariantConv / ResContextBlock (pc_processor/models/epmf_net.py:30-50, 66-80)
+// mask = (sum_c |x| != 0);  dilated mask = max-pool of the zero-padded mask with the conv's kernel / stride / dilation;
+// x * mask on the way in, (conv + bias) * dilated mask on the way out (the latter lives in the conv epilogue).
+__global__ void pmask_from_k(pmf_view_t v, int64_t npix, int HW, int Q, float* __restrict__ m) {
+  for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < npix; p += (int64_t)gridDim.x * blockDim.x) {
+    const int n = (int)(p / HW);
+    float s = 0.f;
+    for (int q = 0; q < Q; ++q) {
+      const f32x4 x = ldv(v, p, n, q * 4);
+      s += fabsf(x.x) + fabsf(x.y) + fabsf(x.z) + fabsf(x.w);
+    }
+    m[p] = s != 0.f ? 1.f : 0.f;
+  }
+}
+extern "C" int pmf_pmask_from(const pmf_view_t* in, int64_t npix, int32_t HW, int32_t C, float* mask, pmf_stream_t s) {
+  if (C % 4) return PMF_E_ARG;
+  hipLaunchKernelGGL(pmask_from_k, dim3(ew_grid(npix)), dim3(EW_BLOCK), 0, (hipStream_t)s, *in, npix, HW, C / 4, mask);
+  PMF_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ void pmask_pool_k(const float* __restrict__ m, int N, int H, int W, int OH, int OW, int kh, int kw, int dil,
+                             int pad, int stride, float* __restrict__ out) {
+  const int64_t total = (int64_t)N * OH * OW;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % OW), oy = (int)((i / OW) % OH), n = (int)(i / ((int64_t)OW * OH));
+    float best = 0.f;    // F.pad pads with zeros and the mask is non-negative
+    for (int ky = 0; ky < kh; ++ky)
+      for (int kx = 0; kx < kw; ++kx) {
+        const int iy = oy * stride + ky * dil - pad, ix = ox * stride + kx * dil - pad;
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) best = fmaxf(best, m[((int64_t)n * H + iy) * W + ix]);
+      }
+    out[i] = best;
+  }
+}
+extern "C" int pmf_pmask_pool(const float* mask, int32_t N, int32_t H, int32_t W, int32_t kh, int32_t kw, int32_t dil,
+                              int32_t pad, int32_t stride, float* out, int32_t OH, int32_t OW, pmf_stream_t s) {
+  hipLaunchKernelGGL(pmask_pool_k, dim3(ew_grid((int64_t)N * OH * OW)), dim3(EW_BLOCK), 0, (hipStream_t)s, mask, N, H, W, OH,
+                     OW, kh, kw, dil, pad, stride, out);
+  PMF_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ void pmask_mul_k(pmf_view_t v, const float* __restrict__ m, int64_t npix, int HW, int Q, float* __restrict__ out,
+                            int out_ldc) {
+  const int64_t total = npix * Q;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = i / Q;
+    const int c = (int)(i - p * Q) * 4, n = (int)(p / HW);
+    *(f32x4*)(out + p * out_ldc + c) = ldv(v, p, n, c) * m[p];
+  }
+}
+extern "C" int pmf_pmask_mul(const pmf_view_t* in, const float* mask, int64_t npix, int32_t HW, int32_t C, float* out,
+                             int32_t out_ldc, pmf_stream_t s) {
+  if (C % 4) return PMF_E_ARG;
+  hipLaunchKernelGGL(pmask_mul_k, dim3(ew_grid(npix * (C / 4))), dim3(EW_BLOCK), 0, (hipStream_t)s, *in, mask, npix, HW,
+                     C / 4, out, out_ldc);
+  PMF_LAUNCH_CHECK();
+  return 0;
+}
+
+// gx (+)= gy * mask   (gx == gy, acc == 0: in place)
+__global__ void pmask_mul_bwd_k(const float* gy, int gy_ldc, const float* __restrict__ m, int64_t npix, int Q, float* gx,
+                                int gx_ldc, int acc) {
+  const int64_t total = npix * Q;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = i / Q;
+    const int c = (int)(i - p * Q) * 4;
+    f32x4 g = *(const f32x4*)(gy + p * gy_ldc + c) * m[p];
+    float* o = gx + p * gx_ldc + c;
+    if (acc) g += *(const f32x4*)o;
+    *(f32x4*)o = g;
+  }
+}
+extern "C" int pmf_pmask_mul_bwd(const float* gy, int32_t gy_ldc, const float* mask, int64_t npix, int32_t C, float* gx,
+                                 int32_t gx_ldc, int32_t acc, pmf_stream_t s) {
+  if (C % 4) return PMF_E_ARG;
+  hipLaunchKernelGGL(pmask_mul_bwd_k, dim3(ew_grid(npix * (C / 4))), dim3(EW_BLOCK), 0, (hipStream_t)s, gy, gy_ldc, mask,
+                     npix, C / 4, gx, gx_ldc, acc);
+  PMF_LAUNCH_CHECK();
+  return 0;
+}
+
+// out[i] = a[i] + (b ? b[i] : 0)    (the two biases of SparseVariantConv; copy of a bias gradient)
+__global__ void vec_add_k(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = a[i] + (b ? b[i] : 0.f);
+}
+extern "C" int pmf_vec_add(const float* a, const float* b, float* out, int32_t n, pmf_stream_t s) {
+  hipLaunchKernelGGL(vec_add_k, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)s, a, b, out, n);
+  PMF_LAUNCH_CHECK();
+  return 0;
+}

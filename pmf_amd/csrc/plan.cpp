@@ -75,6 +75,16 @@ static int run_one(const pmf_op_t& o, pmf_stream_t s) {
       return pmf_nchw_to_nhwc((const float*)a.p[0], a.l[0], a.l[1], i[0], i[1], i[2], (float*)a.p[1], i[3], s);
     case PMF_OP_FILL:  // p0 | f0 value | l0 count
       return pmf_fill((float*)a.p[0], a.f[0], a.l[0], s);
+    case PMF_OP_PMASK_FROM:  // v0 in | p: mask | i: HW C | l0 npix
+      return pmf_pmask_from(&a.v[0], a.l[0], i[0], i[1], (float*)a.p[0], s);
+    case PMF_OP_PMASK_POOL:  // p: mask out | i: N H W kh kw dil pad stride OH OW
+      return pmf_pmask_pool((const float*)a.p[0], i[0], i[1], i[2], i[3], i[4], i[5], i[6], i[7], (float*)a.p[1], i[8], i[9], s);
+    case PMF_OP_PMASK_MUL:  // v0 in | p: mask out | i: HW C out_ldc | l0 npix
+      return pmf_pmask_mul(&a.v[0], (const float*)a.p[0], a.l[0], i[0], i[1], (float*)a.p[1], i[2], s);
+    case PMF_OP_PMASK_MUL_BWD:  // p: gy mask gx | i: gy_ldc C gx_ldc acc | l0 npix
+      return pmf_pmask_mul_bwd((const float*)a.p[0], i[0], (const float*)a.p[1], a.l[0], i[1], (float*)a.p[2], i[2], i[3], s);
+    case PMF_OP_VEC_ADD:  // p: a b out | i: n
+      return pmf_vec_add((const float*)a.p[0], (const float*)a.p[1], (float*)a.p[2], i[0], s);
     default: return PMF_E_ARG;
   }
 }

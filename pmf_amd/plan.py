@@ -105,6 +105,14 @@ class T:
         return self.N * self.H * self.W
 
 
+class PM:
+    """per-pixel validity mask, dense float [N, H, W] (EPMF SparseVariantConv, epmf_net.py:30-50)."""
+
+    def __init__(self, plan, N, H, W):
+        self.N, self.H, self.W = N, H, W
+        self.buf = plan.act.alloc(4 * N * H * W)
+
+
 class V:
     def __init__(self, t, scale=None, shift=None, cmul=None, cmul_ld=0, relu=False, bcast=False, bn=None):
         self.t, self.scale, self.shift = t, scale, shift
@@ -225,7 +233,8 @@ class Plan:
         self.pack_jobs.append((weight, buf, list(taps_widx), transpose, K_pad, ldw))
         return buf
 
-    def conv(self, srcs, conv, act=L.ACT_NONE, bn=None, order="act_bn", relu_view=False, name=""):
+    def conv(self, srcs, conv, act=L.ACT_NONE, bn=None, order="act_bn", relu_view=False, name="", pmask=None,
+             extra_bias=None):
         """Conv2d (+bias) -> act -> [BatchNorm]  (order 'act_bn', SalsaNext style) or
         Conv2d -> BatchNorm -> [ReLU on the view]  (order 'bn_act', ResNet / attention style).
         Returns a V.  Registers the backward (BN backward, input gradients, weight gradient)."""
@@ -254,6 +263,19 @@ class Plan:
         train_bn = bn is not None and self.training
         has_bias = conv.bias is not None
         k_act = act if order == "act_bn" else L.ACT_NONE
+        # EPMF SparseVariantConv: (conv + conv.bias + extra bias) * dilated mask; the mask multiplies after the
+        # activation (LeakyReLU(0) = 0 and the mask is 0/1, so act(z*m) == act(z)*m) and before the BN statistics
+        bsum = None
+        if extra_bias is not None:
+            if not has_bias:
+                raise NotImplementedError("extra_bias needs a conv bias to add to")
+            bsum = self.persist.alloc(4 * Cout)
+
+            def fv(op):
+                a = op.u.sm
+                a.p[0], a.p[1], a.p[2] = conv.bias.data_ptr(), extra_bias.data_ptr(), bsum.ptr
+                a.i[0] = Cout
+            self.emit(self.fwd, L.OP_VEC_ADD, fv)
 
         def shape_fill(d):
             d.N, d.OH, d.OW, d.Cout, d.nsrc = N, OH, OW, Cout, len(srcs)
@@ -279,11 +301,12 @@ class Plan:
             for i, s in enumerate(srcs):
                 self.src_struct(s, d.src[i])
             d.w, d.ldw = wbuf.ptr, ldw
-            d.bias = conv.bias.data_ptr() if has_bias else None
+            d.bias = (bsum.ptr if bsum is not None else conv.bias.data_ptr()) if has_bias else None
             d.act = k_act
             d.out, d.out_ldc, d.out_H, d.out_W = out.buf.ptr, out.ldc, OH, OW
             d.out_sy = d.out_sx = 1
             d.stats = stats.ptr if stats is not None else None
+            d.ep_pmask = pmask.buf.ptr if pmask is not None else None
             d.splitk_ws, d.splitk_ws_bytes = self.sk_buf.ptr, self.sk_buf.nbytes
         self.emit(self.fwd, L.OP_CONV, f)
         conv_flops = 2.0 * N * OH * OW * Cout * conv.in_channels * len(taps)   # algorithmic (SURVEY.md 8d rule)
@@ -351,13 +374,13 @@ class Plan:
                 def r2(op):
                     a = op.u.sm
                     ps = (gyt.buf.ptr, out.buf.ptr, coef.ptr, info["mean"].ptr, dz.buf.ptr,
-                          self.dbrows_buf.ptr if has_bias else None)
+                          self.dbrows_buf.ptr if (has_bias and pmask is None) else None)
                     for i, p in enumerate(ps):
                         a.p[i] = p
                     a.i[0], a.i[1], a.i[2], a.i[3], a.i[4], a.i[5] = gyt.ldc, out.ldc, Cout, k_act, dz.ldc, DBIAS_LD
                     a.l[0] = out.npix
                 self.emit(self.bwd, L.OP_BN_BWD_APPLY, r2)
-                dbias_rows = L.lib().pmf_col_rows(out.npix, Cout) if has_bias else 0
+                dbias_rows = L.lib().pmf_col_rows(out.npix, Cout) if (has_bias and pmask is None) else 0
             else:
                 dz = self.tgrad(out)
                 dbias_rows = 0
@@ -365,12 +388,41 @@ class Plan:
                     def r3(op):
                         a = op.u.sm
                         a.p[0], a.p[1] = dz.buf.ptr, out.buf.ptr
-                        a.p[2] = self.dbrows_buf.ptr if has_bias else None
+                        a.p[2] = self.dbrows_buf.ptr if (has_bias and pmask is None) else None
                         a.i[0], a.i[1], a.i[2], a.i[3], a.i[4] = dz.ldc, out.ldc, k_act, _ru(Cout, 4), DBIAS_LD
                         a.l[0] = out.npix
                     self.emit(self.bwd, L.OP_ACT_BWD, r3)
-                    dbias_rows = L.lib().pmf_col_rows(out.npix, _ru(Cout, 4)) if has_bias else 0
+                    dbias_rows = L.lib().pmf_col_rows(out.npix, _ru(Cout, 4)) if (has_bias and pmask is None) else 0
             dz = out.g
+            if pmask is not None:
+                # d/dz of act(z) * m: the activation derivative above was taken from a = act(z)*m (slope of the
+                # masked-out zeros is irrelevant) -- multiply by the mask, then the bias gradients are plain column
+                # sums of the masked dz (both bias vectors of SparseVariantConv receive the same gradient)
+                def rm(op, dz=dz):
+                    a = op.u.sm
+                    a.p[0], a.p[1], a.p[2] = dz.buf.ptr, pmask.buf.ptr, dz.buf.ptr
+                    a.i[0], a.i[1], a.i[2], a.i[3] = dz.ldc, _ru(Cout, 4), dz.ldc, 0
+                    a.l[0] = dz.npix
+                self.emit(self.bwd, L.OP_PMASK_MUL_BWD, rm)
+                if has_bias:
+                    boff = self.pgrad(conv.bias)
+
+                    def rb(op, dz=dz, boff=boff):
+                        a = op.u.sm
+                        a.p[0], a.p[1] = dz.buf.ptr, self.pgrad_buf.at(boff)
+                        a.i[0], a.i[1], a.i[2] = dz.ldc, Cout, 1
+                        a.l[0] = dz.npix
+                    self.emit(self.bwd, L.OP_COLSUM, rb)
+                    self.grad_done[id(conv.bias)] = len(self.bwd) - 1
+                    if extra_bias is not None:
+                        eoff = self.pgrad(extra_bias)
+
+                        def re(op, boff=boff, eoff=eoff):
+                            a = op.u.sm
+                            a.p[0], a.p[1], a.p[2] = self.pgrad_buf.at(boff), None, self.pgrad_buf.at(eoff)
+                            a.i[0] = Cout
+                        self.emit(self.bwd, L.OP_VEC_ADD, re)
+                        self.grad_done[id(extra_bias)] = len(self.bwd) - 1
             self._dgrad(srcs, conv, dz, taps, stride, gather, name)
             self._wgrad(srcs, conv, dz, taps, stride, gather, name, dbias_rows)
         self.tape.append(backward)
@@ -540,6 +592,68 @@ class Plan:
                     s.l[0] = out.npix
                 self.emit(self.bwd, L.OP_ADD_ACT_BWD, fb)
             self.tape.append(backward)
+        return out
+
+    # ---- per-pixel validity masks (EPMF) ---------------------------------------------------------------
+    def pmask_from(self, v):
+        """mask = (sum_c |x| != 0) of a view (epmf_net.py:67)."""
+        t = v.t
+        pm = PM(self, t.N, t.H, t.W)
+
+        def f(op):
+            s = op.u.sm
+            self.view_struct(v, s.v[0])
+            s.p[0] = pm.buf.ptr
+            s.i[0], s.i[1] = t.H * t.W, _ru(t.C, 4)
+            s.l[0] = t.npix
+        self.emit(self.fwd, L.OP_PMASK_FROM, f)
+        return pm
+
+    def pmask_pool(self, pm, conv):
+        """dilated mask of a SparseVariantConv: max-pool of the zero-padded mask with the conv's geometry (:41-43)."""
+        kh, kw = conv.kernel_size
+        dil, pad, stride = conv.dilation[0], conv.padding[0], conv.stride[0]
+        OH = (pm.H + 2 * pad - dil * (kh - 1) - 1) // stride + 1
+        OW = (pm.W + 2 * pad - dil * (kw - 1) - 1) // stride + 1
+        out = PM(self, pm.N, OH, OW)
+
+        def f(op):
+            s = op.u.sm
+            s.p[0], s.p[1] = pm.buf.ptr, out.buf.ptr
+            for i, val in enumerate((pm.N, pm.H, pm.W, kh, kw, dil, pad, stride, OH, OW)):
+                s.i[i] = val
+        self.emit(self.fwd, L.OP_PMASK_POOL, f)
+        return out
+
+    def pmask_mul(self, v, pm, name=""):
+        """y = view(v) * mask, materialised; backward gx (+)= gy * mask."""
+        t = v.t
+        out = T(self, t.N, t.H, t.W, t.C, name)
+
+        def f(op):
+            s = op.u.sm
+            self.view_struct(v, s.v[0])
+            s.p[0], s.p[1] = pm.buf.ptr, out.buf.ptr
+            s.i[0], s.i[1], s.i[2] = t.H * t.W, _ru(t.C, 4), out.ldc
+            s.l[0] = t.npix
+        self.emit(self.fwd, L.OP_PMASK_MUL, f)
+        if self.training and t.needs_grad:
+            if v.cmul is not None:
+                raise NotImplementedError("pmask_mul: (n,c) multiplier on the operand has no backward here")
+
+            def backward():
+                g = self.tgrad(out)
+                gin, acc = self.grad_of(v)
+
+                def fb(op):
+                    s = op.u.sm
+                    s.p[0], s.p[1], s.p[2] = g.buf.ptr, pm.buf.ptr, gin.buf.ptr
+                    s.i[0], s.i[1], s.i[2], s.i[3] = g.ldc, _ru(t.C, 4), gin.ldc, acc
+                    s.l[0] = t.npix
+                self.emit(self.bwd, L.OP_PMASK_MUL_BWD, fb)
+            self.tape.append(backward)
+        else:
+            out.needs_grad = False
         return out
 
     def _pool(self, v, kind_f, kind_b, name, with_idx=False):

@@ -463,3 +463,78 @@ def test_data_parallel_range_allreduce_world1():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+# ---- EPMF ------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_epmf_eval_and_train_match_oracle(golden):
+    """EPMFNet on the HIP plan (SparseVariantConv masks in the conv epilogue, stride-2 context block, extraUpSample,
+    LiDAR feature into the camera decoder) against the reference-run fixture g8_epmf (eval logits) and the float64
+    oracle (train: loss, running statistics, gradients of every parameter)."""
+    import copy
+    from pmf_amd.models import EPMFNet
+    from oracle import epmf_torch as E
+    from oracle import pmf_torch as O
+    from oracle import losses_ref
+    g = golden("g8_epmf")
+    hip = deterministic_init(EPMFNet(5, 3, 20, 32, False, "resnet34")).cuda()
+    ref = deterministic_init(E.EPMFNet(5, 3, 20, 32, False, "resnet34"))
+    assert sorted(hip.state_dict().keys()) == list(g["keys"])
+    n, h, w = 2, 64, 128
+    pcd, rgb, label, _ = synthetic_batch(n, h, w, 20, seed=1, fill=0.3)
+    hip.eval()
+    ref.eval()
+    with torch.no_grad():
+        rl, rc = ref(pcd, rgb)
+        lp, cp = hip(pcd.cuda(), rgb.cuda())
+    plan = next(iter(hip._plans.values()))
+    assert G.rel_err(plan.read(plan.tensors["logits"]).cpu().numpy(), g["eval.lidar_logits"]) < 1e-3
+    assert G.rel_err(plan.read(plan.tensors["dec.logits"]).cpu().numpy(), g["eval.cam_logits"]) < 1e-3
+    assert (lp.cpu() - rl).abs().max() < 1e-4 and (cp.cpu() - rc).abs().max() < 1e-4
+    # ---- train step, dropout on with injected masks
+    hip.train()
+    ref.train()
+    m = _masks(ref, n)
+    O.set_dropout_masks(ref, m)
+    hip.set_dropout_masks({k: v.cuda() for k, v in m.items()})
+    ref64 = copy.deepcopy(ref).double()
+    O.set_dropout_masks(ref64, {k: v.double() for k, v in m.items()})
+    alpha = torch.linspace(0.2, 1.0, 20)
+    alpha[0] = 0
+    rl, rc = ref(pcd, rgb)
+    losses_ref.pmf_total_loss(rl, rc, label, alpha)[0].backward()
+    dl, dc = ref64(pcd.double(), rgb.double())
+    total_d, _ = losses_ref.pmf_total_loss(dl, dc, label, alpha.double())
+    total_d.backward()
+    lp, cp = hip(pcd.cuda(), rgb.cuda())
+    total_h, _ = losses_ref.pmf_total_loss(lp, cp, label.cuda(), alpha.cuda())
+    total_h.backward()
+    torch.cuda.synchronize()
+    plan = [p for p in hip._plans.values() if p.training][0]
+    assert G.rel_err(plan.read(plan.tensors["logits"]).cpu().numpy(), ref64.lidar_stream.last_logits.detach().float().numpy()) < 1e-3
+    assert abs(total_h.item() - total_d.item()) < 1e-4 * max(1.0, abs(total_d.item()))
+    rsd = ref.state_dict()
+    for k, v in hip.state_dict().items():
+        if "running_" in k:
+            assert G.scale_err(v.cpu().numpy(), rsd[k].numpy()) < 1e-4, k
+    rp, dp = dict(ref.named_parameters()), dict(ref64.named_parameters())
+    rows, bad = [], []
+    for k, p in hip.named_parameters():
+        assert p.grad is not None, k
+        g64 = dp[k].grad
+        wk = k.rsplit(".", 1)[0] + ".weight"
+        floor = 1e-6 * dp[wk].grad.norm().item() if wk in dp else 0.0
+        den = max(g64.norm().item(), floor, 1e-30)
+        e_h = (p.grad.cpu().double() - g64).norm().item() / den
+        e_r = (rp[k].grad.double() - g64).norm().item() / den
+        rows.append((k, e_h, e_r))
+        if not e_h <= max(20 * e_r, 5e-4):
+            bad.append((k, e_h, e_r))
+    _dump("epmf_train_grads.txt", rows)
+    # ill-conditioned parameters (bias before BatchNorm: true gradient ~0) are as far from float64 in the CPU fp32
+    # oracle as here (e.g. upBlock3.conv1.bias 6.2e-2 vs 6.4e-2): only errors the CPU oracle does not share count
+    worst = max([r[1] for r in rows if r[1] > 2 * r[2]] + [0.0])
+    assert worst < 5e-2, "gradient error vs float64 oracle: worst %.3e\n" % worst + "\n".join(
+        "%-50s %.3e %.3e" % b for b in sorted(bad, key=lambda t: -t[1])[:20])
+    assert len(bad) <= 0.15 * len(rows), "too many parameters far from float64 (%d of %d):\n" % (len(bad), len(rows)) + \
+        "\n".join("%-50s %.3e %.3e" % b for b in bad[:40])
