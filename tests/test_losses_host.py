@@ -60,3 +60,39 @@ def test_engine_two_steps_match_reference_trace(golden):
         name = k[len("trace.param."):]
         got = np.array([sd[name].double().sum().item(), sd[name].double().abs().sum().item()])
         assert np.abs(got - g[k]).max() <= 1e-3 * max(np.abs(g[k]).max(), 1e-3), name
+
+
+def test_multitask_loss_matches_reference_fixture(golden):
+    """pmf_amd.loss.MultiTaskLoss (pc_processor/loss/multi_task_loss.py:5-19) vs the reference-run values in g8_epmf."""
+    import numpy as np
+    import torch
+    from pmf_amd.loss import MultiTaskLoss
+    g = golden("g8_epmf")
+    mtl = MultiTaskLoss(6)
+    ls = [torch.tensor(v, requires_grad=True) for v in (0.7, 1.3, 0.2, 2.1, 0.9, 0.05)]
+    tot = mtl(ls)
+    tot.backward()
+    assert abs(tot.item() - float(g["mtl.total"][0])) < 1e-6
+    assert np.abs(mtl.sigma.grad.numpy() - g["mtl.gsigma"]).max() < 1e-5
+    assert np.abs(np.array([l.grad.item() for l in ls]) - g["mtl.gloss"]).max() < 1e-6
+
+
+def test_epmf_surface_and_no_cpu_fallback():
+    """EPMFNet keeps the reference's constructor / attribute surface and state-dict keys, and refuses CPU tensors."""
+    import numpy as np
+    import pytest
+    import torch
+    import pc_processor
+    g = np.load(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "g8_epmf.npz"))
+    m = pc_processor.models.EPMFNet(pcd_channels=5, img_channels=3, nclasses=20, base_channels=32,
+                                    imagenet_pretrained=False, image_backbone="resnet34")
+    assert sorted(m.state_dict().keys()) == list(g["keys"])
+    assert sum(p.numel() for p in m.parameters()) == int(g["nparams"][0])
+    for attr in ("lidar_stream", "camera_stream_encoder", "camera_stream_decoder"):
+        assert len(list(getattr(m, attr).parameters())) > 0
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 5, 64, 64), torch.zeros(1, 3, 64, 64))
+    with pytest.raises(AssertionError):
+        m(torch.zeros(1, 5, 48, 64), torch.zeros(1, 3, 48, 64))
+    with pytest.raises(NotImplementedError):
+        pc_processor.models.EPMFNet(image_backbone="vgg16")
