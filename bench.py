@@ -79,6 +79,9 @@ def main():
     ap.add_argument("--height", type=int, default=64)
     ap.add_argument("--width", type=int, default=2048)
     ap.add_argument("--bs", type=int, default=2)
+    ap.add_argument("--model", default="pmf", choices=["pmf", "epmf"],
+                    help="pmf = the headline workload (BASELINE configs[2]); epmf = configs[4] (EPMF-R34), reported "
+                         "under its own metric name, no CPU baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--profile-out", default=None, help="write the per-launch HIP-event profile (one line per op)")
@@ -96,11 +99,12 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", init_method="env://", world_size=world, rank=rank)
     from pmf_amd.engine import TrainEngine
-    from pmf_amd.models import PMFNet
+    from pmf_amd.models import PMFNet, EPMFNet
 
     torch.manual_seed(1)                 # tasks/pmf/main.py:20-21: same seed on every rank
     torch.cuda.manual_seed(1)
-    model = PMFNet(5, 3, 20, 32, imagenet_pretrained=False, image_backbone="resnet34").to(dev)
+    net = PMFNet if args.model == "pmf" else EPMFNet
+    model = net(5, 3, 20, 32, imagenet_pretrained=False, image_backbone="resnet34").to(dev)
     eng = TrainEngine(model, 20, lr=1e-3, momentum=0.9, weight_decay=1e-5, lambda_=1.0, gamma=0.5, tau=0.7,
                       feature_mean=KITTI_MEAN, feature_std=KITTI_STD, warmup_steps=10 * 100, max_steps=49 * 100,
                       distributed=world > 1, device_ids=[local] if world > 1 else None)
@@ -167,20 +171,21 @@ def main():
                   for k, v in sorted(fam.items(), key=lambda kv: -kv[1][2])}
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.model == "pmf":
         cpu = cpu_baseline(args.bs, args.height, args.width)
 
     if rank == 0:
         iters = world * args.steps
+        tag = "PMF" if args.model == "pmf" else "EPMF"
         out = {
-            "metric": "train iters/sec PMF-ResNet34 64x2048 bs=2/GPU (full iteration: fwd + 5-term loss + bwd + "
-                      "AdamW/SGD steps)",
+            "metric": "train iters/sec %s-ResNet34 64x2048 bs=2/GPU (full iteration: fwd + 5-term loss + bwd + "
+                      "AdamW/SGD steps)" % tag,
             "value": iters / dt, "unit": "iter/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "PMF-ResNet34 SemanticKITTI config, full train loop, both streams %dx%d "
-                                   "(BASELINE configs[2], S_A), bs=%d/GPU, 20 classes, dropout on, local-stat BN"
-                                   % (args.height, args.width, args.bs),
+            "config": {"workload": "%s-ResNet34 SemanticKITTI config, full train loop, both streams %dx%d "
+                                   "(BASELINE configs[%d], S_A), bs=%d/GPU, 20 classes, dropout on, local-stat BN"
+                                   % (tag, args.height, args.width, 2 if args.model == "pmf" else 4, args.bs),
                        "global_batch": world * args.bs, "parallelism": "dp%d" % world,
                        "samples_per_s": world * args.bs * args.steps / dt, "final_loss": loss_val},
             "roofline": roof, "cpu_baseline": cpu, "kernel_time_breakdown": detail,
