@@ -81,3 +81,57 @@ def test_ddp_gradients_equal_mean_of_per_rank_gradients():
     big = [p.grad / 2 for p in m.parameters()]
     diff = max((a - b).abs().max().item() for a, b in zip(mean, big))
     assert diff > 1e-6, "local-stat BN must differ from big-batch BN (sync_bn.py:53: no sync under DDP)"
+
+
+# ---- the GPU data-parallel path: range all-reduce over the flat gradient buffer, scheduler logic on CPU/gloo --------
+def _range_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pmf_amd.engine import TrainEngine
+
+    class Flat:            # two optimiser groups, like FlatState
+        ranges = [(0, 640), (640, 1024)]
+        grad = torch.arange(1024, dtype=torch.float32) * (rank + 1)
+
+    class FakePlan:        # frontiers as Plan.grad_frontier reports them after each backward segment
+        n_bwd = 40
+        fronts = {10: [128, 640], 20: [128, 832], 30: [512, 832], 40: [640, 1024]}
+
+        def grad_frontier(self, op_end):
+            return self.fronts[op_end]
+
+    eng = TrainEngine.__new__(TrainEngine)
+    eng.flat, eng._pending, eng._frontier = Flat, [], None
+    calls = []
+    real = dist.all_reduce
+
+    def spy(t, *a, **k):
+        calls.append((t.storage_offset(), t.numel()))
+        return real(t, *a, **k)
+    dist.all_reduce = spy
+    for cut in (10, 20, 30, 40):
+        eng._allreduce_ready_ranges(FakePlan(), cut)
+    eng._finish_allreduce()
+    dist.all_reduce = real
+    want = torch.arange(1024, dtype=torch.float32) * sum(r + 1 for r in range(world)) / world
+    if rank == 0:
+        ret["ok"] = bool(torch.allclose(Flat.grad, want))
+        ret["calls"] = calls
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_range_allreduce_covers_every_gradient_once():
+    """each float of the flat gradient buffer is all-reduced exactly once, in front-to-back ranges per group, and the
+    result is the mean over ranks (what DistributedDataParallel produces in the reference, trainer.py:38-39)."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_range_worker, args=(2, 29541, ret), nprocs=2, join=True)
+    assert ret["ok"]
+    calls = sorted(ret["calls"])
+    covered = []
+    for off, n in calls:
+        covered += list(range(off, off + n))
+    assert covered == list(range(1024)), "ranges overlap or leave gaps: %s" % (calls,)
