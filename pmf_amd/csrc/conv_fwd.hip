@@ -143,26 +143,31 @@ __device__ __forceinline__ void conv_half(f32x16 (&acc)[MT][BN / 32], const floa
   }
 }
 
-template <int BN, int MT>
+// VT > 1 (1x1 convolutions whose operands are multiples of 16*VT channels): one stage carries VT consecutive
+// 16-channel chunks as "virtual taps" (same pixel, channel offset 16*t): a 16-channel stage of a 1x1 layer holds only
+// 16 MFMAs per wave between three barriers (latency-bound); 64-channel stages amortise them 4x.
+template <int BN, int MT, int VT>
 __device__ __forceinline__ void conv_kloop_pipe(const pmf_conv_desc_t& d, const ConvGeom& g, f32x16 (&acc)[MT][BN / 32],
                                                 float* __restrict__ As, float* __restrict__ Bs, const int (&segrow)[MT],
                                                 const int (&segcol)[MT], int tid, int li, int lh, int n, int n0, int ks,
                                                 int oy0, int ox0, int& tri_) {
-  constexpr int ASL = MT == 2 ? 7 : 4;            // float4 slots per thread for the input tile
+  constexpr int ASL = VT > 1 ? 2 * VT : (MT == 2 ? 7 : 4);   // float4 slots per thread for the input tile
   constexpr int RPI = 256 / BN;                   // weight rows one 1-KiB DMA wave-instruction covers
-  constexpr int NDMA = (TAPG * 8 / RPI + 3) / 4;  // DMA instructions per wave per half slab
+  constexpr int NDMA = ((VT > 1 ? VT : TAPG) * 8 / RPI + 3) / 4;  // DMA instructions per wave per half slab
   const int in_cols = g.in_cols;
   const int sH = d.src[0].H, sW = d.src[0].W;
   const int q = tid & 3;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  const int totalA = g.in_rows * in_cols * 4;
-  const int hrows = d.ntaps * 8;                  // rows of one half slab
+  const int npixA = g.in_rows * in_cols;
+  const int totalA = npixA * 4 * VT;
+  const int ntaps_eff = VT > 1 ? VT : d.ntaps;
+  const int hrows = ntaps_eff * 8;                // rows of one half slab
   float* __restrict__ Bh1 = Bs + hrows * BN;
   int gA[ASL];
   unsigned okA = 0u;
 #pragma unroll
   for (int j = 0; j < ASL; ++j) {
-    const int f = tid + 256 * j, pix = f >> 2;
+    const int f = tid + 256 * j, pix = VT > 1 ? (f >> 2) % npixA : (f >> 2);
     const int r = pix / in_cols, c = pix - r * in_cols;
     const int iy = oy0 + g.dy_min + r, ix = ox0 + g.dx_min + c;
     const bool ok = f < totalA && iy >= 0 && iy < sH && ix >= 0 && ix < sW;
@@ -173,27 +178,29 @@ __device__ __forceinline__ void conv_kloop_pipe(const pmf_conv_desc_t& d, const 
 #pragma unroll
   for (int jj = 0; jj < NDMA; ++jj) {
     const int row = (wave + 4 * jj) * RPI + lane / (BN / 4);
-    offB[jj] = ((row >> 3) * g.Ktot + (row & 7)) * d.ldw + (lane % (BN / 4)) * 4;
+    offB[jj] = ((row >> 3) * (VT > 1 ? KC : g.Ktot) + (row & 7)) * d.ldw + (lane % (BN / 4)) * 4;
   }
   int aoff[TAPG];
 #pragma unroll
-  for (int t = 0; t < TAPG; ++t)
-    aoff[t] = t < d.ntaps ? (((int)d.tdy[t] - g.dy_min) * in_cols + ((int)d.tdx[t] - g.dx_min)) * APITCH : 0;
+  for (int t = 0; t < TAPG; ++t) {
+    if (VT > 1) aoff[t] = t < VT ? t * g.a_floats : 0;     // virtual tap t = 16-channel chunk t of the stage
+    else aoff[t] = t < d.ntaps ? (((int)d.tdy[t] - g.dy_min) * in_cols + ((int)d.tdx[t] - g.dx_min)) * APITCH : 0;
+  }
   int abase[MT];
 #pragma unroll
   for (int m = 0; m < MT; ++m) abase[m] = (segrow[m] * in_cols + segcol[m] * 32 + li) * APITCH + lh * 4;
 
-  // stage iterator over (operand, 16-channel chunk), split-K chunks dealt round-robin
+  // stage iterator over (operand, 16*VT-channel stage), split-K stages dealt round-robin
   int si = 0, c0 = 0, kb = 0, cn = 0;
   auto settle = [&]() {   // move (si, c0) forward to the next chunk owned by this workgroup; false at the end
     for (;;) {
       if (si >= d.nsrc) return false;
       if (c0 >= d.src[si].C) { kb += d.src[si].C; ++si; c0 = 0; continue; }
       if ((cn % g.ksplit) == ks) return true;
-      ++cn; c0 += KC;
+      ++cn; c0 += KC * VT;
     }
   };
-  f32x4 rA[ASL], sc4, sh4, cm4;
+  f32x4 rA[ASL], sc4[VT], sh4[VT], cm4[VT];
   int cur_flags = 0;
   bool cur_aff = false;
   __amdgpu_buffer_rsrc_t nrs;           // operand of the stage being fetched
@@ -204,13 +211,22 @@ __device__ __forceinline__ void conv_kloop_pipe(const pmf_conv_desc_t& d, const 
     nld = d.src[si].ldc; ncch = c0 + q * 4;
     cur_flags = d.src[si].flags;
     cur_aff = d.src[si].scale != nullptr;
-    sc4 = f32x4{1.f, 1.f, 1.f, 1.f}; sh4 = f32x4{0.f, 0.f, 0.f, 0.f}; cm4 = f32x4{1.f, 1.f, 1.f, 1.f};
-    if (cur_aff) { sc4 = *(const f32x4*)(d.src[si].scale + ncch); sh4 = *(const f32x4*)(d.src[si].shift + ncch); }
-    if (d.src[si].cmul) cm4 = *(const f32x4*)(d.src[si].cmul + (size_t)n * d.src[si].cmul_ld + ncch);
+#pragma unroll
+    for (int v = 0; v < VT; ++v) {      // channel transform of virtual tap v (channels ncch + 16 v ...)
+      sc4[v] = f32x4{1.f, 1.f, 1.f, 1.f}; sh4[v] = f32x4{0.f, 0.f, 0.f, 0.f}; cm4[v] = f32x4{1.f, 1.f, 1.f, 1.f};
+      if (cur_aff) {
+        sc4[v] = *(const f32x4*)(d.src[si].scale + ncch + KC * v);
+        sh4[v] = *(const f32x4*)(d.src[si].shift + ncch + KC * v);
+      }
+      if (d.src[si].cmul) cm4[v] = *(const f32x4*)(d.src[si].cmul + (size_t)n * d.src[si].cmul_ld + ncch + KC * v);
+    }
     nw = d.w + (size_t)(kb + c0) * d.ldw + n0;
   };
+  // slot j of the staging tile: VT > 1 lays the tile out [virtual tap][pixel][4 float4]; with 128-pixel tiles
+  // (no halo) slots 2v and 2v+1 belong to virtual tap v
   auto loadA = [&](int j) {   // j is a compile-time constant after unrolling; branch-free (see gA)
-    rA[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(nrs, (gA[j] * nld + ncch) * 4, 0, 0));
+    const int vch = VT > 1 ? ((tid + 256 * j) >> 2) / npixA * KC : 0;
+    rA[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(nrs, (gA[j] * nld + ncch + vch) * 4, 0, 0));
   };
   auto dma_half = [&](const float* __restrict__ wsrc, float* __restrict__ dst) {
 #pragma unroll
@@ -236,23 +252,26 @@ __device__ __forceinline__ void conv_kloop_pipe(const pmf_conv_desc_t& d, const 
     for (int j = 0; j < ASL; ++j) {
       const int f = tid + 256 * j;
       if (f < totalA) {
+        // VT > 1: the tile has no halo and 128 pixels, so the virtual tap of slot j is the compile-time j / 2
+        const int v = VT > 1 ? (j * 256 * VT) / (ASL * 256) : 0;
         f32x4 t = {0.f, 0.f, 0.f, 0.f};
         if ((okA >> j) & 1u) {
           t = rA[j];
-          if (cur_aff) t = t * sc4 + sh4;
+          if (cur_aff) t = t * sc4[v] + sh4[v];
           if (cur_flags & PMF_SRC_RELU) {
             t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f);
           }
-          t = t * cm4;
+          t = t * cm4[v];
         }
-        *(f32x4*)(As + (f >> 2) * APITCH + q * 4) = t;
+        if (VT > 1) *(f32x4*)(As + v * g.a_floats + ((f >> 2) - v * npixA) * APITCH + q * 4) = t;
+        else *(f32x4*)(As + (f >> 2) * APITCH + q * 4) = t;
       }
     }
     wcur = nw;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of B(h0) has landed in LDS
     __syncthreads();                       // Y: input tile + half 0 visible
     TR();
-    ++cn; c0 += KC;
+    ++cn; c0 += KC * VT;
     have = settle();
     if (have) head();
     else nrs = __builtin_amdgcn_make_buffer_rsrc((void*)d.src[0].x, 0, 0, 0x00020000);   // last chunk: loads fetch nothing
@@ -273,7 +292,8 @@ __device__ __forceinline__ void conv_kloop_pipe(const pmf_conv_desc_t& d, const 
 #pragma unroll
     for (int m = 0; m < MT; ++m) asm volatile("" : "+v"(abase[m]));
     __builtin_amdgcn_sched_barrier(0);
-    if (d.ntaps == 9) conv_half<BN, MT, 9>(acc, As, Bs, abase, aoff, 0, li, lh, fill);
+    if (VT > 1) conv_half<BN, MT, VT>(acc, As, Bs, abase, aoff, 0, li, lh, fill);
+    else if (d.ntaps == 9) conv_half<BN, MT, 9>(acc, As, Bs, abase, aoff, 0, li, lh, fill);
     else if (d.ntaps == 3) conv_half<BN, MT, 3>(acc, As, Bs, abase, aoff, 0, li, lh, fill);
     else if (d.ntaps == 4) conv_half<BN, MT, 4>(acc, As, Bs, abase, aoff, 0, li, lh, fill);
     else conv_half<BN, MT, 1>(acc, As, Bs, abase, aoff, 0, li, lh, fill);
@@ -284,7 +304,8 @@ __device__ __forceinline__ void conv_kloop_pipe(const pmf_conv_desc_t& d, const 
 #pragma unroll
     for (int m = 0; m < MT; ++m) asm volatile("" : "+v"(abase[m]));
     __builtin_amdgcn_sched_barrier(0);
-    if (d.ntaps == 9) conv_half<BN, MT, 9>(acc, As, Bh1, abase, aoff, 8, li, lh);
+    if (VT > 1) conv_half<BN, MT, VT>(acc, As, Bh1, abase, aoff, 8, li, lh);
+    else if (d.ntaps == 9) conv_half<BN, MT, 9>(acc, As, Bh1, abase, aoff, 8, li, lh);
     else if (d.ntaps == 3) conv_half<BN, MT, 3>(acc, As, Bh1, abase, aoff, 8, li, lh);
     else if (d.ntaps == 4) conv_half<BN, MT, 4>(acc, As, Bh1, abase, aoff, 8, li, lh);
     else conv_half<BN, MT, 1>(acc, As, Bh1, abase, aoff, 8, li, lh);
@@ -292,11 +313,11 @@ __device__ __forceinline__ void conv_kloop_pipe(const pmf_conv_desc_t& d, const 
   }
 }
 
-template <int BN, int MT, bool PIPE>
+template <int BN, int MT, int PIPE>   // PIPE: 0 generic K loop, 1 pipelined, 4 pipelined with 64-channel stages (1x1 convs)
 __global__ __launch_bounds__(256) void conv_fwd_k(const pmf_conv_desc_t d, const ConvGeom g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* __restrict__ As = smem;
-  float* __restrict__ Bs = smem + g.a_floats;
+  float* __restrict__ Bs = smem + g.a_floats * (PIPE > 1 ? PIPE : 1);
   constexpr int NT = BN / 32;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
@@ -339,7 +360,7 @@ __global__ __launch_bounds__(256) void conv_fwd_k(const pmf_conv_desc_t d, const
   }
 
   if constexpr (PIPE) {
-    conv_kloop_pipe<BN, MT>(d, g, acc, As, Bs, segrow, segcol, tid, li, lh, n, n0, ks, oy0, ox0, tri_);
+    conv_kloop_pipe<BN, MT, (PIPE > 1 ? PIPE : 1)>(d, g, acc, As, Bs, segrow, segcol, tid, li, lh, n, n0, ks, oy0, ox0, tri_);
   } else {
   const int ngroups = d.gather ? d.ntaps : 1;
   int k_base = 0, chunk_no = 0;
@@ -741,16 +762,21 @@ static int choose_ksplit(const pmf_conv_desc_t* d, int blocks_mn, int nchunks, i
   return k < 2 ? 1 : k;
 }
 
-// the software-pipelined K loop applies when ...
-static bool conv_simple(const pmf_conv_desc_t* d, const ConvGeom& g, int gather, int MT) {
-  if (gather || d->in_stride != 1) return false;
-  if (d->ntaps != 1 && d->ntaps != 3 && d->ntaps != 4 && d->ntaps != 9) return false;
+// K-loop variant: 0 generic, 1 software-pipelined (halo tile, 1/3/4/9 taps, stride 1, operands multiples of 16
+// channels with the same H x W, no broadcast), 4 pipelined with 64-channel stages (1x1, operands multiples of 64)
+static int conv_pipe_mode(const pmf_conv_desc_t* d, const ConvGeom& g, int gather, int MT) {
+  if (gather || d->in_stride != 1) return 0;
+  if (d->ntaps != 1 && d->ntaps != 3 && d->ntaps != 4 && d->ntaps != 9) return 0;
+  bool c64 = true;
   for (int i = 0; i < d->nsrc; ++i) {
-    if (d->src[i].C % 16 || (d->src[i].flags & PMF_SRC_BCAST)) return false;
-    if (d->src[i].H != d->src[0].H || d->src[i].W != d->src[0].W) return false;
-    if ((int64_t)d->N * d->src[i].H * d->src[i].W * d->src[i].ldc * 4 >= (1ll << 31)) return false;
+    if (d->src[i].C % 16 || (d->src[i].flags & PMF_SRC_BCAST)) return 0;
+    if (d->src[i].H != d->src[0].H || d->src[i].W != d->src[0].W) return 0;
+    if ((int64_t)d->N * d->src[i].H * d->src[i].W * d->src[i].ldc * 4 >= (1ll << 31)) return 0;
+    c64 = c64 && d->src[i].C % 64 == 0;
   }
-  return g.in_rows * g.in_cols * 4 <= 256 * (MT == 2 ? 7 : 4);
+  if (g.in_rows * g.in_cols * 4 > 256 * (MT == 2 ? 7 : 4)) return 0;
+  if (d->ntaps == 1 && MT == 1 && c64 && g.in_rows * g.in_cols == 128 && !getenv("PMF_CONV_NOVT")) return 4;
+  return 1;
 }
 
 template <int BN, int MT>
@@ -772,20 +798,30 @@ static int launch(const pmf_conv_desc_t* d, hipStream_t s) {
   dd.gather = gather;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv_fwd_k<BN, MT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)conv_fwd_k<BN, MT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_fwd_k<BN, MT, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_fwd_k<BN, MT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if constexpr (MT == 1)
+      (void)hipFuncSetAttribute((const void*)conv_fwd_k<BN, 1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   const int co_tiles = cdiv(d->Cout, BN);
+  const int mode = conv_pipe_mode(d, g, gather, MT);
+  if (mode == 4) {           // 64-channel stages
+    nchunks = 0;
+    for (int i = 0; i < d->nsrc; ++i) nchunks += d->src[i].C / (KC * 4);
+    lds = (g.a_floats * 4 + 4 * KC * BN) * 4;
+  }
   g.ksplit = choose_ksplit(d, g.tiles_x * g.tiles_y * d->N * co_tiles, nchunks, d->ntaps * 8 * MT * (BN / 32));
   g.ws = d->splitk_ws;
   g.ws_ld = round_up(d->Cout, 4);
   dim3 grid(g.tiles_x * g.tiles_y, co_tiles * g.ksplit, d->N);
-  if (conv_simple(d, g, gather, MT)) {
+  if (mode == 4) {
+    if constexpr (MT == 1) hipLaunchKernelGGL((conv_fwd_k<BN, 1, 4>), grid, dim3(256), lds, s, dd, g);
+  } else if (mode == 1) {
     g.kc_alloc = KC;   // the pipelined loop lays the weight slab out as [tap][16][BN]
-    hipLaunchKernelGGL((conv_fwd_k<BN, MT, true>), grid, dim3(256), lds, s, dd, g);
+    hipLaunchKernelGGL((conv_fwd_k<BN, MT, 1>), grid, dim3(256), lds, s, dd, g);
   } else {
-    hipLaunchKernelGGL((conv_fwd_k<BN, MT, false>), grid, dim3(256), lds, s, dd, g);
+    hipLaunchKernelGGL((conv_fwd_k<BN, MT, 0>), grid, dim3(256), lds, s, dd, g);
   }
   PMF_LAUNCH_CHECK();
   if (g.ksplit > 1) {
@@ -809,6 +845,10 @@ extern "C" int pmf_conv_fwd_stat_rows(const pmf_conv_desc_t* d) {
   pmf_conv_geometry(d->OH, d->OW, d->ntaps, d->tdy, d->tdx, d->in_stride, d->gather, BN, MT, cmax < KC ? cmax : KC, &g,
                     &gather);
   const int tiles = g.tiles_x * g.tiles_y;
+  if (conv_pipe_mode(d, g, gather, MT) == 4) {      // same stage count as launch<>()
+    nchunks = 0;
+    for (int i = 0; i < d->nsrc; ++i) nchunks += d->src[i].C / (KC * 4);
+  }
   if (choose_ksplit(d, tiles * d->N * cdiv(d->Cout, BN), nchunks, d->ntaps * 8 * MT * (BN / 32)) > 1) return finish_rows(d);
   return tiles * d->N;
 }

@@ -282,6 +282,8 @@ class Plan:
             for i, s in enumerate(srcs):
                 d.src[i].C = _ru(s.t.C, 8)
                 d.src[i].ldc, d.src[i].H, d.src[i].W = s.t.ldc, s.t.H, s.t.W
+                # flags steer the kernel variant (hence the split-K decision the statistics-row probe must match)
+                d.src[i].flags = (L.SRC_RELU if s.relu else 0) | (L.SRC_BCAST if s.bcast else 0)
             d.ntaps = len(taps)
             for i, (dy, dx, _) in enumerate(taps):
                 d.tdy[i], d.tdx[i] = dy, dx
