@@ -660,8 +660,18 @@ __global__ void conv_finish_k(const pmf_conv_desc_t d, int ksplit, const float* 
       for (int k = 0; k < 4; ++k) if (c + k < d.Cout) bias[k] = d.bias[c + k];
     }
     for (int64_t p = (int64_t)blockIdx.x * rows + row; p < npix; p += (int64_t)gridDim.x * rows) {
+      // slabs in batches of 8 independent loads (a load -> add loop exposes one L2 round trip per slab), summed in
+      // slab order: the result does not depend on the batching
       f32x4 v = bias;
-      for (int s = 0; s < ksplit; ++s) v += *(const f32x4*)(ws + ((int64_t)s * npix + p) * ws_ld + c);
+      for (int s0 = 0; s0 < ksplit; s0 += 8) {
+        f32x4 t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (s0 + j < ksplit) t[j] = *(const f32x4*)(ws + ((int64_t)(s0 + j) * npix + p) * ws_ld + c);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (s0 + j < ksplit) v += t[j];
+      }
       const int n = (int)(p / hw);
       const int rem = (int)(p - (int64_t)n * hw), oy = rem / d.OW, ox = rem - oy * d.OW;
       // strided / offset outputs (stride-2 input-gradient parity classes, pixel-shuffle style scatter)

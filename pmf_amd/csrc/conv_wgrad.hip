@@ -615,8 +615,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce_k(const pmf_wgrad_desc_t d, 
     const int64_t i = base + ol;
     float s = 0.f;
     if (i < total) {
-#pragma unroll 8
-      for (int sp = sl; sp < d.nsplit; sp += 8) s += d.partial[sp * slab + i];
+      for (int sp0 = sl; sp0 < d.nsplit; sp0 += 64) {   // 8 independent loads in flight per thread, fixed summation order
+        float t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = sp0 + 8 * j < d.nsplit ? d.partial[(int64_t)(sp0 + 8 * j) * slab + i] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += t[j];
+      }
     }
     shr[sl][ol] = s;
     __syncthreads();
