@@ -2,6 +2,7 @@
 // host (static shapes, static buffers); running it is ONE C call that enqueues every kernel on the caller's
 // HIP stream -- no Python between launches, and the array can be captured into a hipGraph by the caller.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include "../../include/pmf_amd.h"
 
 extern "C" int pmf_pack_weights_batched(const pmf_pack_job_t*, int32_t, int32_t, pmf_stream_t);
@@ -89,26 +90,63 @@ static int run_one(const pmf_op_t& o, pmf_stream_t s) {
   }
 }
 
-extern "C" int pmf_plan_run(const pmf_op_t* ops, int32_t n, pmf_stream_t s, int32_t* failed_at) {
-  for (int32_t k = 0; k < n; ++k) {
-    const int rc = run_one(ops[k], s);
+// Two lanes: ops with pad_ == 1 (weight gradients) go to a private side stream.  A side op waits for everything issued
+// on the main stream before it (its inputs were produced there) and nothing on the main stream waits for it until
+// the end of the range, so the big weight-gradient kernels fill the machine while the main stream walks the
+// latency-bound chain BatchNorm-backward -> input gradient -> next layer.  Measured on MI355X / ROCm 7.2 with hipGraph
+// replay: no gain (26.1 vs 26.1 ms per step -- the two branches do not overlap usefully), so the side lane is OFF unless
+// PMF_SIDE=1 is set; the plumbing (per-layer bias-row buffers, fork/join inside the capture) stays for the next round.
+static hipStream_t g_side = nullptr;
+static hipEvent_t g_fork = nullptr, g_join = nullptr;
+static int lanes_init() {
+  if (g_side) return 0;
+  hipError_t e = hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking);
+  if (e != hipSuccess) return (int)e;
+  e = hipEventCreateWithFlags(&g_fork, hipEventDisableTiming);
+  if (e != hipSuccess) return (int)e;
+  e = hipEventCreateWithFlags(&g_join, hipEventDisableTiming);
+  return (int)e;
+}
+static bool lanes_enabled() {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("PMF_SIDE"); on = (e && e[0] == '1') ? 1 : 0; }
+  return on == 1;
+}
+
+static int run_range(const pmf_op_t* ops, int32_t begin, int32_t end, hipStream_t main_s, int32_t* failed_at) {
+  bool side_used = false;
+  const bool lanes = lanes_enabled();
+  for (int32_t k = begin; k < end; ++k) {
+    int rc;
+    if (lanes && ops[k].pad_ == 1) {
+      rc = lanes_init();
+      if (rc == 0) rc = (int)hipEventRecord(g_fork, main_s);
+      if (rc == 0) rc = (int)hipStreamWaitEvent(g_side, g_fork, 0);
+      if (rc == 0) rc = run_one(ops[k], (pmf_stream_t)g_side);
+      side_used = true;
+    } else {
+      rc = run_one(ops[k], (pmf_stream_t)main_s);
+    }
     if (rc != 0) {
       if (failed_at) *failed_at = k;
+      if (side_used) { (void)hipEventRecord(g_join, g_side); (void)hipStreamWaitEvent(main_s, g_join, 0); }
       return rc;
     }
+  }
+  if (side_used) {
+    hipError_t e = hipEventRecord(g_join, g_side);
+    if (e == hipSuccess) e = hipStreamWaitEvent(main_s, g_join, 0);
+    if (e != hipSuccess) return (int)e;
   }
   return 0;
 }
 
+extern "C" int pmf_plan_run(const pmf_op_t* ops, int32_t n, pmf_stream_t s, int32_t* failed_at) {
+  return run_range(ops, 0, n, (hipStream_t)s, failed_at);
+}
+
 extern "C" int pmf_plan_run_range(const pmf_op_t* ops, int32_t begin, int32_t end, pmf_stream_t s, int32_t* failed_at) {
-  for (int32_t k = begin; k < end; ++k) {
-    const int rc = run_one(ops[k], s);
-    if (rc != 0) {
-      if (failed_at) *failed_at = k;
-      return rc;
-    }
-  }
-  return 0;
+  return run_range(ops, begin, end, (hipStream_t)s, failed_at);
 }
 
 // ---- hipGraph capture of a plan range --------------------------------------------------------------------------
@@ -130,11 +168,7 @@ extern "C" int pmf_plan_capture(const pmf_op_t* ops, int32_t begin, int32_t end,
   }
   e = hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal);
   if (e != hipSuccess) return (int)e;
-  int rc = 0;
-  for (int32_t k = begin; k < end && rc == 0; ++k) {
-    rc = run_one(ops[k], (pmf_stream_t)cap);
-    if (rc != 0 && failed_at) *failed_at = k;
-  }
+  int rc = run_range(ops, begin, end, cap, failed_at);   // side-lane ops fork / join inside the capture
   hipGraph_t graph = nullptr;
   e = hipStreamEndCapture(cap, &graph);
   if (rc != 0) { if (graph) (void)hipGraphDestroy(graph); return rc; }

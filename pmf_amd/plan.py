@@ -169,9 +169,11 @@ class Plan:
         return self._pid[id(p)][1]
 
     # ------------------------------------------------------------------ op emission helpers
-    def emit(self, lst, kind, fill):
-        """fill(op) populates a zeroed L.Op at finalise time (pointers are known only then)."""
-        lst.append((kind, fill))
+    def emit(self, lst, kind, fill, lane=0):
+        """fill(op) populates a zeroed L.Op at finalise time (pointers are known only then).
+        lane 1 = side stream: the op only waits for what was issued before it and is joined at the end of the range
+        (weight gradients: off the critical path, they overlap the latency-bound BatchNorm / finish kernels)."""
+        lst.append((kind, fill) if lane == 0 else (kind, fill, lane))
 
     def view_struct(self, v, dst):
         dst.x = v.t.buf.ptr
@@ -351,6 +353,10 @@ class Plan:
 
         # ------------------------------------------------------------------ backward
         def backward():
+            # partial column sums of dz for the conv-bias gradient: one buffer PER LAYER (the weight-gradient op that
+            # folds them runs on the side stream while the main stream already works on the next layer)
+            dbr_ld = _ru(Cout, 4)
+            dbr = self.act.alloc(COL_ROWS * dbr_ld * 4) if (has_bias and pmask is None) else None
             if bn is not None:
                 if view.gy is None:
                     raise RuntimeError("plan: no gradient reached BN output of %s" % name)
@@ -376,10 +382,10 @@ class Plan:
                 def r2(op):
                     a = op.u.sm
                     ps = (gyt.buf.ptr, out.buf.ptr, coef.ptr, info["mean"].ptr, dz.buf.ptr,
-                          self.dbrows_buf.ptr if (has_bias and pmask is None) else None)
+                          dbr.ptr if dbr is not None else None)
                     for i, p in enumerate(ps):
                         a.p[i] = p
-                    a.i[0], a.i[1], a.i[2], a.i[3], a.i[4], a.i[5] = gyt.ldc, out.ldc, Cout, k_act, dz.ldc, DBIAS_LD
+                    a.i[0], a.i[1], a.i[2], a.i[3], a.i[4], a.i[5] = gyt.ldc, out.ldc, Cout, k_act, dz.ldc, dbr_ld
                     a.l[0] = out.npix
                 self.emit(self.bwd, L.OP_BN_BWD_APPLY, r2)
                 dbias_rows = L.lib().pmf_col_rows(out.npix, Cout) if (has_bias and pmask is None) else 0
@@ -390,8 +396,8 @@ class Plan:
                     def r3(op):
                         a = op.u.sm
                         a.p[0], a.p[1] = dz.buf.ptr, out.buf.ptr
-                        a.p[2] = self.dbrows_buf.ptr if (has_bias and pmask is None) else None
-                        a.i[0], a.i[1], a.i[2], a.i[3], a.i[4] = dz.ldc, out.ldc, k_act, _ru(Cout, 4), DBIAS_LD
+                        a.p[2] = dbr.ptr if dbr is not None else None
+                        a.i[0], a.i[1], a.i[2], a.i[3], a.i[4] = dz.ldc, out.ldc, k_act, _ru(Cout, 4), dbr_ld
                         a.l[0] = out.npix
                     self.emit(self.bwd, L.OP_ACT_BWD, r3)
                     dbias_rows = L.lib().pmf_col_rows(out.npix, _ru(Cout, 4)) if (has_bias and pmask is None) else 0
@@ -426,7 +432,7 @@ class Plan:
                         self.emit(self.bwd, L.OP_VEC_ADD, re)
                         self.grad_done[id(extra_bias)] = len(self.bwd) - 1
             self._dgrad(srcs, conv, dz, taps, stride, gather, name)
-            self._wgrad(srcs, conv, dz, taps, stride, gather, name, dbias_rows)
+            self._wgrad(srcs, conv, dz, taps, stride, gather, name, dbias_rows, dbr, dbr_ld)
         self.tape.append(backward)
         return view
 
@@ -514,7 +520,7 @@ class Plan:
                     self.emit(self.bwd, L.OP_COLSUM, fc)
             coloff += Cs
 
-    def _wgrad(self, srcs, conv, dz, taps, stride, gather, name, dbias_rows=0):
+    def _wgrad(self, srcs, conv, dz, taps, stride, gather, name, dbias_rows=0, dbr=None, dbr_ld=0):
         Cout = conv.out_channels
         goff = self.pgrad(conv.weight)
         kh, kw = conv.kernel_size
@@ -549,10 +555,10 @@ class Plan:
             d.dw_oihw = self.pgrad_buf.at(goff)
             d.accumulate = 0
             if dbias_rows:
-                d.dbias_rows, d.dbias_nrows, d.dbias_ld = self.dbrows_buf.ptr, dbias_rows, DBIAS_LD
+                d.dbias_rows, d.dbias_nrows, d.dbias_ld = dbr.ptr, dbias_rows, dbr_ld
                 d.dbias_out = self.pgrad_buf.at(boff)
         boff = self.pgrad(conv.bias) if dbias_rows else None
-        self.emit(self.bwd, L.OP_WGRAD, f)
+        self.emit(self.bwd, L.OP_WGRAD, f, lane=1)
         self.grad_done[id(conv.weight)] = len(self.bwd) - 1
         if dbias_rows:
             self.grad_done[id(conv.bias)] = len(self.bwd) - 1
@@ -871,7 +877,6 @@ class Plan:
         self.wg_buf = self.act.alloc(max(self.wg_scratch, 256)) if self.training else None
         self.sk_buf = self.act.alloc(SPLITK_BYTES)   # shared split-K scratch (small maps only; ops run in stream order)
         self.bnpart_buf = self.act.alloc(COL_ROWS * 2 * max(self.colrows_max, 4) * 8)   # float64 partial rows
-        self.dbrows_buf = self.act.alloc(COL_ROWS * DBIAS_LD * 4)
         for a, zero in ((self.act, False), (self.zero_fwd, True), (self.zero_bwd, True), (self.persist, True)):
             a.materialise(dev, zero)
         self.masks_ptr = self.masks.data_ptr() if self.masks is not None else 0
@@ -901,8 +906,10 @@ class Plan:
             n = len(lst) + len(prologue)
             arr = (L.Op * max(n, 1))()
             k = 0
-            for kind, fill in prologue + lst:
+            for ent in prologue + lst:
+                kind, fill = ent[0], ent[1]
                 arr[k].kind = kind
+                arr[k].pad_ = ent[2] if len(ent) > 2 else 0
                 fill(arr[k])
                 k += 1
             return arr, n
@@ -934,8 +941,8 @@ class Plan:
             self.bwd_ops, self.n_bwd = build(self.bwd, pro_b)
         else:
             self.bwd_ops, self.n_bwd, self.bwd_shift = None, 0, 0
-        self.fwd_kinds = [k for k, _ in pro_f + self.fwd]
-        self.bwd_kinds = [k for k, _ in (pro_b + self.bwd)] if self.training else []
+        self.fwd_kinds = [e[0] for e in pro_f + self.fwd]
+        self.bwd_kinds = [e[0] for e in (pro_b + self.bwd)] if self.training else []
         self.fwd = self.bwd = None
         self.param_ptrs = [p.data_ptr() for p in self.params]
         return self
