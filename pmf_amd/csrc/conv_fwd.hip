@@ -758,6 +758,10 @@ static void conv_config(const pmf_conv_desc_t* d, int* BN, int* MT) {
   // enough workgroups to fill 256 CUs: fall back to 128-pixel tiles on small maps
   const long px = (long)d->N * cdiv(d->OH, 8) * cdiv(d->OW, 32) * cdiv(d->Cout, *BN);
   *MT = px >= 512 ? 2 : 1;
+  // 200..511 workgroups with 64-wide tiles = one workgroup per CU, nothing to overlap its staging with: 32-wide tiles
+  // double the grid (measured +5 % on 128 -> 128 at 16x512); below 200 the K loop is split instead
+  const long b64 = (long)d->N * cdiv(d->OH, 4) * cdiv(d->OW, 32) * cdiv(d->Cout, 64);
+  if (*MT == 1 && *BN == 64 && b64 >= 200 && b64 < 512) *BN = 32;
 }
 
 // split-K factor: only when the M x N grid cannot fill the 256 CUs (low-resolution, many-channel layers)
