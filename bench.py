@@ -161,9 +161,17 @@ def main():
         mfma_fl = fam["conv_fwd"][1] + fam["conv_dgrad"][1]
         n_launch = fam["conv_fwd"][0] + fam["conv_dgrad"][0]
         achieved = mfma_fl / (mfma_ms * 1e-3) / 1e12
+        # HBM-side bytes per launch come from a separate rocprofv3 --pmc run of this command (counters cannot be read
+        # from inside the process); tools/pmc_traffic.py wrote the summary that is committed under profiles/
+        traffic, tsrc = None, None
+        tp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+        if args.model == "pmf" and (args.height, args.width, args.bs) == (64, 2048, 2) and os.path.exists(tp):
+            with open(tp) as f:
+                tj = json.load(f)
+            traffic, tsrc = round(tj["hbm_bytes_per_launch"]), "profiles/r01_pmc_traffic.json (" + tj["method"] + ")"
         roof = {"bound": "mfma", "kernel": "conv_fwd_k (forward + input-gradient launches, fp32 MFMA 32x32x2)",
                 "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_FP32_MFMA, 4), "traffic": None,
+                "frac": round(achieved / PEAK_FP32_MFMA, 4), "traffic": traffic, "traffic_source": tsrc,
                 "launches_per_iter": n_launch, "avg_launch_us": round(1e3 * mfma_ms / n_launch, 2),
                 "algorithmic_gflop_per_iter": round(mfma_fl / 1e9, 1)}
         detail = {k: {"launches": v[0], "gflop": round(v[1] / 1e9, 1), "ms": round(v[2], 3),

@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""HBM-side traffic of the conv_fwd_k launches from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs
+as MI355X_MICROARCH.md prescribes).  FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 128-B requests at
+64 B, so it is doubled (the guide's correction); WRITE_SIZE is reported uncorrected (uncalibrated per the guide).
+usage: pmc_traffic.py fetch.db write.db out.json"""
+import json, sqlite3, sys
+
+def per_kernel(db, counter):
+    c = sqlite3.connect(db)
+    tab = lambda p: [r[0] for r in c.execute("select name from sqlite_master where type='table' and name like '%s%%'" % p)][0]
+    kd, ks, pe, pi = tab("rocpd_kernel_dispatch"), tab("rocpd_info_kernel_symbol"), tab("rocpd_pmc_event"), tab("rocpd_info_pmc")
+    q = ("select s.kernel_name, sum(e.value), count(distinct d.id) from %s e join %s p on e.pmc_id=p.id join %s d on "
+         "e.event_id=d.event_id join %s s on d.kernel_id=s.id where p.name=? group by s.kernel_name" % (pe, pi, kd, ks))
+    return {k: (v, n) for k, v, n in c.execute(q, (counter,))}
+
+f = per_kernel(sys.argv[1], "FETCH_SIZE")
+w = per_kernel(sys.argv[2], "WRITE_SIZE")
+sel = [k for k in f if "conv_fwd_k" in k or "conv_finish_k" in k]
+launches = sum(f[k][1] for k in sel if "conv_fwd_k" in k)
+fetch = 2.0 * sum(f[k][0] for k in sel) * 1024.0            # bytes, gfx950 x2 correction
+write = sum(w[k][0] for k in sel if k in w) * 1024.0
+out = {"kernel": "conv_fwd_k (+ conv_finish_k) launches of bench.py", "launches": launches,
+       "fetch_bytes_per_launch": fetch / launches, "write_bytes_per_launch": write / launches,
+       "hbm_bytes_per_launch": (fetch + write) / launches,
+       "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), KiB -> bytes, "
+                 "FETCH_SIZE x2 (gfx950 correction, MI355X_MICROARCH.md), WRITE_SIZE uncorrected"}
+json.dump(out, open(sys.argv[3], "w"), indent=1)
+print(json.dumps(out))
