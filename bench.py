@@ -45,6 +45,47 @@ def make_batch(bs, h, w, seed, device):
     return feat.to(device), mask.to(device), label.to(device)
 
 
+def infer_bench(args, model, dev):
+    """BASELINE configs[1]: eval forward of bs frames + per-frame KNN vote (postproc/knn.py), everything resident."""
+    from pmf_amd.postproc import KNN
+    bs = 4 if args.bs == 2 else args.bs
+    feat, mask, _ = make_batch(bs, args.height, args.width, 1, dev)
+    model.eval()
+    knn = KNN({"knn": 5, "search": 5, "sigma": 1.0, "cutoff": 1.0}, 20)
+    # SURVEY 8(d) config 2: range image = depth channel (-1 on empty pixels), points = mask pixels x 1.3 with repeats
+    frames = []
+    g = torch.Generator(device="cpu").manual_seed(3)
+    for b in range(bs):
+        pr = torch.where(mask[b] > 0, feat[b, 0].abs() + 2.0, torch.full_like(feat[b, 0], -1.0))
+        occ = torch.nonzero(mask[b] > 0)
+        sel = torch.randint(0, occ.shape[0], (int(occ.shape[0] * 1.3),), generator=g).to(dev)
+        py, px = occ[sel, 0].contiguous(), occ[sel, 1].contiguous()
+        ur = pr[py, px] + torch.rand(sel.numel(), generator=g).to(dev) * 0.2
+        frames.append((pr.contiguous(), ur.contiguous(), px, py))
+
+    def step():
+        with torch.no_grad():
+            lp, _ = model(feat[:, 0:5], feat[:, 5:8])
+            am = lp.argmax(1)
+            return [knn(pr, ur, am[b], px, py) for b, (pr, ur, px, py) in enumerate(frames)]
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(json.dumps({
+        "metric": "inference frames/sec PMF-ResNet34 64x2048 bs=%d (eval forward + KNN post-processing)" % bs,
+        "value": bs * args.steps / dt, "unit": "frame/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "PMF-ResNet34 inference, both streams %dx%d (BASELINE configs[1]), bs=%d, KNN 5/5/1.0/1.0 "
+                               "on %d points per frame" % (args.height, args.width, bs, frames[0][1].numel())},
+        "roofline": None, "cpu_baseline": None}))
+
+
 def cpu_baseline(bs, h, w):
     """the oracle port on the host cores.  Bounded sample: the same full iteration on a 1/8-area slice of the
     workload (bs=1, H x W/4), 1 warm-up + 2 timed steps, scaled by pixel count (every term of the step is linear
@@ -79,6 +120,9 @@ def main():
     ap.add_argument("--height", type=int, default=64)
     ap.add_argument("--width", type=int, default=2048)
     ap.add_argument("--bs", type=int, default=2)
+    ap.add_argument("--mode", default="train", choices=["train", "infer"],
+                    help="train = the headline metric; infer = BASELINE configs[1]: eval-mode forward at bs=4 + KNN "
+                         "post-processing per frame, reported as frames/s under its own metric name")
     ap.add_argument("--model", default="pmf", choices=["pmf", "epmf"],
                     help="pmf = the headline workload (BASELINE configs[2]); epmf = configs[4] (EPMF-R34), reported "
                          "under its own metric name, no CPU baseline")
@@ -112,6 +156,9 @@ def main():
 
     def step():
         return eng.train_step(feat0.clone(), mask, label)     # clone: the trainer normalises in place
+
+    if args.mode == "infer":
+        return infer_bench(args, model, dev)
 
     for _ in range(args.warmup):
         step()
