@@ -51,8 +51,13 @@ class TrainEngine:
             self.flat = flatten_training_state(model, groups, dev)
             lidar_params, camera_params = [self.flat.group_params[0]], [self.flat.group_params[1]]
             if distributed:
+                import torch.distributed as dist
                 self._pending, self._frontier = [], None
                 model._bwd_segment_hook = self._allreduce_ready_ranges
+                # what DistributedDataParallel does at construction: every rank starts from rank 0's state
+                dist.broadcast(self.flat.param, 0)
+                for b in model.buffers():
+                    dist.broadcast(b, 0)
         else:
             lidar_params = list(model.lidar_stream.parameters())
             camera_params = list(model.camera_stream_encoder.parameters()) + list(model.camera_stream_decoder.parameters())
