@@ -37,9 +37,9 @@ KITTI_STD = [12.32, 11.47, 6.91, 0.86, 0.16]
 PEAK_FP32_MFMA = 157.3                                # TFLOP/s, MI355X_MICROARCH.md
 
 
-def make_batch(bs, h, w, seed, device):
+def make_batch(bs, h, w, seed, device, nclasses=20):
     from pmf_amd.utils.detinit import synthetic_batch
-    pcd, rgb, label, mask = synthetic_batch(bs, h, w, 20, seed=seed)
+    pcd, rgb, label, mask = synthetic_batch(bs, h, w, nclasses, seed=seed)
     pcd = pcd * torch.tensor(KITTI_STD).view(1, 5, 1, 1) + torch.tensor(KITTI_MEAN).view(1, 5, 1, 1) * mask[:, None]
     feat = torch.cat((pcd, rgb), 1).contiguous()
     return feat.to(device), mask.to(device), label.to(device)
@@ -123,6 +123,8 @@ def main():
     ap.add_argument("--mode", default="train", choices=["train", "infer"],
                     help="train = the headline metric; infer = BASELINE configs[1]: eval-mode forward at bs=4 + KNN "
                          "post-processing per frame, reported as frames/s under its own metric name")
+    ap.add_argument("--backbone", default="resnet34", help="camera backbone (resnet50: BASELINE configs[3] family)")
+    ap.add_argument("--nclasses", type=int, default=20)
     ap.add_argument("--model", default="pmf", choices=["pmf", "epmf"],
                     help="pmf = the headline workload (BASELINE configs[2]); epmf = configs[4] (EPMF-R34), reported "
                          "under its own metric name, no CPU baseline")
@@ -148,11 +150,11 @@ def main():
     torch.manual_seed(1)                 # tasks/pmf/main.py:20-21: same seed on every rank
     torch.cuda.manual_seed(1)
     net = PMFNet if args.model == "pmf" else EPMFNet
-    model = net(5, 3, 20, 32, imagenet_pretrained=False, image_backbone="resnet34").to(dev)
-    eng = TrainEngine(model, 20, lr=1e-3, momentum=0.9, weight_decay=1e-5, lambda_=1.0, gamma=0.5, tau=0.7,
+    model = net(5, 3, args.nclasses, 32, imagenet_pretrained=False, image_backbone=args.backbone).to(dev)
+    eng = TrainEngine(model, args.nclasses, lr=1e-3, momentum=0.9, weight_decay=1e-5, lambda_=1.0, gamma=0.5, tau=0.7,
                       feature_mean=KITTI_MEAN, feature_std=KITTI_STD, warmup_steps=10 * 100, max_steps=49 * 100,
                       distributed=world > 1, device_ids=[local] if world > 1 else None)
-    feat0, mask, label = make_batch(args.bs, args.height, args.width, 1 + rank, dev)   # per-rank data differs
+    feat0, mask, label = make_batch(args.bs, args.height, args.width, 1 + rank, dev, args.nclasses)   # per-rank data
 
     def step():
         return eng.train_step(feat0.clone(), mask, label)     # clone: the trainer normalises in place
@@ -212,7 +214,9 @@ def main():
         # from inside the process); tools/pmc_traffic.py wrote the summary that is committed under profiles/
         traffic, tsrc = None, None
         tp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
-        if args.model == "pmf" and (args.height, args.width, args.bs) == (64, 2048, 2) and os.path.exists(tp):
+        headline = args.model == "pmf" and args.backbone == "resnet34" and args.nclasses == 20 and \
+            (args.height, args.width, args.bs) == (64, 2048, 2)
+        if headline and os.path.exists(tp):
             with open(tp) as f:
                 tj = json.load(f)
             traffic, tsrc = round(tj["hbm_bytes_per_launch"]), "profiles/r01_pmc_traffic.json (" + tj["method"] + ")"
@@ -231,16 +235,20 @@ def main():
 
     if rank == 0:
         iters = world * args.steps
-        tag = "PMF" if args.model == "pmf" else "EPMF"
+        tag = ("PMF" if args.model == "pmf" else "EPMF")
+        bb = {"resnet34": "ResNet34", "resnet50": "ResNet50"}.get(args.backbone, args.backbone)
         out = {
-            "metric": "train iters/sec %s-ResNet34 64x2048 bs=2/GPU (full iteration: fwd + 5-term loss + bwd + "
-                      "AdamW/SGD steps)" % tag,
+            "metric": "train iters/sec %s-%s %dx%d bs=%d/GPU (full iteration: fwd + 5-term loss + bwd + "
+                      "AdamW/SGD steps)" % (tag, bb, args.height, args.width, args.bs),
             "value": iters / dt, "unit": "iter/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s-ResNet34 SemanticKITTI config, full train loop, both streams %dx%d "
-                                   "(BASELINE configs[%d], S_A), bs=%d/GPU, 20 classes, dropout on, local-stat BN"
-                                   % (tag, args.height, args.width, 2 if args.model == "pmf" else 4, args.bs),
+            "config": {"workload": "%s-%s, full train loop, both streams %dx%d (BASELINE configs[%d]%s), bs=%d/GPU, "
+                                   "%d classes, dropout on, local-stat BN"
+                                   % (tag, bb, args.height, args.width,
+                                      4 if args.model == "epmf" else (3 if args.backbone == "resnet50" else 2),
+                                      ", S_A" if (args.height, args.width) == (64, 2048) else "", args.bs,
+                                      args.nclasses),
                        "global_batch": world * args.bs, "parallelism": "dp%d" % world,
                        "samples_per_s": world * args.bs * args.steps / dt, "final_loss": loss_val},
             "roofline": roof, "cpu_baseline": cpu, "kernel_time_breakdown": detail,

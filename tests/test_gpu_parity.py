@@ -538,3 +538,52 @@ def test_epmf_eval_and_train_match_oracle(golden):
         "%-50s %.3e %.3e" % b for b in sorted(bad, key=lambda t: -t[1])[:20])
     assert len(bad) <= 0.15 * len(rows), "too many parameters far from float64 (%d of %d):\n" % (len(bad), len(rows)) + \
         "\n".join("%-50s %.3e %.3e" % b for b in bad[:40])
+
+
+@pytest.mark.gpu
+def test_r50_train_step_matches_oracle():
+    """BASELINE configs[3] family: PMF-ResNet50 (Bottleneck blocks, 17 classes) forward + backward against the float64
+    oracle (same criteria as the ResNet34 train-step test)."""
+    import copy
+    from oracle import pmf_torch as O
+    from oracle import losses_ref
+    hip, ref = _models("resnet50", 17)
+    hip.train()
+    ref.train()
+    n, h, w = 1, 32, 64
+    m = _masks(ref, n)
+    O.set_dropout_masks(ref, m)
+    hip.set_dropout_masks({k: v.cuda() for k, v in m.items()})
+    ref64 = copy.deepcopy(ref).double()
+    O.set_dropout_masks(ref64, {k: v.double() for k, v in m.items()})
+    pcd, rgb, label, _ = synthetic_batch(n, h, w, 17, seed=1, fill=0.4)
+    alpha = torch.linspace(0.2, 1.0, 17)
+    alpha[0] = 0
+    rl, rc = ref(pcd, rgb)
+    losses_ref.pmf_total_loss(rl, rc, label, alpha)[0].backward()
+    dl, dc = ref64(pcd.double(), rgb.double())
+    total_d, _ = losses_ref.pmf_total_loss(dl, dc, label, alpha.double())
+    total_d.backward()
+    lp, cp = hip(pcd.cuda(), rgb.cuda())
+    total_h, _ = losses_ref.pmf_total_loss(lp, cp, label.cuda(), alpha.cuda())
+    total_h.backward()
+    torch.cuda.synchronize()
+    assert abs(total_h.item() - total_d.item()) < 1e-4 * max(1.0, abs(total_d.item()))
+    rp, dp = dict(ref.named_parameters()), dict(ref64.named_parameters())
+    rows, bad = [], []
+    for k, p in hip.named_parameters():
+        assert p.grad is not None, k
+        g64 = dp[k].grad
+        wk = k.rsplit(".", 1)[0] + ".weight"
+        floor = 1e-6 * dp[wk].grad.norm().item() if wk in dp else 0.0
+        den = max(g64.norm().item(), floor, 1e-30)
+        e_h = (p.grad.cpu().double() - g64).norm().item() / den
+        e_r = (rp[k].grad.double() - g64).norm().item() / den
+        rows.append((k, e_h, e_r))
+        if not e_h <= max(20 * e_r, 5e-4):
+            bad.append((k, e_h, e_r))
+    _dump("r50_train_grads.txt", rows)
+    worst = max([r[1] for r in rows if r[1] > 2 * r[2]] + [0.0])
+    assert worst < 5e-2, "gradient error vs float64 oracle: worst %.3e\n" % worst + "\n".join(
+        "%-50s %.3e %.3e" % b for b in sorted(bad, key=lambda t: -t[1])[:20])
+    assert len(bad) <= 0.15 * len(rows), "too many parameters far from float64 (%d of %d)" % (len(bad), len(rows))
