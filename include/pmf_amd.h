@@ -254,6 +254,18 @@ int pmf_project_scatter(const float* points, const int32_t* sem, int64_t P, cons
                         int32_t w, const double* proj, const int32_t* lut, int32_t nlut, float* proj_out,
                         uint8_t* keep, int32_t* x_data, int32_t* y_data, float* depth, int32_t* n_kept,
                         int32_t* pix_idx, int32_t* blk_cnt, pmf_stream_t s);
+/* EPMF loader (perspective_view_loader_v2.py:42-157, parser.py:229-257 mapLidar2CameraCropYaw): keep = |xyz| > 0.5 and
+ * fov_left <= -atan2(y,x) <= fov_right, no image-bounds filter; pass 1 compacts (source index, trunc row/col, float64
+ * (v,u), depth) in file order and returns n_kept + bbox {row_min,row_max,col_min,col_max} (device); the caller sizes the
+ * frame from the bbox (h = row_max-row_min+1, w = col_max-col_min+1), pass 2 writes proj_out f32[10][h][w] =
+ * depth,x,y,z,i,r,g,b (image window at (row_min,col_min), zero outside),mask,label; last kept point wins per pixel. */
+int pmf_project_v2_index(const float* points, int64_t P, const double* proj, float fov_left, float fov_right,
+                         uint8_t* keep, int32_t* src_idx, int32_t* x_data, int32_t* y_data, double* xy_index,
+                         float* depth, int32_t* n_kept, int32_t* bbox, int32_t* blk_cnt, pmf_stream_t s);
+int pmf_project_v2_scatter(const float* points, const int32_t* sem, const int32_t* src_idx, const int32_t* x_data,
+                           const int32_t* y_data, const float* depth, int32_t K, const uint8_t* image, int32_t ih,
+                           int32_t iw, const int32_t* lut, int32_t nlut, int32_t x_min, int32_t y_min, int32_t h,
+                           int32_t w, float* proj_out, int32_t* pix_idx, pmf_stream_t s);
 /* validation crop/pad (perspective_view_loader.py:71-74,138-141): dst[c][oh][ow] window copy with zero fill */
 int pmf_crop_pad(const float* src, int32_t C, int32_t h, int32_t w, int32_t top, int32_t left, float* dst,
                  int32_t oh, int32_t ow, int32_t pad_top, int32_t pad_left, int32_t ch, int32_t cw, pmf_stream_t s);

@@ -376,6 +376,36 @@ def epmf(R):
     print("g8_epmf: %d arrays" % len(out))
 
 
+def loader_v2(R):
+    """G9: reference PerspectiveViewLoaderV2 (return_uproj path) + SemanticKitti.mapLidar2CameraCropYaw."""
+    from PIL import Image
+    cv2 = types.ModuleType("cv2")
+    cv2.rotate = lambda *a, **k: None          # imported by name only (perspective_view_loader_v2.py:2), never called
+    sys.modules["cv2"] = cv2
+    V2 = _load("refpc_loader_v2", "pc_processor/dataset/perspective_view_loader_v2.py")
+    out = {}
+    for tag, seed, npts, h, w in (("a", 0, 5000, 96, 320), ("b", 5, 20000, 64, 208)):
+        M, pts, sem, img, lut = loader_ref.synthetic_frame(seed, npts, h, w)
+        ds = object.__new__(R.parser.SemanticKitti)
+        ds.has_image = True
+        ds.proj_matrix = {"00": M}
+        ds.class_map_lut = lut
+        ds.fov_left, ds.fov_right = -45 / 180.0 * np.pi, 45 / 180.0 * np.pi
+        ds.loadDataByIndex = lambda i: (pts, sem, np.zeros_like(sem))
+        ds.loadImage = lambda i: Image.fromarray(img)
+        ds.parsePathInfoByIndex = lambda i: ("00", "000000")
+        ds.pointcloud_files = [None]
+        cfg = {"PVconfig": {"proj_h": h, "proj_w": w, "proj_ht": h, "proj_wt": w, "img_jitter": [0.4, 0.4, 0.4]}}
+        ld = V2.PerspectiveViewLoaderV2(ds, cfg, is_train=False, return_uproj=True)
+        proj, xy, depth, keep, pc = ld[0]
+        out["v2.%s.proj" % tag] = proj.numpy()
+        out["v2.%s.xy" % tag] = xy.numpy()
+        out["v2.%s.depth" % tag] = depth.numpy()
+        out["v2.%s.keep" % tag] = keep.numpy()
+    np.savez_compressed(os.path.join(OUT, "g9_loader_v2.npz"), **out)
+    print("g9_loader_v2: %d arrays, frames %s" % (len(out), [out["v2.%s.proj" % t].shape for t in ("a", "b")]))
+
+
 def trainer_trace(R):
     """G7: two consecutive optimisation steps (AdamW lidar / SGD-Nesterov camera, trainer.py:80-98,214-219)
     on config-1 shapes (64x512, bs 1), dropout p=0."""
@@ -418,6 +448,6 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     R = import_reference()
-    which = sys.argv[1:] or ["blocks", "whole_net", "losses_metrics", "knn", "loader", "trainer_trace", "epmf"]
+    which = sys.argv[1:] or ["blocks", "whole_net", "losses_metrics", "knn", "loader", "trainer_trace", "epmf", "loader_v2"]
     for name in which:
         globals()[name](R)

@@ -164,3 +164,136 @@ extern "C" int pmf_crop_pad(const float* src, int32_t C, int32_t h, int32_t w, i
   PMF_LAUNCH_CHECK();
   return 0;
 }
+
+// ---- EPMF loader (perspective_view_loader_v2.py:42-157 + parser.py:229-257 mapLidar2CameraCropYaw) ----------------
+// keep = |xyz| > 0.5 && fov_left <= -atan2(y, x) <= fov_right (NO image-bounds filter); same float64 projection;
+// (row, col) = trunc(v), trunc(u) may be negative -- the frame is the points' bounding box.
+// Pass 1 (pmf_project_v2_index): keep mask, order-preserving compaction of (source index, row, col, (v,u) float64,
+// depth) and the bounding box.  The caller reads n_kept / bbox (the output size is data dependent, as in the
+// reference), then pass 2 (pmf_project_v2_scatter) resolves duplicates (last point wins) and writes [10][h][w] =
+// depth, x, y, z, intensity, r, g, b (image window, zero outside), mask, label.
+__device__ __forceinline__ bool v2_point(const float* __restrict__ pt, const double* __restrict__ m, float fl, float fr,
+                                         int& row, int& col, double& v_out, double& u_out, float& dep) {
+  const float xf = pt[0], yf = pt[1], zf = pt[2];
+  dep = sqrtf((xf * xf + yf * yf) + zf * zf);
+  const float yaw = -atan2f(yf, xf);
+  if (!(dep > 0.5f) || !((double)yaw >= (double)fl && (double)yaw <= (double)fr)) return false;
+  const double x = (double)xf, y = (double)yf, z = (double)zf;
+  const double a = fma(m[3], 1.0, fma(m[2], z, fma(m[1], y, m[0] * x)));
+  const double b = fma(m[7], 1.0, fma(m[6], z, fma(m[5], y, m[4] * x)));
+  const double c = fma(m[11], 1.0, fma(m[10], z, fma(m[9], y, m[8] * x)));
+  u_out = a / c; v_out = b / c;
+  row = (int)v_out; col = (int)u_out;
+  return true;
+}
+
+__global__ __launch_bounds__(PB) void v2_count_k(const float* __restrict__ pts, int64_t P, const double* __restrict__ m,
+                                                 float fl, float fr, uint8_t* __restrict__ keep,
+                                                 int32_t* __restrict__ blk_cnt) {
+  const int64_t i = blockIdx.x * (int64_t)PB + threadIdx.x;
+  int k = 0;
+  if (i < P) {
+    int r, c; double v, u; float d;
+    k = v2_point(pts + i * 4, m, fl, fr, r, c, v, u, d) ? 1 : 0;
+    keep[i] = (uint8_t)k;
+  }
+  const int cnt = __syncthreads_count(k);
+  if (threadIdx.x == 0) blk_cnt[blockIdx.x] = cnt;
+}
+
+__global__ __launch_bounds__(PB) void v2_compact_k(const float* __restrict__ pts, int64_t P, const double* __restrict__ m,
+                                                   float fl, float fr, const int32_t* __restrict__ blk_off,
+                                                   int32_t* __restrict__ src_idx, int32_t* __restrict__ x_data,
+                                                   int32_t* __restrict__ y_data, double* __restrict__ xy,
+                                                   float* __restrict__ depth, int32_t* __restrict__ bbox) {
+  __shared__ int wave_cnt[PB / 64];
+  const int64_t i = blockIdx.x * (int64_t)PB + threadIdx.x;
+  int r = 0, c = 0; double v = 0, u = 0; float d = 0.f;
+  const bool k = i < P && v2_point(pts + i * 4, m, fl, fr, r, c, v, u, d);
+  const unsigned long long bal = __ballot(k);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int before = __popcll(bal & ((1ull << lane) - 1ull));
+  if (lane == 0) wave_cnt[wv] = __popcll(bal);
+  __syncthreads();
+  int woff = 0;
+  for (int j = 0; j < wv; ++j) woff += wave_cnt[j];
+  if (k) {
+    const int dst = blk_off[blockIdx.x] + woff + before;
+    src_idx[dst] = (int)i; x_data[dst] = r; y_data[dst] = c;
+    xy[2 * (size_t)dst] = v; xy[2 * (size_t)dst + 1] = u;
+    depth[dst] = d;
+    atomicMin(bbox + 0, r); atomicMax(bbox + 1, r); atomicMin(bbox + 2, c); atomicMax(bbox + 3, c);
+  }
+}
+
+extern "C" int pmf_project_v2_index(const float* points, int64_t P, const double* proj, float fov_left, float fov_right,
+                                    uint8_t* keep, int32_t* src_idx, int32_t* x_data, int32_t* y_data, double* xy_index,
+                                    float* depth, int32_t* n_kept, int32_t* bbox, int32_t* blk_cnt, pmf_stream_t s) {
+  hipStream_t st = (hipStream_t)s;
+  if (P < 0) return PMF_E_ARG;
+  const int32_t init[4] = {2147483647, -2147483647 - 1, 2147483647, -2147483647 - 1};
+  hipError_t e = hipMemcpyAsync(bbox, init, sizeof(init), hipMemcpyHostToDevice, st);
+  if (e != hipSuccess) return (int)e;
+  const int nblk = (int)cdiv64(P > 0 ? P : 1, PB);
+  hipLaunchKernelGGL(v2_count_k, dim3(nblk), dim3(PB), 0, st, points, P, proj, fov_left, fov_right, keep, blk_cnt);
+  hipLaunchKernelGGL(proj_scan_k, dim3(1), dim3(1024), 0, st, blk_cnt, nblk, n_kept);
+  hipLaunchKernelGGL(v2_compact_k, dim3(nblk), dim3(PB), 0, st, points, P, proj, fov_left, fov_right, blk_cnt, src_idx,
+                     x_data, y_data, xy_index, depth, bbox);
+  PMF_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ void v2_winner_k(const int32_t* __restrict__ x_data, const int32_t* __restrict__ y_data, int K, int x_min,
+                            int y_min, int w, int32_t* __restrict__ pix_idx) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < K) atomicMax(pix_idx + (size_t)(x_data[k] - x_min) * w + (y_data[k] - y_min), k);   // last kept point wins
+}
+
+__global__ void v2_gather_k(const float* __restrict__ pts, const int32_t* __restrict__ sem, const int32_t* __restrict__ src_idx,
+                            const float* __restrict__ depth, const uint8_t* __restrict__ img, int ih, int iw,
+                            const int32_t* __restrict__ lut, int nlut, const int32_t* __restrict__ pix_idx, int h, int w,
+                            int x_min, int y_min, float* __restrict__ out) {
+  const int64_t hw = (int64_t)h * w;
+  for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < hw; p += (int64_t)gridDim.x * blockDim.x) {
+    const int k = pix_idx[p];
+    float d = 0.f, x = 0.f, y = 0.f, z = 0.f, it = 0.f, mk = 0.f, lb = 0.f;
+    if (k >= 0) {
+      const int i = src_idx[k];
+      const f32x4 q = *(const f32x4*)(pts + (size_t)i * 4);
+      x = q.x; y = q.y; z = q.z; it = q.w;
+      d = depth[k];
+      mk = 1.f;
+      const int sl = sem[i];
+      lb = (float)((sl >= 0 && sl < nlut) ? lut[sl] : 0);
+    }
+    const int r = (int)(p / w), c = (int)(p - (int64_t)r * w);
+    const int ir = r + x_min, ic = c + y_min;          // image window (perspective_view_loader_v2.py:105-125)
+    float cr = 0.f, cg = 0.f, cb = 0.f;
+    if (ir >= 0 && ir < ih && ic >= 0 && ic < iw) {
+      const uint8_t* px = img + ((size_t)ir * iw + ic) * 3;
+      cr = (float)px[0] / 255.0f; cg = (float)px[1] / 255.0f; cb = (float)px[2] / 255.0f;
+    }
+    out[0 * hw + p] = d; out[1 * hw + p] = x; out[2 * hw + p] = y; out[3 * hw + p] = z; out[4 * hw + p] = it;
+    out[5 * hw + p] = cr; out[6 * hw + p] = cg; out[7 * hw + p] = cb;
+    out[8 * hw + p] = mk;
+    out[9 * hw + p] = lb;
+  }
+}
+
+extern "C" int pmf_project_v2_scatter(const float* points, const int32_t* sem, const int32_t* src_idx,
+                                      const int32_t* x_data, const int32_t* y_data, const float* depth, int32_t K,
+                                      const uint8_t* image, int32_t ih, int32_t iw, const int32_t* lut, int32_t nlut,
+                                      int32_t x_min, int32_t y_min, int32_t h, int32_t w, float* proj_out,
+                                      int32_t* pix_idx, pmf_stream_t s) {
+  hipStream_t st = (hipStream_t)s;
+  if (K < 0 || h < 1 || w < 1) return PMF_E_ARG;
+  hipError_t e = hipMemsetAsync(pix_idx, 0xFF, (size_t)h * w * 4, st);
+  if (e != hipSuccess) return (int)e;
+  if (K > 0) hipLaunchKernelGGL(v2_winner_k, dim3(cdiv(K, 256)), dim3(256), 0, st, x_data, y_data, K, x_min, y_min, w, pix_idx);
+  const int64_t hw = (int64_t)h * w;
+  const int g = (int)cdiv64(hw, 256);
+  hipLaunchKernelGGL(v2_gather_k, dim3(g > 2048 ? 2048 : g), dim3(256), 0, st, points, sem, src_idx, depth, image, ih, iw, lut,
+                     nlut, pix_idx, h, w, x_min, y_min, proj_out);
+  PMF_LAUNCH_CHECK();
+  return 0;
+}

@@ -587,3 +587,36 @@ def test_r50_train_step_matches_oracle():
     assert worst < 5e-2, "gradient error vs float64 oracle: worst %.3e\n" % worst + "\n".join(
         "%-50s %.3e %.3e" % b for b in sorted(bad, key=lambda t: -t[1])[:20])
     assert len(bad) <= 0.15 * len(rows), "too many parameters far from float64 (%d of %d)" % (len(bad), len(rows))
+
+
+@pytest.mark.gpu
+def test_loader_v2_matches_oracle_and_fixture(golden):
+    """EPMF loader on the GPU (pmf_project_v2_*): keep mask, float64 (row, col), depth and the [10,h,w] frame are
+    bit-exact against the reference-run fixture and the numpy oracle; validation pad + centre crop vs the oracle."""
+    from oracle import loader_ref, loader_v2_ref
+    from pmf_amd.dataset import PerspectiveViewLoaderV2
+    g = golden("g9_loader_v2")
+    for tag, seed, npts, h, w in (("a", 0, 5000, 96, 320), ("b", 5, 20000, 64, 208), ("c", 9, 130000, 376, 1241)):
+        M, pts, sem, img, lut = loader_ref.synthetic_frame(seed, npts, h, w)
+
+        class DS:
+            proj_matrix = {"00": M}
+            class_map_lut = lut
+            def loadDataByIndex(self, i): return pts, sem, np.zeros_like(sem)
+            def loadImage(self, i): return img
+            def parsePathInfoByIndex(self, i): return "00", "000000"
+            def __len__(self): return 1
+        cfg = {"PVconfig": {"proj_h": h, "proj_w": w, "proj_ht": h, "proj_wt": w}}
+        proj, xy, depth, keep, pc = PerspectiveViewLoaderV2(DS(), cfg, is_train=False, return_uproj=True)[0]
+        rp, rxy, rd, rk = loader_v2_ref.project_frame_v2(pts, sem, img, M, lut)
+        assert np.array_equal(keep.cpu().numpy(), rk)
+        assert np.array_equal(xy.cpu().numpy(), rxy)
+        assert np.array_equal(depth.cpu().numpy(), rd)
+        assert np.array_equal(proj.cpu().numpy(), rp)
+        if tag in ("a", "b"):
+            assert np.array_equal(proj.cpu().numpy(), g["v2.%s.proj" % tag])
+            assert np.array_equal(xy.cpu().numpy(), g["v2.%s.xy" % tag])
+        val = PerspectiveViewLoaderV2(DS(), cfg, is_train=False)[0]
+        assert np.array_equal(val.cpu().numpy(), loader_v2_ref.pad_center_crop(rp, h, w, h, w))
+    with pytest.raises(NotImplementedError):
+        PerspectiveViewLoaderV2(DS(), cfg, is_train=True)
