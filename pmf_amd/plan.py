@@ -969,6 +969,8 @@ class Plan:
     def segment_cuts(self, k):
         """op indices that split the backward plan into k segments of similar algorithmic work (by op count where no
         flop estimate exists)."""
+        if getattr(self, "_cuts", None) is not None and self._cuts[0] == k:
+            return self._cuts[1]
         n = self.n_bwd
         w = [1.0 + self.meta_bwd.get(i - self.bwd_shift, {}).get("flops", 0.0) / 2e9 for i in range(n)]
         tot, acc, cuts = sum(w), 0.0, [0]
@@ -978,6 +980,7 @@ class Plan:
                 cuts.append(i + 1)
         if cuts[-1] != n:
             cuts.append(n)
+        self._cuts = (k, cuts)
         return cuts
 
     def grad_frontier(self, op_end):
