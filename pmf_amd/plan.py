@@ -986,6 +986,9 @@ class Plan:
     def grad_frontier(self, op_end):
         """per FlatState group: float offset up to which the gradient buffer is final once ops [0, op_end) have run
         (members are laid out in backward order, so the finished part of a group is a prefix of its range)."""
+        cache = self.__dict__.setdefault("_frontiers", {})
+        if op_end in cache:
+            return cache[op_end]
         out = []
         for (a, b), mem in zip(self.flat.ranges, self.flat.members):
             f = a
@@ -995,6 +998,7 @@ class Plan:
                     break
                 f = self.flat.offset[id(p)] + (p.numel() + 63) // 64 * 64
             out.append(b if op_end >= self.n_bwd else f)
+        cache[op_end] = out
         return out
 
     def run_profiled(self, what):
