@@ -83,6 +83,9 @@ typedef struct {
                               * statistics (EPMF SparseVariantConv: output * dilated mask, epmf_net.py:44-49) */
   float* splitk_ws;          /* optional scratch for deterministic split-K on small maps (NULL = never split) */
   int64_t splitk_ws_bytes;
+  int32_t cfg;               /* 0 = built-in heuristics; else tile configuration chosen by the caller's autotuner:
+                              * BN (32|64) | MT (1|2) << 8 | K splits (1 = none) << 16, see pmf_conv_fwd_stat_rows */
+  int32_t cfg_pad_;
 } pmf_conv_desc_t;
 
 int pmf_conv_fwd(const pmf_conv_desc_t* d, pmf_stream_t s);
@@ -138,6 +141,10 @@ int pmf_pack_weights_batched(const pmf_pack_job_t* jobs_dev, int32_t njobs, int3
  *        -> scale/shift for apply-on-load, saved mean/invstd, running_mean/var update (unbiased var).
  * eval:  running stats -> scale/shift. */
 int pmf_conv_fwd_stat_rows(const pmf_conv_desc_t* d);
+/* upper bound of pmf_conv_fwd_stat_rows over every tile configuration `cfg` may select (sizes `stats`) */
+int pmf_conv_fwd_stat_rows_max(const pmf_conv_desc_t* d);
+/* number of 16-channel K stages (after 64-channel stage merging) of this descriptor under cfg: bounds the K splits */
+int pmf_conv_fwd_kstages(const pmf_conv_desc_t* d);
 int pmf_bn_finalize(const double* stats, int32_t nrows, float count, const float* gamma, const float* beta,
                     float* running_mean, float* running_var, float momentum, float eps, float* scale, float* shift,
                     float* save_mean, float* save_invstd, int32_t C, pmf_stream_t s);

@@ -39,7 +39,7 @@ class ConvDesc(C.Structure):
                 ("ep_cmul", C.c_void_p), ("ep_cmul_ld", C.c_int32), ("ep_relu_x", C.c_void_p),
                 ("ep_relu_scale", C.c_void_p), ("ep_relu_shift", C.c_void_p), ("ep_relu_ldc", C.c_int32),
                 ("stats", C.c_void_p), ("ep_pmask", C.c_void_p), ("splitk_ws", C.c_void_p),
-                ("splitk_ws_bytes", C.c_int64)]
+                ("splitk_ws_bytes", C.c_int64), ("cfg", C.c_int32), ("cfg_pad_", C.c_int32)]
 
 
 class WgradDesc(C.Structure):
@@ -163,7 +163,7 @@ def lib():
 
 EXPORTS = [
     "pmf_conv_fwd", "pmf_conv_wgrad", "pmf_conv_wgrad_workspace", "pmf_conv_wgrad_nsplit", "pmf_pack_tile_ci",
-    "pmf_pack_weights_batched", "pmf_conv_fwd_stat_rows", "pmf_col_rows", "pmf_bn_finalize", "pmf_bn_eval_affine", "pmf_bn_bwd_reduce", "pmf_bn_bwd_apply",
+    "pmf_pack_weights_batched", "pmf_conv_fwd_stat_rows", "pmf_conv_fwd_stat_rows_max", "pmf_conv_fwd_kstages", "pmf_col_rows", "pmf_bn_finalize", "pmf_bn_eval_affine", "pmf_bn_bwd_reduce", "pmf_bn_bwd_apply",
     "pmf_add_act", "pmf_add_act_bwd", "pmf_act_bwd", "pmf_avgpool3s2", "pmf_avgpool3s2_bwd", "pmf_maxpool3s2",
     "pmf_maxpool3s2_bwd", "pmf_bilinear2x", "pmf_bilinear2x_bwd", "pmf_pixel_shuffle2", "pmf_pixel_shuffle2_bwd",
     "pmf_fusion_gate", "pmf_fusion_gate_bwd", "pmf_global_mean", "pmf_global_mean_bwd", "pmf_colsum",

@@ -11,6 +11,7 @@
 // Epilogue: + bias, activation, optional (n,c) multiplier / ReLU mask (input-gradient form), optional
 // per-channel sum / sum-of-squares for the BatchNorm that follows, coalesced 128-B row stores.
 #include "common.h"
+#include <stdio.h>
 #include <stdlib.h>
 
 #define KC 16
@@ -754,6 +755,12 @@ static int finish_rows(const pmf_conv_desc_t* d) {
 }
 
 static void conv_config(const pmf_conv_desc_t* d, int* BN, int* MT) {
+  if (d->cfg) {                       // caller-tuned tile configuration
+    const int bn = d->cfg & 0xff, mt = (d->cfg >> 8) & 0xff;
+    *BN = (bn == 64 && d->Cout > 32) ? 64 : 32;
+    *MT = mt == 2 ? 2 : 1;
+    return;
+  }
   *BN = d->Cout > 32 ? 64 : 32;
   // enough workgroups to fill 256 CUs: fall back to 128-pixel tiles on small maps
   const long px = (long)d->N * cdiv(d->OH, 8) * cdiv(d->OW, 32) * cdiv(d->Cout, *BN);
@@ -762,10 +769,36 @@ static void conv_config(const pmf_conv_desc_t* d, int* BN, int* MT) {
   // double the grid (measured +5 % on 128 -> 128 at 16x512); below 200 the K loop is split instead
   const long b64 = (long)d->N * cdiv(d->OH, 4) * cdiv(d->OW, 32) * cdiv(d->Cout, 64);
   if (*MT == 1 && *BN == 64 && b64 >= 200 && b64 < 512) *BN = 32;
+  if (const char* e = getenv("PMF_CONV_FORCE")) {   // tools/bench_conv.py sweeps: "BN,MT,KS" (0 = keep the heuristic)
+    int bn = 0, mt = 0, ks = 0;
+    sscanf(e, "%d,%d,%d", &bn, &mt, &ks);
+    if (bn == 32 || (bn == 64 && d->Cout > 32)) *BN = bn;
+    if (mt == 1 || mt == 2) *MT = mt;
+  }
 }
 
 // split-K factor: only when the M x N grid cannot fill the 256 CUs (low-resolution, many-channel layers)
 static int choose_ksplit(const pmf_conv_desc_t* d, int blocks_mn, int nchunks, int mfma_per_chunk) {
+  if (const char* e = getenv("PMF_CONV_FORCE")) {   // sweeps only
+    int bn = 0, mt = 0, ks = 0;
+    sscanf(e, "%d,%d,%d", &bn, &mt, &ks);
+    if (ks >= 1 && d->splitk_ws) {
+      int k = ks > nchunks ? nchunks : ks;
+      if (k > 32) k = 32;
+      const int64_t sl = (int64_t)d->N * d->OH * d->OW * round_up(d->Cout, 4) * 4;
+      while (k > 1 && sl * k > d->splitk_ws_bytes) --k;
+      return k < 2 ? 1 : k;
+    }
+  }
+  if (d->cfg && ((d->cfg >> 16) & 0xff)) {     // caller-tuned number of K splits
+    int k = (d->cfg >> 16) & 0xff;
+    if (!d->splitk_ws || blocks_mn > 1024) return 1;
+    if (k > nchunks) k = nchunks;
+    if (k > 32) k = 32;
+    const int64_t sl = (int64_t)d->N * d->OH * d->OW * round_up(d->Cout, 4) * 4;
+    while (k > 1 && sl * k > d->splitk_ws_bytes) --k;
+    return k < 2 ? 1 : k;
+  }
   if (!d->splitk_ws || blocks_mn >= 200 || nchunks < 4) return 1;
   int k = 512 / (blocks_mn > 0 ? blocks_mn : 1);
   if (k > nchunks / 2) k = nchunks / 2;
@@ -865,6 +898,30 @@ extern "C" int pmf_conv_fwd_stat_rows(const pmf_conv_desc_t* d) {
   }
   if (choose_ksplit(d, tiles * d->N * cdiv(d->Cout, BN), nchunks, d->ntaps * 8 * MT * (BN / 32)) > 1) return finish_rows(d);
   return tiles * d->N;
+}
+
+extern "C" int pmf_conv_fwd_stat_rows_max(const pmf_conv_desc_t* d) {
+  int gather, cmax = 0;
+  for (int i = 0; i < d->nsrc; ++i) cmax = d->src[i].C > cmax ? d->src[i].C : cmax;
+  ConvGeom g;
+  pmf_conv_geometry(d->OH, d->OW, d->ntaps, d->tdy, d->tdx, d->in_stride, d->gather, 32, 1, cmax < KC ? cmax : KC, &g,
+                    &gather);
+  const int rows = g.tiles_x * g.tiles_y * d->N;     // 128-pixel tiles give the most rows; split-K gives <= 512
+  return rows > 512 ? rows : 512;
+}
+
+extern "C" int pmf_conv_fwd_kstages(const pmf_conv_desc_t* d) {
+  int BN, MT, gather, cmax = 0, nchunks = 0;
+  conv_config(d, &BN, &MT);
+  for (int i = 0; i < d->nsrc; ++i) { cmax = d->src[i].C > cmax ? d->src[i].C : cmax; nchunks += cdiv(d->src[i].C, KC); }
+  ConvGeom g;
+  pmf_conv_geometry(d->OH, d->OW, d->ntaps, d->tdy, d->tdx, d->in_stride, d->gather, BN, MT, cmax < KC ? cmax : KC, &g,
+                    &gather);
+  if (conv_pipe_mode(d, g, gather, MT) == 4) {
+    nchunks = 0;
+    for (int i = 0; i < d->nsrc; ++i) nchunks += d->src[i].C / (KC * 4);
+  }
+  return nchunks;
 }
 
 extern "C" int pmf_conv_fwd(const pmf_conv_desc_t* d, pmf_stream_t st) {

@@ -50,6 +50,9 @@ class Buf:
         return self.arena.t[self.off:self.off + n * esz].view(dtype).view(shape)
 
 
+_TUNED = {}      # process-wide autotuner cache: conv shape key -> tile configuration (Plan.autotune)
+
+
 class ExternalBuf:
     """a caller-owned device tensor seen through the Buf interface (the flat gradient buffer of FlatState)."""
 
@@ -145,6 +148,7 @@ class Plan:
         self.wg_scratch = 0                 # bytes of the shared wgrad partial-sum workspace
         self.params = []                    # (param, grad Buf float offset)
         self._graphs, self._graph_seen = {}, {}   # hipGraph replay cache (see run)
+        self._conv_fin = {}                 # forward conv op index -> index of the BN finalize op reading its rows
         self.grad_done = {}                 # id(param) -> index (in self.bwd) of the last op writing its gradient
         self.pgrad_floats = 0
         self._pid = {}
@@ -297,7 +301,9 @@ class Plan:
             probe = L.ConvDesc()
             shape_fill(probe)
             stat_rows = L.lib().pmf_conv_fwd_stat_rows(C.byref(probe))
-        stats = self.act.alloc(16 * Cout * stat_rows) if train_bn else None   # float64 [rows][2][Cout] partials
+            # the autotuner (Plan.autotune) may pick another tile configuration: size the rows for any of them
+            max_rows = max(stat_rows, L.lib().pmf_conv_fwd_stat_rows_max(C.byref(probe)))
+        stats = self.act.alloc(16 * Cout * max_rows) if train_bn else None   # float64 [rows][2][Cout] partials
 
         def f(op, srcs=srcs):
             d = op.u.conv
@@ -313,6 +319,7 @@ class Plan:
             d.ep_pmask = pmask.buf.ptr if pmask is not None else None
             d.splitk_ws, d.splitk_ws_bytes = self.sk_buf.ptr, self.sk_buf.nbytes
         self.emit(self.fwd, L.OP_CONV, f)
+        conv_fwd_index = len(self.fwd) - 1
         conv_flops = 2.0 * N * OH * OW * Cout * conv.in_channels * len(taps)   # algorithmic (SURVEY.md 8d rule)
         self.meta_fwd[len(self.fwd) - 1] = dict(family="conv_fwd", flops=conv_flops, name=name, shape="%dx%dx%d %d->%d t%d s%d" % (
             N, OH, OW, conv.in_channels, Cout, len(taps), stride))
@@ -334,6 +341,7 @@ class Plan:
                     a.f[0], a.f[1], a.f[2] = count, bn.momentum, bn.eps
                     a.i[0], a.i[1] = Cb, stat_rows
                 self.emit(self.fwd, L.OP_BN_FINALIZE, fb)
+                self._conv_fin[conv_fwd_index] = len(self.fwd) - 1      # its row count follows the conv's tile config
             else:
                 def fb(op):
                     a = op.u.sm
@@ -945,7 +953,70 @@ class Plan:
         self.bwd_kinds = [e[0] for e in (pro_b + self.bwd)] if self.training else []
         self.fwd = self.bwd = None
         self.param_ptrs = [p.data_ptr() for p in self.params]
+        import os
+        if self.device.type == "cuda" and os.environ.get("PMF_AUTOTUNE", "1") != "0":
+            self.autotune()
         return self
+
+    # ------------------------------------------------------------------ tile-configuration autotuner
+    def autotune(self):
+        """Every conv launch (forward and input gradient) is timed once per distinct shape with a handful of tile
+        configurations (output-channel tile 32/64, 128- or 256-pixel tile, K splits) and keeps the fastest; the
+        built-in heuristics are one of the candidates.  Choices are cached process-wide by shape, so two plans of one
+        process agree bit for bit.  Measured gains over the heuristics: 0-16 % per layer (tools/sweep_conv.sh)."""
+        lib = L.lib()
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        failed = C.c_int32(-1)
+
+        def time_op(ops, k, reps=5):
+            for _ in range(2):
+                lib.pmf_plan_run_range(C.addressof(ops), k, k + 1, stream, C.byref(failed))
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                rc = lib.pmf_plan_run_range(C.addressof(ops), k, k + 1, stream, C.byref(failed))
+                if rc != 0:
+                    return float("inf")
+            e1.record()
+            e1.synchronize()
+            return e0.elapsed_time(e1) / reps
+
+        def key_of(d):
+            return (d.N, d.OH, d.OW, d.Cout, d.nsrc,
+                    tuple((d.src[i].C, d.src[i].H, d.src[i].W, d.src[i].flags, bool(d.src[i].scale), bool(d.src[i].cmul))
+                          for i in range(d.nsrc)),
+                    d.ntaps, tuple(d.tdy[i] for i in range(d.ntaps)), tuple(d.tdx[i] for i in range(d.ntaps)),
+                    d.in_stride, d.gather, d.act, d.out_sy, d.out_sx, d.accumulate, bool(d.bias), bool(d.ep_cmul),
+                    bool(d.ep_relu_x), bool(d.stats), bool(d.ep_pmask))
+
+        for ops, n, kinds, shift, fins in ((self.fwd_ops, self.n_fwd, self.fwd_kinds, self.fwd_shift, self._conv_fin),
+                                           (self.bwd_ops, self.n_bwd, self.bwd_kinds, self.bwd_shift, {})):
+            for k in range(n):
+                if kinds[k] != L.OP_CONV:
+                    continue
+                d = ops[k].u.conv
+                key = key_of(d)
+                if key not in _TUNED:
+                    d.cfg = 0
+                    stages = lib.pmf_conv_fwd_kstages(C.byref(d))
+                    cands = [0]
+                    for bn in ((32, 64) if d.Cout > 32 else (32,)):
+                        cands.append(bn | (2 << 8) | (1 << 16))
+                        for ks in (1, 2, 4, 8, 16):
+                            if ks == 1 or (ks <= stages // 2 and d.N * d.OH * d.OW <= 65536):
+                                cands.append(bn | (1 << 8) | (ks << 16))
+                    best_t, best = float("inf"), 0
+                    for cfg in cands:
+                        d.cfg = cfg
+                        t = time_op(ops, k)
+                        if t < best_t * 0.97 or (cfg == 0 and t <= best_t):   # 3 % hysteresis against timing noise
+                            best_t, best = min(t, best_t), cfg
+                    _TUNED[key] = best
+                d.cfg = _TUNED[key]
+                fin = fins.get(k - shift)
+                if fin is not None:
+                    ops[fin + shift].u.sm.i[1] = lib.pmf_conv_fwd_stat_rows(C.byref(d))
+        torch.cuda.synchronize(self.device)
 
     # ------------------------------------------------------------------ debug readers (tests / tools only)
     def read(self, t):
