@@ -114,6 +114,9 @@ typedef struct {
   const float* dbias_rows; /* optional: partial column sums of dz [dbias_nrows][dbias_ld] (pmf_bn_bwd_apply / */
   int32_t dbias_nrows, dbias_ld; /* pmf_act_bwd output); stage 2 folds them: dbias_out[co] += sum_r rows[r][co] */
   float* dbias_out;
+  int32_t cfg;            /* 0 = built-in heuristics; else (autotuner) NT | kernel << 8: NT = 32-channel output tiles per
+                           * workgroup (1, 2, 4); kernel 1 = pipelined (needs NT 1 and its shape conditions), 2 = unit-dealing */
+  int32_t cfg_pad_;
 } pmf_wgrad_desc_t;
 
 int pmf_conv_wgrad(const pmf_wgrad_desc_t* d, pmf_stream_t s);

@@ -51,7 +51,7 @@ class WgradDesc(C.Structure):
                 ("partial", C.c_void_p), ("nsplit", C.c_int32), ("dw_oihw", C.c_void_p),
                 ("Cin_real", C.c_int32), ("KHW", C.c_int32), ("accumulate", C.c_int32),
                 ("dbias_rows", C.c_void_p), ("dbias_nrows", C.c_int32), ("dbias_ld", C.c_int32),
-                ("dbias_out", C.c_void_p)]
+                ("dbias_out", C.c_void_p), ("cfg", C.c_int32), ("cfg_pad_", C.c_int32)]
 
 
 class View(C.Structure):

@@ -706,6 +706,16 @@ static void wg_config(const pmf_wgrad_desc_t* d, int* TB, int* NT) {
   // 1x1 convolutions with wide outputs are plain GEMMs: one MFMA per operand pair either way, so the wider tile of
   // the unit-dealing kernel (fewer re-reads of the input tile) wins there (measured 123 vs 164 us on 384 -> 128)
   const bool wide_1x1 = d->ntaps == 1 && d->Cout > 64;
+  if (d->cfg) {                        // caller-tuned
+    int nt = d->cfg & 0xff;
+    const int kern = (d->cfg >> 8) & 0xff;
+    if (nt != 1 && nt != 2 && nt != 4) nt = 1;
+    if (nt == 4 && *TB != 1) nt = 2;                        // 128-wide tiles are only built for per-tap staging
+    while (nt > 1 && (nt - 1) * 32 >= d->Cout) nt >>= 1;
+    if (kern == 1 && wg_simple(d, g, *TB, 32)) nt = 1;
+    *NT = nt;
+    return;
+  }
   if (!wide_1x1 && wg_simple(d, g, *TB, 32) && !getenv("PMF_WGRAD_NOPIPE")) { *NT = 1; return; }
   *NT = wide_1x1 ? 4 : (d->Cout > 32 ? 2 : 1);
 }
@@ -751,7 +761,7 @@ static int wg_launch(const pmf_wgrad_desc_t* d, hipStream_t s) {
   dim3 grid(d->nsplit, g.nchunks, g.co_tiles * g.tap_batches);
   bool piped = false;
   if constexpr (NT == 1) {
-    if (wg_simple(d, g, TB, 32) && !getenv("PMF_WGRAD_NOPIPE")) {
+    if (wg_simple(d, g, TB, 32) && !getenv("PMF_WGRAD_NOPIPE") && ((d->cfg >> 8) & 0xff) != 2) {
       const int lds2 = lds < 16 * 1024 ? 16 * 1024 : lds;   // room for the pixel-group reduction
       if (g.in_rows * g.in_cols * 8 <= 256 * 7) hipLaunchKernelGGL((conv_wgrad_pipe_k<TB, 1, 7>), grid, dim3(256), lds2, s, *d, g);
       else hipLaunchKernelGGL((conv_wgrad_pipe_k<TB, 1, 9>), grid, dim3(256), lds2, s, *d, g);

@@ -1016,6 +1016,40 @@ class Plan:
                 fin = fins.get(k - shift)
                 if fin is not None:
                     ops[fin + shift].u.sm.i[1] = lib.pmf_conv_fwd_stat_rows(C.byref(d))
+        # weight gradients: kernel variant (pipelined / unit-dealing), output tile width and pixel-split count.
+        # Measured: the tuned choices equal the built-in ones in time (25.44 vs 25.45 ms per step), so this pass only
+        # runs on request (PMF_AUTOTUNE_WGRAD=1) -- it costs ~1 s of plan-build time.
+        import os
+        if self.training and os.environ.get("PMF_AUTOTUNE_WGRAD", "0") == "1":
+            ops, kinds = self.bwd_ops, self.bwd_kinds
+            for k in range(self.n_bwd):
+                if kinds[k] != L.OP_WGRAD:
+                    continue
+                d = ops[k].u.wgrad
+                key = ("wgrad", d.N, d.OH, d.OW, d.Cout, d.nsrc,
+                       tuple((d.src[i].C, d.src[i].H, d.src[i].W, d.src[i].flags, bool(d.src[i].scale),
+                              bool(d.src[i].cmul)) for i in range(d.nsrc)),
+                       d.ntaps, tuple(d.tdy[i] for i in range(d.ntaps)), tuple(d.tdx[i] for i in range(d.ntaps)),
+                       d.in_stride, d.gather, d.Cin_real, d.KHW, bool(d.dbias_rows), d.nsplit)
+                if key not in _TUNED:
+                    h0 = d.nsplit
+                    tiles = d.N * ((d.OH + 3) // 4) * ((d.OW + 31) // 32)
+                    kern = [0, 1 | (1 << 8), 1 | (2 << 8), 2 | (2 << 8)]
+                    if d.ntaps == 1 or d.gather:
+                        kern.append(4 | (2 << 8))
+                    best_t, best = float("inf"), (0, h0)
+                    for cfg in kern:
+                        for ns in sorted({max(1, h0 // 2), h0, h0 * 2, h0 * 4}):
+                            if ns > tiles:
+                                continue
+                            d.cfg, d.nsplit = cfg, ns
+                            if lib.pmf_conv_wgrad_workspace(C.byref(d)) > self.wg_buf.nbytes:
+                                continue
+                            t = time_op(ops, k)
+                            if t < best_t * 0.97 or ((cfg, ns) == (0, h0) and t <= best_t):
+                                best_t, best = min(t, best_t), (cfg, ns)
+                    _TUNED[key] = best
+                d.cfg, d.nsplit = _TUNED[key]
         torch.cuda.synchronize(self.device)
 
     # ------------------------------------------------------------------ debug readers (tests / tools only)
