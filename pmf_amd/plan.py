@@ -967,6 +967,13 @@ class Plan:
         lib = L.lib()
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         failed = C.c_int32(-1)
+        import ast
+        import os
+        cache_file = os.environ.get("PMF_TUNE_CACHE")     # optional: persist / reuse the choices across processes
+        if cache_file and os.path.exists(cache_file) and not _TUNED:
+            with open(cache_file) as f:
+                _TUNED.update(ast.literal_eval(f.read()))
+        n_known = len(_TUNED)
 
         def time_op(ops, k, reps=5):
             for _ in range(2):
@@ -1051,6 +1058,9 @@ class Plan:
                     _TUNED[key] = best
                 d.cfg, d.nsplit = _TUNED[key]
         torch.cuda.synchronize(self.device)
+        if cache_file and len(_TUNED) != n_known:
+            with open(cache_file, "w") as f:
+                f.write(repr(_TUNED))
 
     # ------------------------------------------------------------------ debug readers (tests / tools only)
     def read(self, t):

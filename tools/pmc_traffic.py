@@ -2,15 +2,22 @@
 """HBM-side traffic of the conv_fwd_k launches from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs
 as MI355X_MICROARCH.md prescribes).  FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 128-B requests at
 64 B, so it is doubled (the guide's correction); WRITE_SIZE is reported uncorrected (uncalibrated per the guide).
-usage: pmc_traffic.py fetch.db write.db out.json"""
+usage: pmc_traffic.py fetch.db write.db out.json [tail]     tail: last fraction of the dispatches only (steady state, without
+the plan-build autotuner's candidate launches)"""
 import json, sqlite3, sys
+
+TAIL = float(sys.argv[4]) if len(sys.argv) > 4 else 1.0
+
 
 def per_kernel(db, counter):
     c = sqlite3.connect(db)
     tab = lambda p: [r[0] for r in c.execute("select name from sqlite_master where type='table' and name like '%s%%'" % p)][0]
     kd, ks, pe, pi = tab("rocpd_kernel_dispatch"), tab("rocpd_info_kernel_symbol"), tab("rocpd_pmc_event"), tab("rocpd_info_pmc")
+    n = c.execute("select count(*) from %s" % kd).fetchone()[0]
+    t0 = c.execute("select start from %s order by start limit 1 offset %d" % (kd, int(n * (1.0 - TAIL)))).fetchone()[0]
     q = ("select s.kernel_name, sum(e.value), count(distinct d.id) from %s e join %s p on e.pmc_id=p.id join %s d on "
-         "e.event_id=d.event_id join %s s on d.kernel_id=s.id where p.name=? group by s.kernel_name" % (pe, pi, kd, ks))
+         "e.event_id=d.event_id join %s s on d.kernel_id=s.id where p.name=? and d.start >= %d group by s.kernel_name"
+         % (pe, pi, kd, ks, t0))
     return {k: (v, n) for k, v, n in c.execute(q, (counter,))}
 
 f = per_kernel(sys.argv[1], "FETCH_SIZE")
