@@ -959,6 +959,22 @@ class Plan:
         return self
 
     # ------------------------------------------------------------------ tile-configuration autotuner
+    def force_conv_cfg(self, cfg):
+        """tests: run EVERY conv launch of this plan with one tile configuration (BN | MT << 8 | K splits << 16;
+        0 = heuristics) -- each configuration the autotuner may choose is pinned against float64 this way."""
+        lib = L.lib()
+        for ops, n, kinds, shift, fins in ((self.fwd_ops, self.n_fwd, self.fwd_kinds, self.fwd_shift, self._conv_fin),
+                                           (self.bwd_ops, self.n_bwd, self.bwd_kinds, self.bwd_shift, {})):
+            for k in range(n):
+                if kinds[k] != L.OP_CONV:
+                    continue
+                d = ops[k].u.conv
+                d.cfg = cfg
+                fin = fins.get(k - shift)
+                if fin is not None:
+                    ops[fin + shift].u.sm.i[1] = lib.pmf_conv_fwd_stat_rows(C.byref(d))
+        self._graphs.clear()
+
     def autotune(self):
         """Every conv launch (forward and input gradient) is timed once per distinct shape with a handful of tile
         configurations (output-channel tile 32/64, 128- or 256-pixel tile, K splits) and keeps the fastest; the

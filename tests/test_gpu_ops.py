@@ -37,12 +37,14 @@ class Harness:
             t.needs_grad = True if needs_grad is None else needs_grad[i]
             self.inputs.append(t)
 
-    def run(self, outs, xs, gouts, params=()):
+    def run(self, outs, xs, gouts, params=(), cfg=0):
         """outs: list of V (plan outputs); xs: cpu float32 inputs; gouts: cpu float32 upstream grads (NCHW)."""
         P = self.P
         gts = [P.external_grad(o) for o in outs]
         # gradient inputs are copied in before the backward pass: emit nothing, just remember buffers
         P.finalise()
+        if cfg:
+            P.force_conv_cfg(cfg)
         for i, x in enumerate(xs):
             xc = x.to(DEV).contiguous()
             a = P.fwd_ops[P.in_slots["in%d" % i] + P.fwd_shift].u.sm
@@ -92,8 +94,26 @@ CONVS = [
 ]
 
 
+TILE_CFGS = [bn | (2 << 8) | (1 << 16) for bn in (32, 64)] + \
+            [bn | (1 << 8) | (ks << 16) for bn in (32, 64) for ks in (1, 2, 4, 8, 16)]
+
+
+@pytest.mark.parametrize("cfg", TILE_CFGS, ids=["bn%d_mt%d_ks%d" % (c & 255, (c >> 8) & 255, c >> 16) for c in TILE_CFGS])
+def test_conv_tile_configs(cfg):
+    """every tile configuration the plan autotuner may write into a conv op (output-channel tile 32/64, 128/256-pixel
+    tile, 1-16 K splits), forward + input gradient + BatchNorm statistics, against float64 -- on a 3x3 dilated conv
+    with BN, a 3-operand 1x1 (64-channel stages), a stride-2 3x3 (parity-class input gradients) and a deep small map"""
+    for case in CONVS:
+        if case[0] in ("c3x3d2", "c1x1cat3", "c3x3s2", "c3x3_big", "c7x7"):
+            _conv_case(case, cfg)
+
+
 @pytest.mark.parametrize("case", CONVS, ids=[c[0] for c in CONVS])
 def test_conv_unit_fwd_bwd(case):
+    _conv_case(case, 0)
+
+
+def _conv_case(case, cfg):
     name, N, H, W, cins, Cout, k, dil, pad, stride, bias, mode, use_bn = case
     conv = nn.Conv2d(sum(cins), Cout, k, stride, pad, dil, bias=bias)
     bn = nn.BatchNorm2d(Cout) if use_bn else None
@@ -154,7 +174,7 @@ def test_conv_unit_fwd_bwd(case):
     # the plan's convention: gradients reach a BatchNorm view w.r.t. the BN OUTPUT (consumers apply relu');
     # the external gradient therefore carries the ReLU mask in the bn_relu cases
     g_in = gout * (y.detach() > 0).float() if mode == "bn_relu" else gout
-    got, gin, gp = Hn.run([out], xs, [g_in], params)
+    got, gin, gp = Hn.run([out], xs, [g_in], params, cfg)
     _check(name + ".out", got[0], y.detach())
     for i, g in enumerate(gin):
         _check(name + ".gin%d" % i, g, xd[i].grad, 1e-4)
