@@ -120,6 +120,8 @@ def main():
     ap.add_argument("--height", type=int, default=64)
     ap.add_argument("--width", type=int, default=2048)
     ap.add_argument("--bs", type=int, default=2)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="testing: take the data-parallel code path (process group, range all-reduce) even with one rank")
     ap.add_argument("--mode", default="train", choices=["train", "infer"],
                     help="train = the headline metric; infer = BASELINE configs[1]: eval-mode forward at bs=4 + KNN "
                          "post-processing per frame, reported as frames/s under its own metric name")
@@ -141,8 +143,10 @@ def main():
         raise SystemExit("bench.py needs an AMD GPU: the HIP hot path has no CPU fallback")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    multi = world > 1 or args.force_dist
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", init_method="env://", world_size=world, rank=rank)
     from pmf_amd.engine import TrainEngine
     from pmf_amd.models import PMFNet, EPMFNet
@@ -153,7 +157,7 @@ def main():
     model = net(5, 3, args.nclasses, 32, imagenet_pretrained=False, image_backbone=args.backbone).to(dev)
     eng = TrainEngine(model, args.nclasses, lr=1e-3, momentum=0.9, weight_decay=1e-5, lambda_=1.0, gamma=0.5, tau=0.7,
                       feature_mean=KITTI_MEAN, feature_std=KITTI_STD, warmup_steps=10 * 100, max_steps=49 * 100,
-                      distributed=world > 1, device_ids=[local] if world > 1 else None)
+                      distributed=multi, device_ids=[local] if multi else None)
     feat0, mask, label = make_batch(args.bs, args.height, args.width, 1 + rank, dev, args.nclasses)   # per-rank data
 
     def step():
@@ -164,19 +168,19 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss, _ = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if world > 1:
+    if multi:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = t.item()
     loss_val = float(loss)
@@ -188,11 +192,15 @@ def main():
         # one extra iteration with a HIP event pair around every launch of the forward and backward plans
         plan = next(iter(model._plans.values()))
         eng.model.train()
+        # rank-local measurement: no collective may be issued here (the other ranks are not taking part)
+        hook = getattr(model, "_bwd_segment_hook", None)
+        model._bwd_segment_hook = None
         pcd, rgb = eng.prepare(feat0.clone(), mask)
         total = eng.forward_loss(pcd, rgb, label.long())[0]
         prof_f = plan.run_profiled("forward")       # re-runs the forward plan op by op (same inputs)
         total.backward()                             # normal backward (needed to patch gradient pointers) ...
         prof_b = plan.run_profiled("backward")      # ... then the backward plan again, op by op
+        model._bwd_segment_hook = hook
         if args.profile_out:
             with open(args.profile_out, "w") as f:
                 for ph, prof in (("fwd", prof_f), ("bwd", prof_b)):
@@ -253,8 +261,14 @@ def main():
                        "samples_per_s": world * args.bs * args.steps / dt, "final_loss": loss_val},
             "roofline": roof, "cpu_baseline": cpu, "kernel_time_breakdown": detail,
         }
-        print(json.dumps(out))
-    if world > 1:
+        try:       # RCCL prints its version banner through C stdio (buffered when piped): push it out first so that the
+            import ctypes           # JSON line is the LAST line of stdout
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
+    if multi:
+        dist.barrier()             # rank 0 measured its roofline alone: leave together
         dist.destroy_process_group()
 
 
