@@ -98,11 +98,9 @@ class TrainEngine:
                 self._frontier[g] = f
 
     def _finish_allreduce(self):
-        import torch.distributed as dist
         for h in self._pending:
             h.wait()
         self._pending, self._frontier = [], None
-        self.flat.grad.mul_(1.0 / dist.get_world_size())      # DDP averages; one pass over the flat buffer
 
     def prepare(self, input_feature, input_mask):
         """trainer.py:291-297: normalise the 5 LiDAR channels in place, return the two channel-slice views."""
@@ -138,9 +136,14 @@ class TrainEngine:
         if self.flat is None:
             self.optimizer.zero_grad(set_to_none=True)
             self.aux_optimizer.zero_grad(set_to_none=True)
-        total.backward()            # flat state: the plan zero-fills and rewrites the gradient buffer itself
         if self.flat is not None and self.distributed:
+            # mean over ranks = sum of gradients of loss / world: scale the upstream gradient (free: the objective's
+            # backward multiplies by it anyway) instead of a pass over the 146 MB gradient buffer after the all-reduce
+            import torch.distributed as dist
+            total.backward(torch.full_like(total, 1.0 / dist.get_world_size()))
             self._finish_allreduce()
+        else:
+            total.backward()        # flat state: the plan zero-fills and rewrites the gradient buffer itself
         self.optimizer.step()
         self.aux_optimizer.step()
         self.scheduler.step()

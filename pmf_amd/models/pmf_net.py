@@ -675,7 +675,8 @@ class _PlanFunction(torch.autograd.Function):
         if hook is None:
             plan.run(plan.bwd_ops, plan.n_bwd, "backward", sig=sig)
         else:       # data parallel: the backward plan in a few segments, finished gradient ranges handed to the hook
-            cuts = plan.segment_cuts(4)
+            import os
+            cuts = plan.segment_cuts(int(os.environ.get("PMF_DP_SEGMENTS", "4")))
             for k in range(len(cuts) - 1):
                 plan.run(plan.bwd_ops, plan.n_bwd, "backward", cuts[k], cuts[k + 1], sig=sig)
                 hook(plan, cuts[k + 1])

@@ -114,7 +114,8 @@ def _range_worker(rank, world, port, ret):
         eng._allreduce_ready_ranges(FakePlan(), cut)
     eng._finish_allreduce()
     dist.all_reduce = real
-    want = torch.arange(1024, dtype=torch.float32) * sum(r + 1 for r in range(world)) / world
+    # the 1/world factor is applied to the upstream gradient before backward (TrainEngine.train_step): ranges are SUMMED
+    want = torch.arange(1024, dtype=torch.float32) * sum(r + 1 for r in range(world))
     if rank == 0:
         ret["ok"] = bool(torch.allclose(Flat.grad, want))
         ret["calls"] = calls
@@ -125,7 +126,8 @@ def _range_worker(rank, world, port, ret):
 @pytest.mark.timeout(300)
 def test_range_allreduce_covers_every_gradient_once():
     """each float of the flat gradient buffer is all-reduced exactly once, in front-to-back ranges per group, and the
-    result is the mean over ranks (what DistributedDataParallel produces in the reference, trainer.py:38-39)."""
+    result is the sum over ranks (train_step scales the loss gradient by 1/world first: together the mean that
+    DistributedDataParallel produces in the reference, trainer.py:38-39)."""
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_range_worker, args=(2, 29541, ret), nprocs=2, join=True)
