@@ -661,3 +661,38 @@ def test_autotuned_plan_matches_heuristic_plan():
 def _masks_for(model, n, seed=3):
     g = torch.Generator().manual_seed(seed)
     return {nm: (torch.rand(n, c, generator=g) > 0.2).float() / 0.8 for nm, c in model._mask_sites()}
+
+
+def _dp_worker(rank, world, port, ret):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)     # two ranks share cuda:0 (RCCL refuses that)
+    from pmf_amd.engine import TrainEngine
+    from pmf_amd.models import PMFNet
+    torch.manual_seed(100 + rank)                                    # DIFFERENT initial weights: rank 0's must win
+    m = PMFNet(5, 3, 20, 32, imagenet_pretrained=False, image_backbone="resnet34").cuda()
+    eng = TrainEngine(m, 20, lr=1e-3, warmup_steps=2, max_steps=10, distributed=True, device_ids=[0])
+    pcd, rgb, label, mask = synthetic_batch(2, 32, 64, 20, seed=20 + rank, fill=0.5)      # per-rank data
+    feat = torch.cat((pcd, rgb), 1).cuda()
+    torch.manual_seed(5)                                             # same dropout masks on both ranks
+    torch.cuda.manual_seed(5)
+    losses = [float(eng.train_step(feat.clone(), mask.cuda(), label.cuda())[0]) for _ in range(2)]
+    flat = eng.flat.param.detach().clone()
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    if rank == 0:
+        ret["same"] = bool(all(torch.equal(gathered[0], g) for g in gathered))
+        ret["finite"] = bool(all(np.isfinite(l) for l in losses))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_rank_data_parallel_on_one_gpu():
+    """the real N>1 path (FlatState, segmented backward graphs, asynchronous range all-reduce, initial broadcast) with
+    two processes on one GPU over gloo: parameters stay identical across ranks although data and initial weights differ."""
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_dp_worker, args=(2, 29551, ret), nprocs=2, join=True)
+    assert ret["finite"] and ret["same"], dict(ret)
