@@ -120,6 +120,9 @@ typedef struct {
 } pmf_wgrad_desc_t;
 
 int pmf_conv_wgrad(const pmf_wgrad_desc_t* d, pmf_stream_t s);
+/* its two stages separately (same descriptor): partial-slab kernel, then the deterministic reduction */
+int pmf_conv_wgrad_partial(const pmf_wgrad_desc_t* d, pmf_stream_t s);
+int pmf_conv_wgrad_reduce(const pmf_wgrad_desc_t* d, pmf_stream_t s);
 int64_t pmf_conv_wgrad_workspace(const pmf_wgrad_desc_t* d);
 
 /* OIHW -> packed GEMM layout, all convs of the network in ONE launch (weights change every optimiser step).
@@ -317,7 +320,7 @@ enum {
   PMF_OP_MAXPOOL, PMF_OP_MAXPOOL_BWD, PMF_OP_BILINEAR, PMF_OP_BILINEAR_BWD, PMF_OP_PSHUFFLE, PMF_OP_PSHUFFLE_BWD,
   PMF_OP_GATE, PMF_OP_GATE_BWD, PMF_OP_GMEAN, PMF_OP_GMEAN_BWD, PMF_OP_COLSUM, PMF_OP_SOFTMAX, PMF_OP_SOFTMAX_BWD,
   PMF_OP_NCHW2NHWC, PMF_OP_FILL, PMF_OP_PMASK_FROM, PMF_OP_PMASK_POOL, PMF_OP_PMASK_MUL, PMF_OP_PMASK_MUL_BWD,
-  PMF_OP_VEC_ADD
+  PMF_OP_VEC_ADD, PMF_OP_WGRAD_PART, PMF_OP_WGRAD_RED
 };
 
 /* generic argument record for the small ops (slot meaning documented next to each dispatcher case in plan.cpp) */
@@ -331,7 +334,9 @@ typedef struct {
 
 typedef struct {
   int32_t kind;
-  int32_t pad_;
+  int32_t pad_;    /* scheduling bits for pmf_plan_run: bit 0 = side stream (forks from the main stream at this point, joined
+                    * at the end of the range); bits 2-3 = k+1: the MAIN stream first waits for side event k; bits 4-5 =
+                    * k+1: record side event k after this op (k = 0, 1) */
   union {
     pmf_conv_desc_t conv;
     pmf_wgrad_desc_t wgrad;

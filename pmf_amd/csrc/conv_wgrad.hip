@@ -743,12 +743,21 @@ extern "C" int64_t pmf_conv_wgrad_workspace(const pmf_wgrad_desc_t* d) {
   return (int64_t)d->nsplit * d->ntaps * Ktot * round_up(d->Cout, 32) * 4;
 }
 
+static int wg_reduce(const pmf_wgrad_desc_t* d, const WgGeom& g, hipStream_t s) {
+  const int64_t total = (int64_t)d->ntaps * g.Ktot * g.Cout32;
+  int gb = (int)cdiv64(total, 32);
+  hipLaunchKernelGGL(wgrad_reduce_k, dim3(gb > 4096 ? 4096 : gb), dim3(256), 0, s, *d, g.Ktot, g.Cout32);
+  PMF_LAUNCH_CHECK();
+  return 0;
+}
+
 template <int TB, int NT>
-static int wg_launch(const pmf_wgrad_desc_t* d, hipStream_t s) {
+static int wg_launch(const pmf_wgrad_desc_t* d, hipStream_t s, int phase) {
   WgGeom g;
   int lds;
   wg_geometry(d, TB, NT * 32, &g, &lds);
   if (lds > 160 * 1024) return PMF_E_UNSUPPORTED;
+  if (!(phase & 1)) return wg_reduce(d, g, s);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)conv_wgrad_k<TB, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -770,11 +779,7 @@ static int wg_launch(const pmf_wgrad_desc_t* d, hipStream_t s) {
   }
   if (!piped) hipLaunchKernelGGL((conv_wgrad_k<TB, NT>), grid, dim3(256), lds, s, *d, g);
   PMF_LAUNCH_CHECK();
-  const int64_t total = (int64_t)d->ntaps * g.Ktot * g.Cout32;
-  int gb = (int)cdiv64(total, 32);
-  hipLaunchKernelGGL(wgrad_reduce_k, dim3(gb > 4096 ? 4096 : gb), dim3(256), 0, s, *d, g.Ktot, g.Cout32);
-  PMF_LAUNCH_CHECK();
-  return 0;
+  return (phase & 2) ? wg_reduce(d, g, s) : 0;
 }
 
 // few-input-channel path (ResNet stem): conditions
@@ -803,10 +808,11 @@ static void wg_geometry_fewc(const pmf_wgrad_desc_t* d, WgGeom* g, int* lds) {
   if (*lds < 16 * 1024) *lds = 16 * 1024;
 }
 
-static int wg_launch_fewc(const pmf_wgrad_desc_t* d, hipStream_t s) {
+static int wg_launch_fewc(const pmf_wgrad_desc_t* d, hipStream_t s, int phase) {
   WgGeom g;
   int lds;
   wg_geometry_fewc(d, &g, &lds);
+  if (!(phase & 1)) return wg_reduce(d, g, s);
   const int KGn = cdiv(d->ntaps * d->Cin_real, 32);
   static bool attr_set = false;
   if (!attr_set) {
@@ -822,24 +828,27 @@ static int wg_launch_fewc(const pmf_wgrad_desc_t* d, hipStream_t s) {
   else if (KGn == 3) hipLaunchKernelGGL((wgrad_fewc_k<3>), grid, dim3(256), lds, s, *d, g);
   else hipLaunchKernelGGL((wgrad_fewc_k<5>), grid, dim3(256), lds, s, *d, g);
   PMF_LAUNCH_CHECK();
-  const int64_t total = (int64_t)d->ntaps * g.Ktot * g.Cout32;
-  int gb = (int)cdiv64(total, 32);
-  hipLaunchKernelGGL(wgrad_reduce_k, dim3(gb > 4096 ? 4096 : gb), dim3(256), 0, s, *d, g.Ktot, g.Cout32);
-  PMF_LAUNCH_CHECK();
-  return 0;
+  return (phase & 2) ? wg_reduce(d, g, s) : 0;
 }
 
-extern "C" int pmf_conv_wgrad(const pmf_wgrad_desc_t* d, pmf_stream_t st) {
+static int wgrad_phases(const pmf_wgrad_desc_t* d, pmf_stream_t st, int phase);
+extern "C" int pmf_conv_wgrad(const pmf_wgrad_desc_t* d, pmf_stream_t st) { return wgrad_phases(d, st, 3); }
+// the two stages separately: the partial-slab kernel, then the deterministic reduction into OIHW (+ bias fold).  A plan
+// runs the reduction on its side stream: nothing downstream needs it before the optimiser (or the gradient all-reduce)
+extern "C" int pmf_conv_wgrad_partial(const pmf_wgrad_desc_t* d, pmf_stream_t st) { return wgrad_phases(d, st, 1); }
+extern "C" int pmf_conv_wgrad_reduce(const pmf_wgrad_desc_t* d, pmf_stream_t st) { return wgrad_phases(d, st, 2); }
+
+static int wgrad_phases(const pmf_wgrad_desc_t* d, pmf_stream_t st, int phase) {
   hipStream_t s = (hipStream_t)st;
   if (!d || d->nsrc < 1 || d->nsrc > PMF_MAX_SRC || d->ntaps < 1 || d->ntaps > PMF_MAX_TAPS || d->nsplit < 1)
     return PMF_E_ARG;
   for (int i = 0; i < d->nsrc; ++i)
     if (d->src[i].C % 8 || d->src[i].ldc % 4) return PMF_E_ARG;
   if (d->gather && false) return PMF_E_ARG;
-  if (wg_fewc(d)) return wg_launch_fewc(d, s);
+  if (wg_fewc(d)) return wg_launch_fewc(d, s, phase);
   int TB, NT;
   wg_config(d, &TB, &NT);
-#define WG_CASE(tb, nt) if (TB == tb && NT == nt) return wg_launch<tb, nt>(d, s)
+#define WG_CASE(tb, nt) if (TB == tb && NT == nt) return wg_launch<tb, nt>(d, s, phase)
   WG_CASE(9, 1); WG_CASE(9, 2);
   WG_CASE(4, 1); WG_CASE(4, 2);
   WG_CASE(1, 1); WG_CASE(1, 2); WG_CASE(1, 4);

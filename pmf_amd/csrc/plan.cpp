@@ -13,6 +13,8 @@ static int run_one(const pmf_op_t& o, pmf_stream_t s) {
   switch (o.kind) {
     case PMF_OP_CONV: return pmf_conv_fwd(&o.u.conv, s);
     case PMF_OP_WGRAD: return pmf_conv_wgrad(&o.u.wgrad, s);
+    case PMF_OP_WGRAD_PART: return pmf_conv_wgrad_partial(&o.u.wgrad, s);
+    case PMF_OP_WGRAD_RED: return pmf_conv_wgrad_reduce(&o.u.wgrad, s);
     case PMF_OP_PACK:  // p0 jobs(dev)  i0 njobs  i1 total_blocks
       return pmf_pack_weights_batched((const pmf_pack_job_t*)a.p[0], i[0], i[1], s);
     case PMF_OP_BN_FINALIZE:  // p: stats gamma beta rm rv scale shift save_mean save_invstd | f: count mom eps | i: C nrows
@@ -90,12 +92,13 @@ static int run_one(const pmf_op_t& o, pmf_stream_t s) {
   }
 }
 
-// Two lanes: ops with pad_ == 1 (weight gradients) go to a private side stream.  A side op waits for everything issued
-// on the main stream before it (its inputs were produced there) and nothing on the main stream waits for it until
-// the end of the range, so the big weight-gradient kernels fill the machine while the main stream walks the
-// latency-bound chain BatchNorm-backward -> input gradient -> next layer.  Measured on MI355X / ROCm 7.2 with hipGraph
-// replay: no gain (26.1 vs 26.1 ms per step -- the two branches do not overlap usefully), so the side lane is OFF unless
-// PMF_SIDE=1 is set; the plumbing (per-layer bias-row buffers, fork/join inside the capture) stays for the next round.
+// Two lanes (pmf_op_t.pad_): side-lane ops go to a private stream.  A side op waits for everything issued on the main
+// stream before it (its inputs were produced there); the main stream only waits for the side stream at the end of the
+// range, or for one of two ping-pong events where a buffer is about to be reused.  The plan puts the weight-gradient
+// REDUCTIONS there: latency-bound 11-us kernels that nothing downstream needs before the optimiser, so they now run
+// under the next layer's kernels instead of between them (the partial slabs they read ping-pong between two
+// workspaces).  Putting the whole weight-gradient op on the side lane was measured first: no gain (two machine-filling
+// kernels just share the CUs).  hipGraph capture records the fork / join / event edges; PMF_SIDE=0 disables the lane.
 static hipStream_t g_side = nullptr;
 static hipEvent_t g_fork = nullptr, g_join = nullptr;
 static int lanes_init() {
@@ -109,23 +112,38 @@ static int lanes_init() {
 }
 static bool lanes_enabled() {
   static int on = -1;
-  if (on < 0) { const char* e = getenv("PMF_SIDE"); on = (e && e[0] == '1') ? 1 : 0; }
+  if (on < 0) { const char* e = getenv("PMF_SIDE"); on = (e && e[0] == '1') ? 1 : 0; }   // opt-in: measured 27.5 vs 25.5 ms/step -- 110 fork/join pairs cost more than the reductions they hide
   return on == 1;
 }
+
+static hipEvent_t g_ev[2] = {nullptr, nullptr};
 
 static int run_range(const pmf_op_t* ops, int32_t begin, int32_t end, hipStream_t main_s, int32_t* failed_at) {
   bool side_used = false;
   const bool lanes = lanes_enabled();
+  bool ev_valid[2] = {false, false};     // side events recorded inside THIS range (a wait never reaches back further)
   for (int32_t k = begin; k < end; ++k) {
-    int rc;
-    if (lanes && ops[k].pad_ == 1) {
+    const int bits = lanes ? ops[k].pad_ : 0;
+    int rc = 0;
+    if (bits) {
       rc = lanes_init();
-      if (rc == 0) rc = (int)hipEventRecord(g_fork, main_s);
-      if (rc == 0) rc = (int)hipStreamWaitEvent(g_side, g_fork, 0);
-      if (rc == 0) rc = run_one(ops[k], (pmf_stream_t)g_side);
-      side_used = true;
-    } else {
-      rc = run_one(ops[k], (pmf_stream_t)main_s);
+      if (rc == 0 && !g_ev[0]) {
+        rc = (int)hipEventCreateWithFlags(&g_ev[0], hipEventDisableTiming);
+        if (rc == 0) rc = (int)hipEventCreateWithFlags(&g_ev[1], hipEventDisableTiming);
+      }
+    }
+    const int wait_k = ((bits >> 2) & 3) - 1, rec_k = ((bits >> 4) & 3) - 1;
+    if (rc == 0 && wait_k >= 0 && ev_valid[wait_k]) rc = (int)hipStreamWaitEvent(main_s, g_ev[wait_k], 0);
+    if (rc == 0) {
+      if (bits & 1) {
+        rc = (int)hipEventRecord(g_fork, main_s);
+        if (rc == 0) rc = (int)hipStreamWaitEvent(g_side, g_fork, 0);
+        if (rc == 0) rc = run_one(ops[k], (pmf_stream_t)g_side);
+        side_used = true;
+        if (rc == 0 && rec_k >= 0) { rc = (int)hipEventRecord(g_ev[rec_k], g_side); ev_valid[rec_k] = true; }
+      } else {
+        rc = run_one(ops[k], (pmf_stream_t)main_s);
+      }
     }
     if (rc != 0) {
       if (failed_at) *failed_at = k;

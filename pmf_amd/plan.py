@@ -149,6 +149,7 @@ class Plan:
         self.params = []                    # (param, grad Buf float offset)
         self._graphs, self._graph_seen = {}, {}   # hipGraph replay cache (see run)
         self._conv_fin = {}                 # forward conv op index -> index of the BN finalize op reading its rows
+        self.n_wgrad = 0                    # weight-gradient ops emitted so far (workspace / event ping-pong)
         self.grad_done = {}                 # id(param) -> index (in self.bwd) of the last op writing its gradient
         self.pgrad_floats = 0
         self._pid = {}
@@ -177,7 +178,7 @@ class Plan:
         """fill(op) populates a zeroed L.Op at finalise time (pointers are known only then).
         lane 1 = side stream: the op only waits for what was issued before it and is joined at the end of the range
         (weight gradients: off the critical path, they overlap the latency-bound BatchNorm / finish kernels)."""
-        lst.append((kind, fill) if lane == 0 else (kind, fill, lane))
+        lst.append((kind, fill) if lane == 0 else (kind, fill, lane))    # lane: the pad_ scheduling bits (pmf_amd.h)
 
     def view_struct(self, v, dst):
         dst.x = v.t.buf.ptr
@@ -558,7 +559,7 @@ class Plan:
             for i, s in enumerate(srcs):
                 self.src_struct(s, d.src[i])
             d.dz, d.dz_ldc = dz.buf.ptr, dz.ldc
-            d.partial = self.wg_buf.ptr
+            d.partial = self.wg_bufs[widx % 2].ptr
             d.nsplit = nsplit
             d.dw_oihw = self.pgrad_buf.at(goff)
             d.accumulate = 0
@@ -566,11 +567,18 @@ class Plan:
                 d.dbias_rows, d.dbias_nrows, d.dbias_ld = dbr.ptr, dbias_rows, dbr_ld
                 d.dbias_out = self.pgrad_buf.at(boff)
         boff = self.pgrad(conv.bias) if dbias_rows else None
-        self.emit(self.bwd, L.OP_WGRAD, f, lane=1)
+        # two ops: the partial-slab kernel on the main stream, the reduction into OIHW on the side stream (nothing
+        # downstream needs it before the optimiser).  Partial slabs ping-pong between two workspaces; side event i % 2
+        # is recorded after reduction i and awaited by the main stream before kernel i + 2 overwrites that workspace.
+        widx = self.n_wgrad
+        self.n_wgrad += 1
+        self.emit(self.bwd, L.OP_WGRAD_PART, f, lane=(((widx % 2) + 1) << 2) if widx >= 2 else 0)
+        part_index = len(self.bwd) - 1
+        self.emit(self.bwd, L.OP_WGRAD_RED, f, lane=1 | (((widx % 2) + 1) << 4))
         self.grad_done[id(conv.weight)] = len(self.bwd) - 1
         if dbias_rows:
             self.grad_done[id(conv.bias)] = len(self.bwd) - 1
-        self.meta_bwd[len(self.bwd) - 1] = dict(
+        self.meta_bwd[part_index] = dict(
             family="conv_wgrad", flops=2.0 * dz.N * dz.H * dz.W * Cout * conv.in_channels * len(taps), name=name,
             shape="%dx%dx%d %d->%d t%d" % (dz.N, dz.H, dz.W, conv.in_channels, Cout, len(taps)))
 
@@ -882,7 +890,8 @@ class Plan:
             self.pgrad_floats = self.flat.grad.numel()
         else:
             self.pgrad_buf = self.zero_bwd.alloc(4 * max(self.pgrad_floats, 64)) if self.training else None
-        self.wg_buf = self.act.alloc(max(self.wg_scratch, 256)) if self.training else None
+        self.wg_bufs = [self.act.alloc(max(self.wg_scratch, 256)) for _ in range(2)] if self.training else None
+        self.wg_buf = self.wg_bufs[0] if self.training else None
         self.sk_buf = self.act.alloc(SPLITK_BYTES)   # shared split-K scratch (small maps only; ops run in stream order)
         self.bnpart_buf = self.act.alloc(COL_ROWS * 2 * max(self.colrows_max, 4) * 8)   # float64 partial rows
         for a, zero in ((self.act, False), (self.zero_fwd, True), (self.zero_bwd, True), (self.persist, True)):
@@ -1039,40 +1048,8 @@ class Plan:
                 fin = fins.get(k - shift)
                 if fin is not None:
                     ops[fin + shift].u.sm.i[1] = lib.pmf_conv_fwd_stat_rows(C.byref(d))
-        # weight gradients: kernel variant (pipelined / unit-dealing), output tile width and pixel-split count.
-        # Measured: the tuned choices equal the built-in ones in time (25.44 vs 25.45 ms per step), so this pass only
-        # runs on request (PMF_AUTOTUNE_WGRAD=1) -- it costs ~1 s of plan-build time.
-        import os
-        if self.training and os.environ.get("PMF_AUTOTUNE_WGRAD", "0") == "1":
-            ops, kinds = self.bwd_ops, self.bwd_kinds
-            for k in range(self.n_bwd):
-                if kinds[k] != L.OP_WGRAD:
-                    continue
-                d = ops[k].u.wgrad
-                key = ("wgrad", d.N, d.OH, d.OW, d.Cout, d.nsrc,
-                       tuple((d.src[i].C, d.src[i].H, d.src[i].W, d.src[i].flags, bool(d.src[i].scale),
-                              bool(d.src[i].cmul)) for i in range(d.nsrc)),
-                       d.ntaps, tuple(d.tdy[i] for i in range(d.ntaps)), tuple(d.tdx[i] for i in range(d.ntaps)),
-                       d.in_stride, d.gather, d.Cin_real, d.KHW, bool(d.dbias_rows), d.nsplit)
-                if key not in _TUNED:
-                    h0 = d.nsplit
-                    tiles = d.N * ((d.OH + 3) // 4) * ((d.OW + 31) // 32)
-                    kern = [0, 1 | (1 << 8), 1 | (2 << 8), 2 | (2 << 8)]
-                    if d.ntaps == 1 or d.gather:
-                        kern.append(4 | (2 << 8))
-                    best_t, best = float("inf"), (0, h0)
-                    for cfg in kern:
-                        for ns in sorted({max(1, h0 // 2), h0, h0 * 2, h0 * 4}):
-                            if ns > tiles:
-                                continue
-                            d.cfg, d.nsplit = cfg, ns
-                            if lib.pmf_conv_wgrad_workspace(C.byref(d)) > self.wg_buf.nbytes:
-                                continue
-                            t = time_op(ops, k)
-                            if t < best_t * 0.97 or ((cfg, ns) == (0, h0) and t <= best_t):
-                                best_t, best = min(t, best_t), (cfg, ns)
-                    _TUNED[key] = best
-                d.cfg, d.nsplit = _TUNED[key]
+        # (a tuner over the weight-gradient kernel variant / pixel-split count was measured at 25.44 vs 25.45 ms per
+        # step -- no gain over the built-in rules -- and removed.)
         torch.cuda.synchronize(self.device)
         if cache_file and len(_TUNED) != n_known:
             with open(cache_file, "w") as f:

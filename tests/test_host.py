@@ -80,7 +80,12 @@ def test_plan_builds_and_is_consistent(training):
             assert sum(d.src[j].C for j in range(d.nsrc)) % 8 == 0
     if training:
         bk = [L.OP_NAMES[k] for k in P.bwd_kinds]
-        assert bk.count("OP_WGRAD") == 110 and bk.count("OP_BN_BWD_APPLY") == 94
+        assert bk.count("OP_WGRAD_PART") == bk.count("OP_WGRAD_RED") == 110 and bk.count("OP_BN_BWD_APPLY") == 94
+        # scheduling bits: reductions on the side lane recording ping-pong events that the kernel two ops later awaits
+        sched = [(k, P.bwd_ops[i].pad_) for i, k in enumerate(bk) if k.startswith("OP_WGRAD")]
+        parts, reds = [b for k, b in sched if k == "OP_WGRAD_PART"], [b for k, b in sched if k == "OP_WGRAD_RED"]
+        assert all(b & 1 and ((b >> 4) & 3) - 1 == i % 2 for i, b in enumerate(reds))
+        assert parts[0] == parts[1] == 0 and all(((b >> 2) & 3) - 1 == i % 2 for i, b in enumerate(parts) if i >= 2)
         # every parameter has a slot in the flat gradient buffer
         assert {id(p) for p in m.parameters()} == {id(p) for p in P.params}
         offs = sorted((P._pid[id(p)][1], p.numel()) for p in P.params)
