@@ -656,6 +656,64 @@ __global__ __launch_bounds__(256) void wgrad_reduce_k(const pmf_wgrad_desc_t d, 
   }
 }
 
+// Stage 2 for layers with many weights: the slabs are [split][tap][k][co32] (co fastest) while the gradient is OIHW
+// (tap fastest), so a thread-per-output reduction scatters 4-byte writes one weight row apart.  Here a workgroup owns
+// 32 output channels x KB input channels x all taps: float4 loads along co (every split summed by the same thread, in
+// slab order), a transpose through LDS, then runs of KB*KHW contiguous floats per output channel.
+#define WGR_ROWS 128
+__global__ __launch_bounds__(256) void wgrad_reduce_tile_k(const pmf_wgrad_desc_t d, int Ktot, int Cout32, int KB) {
+  __shared__ float tile[WGR_ROWS][33];
+  const int T = d.ntaps, RB = T * KB;
+  const int co0 = blockIdx.x * 32, k0 = blockIdx.y * KB;
+  const int q = threadIdx.x & 7, rs = threadIdx.x >> 3;
+  const int64_t slab = (int64_t)T * Ktot * Cout32;
+  for (int j = rs; j < RB; j += 32) {
+    const int kk = j / T, t = j - kk * T, k = k0 + kk;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (k < Ktot) {
+      const float* src = d.partial + ((int64_t)t * Ktot + k) * Cout32 + co0 + q * 4;
+      for (int s0 = 0; s0 < d.nsplit; s0 += 8) {
+        f32x4 u[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) if (s0 + i < d.nsplit) u[i] = *(const f32x4*)(src + (int64_t)(s0 + i) * slab);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) if (s0 + i < d.nsplit) v += u[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) tile[j][q * 4 + i] = v[i];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int cl = w; cl < 32; cl += 4) {
+    const int co = co0 + cl;
+    if (co >= d.Cout) break;
+    for (int j = lane; j < RB; j += 64) {
+      const int kk = j / T, t = j - kk * T, k = k0 + kk;
+      if (k >= d.Cin_real) continue;
+      float* o = d.dw_oihw + ((size_t)co * d.Cin_real + k) * d.KHW + d.tap_widx[t];
+      const float x = tile[j][cl];
+      *o = d.accumulate ? *o + x : x;
+    }
+  }
+  if (d.dbias_rows) {
+    __shared__ float shb[256];
+    const int nb = gridDim.x * gridDim.y;
+    for (int co = blockIdx.y * gridDim.x + blockIdx.x; co < d.Cout; co += nb) {
+      float s = 0.f;
+      for (int r = threadIdx.x; r < d.dbias_nrows; r += blockDim.x) s += d.dbias_rows[(size_t)r * d.dbias_ld + co];
+      shb[threadIdx.x] = s;
+      __syncthreads();
+      for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) shb[threadIdx.x] += shb[threadIdx.x + o];
+        __syncthreads();
+      }
+      if (threadIdx.x == 0) d.dbias_out[co] += shb[0];
+      __syncthreads();
+    }
+  }
+}
+
 static int wg_geometry(const pmf_wgrad_desc_t* d, int TB, int BN, WgGeom* g, int* lds) {
   int Ktot = 0, nchunks = 0;
   for (int i = 0; i < d->nsrc; ++i) { Ktot += d->src[i].C; nchunks += cdiv(d->src[i].C, WG_CI); }
@@ -745,6 +803,15 @@ extern "C" int64_t pmf_conv_wgrad_workspace(const pmf_wgrad_desc_t* d) {
 
 static int wg_reduce(const pmf_wgrad_desc_t* d, const WgGeom& g, hipStream_t s) {
   const int64_t total = (int64_t)d->ntaps * g.Ktot * g.Cout32;
+  if (total >= 131072 && d->nsplit <= 32 && d->ntaps <= WGR_ROWS && !getenv("PMF_WGRAD_RED_FLAT")) {
+    int KB = WGR_ROWS / d->ntaps;
+    if (KB > g.Ktot) KB = g.Ktot;
+    const int cog = g.Cout32 / 32;
+    while (KB > 4 && cog * cdiv(g.Ktot, KB) < 512) KB = (KB + 1) / 2;
+    hipLaunchKernelGGL(wgrad_reduce_tile_k, dim3(cog, cdiv(g.Ktot, KB)), dim3(256), 0, s, *d, g.Ktot, g.Cout32, KB);
+    PMF_LAUNCH_CHECK();
+    return 0;
+  }
   int gb = (int)cdiv64(total, 32);
   hipLaunchKernelGGL(wgrad_reduce_k, dim3(gb > 4096 ? 4096 : gb), dim3(256), 0, s, *d, g.Ktot, g.Cout32);
   PMF_LAUNCH_CHECK();
