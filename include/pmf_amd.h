@@ -283,6 +283,27 @@ int pmf_project_v2_scatter(const float* points, const int32_t* sem, const int32_
 int pmf_crop_pad(const float* src, int32_t C, int32_t h, int32_t w, int32_t top, int32_t left, float* dst,
                  int32_t oh, int32_t ow, int32_t pad_top, int32_t pad_left, int32_t ch, int32_t cw, pmf_stream_t s);
 
+/* SalsaNext range-image loader (replaces pc_processor/dataset/preprocess/projection.py:31-86 RangeProjection.doProjection,
+ * salsanext_loader.py:48-84 and augmentor.py:97-180).
+ * pmf_points_transform: in place on points f32[P][C] -- flips (x <- -x, y <- -y), float32 translation, then
+ *   xyz <- float32(float64(xyz) . R^T) with rot9 = R row-major float64[9] (NULL: no rotation).
+ * pmf_range_project_index: per point depth / column / row (float32 arithmetic of the reference, arctan2 / arcsin
+ *   rounded once from float64), optional uproj_x/uproj_y/uproj_depth [P] (all three or none), and per pixel the key
+ *   (depth bits << 32 | point index) of its nearest point in keys u64[H][W] (all ones = empty); fov_* are the float32
+ *   values |fov_left|, |fov_left|+|fov_right|, |fov_down|, |fov_up|+|fov_down| in radians.
+ * pmf_range_project_gather: per pixel range f32[H][W] (-1 empty), idx i32[H][W] (-1 empty), mask i32[H][W] = idx > 0,
+ *   label f32[H][W] = mapped_label[idx] * mask, feature f32[5][H][W] = ((range,x,y,z,i*(i != -1)) - mean5) / std5 * mask,
+ *   proj_points f32[H][W][C] (-1 empty); every output pointer may be NULL. */
+int pmf_points_transform(float* points, int64_t P, int32_t C, int32_t flipx, int32_t flipy, float tx, float ty, float tz,
+                         const double* rot9, pmf_stream_t s);
+int pmf_range_project_index(const float* points, int64_t P, int32_t C, float fov_left_abs, float fov_h,
+                            float fov_down_abs, float fov_v, int32_t H, int32_t W, uint64_t* keys, int32_t* uproj_x,
+                            int32_t* uproj_y, float* uproj_depth, pmf_stream_t s);
+int pmf_range_project_gather(const float* points, int64_t P, int32_t C, const uint64_t* keys, int32_t H, int32_t W,
+                             const int32_t* mapped_label, const float* mean5, const float* std5, float* feature,
+                             float* label, int32_t* mask, float* range, int32_t* idx, float* proj_points,
+                             pmf_stream_t s);
+
 /* ---- loss-side kernels ------------------------------------------------------------------------------------ */
 /* Lovasz-softmax Jaccard gradient (pc_processor/loss/lovasz_softmax.py:56-68) for C class rows at once.
  * fg_sorted f32[C][P]: 0/1 foreground indicator, each row ordered by DESCENDING error with ignored pixels last;

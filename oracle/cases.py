@@ -35,3 +35,40 @@ def knn_case(seed, h, w, npts, quantize=False):
         jitter = np.round(jitter * 4) / 4
     ur = (pr[py, px] + jitter).astype(np.float32)
     return pr, ur, am, px, py
+
+
+def lidar_sweep(seed, npts, fov_up=3.0, fov_down=-25.0, duplicates=False):
+    """A spinning-LiDAR-like sweep: f32[npts,4] (x,y,z,intensity), raw labels int32[npts], label LUT int32[260].
+    Azimuth covers the full circle, elevation a little more than [fov_down, fov_up] (so rows clamp at both edges),
+    ranges 1.5..80 m with ring structure; a few points sit on the coordinate axes and point 0 is a valid hit (the
+    reference's mask drops it).  duplicates=True repeats a tenth of the points exactly (equal-depth ties)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    az = rng.uniform(-np.pi, np.pi, npts)
+    el = np.deg2rad(rng.uniform(fov_down - 2.0, fov_up + 2.0, npts))
+    r = 1.5 + 78.5 * rng.random(npts) ** 2
+    x, y, z = r * np.cos(el) * np.cos(az), r * np.cos(el) * np.sin(az), r * np.sin(el)
+    pts = np.stack([x, y, z, rng.random(npts)], 1).astype(np.float32)
+    pts[0, :3] = (1.2, 0.05, -0.1)           # nearer than every other point: wins its pixel, and the mask drops it
+    pts[1, :3] = (10.0, 0.0, 0.0)
+    pts[2, :3] = (0.0, 7.5, 0.0)
+    pts[3, :3] = (-12.0, 0.0, -1.0)          # yaw = -pi exactly
+    pts[4, :3] = (0.0, -3.0, 0.5)
+    if duplicates:
+        k = npts // 10
+        pts[k:2 * k] = pts[2 * k:3 * k]
+    sem = rng.integers(0, 260, npts).astype(np.int32)
+    lut = rng.integers(0, 20, 260).astype(np.int32)
+    return pts, sem, lut
+
+
+_AUG = dict(p_flipx=0., p_flipy=0.5, p_transx=0.5, trans_xmin=-5, trans_xmax=5, p_transy=0.5, trans_ymin=-3, trans_ymax=3,
+            p_transz=0.5, trans_zmin=-1, trans_zmax=0., p_rot_roll=0.5, rot_rollmin=-5, rot_rollmax=5, p_rot_pitch=0.5,
+            rot_pitchmin=-5, rot_pitchmax=5, p_rot_yaw=0.5, rot_yawmin=5, rot_yawmax=-5)
+_MEAN, _STDS = [12.12, 10.88, 0.23, -1.04, 0.21], [12.32, 11.47, 6.91, 0.86, 0.16]
+# (tag, seed, points, loader config) -- the sensor blocks of tasks/salsanext/config_server_{kitti,nus}.yaml
+RANGE_CASES = (
+    ("kitti", 0, 30000, {"augmentation": _AUG, "sensor": dict(proj_h=64, proj_w=512, fov_up=3., fov_down=-25., fov_left=-45,
+                                                             fov_right=45, img_mean=_MEAN, img_stds=_STDS)}),
+    ("nus", 3, 30000, {"augmentation": _AUG, "sensor": dict(proj_h=32, proj_w=2048, fov_up=10., fov_down=-30.,
+                                                           fov_left=-180, fov_right=180, img_mean=_MEAN, img_stds=_STDS)}),
+)

@@ -33,7 +33,7 @@ OUT = os.path.join(ROOT, "tests", "golden")
 from pmf_amd.utils.detinit import deterministic_init, det_tensor, synthetic_batch  # noqa: E402
 from oracle import pmf_torch as O  # noqa: E402
 from oracle import knn_ref, loader_ref  # noqa: E402,F401
-from oracle.cases import knn_case  # noqa: E402
+from oracle.cases import knn_case, RANGE_CASES  # noqa: E402
 
 
 def _load(modname, relpath):
@@ -406,6 +406,46 @@ def loader_v2(R):
     print("g9_loader_v2: %d arrays, frames %s" % (len(out), [out["v2.%s.proj" % t].shape for t in ("a", "b")]))
 
 
+def range_loader(R):
+    """G10: reference RangeProjection / SalsaNextLoader (return_uproj path) and Augmentor on synthetic sweeps."""
+    import random
+    from oracle.cases import lidar_sweep
+    proj = _load("pc_processor.dataset.preprocess.projection", "pc_processor/dataset/preprocess/projection.py")
+    sys.modules["pc_processor.dataset.preprocess"].projection = proj
+    SL = _load("refpc_salsanext_loader", "pc_processor/dataset/salsanext_loader.py")
+    aug = sys.modules["pc_processor.dataset.preprocess.augmentor"]
+    out = {}
+    for tag, seed, npts, cfg in RANGE_CASES:
+        pts, sem, lut = lidar_sweep(seed, npts, cfg["sensor"]["fov_up"], cfg["sensor"]["fov_down"])
+        ds = types.SimpleNamespace()
+        ds.loadDataByIndex = lambda i: (pts.copy(), sem, np.zeros_like(sem))
+        ds.labelMapping = lambda l: lut[l]
+        ds.__len__ = lambda: 1
+        ld = SL.SalsaNextLoader(ds, cfg, is_train=False, return_uproj=True)
+        feat, label, mask, rng_img, ux, uy, ud = ld[0]
+        pc, pr, pidx, pmask = ld.projection.doProjection(pts.copy())
+        out.update({"%s.feature" % tag: feat.numpy(), "%s.label" % tag: label.numpy(), "%s.mask" % tag: mask.numpy(),
+                    "%s.range" % tag: rng_img.numpy(), "%s.ux" % tag: ux.numpy().astype(np.int32),
+                    "%s.uy" % tag: uy.numpy().astype(np.int32), "%s.ud" % tag: ud.numpy(),
+                    "%s.proj_idx" % tag: pidx, "%s.proj_mask" % tag: pmask})
+        assert np.array_equal(pc[pidx >= 0], pts[pidx[pidx >= 0]]) and (pc[pidx < 0] == -1).all()
+        # training path: the augmentation driven by Python's `random`
+        random.seed(100 + seed)
+        params = aug.AugmentParams()
+        a = cfg["augmentation"]
+        params.setFlipProb(p_flipx=a["p_flipx"], p_flipy=a["p_flipy"])
+        params.setTranslationParams(**{k: a[k] for k in a if "trans" in k})
+        params.setRotationParams(**{k: a[k] for k in a if "rot" in k})
+        out["%s.augmented" % tag] = aug.Augmentor(params).doAugmentation(pts.copy())
+        random.seed(100 + seed)
+        ldt = SL.SalsaNextLoader(ds, cfg, is_train=True, return_uproj=False)
+        ft, lt, mt = ldt[0]
+        out.update({"%s.train.feature" % tag: ft.numpy(), "%s.train.label" % tag: lt.numpy(),
+                    "%s.train.mask" % tag: mt.numpy()})
+    np.savez_compressed(os.path.join(OUT, "g10_range.npz"), **out)
+    print("g10_range: %d arrays" % len(out), {k: v.shape for k, v in out.items() if k.endswith("feature")})
+
+
 def trainer_trace(R):
     """G7: two consecutive optimisation steps (AdamW lidar / SGD-Nesterov camera, trainer.py:80-98,214-219)
     on config-1 shapes (64x512, bs 1), dropout p=0."""
@@ -448,6 +488,6 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     R = import_reference()
-    which = sys.argv[1:] or ["blocks", "whole_net", "losses_metrics", "knn", "loader", "trainer_trace", "epmf", "loader_v2"]
+    which = sys.argv[1:] or ["blocks", "whole_net", "losses_metrics", "knn", "loader", "trainer_trace", "epmf", "loader_v2", "range_loader"]
     for name in which:
         globals()[name](R)

@@ -696,3 +696,112 @@ def test_two_rank_data_parallel_on_one_gpu():
     ret = mgr.dict()
     mp.spawn(_dp_worker, args=(2, 29551, ret), nprocs=2, join=True)
     assert ret["finite"] and ret["same"], dict(ret)
+
+
+# ---------------------------------------------------------------------------------------------- SalsaNext range loader
+def _range_boundary_ok(pts, cfg, ux_a, uy_a, ux_b, uy_b):
+    """index pairs may differ only for points whose exact (float64) pixel coordinate sits on a pixel edge: numpy's
+    float32 arctan2 / arcsin are platform dependent in the last ulp (see range_project.hip) -> affected pixel set"""
+    s = cfg["sensor"]
+    bad = np.nonzero((ux_a != ux_b) | (uy_a != uy_b))[0]
+    assert bad.size <= 8, "%d index mismatches" % bad.size
+    p = pts[bad].astype(np.float64)
+    d = np.sqrt((p[:, :3] ** 2).sum(1))
+    fl, fr = abs(s["fov_left"]) / 180 * np.pi, abs(s["fov_right"]) / 180 * np.pi
+    fu, fd = abs(s["fov_up"]) / 180 * np.pi, abs(s["fov_down"]) / 180 * np.pi
+    col = (-np.arctan2(p[:, 1], p[:, 0]) + fl) / (fl + fr) * s["proj_w"]
+    row = (1 - (np.arcsin(p[:, 2] / d) + fd) / (fu + fd)) * s["proj_h"]
+    for i in range(bad.size):
+        near = min(abs(col[i] - round(col[i])), abs(row[i] - round(row[i])))
+        assert near < 1e-3, "point %d: indices differ away from a pixel edge" % bad[i]
+        assert abs(int(ux_a[bad[i]]) - int(ux_b[bad[i]])) <= 1 and abs(int(uy_a[bad[i]]) - int(uy_b[bad[i]])) <= 1
+    touched = np.zeros((s["proj_h"], s["proj_w"]), bool)
+    touched[uy_a[bad], ux_a[bad]] = True
+    touched[uy_b[bad], ux_b[bad]] = True
+    return ~touched
+
+
+def _range_dataset(pts, sem, lut):
+    import types
+    ds = types.SimpleNamespace()
+    ds.loadDataByIndex = lambda i: (pts.copy(), sem, np.zeros_like(sem))
+    ds.labelMapping = lambda l: lut[l]
+    return ds
+
+
+@pytest.mark.parametrize("case_id", [0, 1])
+def test_range_loader_matches_oracle_and_fixture(case_id, golden):
+    """SalsaNextLoader (HIP kernels through the C ABI) vs oracle/range_projection_ref.py and the reference's outputs"""
+    import random
+    from oracle import range_projection_ref as RR
+    from oracle.cases import lidar_sweep, RANGE_CASES
+    from pmf_amd.dataset import SalsaNextLoader
+    tag, seed, npts, cfg = RANGE_CASES[case_id]
+    s = cfg["sensor"]
+    g = golden("g10_range")
+    pts, sem, lut = lidar_sweep(seed, npts, s["fov_up"], s["fov_down"])
+    ds = _range_dataset(pts, sem, lut)
+    ld = SalsaNextLoader(ds, cfg, is_train=False, return_uproj=True)
+    feat, label, mask, rng, ux, uy, ud = [t.cpu().numpy() for t in ld[0]]
+    pc, pr, pidx, pmask = [t.cpu().numpy() for t in ld.projection.doProjection(pts)]
+    fov = RR.fov_constants(s["fov_up"], s["fov_down"], s["fov_left"], s["fov_right"])
+    o = RR.loader_item(pts, lut[sem], fov, s["proj_h"], s["proj_w"], s["img_mean"], s["img_stds"])
+    opc, _, oidx, omask, _, _, _ = RR.do_projection(pts, fov, s["proj_h"], s["proj_w"])
+    assert ux.dtype == np.int64 and ud.dtype == np.float32 and mask.dtype == np.int32 and feat.shape == (5, s["proj_h"], s["proj_w"])
+    np.testing.assert_array_equal(ud, o[6])                      # depth: sqrt / mul / add only -> exact everywhere
+    np.testing.assert_array_equal(ud, g[tag + ".ud"])
+    ok = _range_boundary_ok(pts, cfg, ux, uy, o[4], o[5])
+    ok &= _range_boundary_ok(pts, cfg, ux, uy, g[tag + ".ux"], g[tag + ".uy"])
+    assert ok.mean() > 0.999
+    for name, got, want in (("feature", feat, o[0]), ("label", label, o[1]), ("mask", mask, o[2]), ("range", rng, o[3]),
+                            ("proj_idx", pidx, oidx), ("proj_mask", pmask, omask), ("proj_range", pr, o[3])):
+        sel = (slice(None), ok) if got.ndim == 3 else ok
+        assert np.array_equal(got[sel], want[sel]), name
+        if name in ("feature", "label", "mask", "range", "proj_idx", "proj_mask"):
+            assert np.array_equal(got[sel], g["%s.%s" % (tag, name)][sel]), name + " (fixture)"
+    assert np.array_equal(pc[ok], opc[ok])
+    # training path: Python's `random` drives the draws as in the reference
+    random.seed(100 + seed)
+    ldt = SalsaNextLoader(ds, cfg, is_train=True, return_uproj=True)
+    aug = ldt.augmentor.doAugmentation(pts.copy()).cpu().numpy()
+    np.testing.assert_array_equal(aug, g[tag + ".augmented"])
+    random.seed(100 + seed)
+    ft, lt, mt, _, uxt, uyt, _ = [t.cpu().numpy() for t in ldt[0]]
+    ot = RR.loader_item(aug, lut[sem], fov, s["proj_h"], s["proj_w"], s["img_mean"], s["img_stds"])
+    okt = _range_boundary_ok(aug, cfg, uxt, uyt, ot[4], ot[5])
+    assert np.array_equal(ft[:, okt], g[tag + ".train.feature"][:, okt]) and np.array_equal(lt[okt], g[tag + ".train.label"][okt])
+    assert np.array_equal(mt[okt], g[tag + ".train.mask"][okt])
+
+
+def test_range_projection_edges_and_knn_chain():
+    """ties (equal depth on one pixel -> lower index), empty sweep, argument errors, and the SalsaNext inference chain
+    loader -> KNN with (x, y) in loader order (tasks/salsanext_eval_nuscenes/infer.py:99-105) against the oracles"""
+    from oracle import range_projection_ref as RR, knn_ref
+    from oracle.cases import lidar_sweep
+    from pmf_amd.dataset.preprocess.projection import RangeProjection
+    from pmf_amd.postproc import KNN
+    fov = RR.fov_constants(3., -25., -45, 45)
+    pts, _, _ = lidar_sweep(1, 4000, duplicates=True)
+    rp = RangeProjection(3., -25., 64, 16, -45, 45)
+    pc, pr, pidx, pmask = [t.cpu().numpy() for t in rp.doProjection(pts)]
+    o = RR.do_projection(pts, fov, 16, 64)
+    ux, uy = rp.cached_data["uproj_x_idx"].cpu().numpy(), rp.cached_data["uproj_y_idx"].cpu().numpy()
+    if np.array_equal(ux, o[4]) and np.array_equal(uy, o[5]):
+        assert np.array_equal(pidx, o[2]) and np.array_equal(pr, o[1]) and np.array_equal(pc, o[0])
+    e = rp.doProjection(np.zeros((0, 4), np.float32))
+    assert (e[2] == -1).all() and (e[1] == -1).all() and e[3].sum() == 0 and (e[0] == -1).all()
+    with pytest.raises(ValueError):
+        rp.doProjection(np.zeros((5, 2), np.float32))
+    assert L.lib().pmf_range_project_index(None, 1, 4, 1.0, 1.0, 1.0, 1.0, 4, 4, None, None, None, None, None) == -1
+    # inference chain on a full sweep: range image + per-point (x, y, depth) from the loader feed the KNN vote
+    pts, _, _ = lidar_sweep(5, 60000, 10., -30.)
+    rp = RangeProjection(10., -30., 2048, 32)
+    _, pr, _, _ = rp.doProjection(pts)
+    c = rp.cached_data
+    rng_ = np.random.Generator(np.random.PCG64(3))
+    am = torch.as_tensor(rng_.integers(0, 17, (32, 2048)), dtype=torch.int64).cuda()
+    knn = KNN({"knn": 5, "search": 5, "sigma": 1.0, "cutoff": 1.0}, 17)
+    got = knn(pr, c["uproj_depth"], am, c["uproj_x_idx"].long(), c["uproj_y_idx"].long()).cpu().numpy()
+    want = knn_ref.knn_vote(pr.cpu().numpy(), c["uproj_depth"].cpu().numpy(), am.cpu().numpy(),
+                            c["uproj_x_idx"].cpu().numpy().astype(np.int64), c["uproj_y_idx"].cpu().numpy().astype(np.int64))
+    np.testing.assert_array_equal(got, want)

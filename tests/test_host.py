@@ -7,6 +7,7 @@ import re
 import numpy as np
 import pytest
 import torch
+import types
 
 from pmf_amd import _lib as L
 from pmf_amd.models import PMFNet, SalsaNext
@@ -36,6 +37,39 @@ def test_argument_errors_without_gpu():
     d = L.ConvDesc()
     assert lib.pmf_conv_fwd(C.byref(d), None) == -1            # nsrc = 0 -> PMF_E_ARG
     assert lib.pmf_knn_vote(None, None, None, None, None, 4, 4, 10, 5, 4, None, C.c_float(1.0), 20, None, None) == -1
+    assert lib.pmf_range_project_index(None, 1, 4, 1.0, 1.0, 1.0, 1.0, 4, 4, None, None, None, None, None) == -1
+    assert lib.pmf_range_project_gather(None, 1, 4, None, 4, 4, None, None, None, None, None, None, None, None, None,
+                                        None) == -1
+    assert lib.pmf_points_transform(None, 1, 2, 0, 0, 0.0, 0.0, 0.0, None, None) == -1
+
+
+def test_range_loader_surface_and_no_cpu_fallback():
+    """salsanext_loader.py / projection.py / augmentor.py mirrors: same names, random-draw order, and a loud failure
+    (never a CPU path) without a GPU"""
+    import random
+    import pytest
+    from oracle import range_projection_ref as RR
+    from oracle.cases import RANGE_CASES
+    from pmf_amd.dataset import SalsaNextLoader
+    from pmf_amd.dataset.preprocess import augmentor, projection
+    cfg = RANGE_CASES[0][3]
+    ds = types.SimpleNamespace(loadDataByIndex=lambda i: (np.ones((8, 4), np.float32), np.zeros(8, np.int32), None),
+                               labelMapping=lambda l: l, __len__=lambda: 3)
+    ld = SalsaNextLoader(ds, cfg, is_train=True, return_uproj=True, device="cpu")
+    assert isinstance(ld.projection, projection.RangeProjection) and isinstance(ld.augmentor, augmentor.Augmentor)
+    p, a = ld.augmentor.parmas, cfg["augmentation"]
+    assert all(getattr(p, k) == a[k] for k in a)
+    random.seed(7)
+    got = ld.augmentor.draw()
+    random.seed(7)
+    assert got == RR.draw_augmentation(a, random)
+    rp = ld.projection
+    assert (np.float32(abs(rp.fov_left)), np.float32(rp.fov_h), np.float32(abs(rp.fov_down)), np.float32(rp.fov_v)) == \
+        RR.fov_constants(3., -25., -45, 45)
+    with pytest.raises(RuntimeError):
+        ld[0]
+    with pytest.raises(AssertionError):
+        projection.RangeProjection(-1., -25., 512, 64)
 
 
 def test_state_dict_matches_reference_keys(golden):
