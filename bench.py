@@ -86,6 +86,63 @@ def infer_bench(args, model, dev):
         "roofline": None, "cpu_baseline": None}))
 
 
+def salsanext_bench(args, dev, multi, rank, world):
+    """the LiDAR-only task (tasks/salsanext) -- range-image loader kernels feeding one
+    SalsaNextEngine iteration per step; the sweep (one per sample, 120 k points) is resident, projected inside the
+    timed region.  Reported under its own metric name."""
+    from oracle.cases import lidar_sweep              # synthetic input recipe only (no oracle arithmetic)
+    from pmf_amd.dataset.preprocess.projection import RangeProjection
+    from pmf_amd.engine import SalsaNextEngine
+    from pmf_amd.models import SalsaNext
+    torch.manual_seed(1)
+    torch.cuda.manual_seed(1)
+    model = SalsaNext(5, args.nclasses, 32).to(dev)
+    eng = SalsaNextEngine(model, args.nclasses, lr=1e-3, warmup_steps=100, max_steps=15000, distributed=multi)
+    rp = RangeProjection(3., -25., args.width, args.height, device=dev)
+    mean, stds = torch.tensor(KITTI_MEAN, device=dev), torch.tensor(KITTI_STD, device=dev)
+    sweeps = []
+    for b in range(args.bs):
+        pts, sem, lut = lidar_sweep(10 * rank + b, 120000)
+        sweeps.append((rp.to_device(pts), torch.as_tensor(lut[sem] % args.nclasses).to(dev)))
+
+    def step():
+        items = [rp.loader_item(p, l, mean, stds) for p, l in sweeps]
+        feat = torch.stack([i[0] for i in items])
+        label = torch.stack([i[1] for i in items])
+        mask = torch.stack([i[2] for i in items])
+        return eng.train_step(feat, mask, label)
+    for _ in range(args.warmup):
+        step()
+    if multi:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _ = step()
+    torch.cuda.synchronize()
+    if multi:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    if multi:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = t.item()
+    if not np.isfinite(float(loss)):
+        raise SystemExit("bench.py: non-finite loss")
+    if rank == 0:
+        print(json.dumps({
+            "metric": "train iters/sec SalsaNext %dx%d bs=%d (range loader + Lovasz/focal step)" % (args.height, args.width, args.bs),
+            "value": world * args.steps / dt, "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "SalsaNext (LiDAR-only task, SURVEY 8f-2) %dx%d range image from 120k-point sweeps, "
+                                   "bs=%d/GPU, AdamW" % (args.height, args.width, args.bs), "final_loss": float(loss)},
+            "roofline": None, "cpu_baseline": None}))
+    if multi:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def cpu_baseline(bs, h, w):
     """the oracle port on the host cores.  Bounded sample: the same full iteration on a 1/8-area slice of the
     workload (bs=1, H x W/4), 1 warm-up + 2 timed steps, scaled by pixel count (every term of the step is linear
@@ -127,7 +184,7 @@ def main():
                          "post-processing per frame, reported as frames/s under its own metric name")
     ap.add_argument("--backbone", default="resnet34", help="camera backbone (resnet50: BASELINE configs[3] family)")
     ap.add_argument("--nclasses", type=int, default=20)
-    ap.add_argument("--model", default="pmf", choices=["pmf", "epmf"],
+    ap.add_argument("--model", default="pmf", choices=["pmf", "epmf", "salsanext"],
                     help="pmf = the headline workload (BASELINE configs[2]); epmf = configs[4] (EPMF-R34), reported "
                          "under its own metric name, no CPU baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -148,6 +205,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", init_method="env://", world_size=world, rank=rank)
+    if args.model == "salsanext":
+        return salsanext_bench(args, dev, multi, rank, world)
     from pmf_amd.engine import TrainEngine
     from pmf_amd.models import PMFNet, EPMFNet
 

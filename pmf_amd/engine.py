@@ -165,3 +165,80 @@ class TrainEngine:
             self.metrics.addBatch(lidar_pred.argmax(dim=1), label)
             self.metrics_img.addBatch(camera_pred.argmax(dim=1), label)
         return total, terms
+
+
+class SalsaNextEngine:
+    """One optimisation step of the LiDAR-only task (tasks/salsanext/trainer.py:171-274 of the reference):
+
+        label <- label * (label >= 1), mask <- mask * (label >= 1) -> SalsaNext (HIP plan) -> Lovasz(ignore 0) +
+        focal(gamma 2, alpha, mask) -> backward (HIP plan) -> AdamW(lr) -> WarmupCosineLR.step -> confusion matrix.
+
+    Parameters and gradients live in one flat buffer (one fused AdamW launch); the reference runs this task under
+    nn.DataParallel -- here one process per GPU with the same range all-reduce as TrainEngine when distributed."""
+
+    def __init__(self, model, nclasses, lr=1e-3, momentum=0.9, alpha=None, ignore_class=(0,), warmup_steps=1, max_steps=1,
+                 distributed=False, flat_state=True):
+        dev = next(model.parameters()).device
+        self.model, self.device, self.nclasses, self.distributed = model, dev, nclasses, distributed
+        fused = dict(fused=True) if dev.type == "cuda" else {}
+        self.flat = None
+        params = list(model.parameters())
+        if dev.type == "cuda" and flat_state:
+            from .models.pmf_net import flatten_training_state
+            self.flat = flatten_training_state(model, [params], dev)
+            params = [self.flat.group_params[0]]
+            if distributed:
+                import torch.distributed as dist
+                self._pending, self._frontier = [], None
+                model._bwd_segment_hook = self._allreduce_ready_ranges
+                dist.broadcast(self.flat.param, 0)
+                for b in model.buffers():
+                    dist.broadcast(b, 0)
+        elif distributed:
+            raise RuntimeError("SalsaNextEngine: data parallelism needs the flat training state on a GPU")
+        self.optimizer = torch.optim.AdamW(params, lr=lr, **fused)                      # trainer.py:57-61
+        if alpha is None:
+            alpha = np.ones(nclasses, np.float32)
+            alpha[0] = 0
+        self.focal = FocalSoftmaxLoss(nclasses, gamma=2, alpha=np.asarray(alpha, np.float32), softmax=False).to(dev)
+        self.lovasz = Lovasz_softmax(ignore=0)
+        self.metrics = IOUEval(nclasses, dev, ignore=list(ignore_class), is_distributed=distributed)
+        self.scheduler = WarmupCosineLR(self.optimizer, lr, warmup_steps, momentum, max_steps)
+        self.iteration = 0
+
+    _allreduce_ready_ranges = TrainEngine._allreduce_ready_ranges
+    _finish_allreduce = TrainEngine._finish_allreduce
+
+    def forward_loss(self, feature, mask, label):
+        label = label.long()
+        label = label * label.ge(1).long()
+        mask = mask.to(feature.dtype) * label.ge(1).to(feature.dtype)
+        output = self.model(feature)
+        loss_s = self.focal(output, label, mask=mask)
+        loss_lovasz = self.lovasz(output, label)
+        return loss_lovasz + loss_s, {"focal": loss_s.detach(), "lovasz": loss_lovasz.detach()}, output, label
+
+    def train_step(self, feature, mask, label):
+        self.model.train()
+        total, terms, output, label = self.forward_loss(feature, mask, label)
+        if self.flat is None:
+            self.optimizer.zero_grad(set_to_none=True)
+        if self.flat is not None and self.distributed:
+            import torch.distributed as dist
+            total.backward(torch.full_like(total, 1.0 / dist.get_world_size()))
+            self._finish_allreduce()
+        else:
+            total.backward()
+        self.optimizer.step()
+        self.scheduler.step()
+        with torch.no_grad():
+            self.metrics.addBatch(output.argmax(dim=1), label)
+        self.iteration += 1
+        return total.detach(), terms
+
+    @torch.no_grad()
+    def eval_step(self, feature, mask, label):
+        self.model.eval()
+        total, terms, output, label = self.forward_loss(feature, mask, label)
+        self.metrics.addBatch(output.argmax(dim=1), label)
+        return total, terms
