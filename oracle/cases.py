@@ -72,3 +72,49 @@ RANGE_CASES = (
     ("nus", 3, 30000, {"augmentation": _AUG, "sensor": dict(proj_h=32, proj_w=2048, fov_up=10., fov_down=-30.,
                                                            fov_left=-180, fov_right=180, img_mean=_MEAN, img_stds=_STDS)}),
 )
+
+
+def kitti_tree(root, seed=0, seqs=(0, 8), frames=3, npts=500, h=24, w=80):
+    """writes a small SemanticKITTI-layout tree (velodyne/labels/image_2/calib.txt per sequence) + its label config;
+    returns (config_path, {(seq, frame): (points, raw uint32 labels, image)})."""
+    import os
+    import yaml
+    from PIL import Image
+    rng = np.random.Generator(np.random.PCG64(seed))
+    ids = [0, 1, 10, 11, 13, 30, 40, 44, 48, 50, 70, 72, 80, 252, 259]
+    learning = {k: (i % 6) for i, k in enumerate(ids)}
+    inv = {v: k for k, v in sorted(learning.items(), reverse=True)}
+    cfg = {"color_map": {k: [int(x) for x in rng.integers(0, 256, 3)] for k in ids},
+           "color_map_inv": {k: [int(x) for x in rng.integers(0, 256, 3)] for k in inv},
+           "learning_map": learning, "learning_map_inv": inv,
+           "content": {k: float(rng.random()) for k in ids},
+           "mapped_class_name": {k: "class%d" % k for k in inv}}
+    os.makedirs(root, exist_ok=True)
+    cfg_path = os.path.join(root, "labels.yaml")
+    with open(cfg_path, "w") as f:
+        yaml.safe_dump(cfg, f)
+    data = {}
+    for s in seqs:
+        sd = os.path.join(root, "%02d" % s)
+        for sub in ("velodyne", "labels", "image_2"):
+            os.makedirs(os.path.join(sd, sub), exist_ok=True)
+        P2 = np.array([[0.58 * w, 0, w / 2.0, 4.5e1], [0, 0.58 * w, h / 2.0, -0.3], [0, 0, 1.0, 2.7e-3]]) + 1e-3 * s
+        Tr = np.array([[4.2e-4, -9.9996e-1, -8.4e-3, -1.2e-2], [-7.2e-3, 8.4e-3, -9.9993e-1, -5.4e-2],
+                       [9.9997e-1, 4.8e-4, -7.2e-3, -2.9e-1]])
+        with open(os.path.join(sd, "calib.txt"), "w") as f:
+            f.write("P0: " + " ".join("%.12e" % v for v in np.zeros(12)) + "\n")
+            f.write("P2: " + " ".join("%.12e" % v for v in P2.reshape(-1)) + "\n")
+            f.write("Tr: " + " ".join("%.12e" % v for v in Tr.reshape(-1)) + "\n")
+        for fr in range(frames):
+            n = npts + 7 * fr
+            pts = np.stack([rng.uniform(-5, 60, n), rng.uniform(-25, 25, n), rng.uniform(-3, 2.5, n), rng.random(n)],
+                           1).astype(np.float32)
+            sem = rng.choice(ids, n).astype(np.uint32)
+            inst = rng.integers(0, 300, n).astype(np.uint32)
+            raw = (inst << 16) | sem
+            img = rng.integers(0, 256, (h, w, 3)).astype(np.uint8)
+            pts.tofile(os.path.join(sd, "velodyne", "%06d.bin" % fr))
+            raw.tofile(os.path.join(sd, "labels", "%06d.label" % fr))
+            Image.fromarray(img).save(os.path.join(sd, "image_2", "%06d.png" % fr))
+            data[("%02d" % s, "%06d" % fr)] = (pts, raw, img)
+    return cfg_path, data

@@ -446,6 +446,28 @@ def range_loader(R):
     print("g10_range: %d arrays" % len(out), {k: v.shape for k, v in out.items() if k.endswith("feature")})
 
 
+def kitti_formats(R):
+    """G11: the reference SemanticKitti parser on a synthetic on-disk tree (oracle/cases.py kitti_tree)."""
+    import tempfile
+    from oracle.cases import kitti_tree
+    root = tempfile.mkdtemp()
+    cfg, data = kitti_tree(root)
+    ds = R.parser.SemanticKitti(root, [8, 0], cfg)
+    out = {"class_map_lut": ds.class_map_lut, "class_map_lut_inv": ds.class_map_lut_inv, "cls_freq": ds.cls_freq,
+           "sem_color_lut": ds.sem_color_lut, "sem_color_lut_inv": ds.sem_color_lut_inv,
+           "order": np.array([os.path.relpath(f, root) for f in ds.pointcloud_files]),
+           "label_order": np.array([os.path.relpath(f, root) for f in ds.label_files]),
+           "image_order": np.array([os.path.relpath(f, root) for f in ds.image_files]),
+           "path_info": np.array([ds.parsePathInfoByIndex(i) for i in range(len(ds.pointcloud_files))])}
+    for seq, m in ds.proj_matrix.items():
+        out["proj." + seq] = m
+    pc, sem, inst = ds.loadDataByIndex(4)
+    out.update({"f4.points": pc, "f4.sem": sem, "f4.inst": inst, "f4.mapped": ds.labelMapping(sem),
+                "f4.image": np.asarray(ds.loadImage(4))})
+    np.savez_compressed(os.path.join(OUT, "g11_kitti_formats.npz"), **out)
+    print("g11_kitti_formats: %d arrays" % len(out))
+
+
 def trainer_trace(R):
     """G7: two consecutive optimisation steps (AdamW lidar / SGD-Nesterov camera, trainer.py:80-98,214-219)
     on config-1 shapes (64x512, bs 1), dropout p=0."""
@@ -488,6 +510,6 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     R = import_reference()
-    which = sys.argv[1:] or ["blocks", "whole_net", "losses_metrics", "knn", "loader", "trainer_trace", "epmf", "loader_v2", "range_loader"]
+    which = sys.argv[1:] or ["blocks", "whole_net", "losses_metrics", "knn", "loader", "trainer_trace", "epmf", "loader_v2", "range_loader", "kitti_formats"]
     for name in which:
         globals()[name](R)

@@ -864,3 +864,37 @@ def test_salsanext_engine_train_steps_match_oracle():
     assert abs(trace[1][1] - trace[1][2]) <= 1e-3 * abs(trace[1][2]), trace
     assert eng.optimizer.param_groups[0]["lr"] == pytest.approx(opt.param_groups[0]["lr"], rel=1e-6)
     assert eng.metrics.conf_matrix.sum().item() == 2 * n * h * w
+
+
+def test_on_disk_kitti_tree_through_both_loaders(tmp_path):
+    """SemanticKITTI files on disk -> SemanticKitti parser -> perspective (PMF) and range (SalsaNext) loaders on the
+    GPU -> prediction file: every stage against the oracles on the arrays that were written"""
+    from oracle import loader_ref, range_projection_ref as RR
+    from oracle.cases import kitti_tree, RANGE_CASES
+    from pmf_amd.dataset import PerspectiveViewLoader, SalsaNextLoader
+    from pmf_amd.dataset.semantic_kitti import SemanticKitti, write_prediction
+    root = str(tmp_path)
+    cfg_path, data = kitti_tree(root, npts=4000, h=48, w=160)
+    ds = SemanticKitti(root, [0, 8], cfg_path)
+    pts, raw, img = data[("08", "000002")]
+    idx = 5
+    assert ds.parsePathInfoByIndex(idx) == ("08", "000002")
+    pv = PerspectiveViewLoader(ds, {"sensor": dict(h_pad=0, w_pad=0, proj_h=48, proj_w=160, proj_ht=48, proj_wt=160)},
+                               is_train=False, return_uproj=True)
+    feat, mask, label, xd, yd, depth = pv[idx]
+    rp, rx, ry, rd = loader_ref.project_frame(pts, (raw & 0xFFFF).astype(np.int32), img, ds.proj_matrix["08"],
+                                              ds.class_map_lut)
+    np.testing.assert_array_equal(torch.cat((feat, mask[None], label[None])).cpu().numpy(), rp)
+    np.testing.assert_array_equal(xd.cpu().numpy(), rx)
+    cfg = RANGE_CASES[0][3]
+    s = cfg["sensor"]
+    item = SalsaNextLoader(ds, cfg, is_train=False, return_uproj=True)[idx]
+    fov = RR.fov_constants(s["fov_up"], s["fov_down"], s["fov_left"], s["fov_right"])
+    o = RR.loader_item(pts, ds.labelMapping((raw & 0xFFFF).astype(np.int32)), fov, s["proj_h"], s["proj_w"],
+                       s["img_mean"], s["img_stds"])
+    ok = _range_boundary_ok(pts, cfg, item[4].cpu().numpy(), item[5].cpu().numpy(), o[4], o[5])
+    assert np.array_equal(item[0].cpu().numpy()[:, ok], o[0][:, ok]) and np.array_equal(item[1].cpu().numpy()[ok], o[1][ok])
+    # per-point prediction (here: the projected label looked up per point) -> KITTI submission file
+    pred = item[1][item[5], item[4]].long().cpu().numpy()
+    path = write_prediction(ds, idx, pred, os.path.join(root, "pred"))
+    assert np.array_equal(np.fromfile(path, np.int32), ds.class_map_lut_inv[pred])

@@ -142,3 +142,41 @@ def test_center_crop_geometry_matches_oracle():
     for (oh, ow, hp, wp) in ((16, 24, 2, 3), (26, 40, 1, 2), (21, 31, 0, 0)):
         ref = loader_ref.center_crop_pad(x, oh, ow, hp, wp)
         assert ref.shape == (3, oh, ow)
+
+
+def test_semantic_kitti_formats_match_reference(golden, tmp_path):
+    """.bin / .label / calib.txt / label config parsing and the prediction writer on a synthetic on-disk tree, against
+    what the reference's parser returned for the same tree (tests/golden/g11_kitti_formats.npz)"""
+    from oracle.cases import kitti_tree
+    from pmf_amd.dataset.semantic_kitti import SemanticKitti, write_prediction
+    root = str(tmp_path)
+    cfg, data = kitti_tree(root)
+    g = golden("g11_kitti_formats")
+    ds = SemanticKitti(root, [8, 0], cfg)
+    assert len(ds) == 6 and ds.sequences == [0, 8]
+    for name in ("class_map_lut", "class_map_lut_inv", "cls_freq", "sem_color_lut", "sem_color_lut_inv"):
+        got = getattr(ds, name)
+        assert got.dtype == g[name].dtype and np.array_equal(got, g[name]), name
+    for name, files in (("order", ds.pointcloud_files), ("label_order", ds.label_files), ("image_order", ds.image_files)):
+        assert [os.path.relpath(f, root) for f in files] == list(g[name])
+    assert [list(ds.parsePathInfoByIndex(i)) for i in range(6)] == g["path_info"].tolist()
+    for seq in ("00", "08"):
+        assert np.array_equal(ds.proj_matrix[seq], g["proj." + seq])            # float64 P2 . Tr, bit for bit
+    pc, sem, inst = ds.loadDataByIndex(4)
+    assert np.array_equal(pc, g["f4.points"]) and np.array_equal(sem, g["f4.sem"]) and np.array_equal(inst, g["f4.inst"])
+    assert sem.dtype == np.int32 and np.array_equal(ds.labelMapping(sem), g["f4.mapped"])
+    assert np.array_equal(np.asarray(ds.loadImage(4)), g["f4.image"])
+    assert np.array_equal(ds.loadLabelByIndex(4)[0], sem)
+    # prediction writer: learning ids -> original ids, int32, KITTI submission layout; round trip through readLabel
+    path = write_prediction(ds, 4, ds.labelMapping(sem), os.path.join(root, "out"))
+    assert path.endswith(os.path.join("sequences", "08", "predictions", "000001.label"))
+    back = np.fromfile(path, dtype=np.int32)
+    assert np.array_equal(back, ds.class_map_lut_inv[ds.class_map_lut[sem]]) and back.shape == sem.shape
+    # without labels: zero labels of the right length; error behaviour of the constructor
+    nl = SemanticKitti(root, [0], cfg, has_image=False, has_label=False)
+    p0, s0, i0 = nl.loadDataByIndex(0)
+    assert s0.shape == (p0.shape[0],) and not s0.any() and not i0.any() and nl.proj_matrix == {}
+    with pytest.raises(ValueError):
+        SemanticKitti(root, [0], os.path.join(root, "missing.yaml"))
+    with pytest.raises(ValueError):
+        SemanticKitti(os.path.join(root, "nowhere"), [0], cfg)
