@@ -2,3 +2,4 @@ from .perspective_view_loader import PerspectiveViewLoader, project_frame_gpu, c
 from .perspective_view_loader_v2 import PerspectiveViewLoaderV2, project_frame_v2_gpu  # noqa: F401
 from .salsanext_loader import SalsaNextLoader  # noqa: F401
 from .preprocess import augmentor, projection  # noqa: F401
+from . import semantic_kitti  # noqa: F401

@@ -180,3 +180,22 @@ def test_semantic_kitti_formats_match_reference(golden, tmp_path):
         SemanticKitti(root, [0], os.path.join(root, "missing.yaml"))
     with pytest.raises(ValueError):
         SemanticKitti(os.path.join(root, "nowhere"), [0], cfg)
+
+
+def test_pc_processor_shim_resolves_reference_imports():
+    """the import statements of tasks/pmf, tasks/epmf and tasks/salsanext resolve to pmf_amd"""
+    import importlib
+    import pc_processor
+    from pc_processor.dataset.preprocess import augmentor, projection
+    from pc_processor.dataset.semantic_kitti import SemanticKitti
+    import pmf_amd
+    assert pc_processor.dataset.SalsaNextLoader is pmf_amd.dataset.SalsaNextLoader
+    assert importlib.import_module("pc_processor.dataset.salsanext_loader").SalsaNextLoader is pmf_amd.dataset.SalsaNextLoader
+    assert projection.RangeProjection is pmf_amd.dataset.preprocess.projection.RangeProjection
+    assert augmentor.Augmentor is pmf_amd.dataset.preprocess.augmentor.Augmentor
+    assert SemanticKitti is pmf_amd.dataset.semantic_kitti.SemanticKitti
+    for name in ("PMFNet", "EPMFNet", "SalsaNext"):
+        assert getattr(pc_processor.models, name) is getattr(pmf_amd.models, name)
+    for name in ("Lovasz_softmax", "FocalSoftmaxLoss", "MultiTaskLoss"):
+        assert hasattr(pc_processor.loss, name)
+    assert pc_processor.postproc.KNN is pmf_amd.postproc.KNN and hasattr(pc_processor.utils, "WarmupCosineLR")
