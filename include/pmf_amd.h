@@ -283,6 +283,14 @@ int pmf_project_v2_scatter(const float* points, const int32_t* sem, const int32_
 int pmf_crop_pad(const float* src, int32_t C, int32_t h, int32_t w, int32_t top, int32_t left, float* dst,
                  int32_t oh, int32_t ow, int32_t pad_top, int32_t pad_left, int32_t ch, int32_t cw, pmf_stream_t s);
 
+/* Multi-camera merge of per-point predictions (replaces tasks/pmf_eval_nuscenes/infer.py:18-38 getMergePred): for each
+ * of pc_size LiDAR points the label of the camera with the highest confidence; point_idx[j] / conf[j] / label[j] are
+ * device arrays of counts[j] entries for camera j (host arrays of device pointers; counts on the host); a camera that
+ * does not list a point counts as confidence 0 / label -1, ties go to the lowest camera index (torch.argmax);
+ * keys: u64[pc_size] scratch; merged: i64[pc_size], -1 where no camera decides. */
+int pmf_merge_pred(int32_t n_cams, const int64_t* const* point_idx, const float* const* conf,
+                   const int64_t* const* label, const int64_t* counts, int64_t pc_size, uint64_t* keys, int64_t* merged,
+                   pmf_stream_t s);
 /* SalsaNext range-image loader (replaces pc_processor/dataset/preprocess/projection.py:31-86 RangeProjection.doProjection,
  * salsanext_loader.py:48-84 and augmentor.py:97-180).
  * pmf_points_transform: in place on points f32[P][C] -- flips (x <- -x, y <- -y), float32 translation, then

@@ -118,3 +118,26 @@ def kitti_tree(root, seed=0, seqs=(0, 8), frames=3, npts=500, h=24, w=80):
             Image.fromarray(img).save(os.path.join(sd, "image_2", "%06d.png" % fr))
             data[("%02d" % s, "%06d" % fr)] = (pts, raw, img)
     return cfg_path, data
+
+
+def merge_case(seed, pc_size, n_cams=6, ncls=17):
+    """per-camera (point_idx int64, conf f32, label int64) lists for the nuScenes view merge: ~30 % of the points per
+    view, unseen points, exact confidence ties between views, and zero-confidence entries (padded image rows)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    idx, conf, lab = [], [], []
+    for j in range(n_cams):
+        sel = np.sort(rng.choice(pc_size, int(0.3 * pc_size), replace=False)).astype(np.int64)
+        sel = sel[sel >= 8]                                   # points 0..7 are placed by hand below
+        c = rng.uniform(0.06, 1.0, sel.size).astype(np.float32)
+        c = (np.round(c * 64) / 64).astype(np.float32)       # coarse values: ties between views are frequent
+        l = rng.integers(0, ncls, sel.size).astype(np.int64)
+        idx.append(sel); conf.append(c); lab.append(l)
+
+    def put(j, p, c, l):
+        idx[j] = np.append(idx[j], np.int64(p)); conf[j] = np.append(conf[j], np.float32(c)); lab[j] = np.append(lab[j], np.int64(l))
+    put(2, 1, 0.0, 0)                  # only a zero-confidence entry, not in view 0 -> -1
+    put(0, 2, 0.0, 5); put(3, 2, 0.0, 7)   # zero confidence in view 0 too -> view 0's label
+    put(1, 3, 0.5, 4); put(4, 3, 0.5, 9)   # tie -> first view
+    put(5, 4, 0.25, 0)                 # label 0 from the last view
+    put(0, 5, 0.3, 2); put(1, 5, 0.9, 11)  # higher confidence wins
+    return idx, conf, lab              # points 0, 6, 7 unseen

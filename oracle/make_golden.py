@@ -468,6 +468,31 @@ def kitti_formats(R):
     print("g11_kitti_formats: %d arrays" % len(out))
 
 
+def merge(R):
+    """G12: the reference's getMergePred (tasks/pmf_eval_nuscenes/infer.py:18-38), executed from its source file.
+    The module imports the nuScenes devkit at the top, so only that function is compiled (ast) -- with Tensor.cuda
+    mapped to the identity, since there is no GPU in the container where fixtures are generated."""
+    import ast
+    from oracle.cases import merge_case
+    path = os.path.join(REF, "tasks/pmf_eval_nuscenes/infer.py")
+    tree = ast.parse(open(path).read())
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "getMergePred"]
+    ns = {"torch": torch}
+    exec(compile(ast.Module(body=fn, type_ignores=[]), path, "exec"), ns)
+    keep = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    out = {}
+    try:
+        for tag, seed, pc in (("a", 0, 3000), ("b", 4, 347)):
+            idx, conf, lab = merge_case(seed, pc)
+            t = lambda xs: [torch.from_numpy(x) for x in xs]
+            out["merge.%s" % tag] = ns["getMergePred"](t(idx), t(conf), t(lab), pc).numpy()
+    finally:
+        torch.Tensor.cuda = keep
+    np.savez_compressed(os.path.join(OUT, "g12_merge.npz"), **out)
+    print("g12_merge:", {k: (v.shape, int((v < 0).sum())) for k, v in out.items()})
+
+
 def trainer_trace(R):
     """G7: two consecutive optimisation steps (AdamW lidar / SGD-Nesterov camera, trainer.py:80-98,214-219)
     on config-1 shapes (64x512, bs 1), dropout p=0."""
@@ -510,6 +535,6 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     R = import_reference()
-    which = sys.argv[1:] or ["blocks", "whole_net", "losses_metrics", "knn", "loader", "trainer_trace", "epmf", "loader_v2", "range_loader", "kitti_formats"]
+    which = sys.argv[1:] or ["blocks", "whole_net", "losses_metrics", "knn", "loader", "trainer_trace", "epmf", "loader_v2", "range_loader", "kitti_formats", "merge"]
     for name in which:
         globals()[name](R)

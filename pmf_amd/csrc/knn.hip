@@ -84,3 +84,51 @@ extern "C" int pmf_knn_vote(const float* proj_range, const float* unproj_range, 
   PMF_LAUNCH_CHECK();
   return 0;
 }
+
+// ---- multi-camera merge (tasks/pmf_eval_nuscenes/infer.py:18-38 getMergePred) --------------------------------------
+// Per LiDAR point the prediction of the camera with the highest confidence; a camera that does not see the point
+// counts as confidence 0 / label -1, torch.argmax breaks ties towards the FIRST camera.  One 64-bit atomicMax per
+// (camera, visible point) on key = confidence bits << 32 | (n_cams-1-camera) << 16 | (label+1): confidences are
+// probabilities (>= 0), so the float bit pattern orders like the value; every key starts as "camera 0, absent".
+// The reference fills a [6, P] table and then walks the P points in a Python loop.
+__global__ __launch_bounds__(256) void merge_scatter_k(const int64_t* __restrict__ point_idx, const float* __restrict__ conf,
+                                                       const int64_t* __restrict__ label, int64_t n, int cam, int n_cams,
+                                                       int64_t pc_size, unsigned long long* __restrict__ keys) {
+  const int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x;
+  if (i >= n) return;
+  const int64_t p = point_idx[i];
+  if (p < 0 || p >= pc_size) return;
+  const unsigned long long key = ((unsigned long long)__float_as_uint(conf[i]) << 32) |
+                                 ((unsigned long long)(n_cams - 1 - cam) << 16) | (unsigned long long)((label[i] + 1) & 0xffff);
+  atomicMax(keys + p, key);
+}
+__global__ __launch_bounds__(256) void merge_init_k(unsigned long long* __restrict__ keys, int64_t pc_size, int n_cams) {
+  const int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x;
+  if (i < pc_size) keys[i] = (unsigned long long)(n_cams - 1) << 16;
+}
+__global__ __launch_bounds__(256) void merge_final_k(const unsigned long long* __restrict__ keys, int64_t pc_size,
+                                                     int64_t* __restrict__ out) {
+  const int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x;
+  if (i < pc_size) out[i] = (int64_t)(keys[i] & 0xffffull) - 1;
+}
+
+extern "C" int pmf_merge_pred(int32_t n_cams, const int64_t* const* point_idx, const float* const* conf,
+                              const int64_t* const* label, const int64_t* counts, int64_t pc_size, uint64_t* keys,
+                              int64_t* merged, pmf_stream_t s) {
+  if (n_cams < 1 || n_cams > 255 || pc_size < 0 || !counts || (pc_size > 0 && (!keys || !merged))) return PMF_E_ARG;
+  for (int j = 0; j < n_cams; ++j)
+    if (counts[j] < 0 || (counts[j] > 0 && (!point_idx || !conf || !label || !point_idx[j] || !conf[j] || !label[j])))
+      return PMF_E_ARG;
+  if (pc_size == 0) return 0;
+  hipStream_t st = (hipStream_t)s;
+  hipLaunchKernelGGL(merge_init_k, dim3((unsigned)cdiv64(pc_size, 256)), dim3(256), 0, st, (unsigned long long*)keys,
+                     pc_size, n_cams);
+  for (int j = 0; j < n_cams; ++j)
+    if (counts[j] > 0)
+      hipLaunchKernelGGL(merge_scatter_k, dim3((unsigned)cdiv64(counts[j], 256)), dim3(256), 0, st, point_idx[j], conf[j],
+                         label[j], counts[j], j, n_cams, pc_size, (unsigned long long*)keys);
+  hipLaunchKernelGGL(merge_final_k, dim3((unsigned)cdiv64(pc_size, 256)), dim3(256), 0, st,
+                     (const unsigned long long*)keys, pc_size, merged);
+  PMF_LAUNCH_CHECK();
+  return 0;
+}

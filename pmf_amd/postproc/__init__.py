@@ -1,1 +1,2 @@
 from .knn import KNN  # noqa: F401
+from .merge import getMergePred  # noqa: F401

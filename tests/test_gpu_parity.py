@@ -898,3 +898,27 @@ def test_on_disk_kitti_tree_through_both_loaders(tmp_path):
     pred = item[1][item[5], item[4]].long().cpu().numpy()
     path = write_prediction(ds, idx, pred, os.path.join(root, "pred"))
     assert np.array_equal(np.fromfile(path, np.int32), ds.class_map_lut_inv[pred])
+
+
+@pytest.mark.parametrize("tag,seed,pc", [("a", 0, 3000), ("b", 4, 347), (None, 9, 34720)])
+def test_camera_merge_exact(tag, seed, pc, golden):
+    """getMergePred (pmf_merge_pred through the C ABI) vs the oracle and the reference-run fixture; edge cases"""
+    from oracle import merge_ref
+    from oracle.cases import merge_case
+    from pmf_amd.postproc import getMergePred
+    idx, conf, lab = merge_case(seed, pc)
+    t = lambda xs: [torch.from_numpy(x).cuda() for x in xs]
+    got = getMergePred(t(idx), t(conf), t(lab), pc).cpu().numpy()
+    np.testing.assert_array_equal(got, merge_ref.get_merge_pred(idx, conf, lab, pc))
+    if tag:
+        np.testing.assert_array_equal(got, golden("g12_merge")["merge." + tag])
+    # a view that sees nothing, a single view, no points at all
+    e = torch.zeros(0, dtype=torch.int64).cuda()
+    one = getMergePred([torch.tensor([2, 0]).cuda(), e], [torch.tensor([0.5, 0.25]).cuda(), e.float()],
+                       [torch.tensor([3, 0]).cuda(), e], 4).cpu().tolist()
+    assert one == [0, -1, 3, -1]
+    assert getMergePred([e], [e.float()], [e], 0).numel() == 0
+    with pytest.raises(ValueError):
+        getMergePred([e], [e.float()], [], 3)
+    with pytest.raises(RuntimeError):
+        getMergePred([e.cpu()], [e.float().cpu()], [e.cpu()], 3)

@@ -41,6 +41,7 @@ def test_argument_errors_without_gpu():
     assert lib.pmf_range_project_gather(None, 1, 4, None, 4, 4, None, None, None, None, None, None, None, None, None,
                                         None) == -1
     assert lib.pmf_points_transform(None, 1, 2, 0, 0, 0.0, 0.0, 0.0, None, None) == -1
+    assert lib.pmf_merge_pred(0, None, None, None, None, 4, None, None, None) == -1
 
 
 def test_range_loader_surface_and_no_cpu_fallback():
