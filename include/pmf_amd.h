@@ -312,6 +312,15 @@ int pmf_range_project_gather(const float* points, int64_t P, int32_t C, const ui
                              float* label, int32_t* mask, float* range, int32_t* idx, float* proj_points,
                              pmf_stream_t s);
 
+/* training-time tensor augmentation of the [C,h,w] frame (perspective_view_loader.py:63-69,138-141: torchvision
+ * RandomHorizontalFlip -> RandomRotation(nearest, zero fill) -> RandomCrop -> Pad) as one gather.  matrix6 (HOST pointer):
+ * the inverse affine matrix [a b c; d e f] torchvision builds for the drawn angle ([cos r, sin r, 0, -sin r, cos r, 0],
+ * r = radians(-angle)); crop window (top, left, crop_h, crop_w) inside the rotated h x w image; the crop lands at
+ * (pad_top, pad_left) of dst f32[C][oh][ow], zero elsewhere. */
+int pmf_flip_rotate_crop(const float* src, int32_t C, int32_t h, int32_t w, int32_t flip, const float* matrix6,
+                         int32_t top, int32_t left, int32_t crop_h, int32_t crop_w, int32_t pad_top, int32_t pad_left,
+                         float* dst, int32_t oh, int32_t ow, pmf_stream_t s);
+
 /* ---- loss-side kernels ------------------------------------------------------------------------------------ */
 /* Lovasz-softmax Jaccard gradient (pc_processor/loss/lovasz_softmax.py:56-68) for C class rows at once.
  * fg_sorted f32[C][P]: 0/1 foreground indicator, each row ordered by DESCENDING error with ignored pixels last;

@@ -297,3 +297,42 @@ extern "C" int pmf_project_v2_scatter(const float* points, const int32_t* sem, c
   PMF_LAUNCH_CHECK();
   return 0;
 }
+
+// ---- training-time tensor augmentation (perspective_view_loader.py:63-69,138-141) -------------------------------------
+// RandomHorizontalFlip -> RandomRotation(nearest, zero fill, about the image centre) -> RandomCrop -> Pad, as ONE gather:
+// every output pixel maps back through the crop offset, the inverse rotation and the flip to one source pixel.
+// Coordinates follow torchvision's tensor path (affine grid over pixel centres, grid_sample(nearest, zeros,
+// align_corners=False)): xg = x - w/2 + 0.5, gx = (m0*xg + m1*yg) / (w/2), ix = ((gx + 1)*w - 1)/2, rint(ix) in float32.
+__global__ void aug_gather_k(const float* __restrict__ src, int C, int h, int w, int flip, float m0, float m1, float m3,
+                             float m4, int top, int left, int ch, int cw, int pad_top, int pad_left, float* __restrict__ dst,
+                             int oh, int ow) {
+  const int ox = blockIdx.x * blockDim.x + threadIdx.x, oy = blockIdx.y;
+  if (ox >= ow) return;
+  const int cy = oy - pad_top, cx = ox - pad_left;
+  int sy = -1, sx = -1;
+  if (cy >= 0 && cy < ch && cx >= 0 && cx < cw) {
+    const float xg = (float)(left + cx) - 0.5f * (float)w + 0.5f, yg = (float)(top + cy) - 0.5f * (float)h + 0.5f;
+    const float gx = fmaf(yg, m1 / (0.5f * (float)w), xg * (m0 / (0.5f * (float)w)));
+    const float gy = fmaf(yg, m4 / (0.5f * (float)h), xg * (m3 / (0.5f * (float)h)));
+    const float ix = ((gx + 1.f) * (float)w - 1.f) / 2.f, iy = ((gy + 1.f) * (float)h - 1.f) / 2.f;
+    const float rx = rintf(ix), ry = rintf(iy);
+    if (rx >= 0.f && rx <= (float)(w - 1) && ry >= 0.f && ry <= (float)(h - 1)) {
+      sx = (int)rx; sy = (int)ry;
+      if (flip) sx = w - 1 - sx;
+    }
+  }
+  for (int c = 0; c < C; ++c)
+    dst[((size_t)c * oh + oy) * ow + ox] = sy >= 0 ? src[((size_t)c * h + sy) * w + sx] : 0.f;
+}
+extern "C" int pmf_flip_rotate_crop(const float* src, int32_t C, int32_t h, int32_t w, int32_t flip, const float* matrix6,
+                                    int32_t top, int32_t left, int32_t crop_h, int32_t crop_w, int32_t pad_top,
+                                    int32_t pad_left, float* dst, int32_t oh, int32_t ow, pmf_stream_t s) {
+  if (!src || !dst || !matrix6 || C <= 0 || h <= 0 || w <= 0 || crop_h <= 0 || crop_w <= 0 || oh <= 0 || ow <= 0)
+    return PMF_E_ARG;
+  if (top < 0 || left < 0 || top + crop_h > h || left + crop_w > w || pad_top < 0 || pad_left < 0 ||
+      pad_top + crop_h > oh || pad_left + crop_w > ow) return PMF_E_ARG;
+  hipLaunchKernelGGL(aug_gather_k, dim3(cdiv(ow, 128), oh), dim3(128), 0, (hipStream_t)s, src, C, h, w, flip, matrix6[0],
+                     matrix6[1], matrix6[3], matrix6[4], top, left, crop_h, crop_w, pad_top, pad_left, dst, oh, ow);
+  PMF_LAUNCH_CHECK();
+  return 0;
+}

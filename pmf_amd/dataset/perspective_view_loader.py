@@ -7,9 +7,12 @@ duck type; only ``proj_matrix`` / ``class_map_lut`` are needed from it beyond th
     loadDataByIndex(i) -> (points f32[P,4], sem i32[P], inst)       loadImage(i) -> PIL / uint8[h,w,3]
     parsePathInfoByIndex(i) -> (seq, frame)                          proj_matrix[seq] -> f64[3,4]
     labelMapping LUT: class_map_lut i32[L]
-The training-time torchvision tensor transforms (RandomHorizontalFlip / RandomRotation(15) / RandomCrop,
-perspective_view_loader.py:63-69) are NOT built (torchvision is a third-party dependency that is absent here;
-no parity definition) -- is_train=True raises unless the caller passes ``aug_ops``.
+The training-time tensor transforms (torchvision RandomHorizontalFlip(0.5) -> RandomRotation(15) -> RandomCrop -> Pad,
+perspective_view_loader.py:63-69,138-141) are ONE HIP gather (pmf_flip_rotate_crop) behind ``FlipRotateCrop``: the draws
+come from torch's global RNG in torchvision's order (seeding torch reproduces its parameters), the rotation is
+nearest-neighbour about the image centre with zero fill.  torchvision itself is absent here: the restatement follows its
+published tensor path and is checked against torch's own grid_sample (oracle/tensor_aug_ref.py), unpinned.  The point
+augmentation (``pcd_aug``, augmentor.py) runs on the GPU before the projection; ``img_aug`` (ColorJitter) is not built.
 """
 import ctypes as C
 
@@ -24,7 +27,10 @@ def project_frame_gpu(points, sem_label, image_u8, proj_matrix, label_lut, devic
     """-> (proj f32[10,h,w], x_data i32[K], y_data i32[K], depth f32[P], keep bool[P]) on `device`."""
     lib = L.lib()
     dev = torch.device(device)
-    pts = torch.as_tensor(np.ascontiguousarray(points, np.float32)).to(dev)
+    if isinstance(points, torch.Tensor):
+        pts = points.to(dev, torch.float32).contiguous()
+    else:
+        pts = torch.as_tensor(np.ascontiguousarray(points, np.float32)).to(dev)
     sem = torch.as_tensor(np.ascontiguousarray(sem_label, np.int32)).to(dev)
     img = torch.as_tensor(np.ascontiguousarray(image_u8, np.uint8)).to(dev)
     mat = torch.as_tensor(np.ascontiguousarray(proj_matrix, np.float64).reshape(12)).to(dev)
@@ -69,6 +75,45 @@ def center_crop_pad_gpu(proj, out_h, out_w, h_pad, w_pad):
     return dst
 
 
+class FlipRotateCrop(object):
+    """the training ``aug_ops`` (+ Pad) of the reference as one call: [C,h,w] device tensor -> [C, crop_h + 2*h_pad,
+    crop_w + 2*w_pad].  ``draw`` exposes the parameters (flip, angle, top, left) for tests."""
+
+    def __init__(self, crop_h, crop_w, h_pad=0, w_pad=0, p=0.5, degrees=15.0):
+        self.crop_h, self.crop_w, self.h_pad, self.w_pad, self.p, self.degrees = crop_h, crop_w, h_pad, w_pad, p, degrees
+
+    def draw(self, h, w):
+        flip = bool(torch.rand(1) < self.p)
+        angle = float(torch.empty(1).uniform_(-float(self.degrees), float(self.degrees)).item())
+        if h < self.crop_h or w < self.crop_w:
+            raise ValueError("Required crop size {} is larger than input image size {}".format(
+                (self.crop_h, self.crop_w), (h, w)))
+        if (h, w) == (self.crop_h, self.crop_w):
+            return flip, angle, 0, 0
+        top = int(torch.randint(0, h - self.crop_h + 1, size=(1,)).item())
+        left = int(torch.randint(0, w - self.crop_w + 1, size=(1,)).item())
+        return flip, angle, top, left
+
+    def apply(self, proj, flip, angle, top, left):
+        import math
+        if not proj.is_cuda:
+            raise RuntimeError("FlipRotateCrop runs on the GPU only (no CPU fallback)")
+        c, h, w = proj.shape
+        r = math.radians(-angle)
+        m = (C.c_float * 6)(math.cos(r), math.sin(r), 0.0, -math.sin(r), math.cos(r), 0.0)
+        oh, ow = self.crop_h + 2 * self.h_pad, self.crop_w + 2 * self.w_pad
+        dst = torch.empty((c, oh, ow), dtype=torch.float32, device=proj.device)
+        src = proj.contiguous().float()
+        L.check(L.lib().pmf_flip_rotate_crop(src.data_ptr(), c, h, w, int(flip), m, top, left, self.crop_h, self.crop_w,
+                                             self.h_pad, self.w_pad, dst.data_ptr(), oh, ow,
+                                             C.c_void_p(torch.cuda.current_stream(proj.device).cuda_stream)),
+                "pmf_flip_rotate_crop")
+        return dst
+
+    def __call__(self, proj):
+        return self.apply(proj, *self.draw(proj.shape[1], proj.shape[2]))
+
+
 class PerspectiveViewLoader(Dataset):
     def __init__(self, dataset, config, data_len=-1, is_train=True, pcd_aug=False, img_aug=False,
                  use_padding=False, return_uproj=False, device="cuda", aug_ops=None):
@@ -77,21 +122,34 @@ class PerspectiveViewLoader(Dataset):
         self.use_padding, self.return_uproj = use_padding, return_uproj
         self.device = device
         self.aug_ops = aug_ops
-        if pcd_aug or img_aug:
-            raise NotImplementedError("pcd_aug / img_aug (python-random point augmentation, torchvision "
-                                      "ColorJitter) are outside the accelerated path; PMF trains with both off "
-                                      "for the point cloud (tasks/pmf/trainer.py:142)")
+        if img_aug and is_train:
+            raise NotImplementedError("img_aug (torchvision ColorJitter: third-party random photometric jitter) is not "
+                                      "built; tasks/pmf trains with it off")
+        self.pcd_aug = bool(pcd_aug and is_train)
+        self.augmentor = None
+        if self.pcd_aug:                    # perspective_view_loader.py:24-41
+            from .preprocess import augmentor
+            a = config["augmentation"]
+            params = augmentor.AugmentParams()
+            params.setFlipProb(p_flipx=a["p_flipx"], p_flipy=a["p_flipy"])
+            params.setTranslationParams(**{k: a[k] for k in a if "trans" in k})
+            params.setRotationParams(**{k: a[k] for k in a if "rot" in k})
+            self.augmentor = augmentor.Augmentor(params, device=device)
         s = config["sensor"]
         self.h_pad = s["h_pad"] if use_padding else 0
         self.w_pad = s["w_pad"] if use_padding else 0
         self.out_h = s["proj_ht"] if is_train else s["proj_h"]
         self.out_w = s["proj_wt"] if is_train else s["proj_w"]
-        if is_train and aug_ops is None and not return_uproj:
-            raise NotImplementedError("training-time flip/rotate/crop needs torchvision tensor transforms; pass "
-                                      "aug_ops=callable([10,h,w] tensor) or use is_train=False")
+        self._own_aug = False
+        if is_train and aug_ops is None:
+            # RandomCrop(size=(proj_ht - 2*h_pad, proj_wt - 2*w_pad)) then Pad((w_pad, h_pad)), both inside the gather
+            self.aug_ops = FlipRotateCrop(s["proj_ht"] - 2 * self.h_pad, s["proj_wt"] - 2 * self.w_pad, self.h_pad, self.w_pad)
+            self._own_aug = True
 
     def __getitem__(self, index):
         pointcloud, sem_label, _ = self.dataset.loadDataByIndex(index)
+        if self.pcd_aug:
+            pointcloud = self.augmentor.doAugmentation(pointcloud)
         image = np.asarray(self.dataset.loadImage(index))
         seq_id, _ = self.dataset.parsePathInfoByIndex(index)
         proj, xd, yd, depth, _ = project_frame_gpu(pointcloud, sem_label, image, self.dataset.proj_matrix[seq_id],
@@ -100,7 +158,7 @@ class PerspectiveViewLoader(Dataset):
             return proj[:8], proj[8], proj[9], xd, yd, depth
         if self.is_train:
             proj = self.aug_ops(proj)
-            if self.use_padding:
+            if self.use_padding and not self._own_aug:
                 proj = torch.nn.functional.pad(proj, (self.w_pad, self.w_pad, self.h_pad, self.h_pad))
         else:
             proj = center_crop_pad_gpu(proj, self.out_h, self.out_w, self.h_pad, self.w_pad)

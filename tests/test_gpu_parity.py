@@ -922,3 +922,53 @@ def test_camera_merge_exact(tag, seed, pc, golden):
         getMergePred([e], [e.float()], [], 3)
     with pytest.raises(RuntimeError):
         getMergePred([e.cpu()], [e.float().cpu()], [e.cpu()], 3)
+
+
+def test_training_tensor_augmentation_matches_torch_grid_sample(tmp_path):
+    """FlipRotateCrop (pmf_flip_rotate_crop) vs the torch-CPU restatement of torchvision's flip -> rotate(nearest) -> crop
+    -> pad: identical except where the inverse-rotated coordinate sits on a rounding edge; then the loader's training path"""
+    import math
+    from oracle import tensor_aug_ref as T
+    from oracle.cases import kitti_tree
+    from pmf_amd.dataset import FlipRotateCrop, PerspectiveViewLoader
+    from pmf_amd.dataset.semantic_kitti import SemanticKitti
+    rng = np.random.Generator(np.random.PCG64(5))
+    total_bad = 0
+    for case, (h, w, ch, cw, hp, wp) in enumerate(((96, 320, 80, 256, 0, 0), (64, 208, 64, 208, 4, 8), (376, 1241, 352, 1216, 0, 0))):
+        img = torch.from_numpy((rng.random((10, h, w)) * (rng.random((1, h, w)) < 0.4)).astype(np.float32))
+        op = FlipRotateCrop(ch, cw, hp, wp)
+        torch.manual_seed(case)
+        for rep in range(3):
+            flip, angle, top, left = op.draw(h, w)
+            if rep == 2:
+                angle = 0.0                                    # flip + crop + pad only: an exact copy
+            got = op.apply(img.cuda(), flip, angle, top, left).cpu()
+            want = T.flip_rotate_crop(img, flip, angle, top, left, ch, cw, hp, wp)
+            assert got.shape == want.shape == (10, ch + 2 * hp, cw + 2 * wp)
+            bad = torch.nonzero((got != want).any(0))
+            if angle == 0.0:
+                assert bad.numel() == 0
+            total_bad += bad.shape[0]
+            assert bad.shape[0] <= 1e-4 * got[0].numel() + 2, (case, rep, bad.shape[0])
+            r = math.radians(-angle)
+            for oy, ox in bad.tolist():                       # exact source coordinate in float64
+                xg, yg = left + ox - wp - w / 2 + 0.5, top + oy - hp - h / 2 + 0.5
+                ix = ((math.cos(r) * xg + math.sin(r) * yg) / (w / 2) + 1) * w / 2 - 0.5
+                iy = ((-math.sin(r) * xg + math.cos(r) * yg) / (h / 2) + 1) * h / 2 - 0.5
+                assert min(abs(ix - math.floor(ix) - 0.5), abs(iy - math.floor(iy) - 0.5)) < 1e-3, (oy, ox, ix, iy)
+    # loader: training item shapes with padding, seeded repeatability, point augmentation on the GPU path
+    root = str(tmp_path)
+    cfg_path, data = kitti_tree(root, npts=4000, h=48, w=160)
+    ds = SemanticKitti(root, [0], cfg_path)
+    from oracle.cases import RANGE_CASES
+    cfg = {"augmentation": RANGE_CASES[0][3]["augmentation"],
+           "sensor": dict(h_pad=2, w_pad=4, proj_h=48, proj_w=160, proj_ht=40, proj_wt=128)}
+    ld = PerspectiveViewLoader(ds, cfg, is_train=True, use_padding=True, pcd_aug=True)
+    import random
+    random.seed(3); torch.manual_seed(3)
+    f1, m1, l1 = ld[1]
+    random.seed(3); torch.manual_seed(3)
+    f2, m2, l2 = ld[1]
+    assert f1.shape == (8, 40, 128) and m1.shape == l1.shape == (40, 128)
+    assert torch.equal(f1, f2) and torch.equal(l1, l2)
+    assert (f1[:, :2] == 0).all() and (f1[:, :, :4] == 0).all() and m1.sum() > 0     # the Pad frame

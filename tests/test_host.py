@@ -200,3 +200,29 @@ def test_pc_processor_shim_resolves_reference_imports():
     for name in ("Lovasz_softmax", "FocalSoftmaxLoss", "MultiTaskLoss"):
         assert hasattr(pc_processor.loss, name)
     assert pc_processor.postproc.KNN is pmf_amd.postproc.KNN and hasattr(pc_processor.utils, "WarmupCosineLR")
+
+
+def test_tensor_augmentation_restatement_and_draw_order():
+    """oracle/tensor_aug_ref.py: documented torchvision behaviour (counter-clockwise for positive angles, identity at 0,
+    zero fill) and the same torch-RNG draw order in the product's FlipRotateCrop"""
+    from oracle import tensor_aug_ref as T
+    from pmf_amd.dataset import FlipRotateCrop
+    img = torch.arange(2 * 6 * 6, dtype=torch.float32).reshape(2, 6, 6)
+    assert torch.equal(T.rotate_nearest(img, 0.0), img)
+    assert torch.equal(T.rotate_nearest(img, 90.0), torch.rot90(img, 1, (1, 2)))
+    assert torch.equal(T.flip_rotate_crop(img, True, 0.0, 1, 2, 3, 4, 1, 2)[:, 1:4, 2:6], img.flip(-1)[:, 1:4, 2:6])
+    big = T.rotate_nearest(torch.ones(1, 40, 64), 15.0)
+    assert big[0, 0, 0] == 0 and big[0, 20, 32] == 1                     # corners leave the frame, centre stays
+    op = FlipRotateCrop(32, 48, 2, 3)
+    torch.manual_seed(11)
+    a = [op.draw(40, 64) for _ in range(5)]
+    torch.manual_seed(11)
+    b = [T.draw_params(40, 64, 32, 48) for _ in range(5)]
+    assert a == b and any(f for f, _, _, _ in a) and not all(f for f, _, _, _ in a)
+    assert all(-15 <= ang <= 15 and 0 <= t <= 8 and 0 <= l <= 16 for _, ang, t, l in a)
+    assert op.draw(32, 48)[2:] == (0, 0)
+    with pytest.raises(ValueError):
+        op.draw(16, 64)
+    with pytest.raises(RuntimeError):
+        op(torch.zeros(10, 40, 64))                                      # CPU tensor: no fallback
+    assert L.lib().pmf_flip_rotate_crop(None, 10, 4, 4, 0, None, 0, 0, 4, 4, 0, 0, None, 4, 4, None) == -1
