@@ -275,6 +275,12 @@ int pmf_project_scatter(const float* points, const int32_t* sem, int64_t P, cons
 int pmf_project_v2_index(const float* points, int64_t P, const double* proj, float fov_left, float fov_right,
                          uint8_t* keep, int32_t* src_idx, int32_t* x_data, int32_t* y_data, double* xy_index,
                          float* depth, int32_t* n_kept, int32_t* bbox, int32_t* blk_cnt, pmf_stream_t s);
+/* same with the row / column coordinates multiplied by img_scale first (training: the reference rescales the image by
+ * a random factor in [1, 1.2] and the projected coordinates with it, perspective_view_loader_v2.py:50-57,74) */
+int pmf_project_v2_index_scaled(const float* points, int64_t P, const double* proj, float fov_left, float fov_right,
+                                double img_scale, uint8_t* keep, int32_t* src_idx, int32_t* x_data, int32_t* y_data,
+                                double* xy_index, float* depth, int32_t* n_kept, int32_t* bbox, int32_t* blk_cnt,
+                                pmf_stream_t s);
 int pmf_project_v2_scatter(const float* points, const int32_t* sem, const int32_t* src_idx, const int32_t* x_data,
                            const int32_t* y_data, const float* depth, int32_t K, const uint8_t* image, int32_t ih,
                            int32_t iw, const int32_t* lut, int32_t nlut, int32_t x_min, int32_t y_min, int32_t h,

@@ -173,7 +173,7 @@ extern "C" int pmf_crop_pad(const float* src, int32_t C, int32_t h, int32_t w, i
 // reference), then pass 2 (pmf_project_v2_scatter) resolves duplicates (last point wins) and writes [10][h][w] =
 // depth, x, y, z, intensity, r, g, b (image window, zero outside), mask, label.
 __device__ __forceinline__ bool v2_point(const float* __restrict__ pt, const double* __restrict__ m, float fl, float fr,
-                                         int& row, int& col, double& v_out, double& u_out, float& dep) {
+                                         double sc, int& row, int& col, double& v_out, double& u_out, float& dep) {
   const float xf = pt[0], yf = pt[1], zf = pt[2];
   dep = sqrtf((xf * xf + yf * yf) + zf * zf);
   const float yaw = -atan2f(yf, xf);
@@ -182,7 +182,7 @@ __device__ __forceinline__ bool v2_point(const float* __restrict__ pt, const dou
   const double a = fma(m[3], 1.0, fma(m[2], z, fma(m[1], y, m[0] * x)));
   const double b = fma(m[7], 1.0, fma(m[6], z, fma(m[5], y, m[4] * x)));
   const double c = fma(m[11], 1.0, fma(m[10], z, fma(m[9], y, m[8] * x)));
-  u_out = a / c; v_out = b / c;
+  u_out = (a / c) * sc; v_out = (b / c) * sc;      // xy_index * img_scale (training: the image is rescaled, :53-57,74)
   row = (int)v_out; col = (int)u_out;
   return true;
 }
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(PB) void v2_count_k(const float* __restrict__ pts, 
   int k = 0;
   if (i < P) {
     int r, c; double v, u; float d;
-    k = v2_point(pts + i * 4, m, fl, fr, r, c, v, u, d) ? 1 : 0;
+    k = v2_point(pts + i * 4, m, fl, fr, 1.0, r, c, v, u, d) ? 1 : 0;
     keep[i] = (uint8_t)k;
   }
   const int cnt = __syncthreads_count(k);
@@ -202,14 +202,14 @@ __global__ __launch_bounds__(PB) void v2_count_k(const float* __restrict__ pts, 
 }
 
 __global__ __launch_bounds__(PB) void v2_compact_k(const float* __restrict__ pts, int64_t P, const double* __restrict__ m,
-                                                   float fl, float fr, const int32_t* __restrict__ blk_off,
+                                                   float fl, float fr, double sc, const int32_t* __restrict__ blk_off,
                                                    int32_t* __restrict__ src_idx, int32_t* __restrict__ x_data,
                                                    int32_t* __restrict__ y_data, double* __restrict__ xy,
                                                    float* __restrict__ depth, int32_t* __restrict__ bbox) {
   __shared__ int wave_cnt[PB / 64];
   const int64_t i = blockIdx.x * (int64_t)PB + threadIdx.x;
   int r = 0, c = 0; double v = 0, u = 0; float d = 0.f;
-  const bool k = i < P && v2_point(pts + i * 4, m, fl, fr, r, c, v, u, d);
+  const bool k = i < P && v2_point(pts + i * 4, m, fl, fr, sc, r, c, v, u, d);
   const unsigned long long bal = __ballot(k);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int before = __popcll(bal & ((1ull << lane) - 1ull));
@@ -226,18 +226,29 @@ __global__ __launch_bounds__(PB) void v2_compact_k(const float* __restrict__ pts
   }
 }
 
+extern "C" int pmf_project_v2_index_scaled(const float* points, int64_t P, const double* proj, float fov_left,
+                                           float fov_right, double img_scale, uint8_t* keep, int32_t* src_idx,
+                                           int32_t* x_data, int32_t* y_data, double* xy_index, float* depth,
+                                           int32_t* n_kept, int32_t* bbox, int32_t* blk_cnt, pmf_stream_t s);
 extern "C" int pmf_project_v2_index(const float* points, int64_t P, const double* proj, float fov_left, float fov_right,
                                     uint8_t* keep, int32_t* src_idx, int32_t* x_data, int32_t* y_data, double* xy_index,
                                     float* depth, int32_t* n_kept, int32_t* bbox, int32_t* blk_cnt, pmf_stream_t s) {
+  return pmf_project_v2_index_scaled(points, P, proj, fov_left, fov_right, 1.0, keep, src_idx, x_data, y_data, xy_index,
+                                     depth, n_kept, bbox, blk_cnt, s);
+}
+extern "C" int pmf_project_v2_index_scaled(const float* points, int64_t P, const double* proj, float fov_left,
+                                           float fov_right, double img_scale, uint8_t* keep, int32_t* src_idx,
+                                           int32_t* x_data, int32_t* y_data, double* xy_index, float* depth,
+                                           int32_t* n_kept, int32_t* bbox, int32_t* blk_cnt, pmf_stream_t s) {
   hipStream_t st = (hipStream_t)s;
-  if (P < 0) return PMF_E_ARG;
+  if (P < 0 || !(img_scale > 0.0)) return PMF_E_ARG;
   const int32_t init[4] = {2147483647, -2147483647 - 1, 2147483647, -2147483647 - 1};
   hipError_t e = hipMemcpyAsync(bbox, init, sizeof(init), hipMemcpyHostToDevice, st);
   if (e != hipSuccess) return (int)e;
   const int nblk = (int)cdiv64(P > 0 ? P : 1, PB);
   hipLaunchKernelGGL(v2_count_k, dim3(nblk), dim3(PB), 0, st, points, P, proj, fov_left, fov_right, keep, blk_cnt);
   hipLaunchKernelGGL(proj_scan_k, dim3(1), dim3(1024), 0, st, blk_cnt, nblk, n_kept);
-  hipLaunchKernelGGL(v2_compact_k, dim3(nblk), dim3(PB), 0, st, points, P, proj, fov_left, fov_right, blk_cnt, src_idx,
+  hipLaunchKernelGGL(v2_compact_k, dim3(nblk), dim3(PB), 0, st, points, P, proj, fov_left, fov_right, img_scale, blk_cnt, src_idx,
                      x_data, y_data, xy_index, depth, bbox);
   PMF_LAUNCH_CHECK();
   return 0;

@@ -6,8 +6,9 @@ are HIP kernels (pmf_project_v2_index / pmf_project_v2_scatter); the frame size 
 (kept count + bounding box) separates the two passes, exactly where the reference computes min / max on the host.
 ``dataset`` duck type: loadDataByIndex, loadImage, parsePathInfoByIndex, proj_matrix[seq], class_map_lut and
 optionally fov_left / fov_right (defaults: +-45 degrees, parser.py:36-37).
-Not built: the training path (random image rescale + torchvision flip / rotation / crop on the tensor; third-party
-transforms without a parity definition) -- is_train=True raises unless return_uproj=True."""
+Training path (:25-34,50-57,142-153): random image rescale in [1, 1.2] (numpy RNG draw, PIL bilinear resize on the host
+as in the reference), coordinates scaled with it inside the projection kernel, bottom / centred horizontal zero padding
+to (proj_ht, proj_wt), then flip / rotate(15) / crop as one HIP gather (FlipRotateCrop).  img_aug (ColorJitter) is not built."""
 import ctypes as C
 import math
 
@@ -18,8 +19,10 @@ from torch.utils.data import Dataset
 from .. import _lib as L
 
 
-def project_frame_v2_gpu(points, sem_label, image_u8, proj_matrix, label_lut, fov_left, fov_right, device="cuda"):
-    """-> (proj f32[10,h,w], xy_index f64[K,2], depth f32[K], keep bool[P]) on `device`."""
+def project_frame_v2_gpu(points, sem_label, image_u8, proj_matrix, label_lut, fov_left, fov_right, device="cuda",
+                         img_scale=1.0):
+    """-> (proj f32[10,h,w], xy_index f64[K,2], depth f32[K], keep bool[P]) on `device`; img_scale multiplies the
+    projected (row, col) coordinates (the caller passes the image already rescaled by it)."""
     lib = L.lib()
     dev = torch.device(device)
     pts = torch.as_tensor(np.ascontiguousarray(points, np.float32)).to(dev)
@@ -38,10 +41,10 @@ def project_frame_v2_gpu(points, sem_label, image_u8, proj_matrix, label_lut, fo
     meta = torch.zeros(5, dtype=torch.int32, device=dev)          # n_kept, row_min, row_max, col_min, col_max
     blk = torch.empty((P + 1023) // 1024 + 1, dtype=torch.int32, device=dev)
     st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-    L.check(lib.pmf_project_v2_index(pts.data_ptr(), P, mat.data_ptr(), float(fov_left), float(fov_right),
-                                     keep.data_ptr(), src.data_ptr(), xd.data_ptr(), yd.data_ptr(), xy.data_ptr(),
+    L.check(lib.pmf_project_v2_index_scaled(pts.data_ptr(), P, mat.data_ptr(), float(fov_left), float(fov_right),
+                                     float(img_scale), keep.data_ptr(), src.data_ptr(), xd.data_ptr(), yd.data_ptr(), xy.data_ptr(),
                                      depth.data_ptr(), meta.data_ptr(), meta.data_ptr() + 4, blk.data_ptr(), st),
-            "pmf_project_v2_index")
+            "pmf_project_v2_index_scaled")
     k, x_min, x_max, y_min, y_max = [int(v) for v in meta.tolist()]    # the one host read (frame size is data)
     if k == 0:
         raise ValueError("PerspectiveViewLoaderV2: no point inside the yaw field of view")
@@ -63,25 +66,40 @@ class PerspectiveViewLoaderV2(Dataset):
         self.return_uproj, self.device = return_uproj, device
         if img_aug:
             raise NotImplementedError("img_aug (torchvision ColorJitter) is outside the accelerated path")
-        if is_train and not return_uproj:
-            raise NotImplementedError("training-time rescale / flip / rotation / crop need torchvision tensor "
-                                      "transforms (no parity definition); use is_train=False or return_uproj=True")
+        self.aug_ops = None
+        if is_train:                      # :25-34 flip / rotate(15) / crop to (proj_ht, proj_wt) as one HIP gather
+            from .perspective_view_loader import FlipRotateCrop
+            self.aug_ops = FlipRotateCrop(self.pv_config["proj_ht"], self.pv_config["proj_wt"])
 
     def __getitem__(self, index):
-        image = np.asarray(self.dataset.loadImage(index))
+        image = self.dataset.loadImage(index)
+        img_scale = 1.0
+        if self.is_train:
+            # :50-57 random rescale of the camera image: numpy's global RNG, PIL's bilinear resize (what
+            # torchvision's Resize calls for a PIL image) -- host image decoding side, as in the reference
+            from PIL import Image
+            if not isinstance(image, Image.Image):
+                image = Image.fromarray(np.asarray(image))
+            img_w, img_h = image.size
+            img_scale = np.random.uniform(low=1.0, high=1.2)
+            image = image.resize((int(img_w * img_scale), int(img_h * img_scale)), Image.BILINEAR)
+        image = np.asarray(image)
         pointcloud, sem_label, _ = self.dataset.loadDataByIndex(index)
         seq_id, _ = self.dataset.parsePathInfoByIndex(index)
         fl = getattr(self.dataset, "fov_left", -45 / 180.0 * math.pi)
         fr = getattr(self.dataset, "fov_right", 45 / 180.0 * math.pi)
         proj, xy, depth, keep = project_frame_v2_gpu(pointcloud, sem_label, image, self.dataset.proj_matrix[seq_id],
-                                                     self.dataset.class_map_lut, fl, fr, self.device)
+                                                     self.dataset.class_map_lut, fl, fr, self.device, img_scale)
         if self.return_uproj:
             return proj, xy, depth, keep, torch.as_tensor(np.asarray(pointcloud))
-        ch, cw = self.pv_config["proj_h"], self.pv_config["proj_w"]
+        ch, cw = (self.pv_config["proj_ht"], self.pv_config["proj_wt"]) if self.is_train else \
+            (self.pv_config["proj_h"], self.pv_config["proj_w"])
         _, h, w = proj.shape
         mh, mw = max(ch, h), max(cw, w)
         left = (mw - w) // 2
         padded = torch.nn.functional.pad(proj, (left, mw - w - left, 0, mh - h))      # :142-147
+        if self.is_train:
+            return self.aug_ops(padded)
         top, lft = int(round((mh - ch) / 2.0)), int(round((mw - cw) / 2.0))            # CenterCrop (:36-39)
         return padded[:, top:top + ch, lft:lft + cw].contiguous()
 

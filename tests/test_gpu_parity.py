@@ -620,8 +620,32 @@ def test_loader_v2_matches_oracle_and_fixture(golden):
             assert np.array_equal(xy.cpu().numpy(), g["v2.%s.xy" % tag])
         val = PerspectiveViewLoaderV2(DS(), cfg, is_train=False)[0]
         assert np.array_equal(val.cpu().numpy(), loader_v2_ref.pad_center_crop(rp, h, w, h, w))
+        # training path: random rescale (numpy RNG + PIL bilinear), scaled coordinates, pad, flip / rotate / crop
+        from PIL import Image
+        from oracle import tensor_aug_ref as T
+        tcfg = {"PVconfig": {"proj_h": h, "proj_w": w, "proj_ht": h - 16, "proj_wt": w - 32}}
+        np.random.seed(40 + seed)
+        torch.manual_seed(40 + seed)
+        got = PerspectiveViewLoaderV2(DS(), tcfg, is_train=True)[0].cpu()
+        np.random.seed(40 + seed)
+        torch.manual_seed(40 + seed)
+        sc = np.random.uniform(low=1.0, high=1.2)
+        big = np.asarray(Image.fromarray(img).resize((int(w * sc), int(h * sc)), Image.BILINEAR))
+        tp, txy, _, _ = loader_v2_ref.project_frame_v2(pts, sem, big, M, lut, sc)
+        fh, fw = tp.shape[1:]
+        mh, mw = max(h - 16, fh), max(w - 32, fw)
+        left = (mw - fw) // 2
+        padded = F.pad(torch.from_numpy(tp), (left, mw - fw - left, 0, mh - fh))
+        flip, angle, top, lft = T.draw_params(mh, mw, h - 16, w - 32)
+        want = T.flip_rotate_crop(padded, flip, angle, top, lft, h - 16, w - 32)
+        assert got.shape == want.shape == (10, h - 16, w - 32)
+        nbad = int((got != want).any(0).sum())
+        assert nbad <= 1e-4 * got[0].numel() + 2, (tag, nbad)           # rounding-edge pixels of the rotation only
+        pu = PerspectiveViewLoaderV2(DS(), tcfg, is_train=True, return_uproj=True)
+        np.random.seed(40 + seed)
+        assert np.array_equal(pu[0][1].cpu().numpy(), txy)              # scaled float64 (row, col), bit for bit
     with pytest.raises(NotImplementedError):
-        PerspectiveViewLoaderV2(DS(), cfg, is_train=True)
+        PerspectiveViewLoaderV2(DS(), cfg, is_train=True, img_aug=True)
 
 
 @pytest.mark.gpu
