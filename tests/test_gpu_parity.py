@@ -996,3 +996,24 @@ def test_training_tensor_augmentation_matches_torch_grid_sample(tmp_path):
     assert f1.shape == (8, 40, 128) and m1.shape == l1.shape == (40, 128)
     assert torch.equal(f1, f2) and torch.equal(l1, l2)
     assert (f1[:, :2] == 0).all() and (f1[:, :, :4] == 0).all() and m1.sum() > 0     # the Pad frame
+
+
+def test_engine_overfits_a_fixed_batch():
+    """end-to-end sanity of the whole training path (plans, fused objective, flat state, both optimisers, schedules):
+    40 iterations on one fixed batch must drive the objective down and keep every parameter finite"""
+    from pmf_amd.engine import TrainEngine
+    from pmf_amd.models import PMFNet
+    torch.manual_seed(0)
+    m = PMFNet(5, 3, 20, 32, imagenet_pretrained=False, image_backbone="resnet34").cuda()
+    eng = TrainEngine(m, 20, lr=2e-3, warmup_steps=5, max_steps=200)
+    pcd, rgb, label, mask = synthetic_batch(2, 32, 64, 20, seed=12, fill=0.7)
+    feat = torch.cat((pcd, rgb), 1).cuda()
+    losses = []
+    for _ in range(40):
+        total, _ = eng.train_step(feat.clone(), mask.cuda(), label.cuda())
+        losses.append(total.item())
+    assert all(np.isfinite(losses)), losses
+    assert np.mean(losses[-5:]) < 0.8 * np.mean(losses[:3]), (losses[:3], losses[-5:])
+    assert all(torch.isfinite(p).all() for p in m.parameters())
+    acc = eng.metrics.getAcc()[0].item()
+    assert 0.0 <= acc <= 1.0
