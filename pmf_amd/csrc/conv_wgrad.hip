@@ -603,6 +603,168 @@ __global__ __launch_bounds__(256) void wgrad_fewc_k(const pmf_wgrad_desc_t d, co
   wgrad_fewc_body<KG>(d, g, smem);
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// 1x1 convolutions: dW[ci][co] = sum_px X[px][ci] * dz[px][co] is a GEMM whose MFMA operands ARE the memory layout --
+// the A register of v_mfma_f32_32x32x2 wants, per lane, (row m = lane % 32, k = lane / 32): 32 consecutive channels of
+// pixel p in the lower half wave and of pixel p+1 in the upper half; B likewise along Cout.  So the operands go
+// global -> registers -> MFMA with no LDS staging and every byte of X and dz read once per (128-channel, CW-channel)
+// output block: a lane loads a float4 of X (channels 4q..4q+3) and NCO floats of dz (channels NCO*q..), component j of
+// X times component j' of dz feeds accumulator tile (j, j') whose row m stands for channel 4m + j (a permuted tile --
+// only the final store needs to know).  The four waves take every fourth pixel pair and are folded through LDS in a
+// fixed order; BatchNorm-apply / ReLU / dropout multipliers of the operand are applied in registers.
+template <int NCO>
+__global__ __launch_bounds__(256, 2) void wgrad_1x1_k(const pmf_wgrad_desc_t d, int Ktot, int Cout32) {
+  extern __shared__ __attribute__((aligned(16))) float fold[];       // [4 * NCO tiles][16][64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = lane & 31, lh = lane >> 5;
+  const int split = blockIdx.x, kb = blockIdx.y, ob = blockIdx.z;
+  constexpr int CW = 32 * NCO;
+  // this lane's four input channels: operand, offset inside it, transform
+  const int kch = kb * 128 + q * 4;
+  int si = 0, cin = kch;
+  bool kok = kch < Ktot;
+  if (kok) while (cin >= d.src[si].C) { cin -= d.src[si].C; ++si; }
+  const float* __restrict__ sx = kok ? d.src[si].x + cin : nullptr;
+  const int sld = kok ? d.src[si].ldc : 0;
+  const bool has_sc = kok && d.src[si].scale != nullptr, relu = kok && (d.src[si].flags & PMF_SRC_RELU);
+  const float* __restrict__ scm = kok ? d.src[si].cmul : nullptr;
+  const int cm_ld = kok ? d.src[si].cmul_ld : 0;
+  f32x4 sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
+  if (has_sc) { sc4 = *(const f32x4*)(d.src[si].scale + cin); sh4 = *(const f32x4*)(d.src[si].shift + cin); }
+  const int co = ob * CW + q * NCO;
+  const bool cok = co < d.Cout;                                          // Cout % NCO == 0 (host-checked)
+  const float* __restrict__ zp = d.dz + co;
+
+  f32x16 acc[4][NCO];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int jj = 0; jj < NCO; ++jj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][jj][r] = 0.f;
+
+  const int64_t hw = (int64_t)d.OH * d.OW, npix = hw * d.N, npair = (npix + 1) >> 1;
+  const int64_t per = (npair + d.nsplit - 1) / d.nsplit, p_begin = (int64_t)split * per,
+                p_end = p_begin + per < npair ? p_begin + per : npair;
+  constexpr int U = 4;                                                   // pixel pairs per wave and step
+  // Operands of step s+1 are requested before the MFMAs of step s are issued and transformed after them (register
+  // double buffer).  The loads are branch-free -- an out-of-range lane reads its operand's first pixel and is zeroed
+  // by a select afterwards -- so all of a step's requests are in flight together instead of one round trip per `if`.
+  const float* __restrict__ xbase = kok ? sx : d.src[0].x;
+  const float* __restrict__ zbase = cok ? zp : d.dz;
+  auto issue = [&](int64_t pr0, f32x4 (&xv)[U], float (&zv)[U][NCO], f32x4 (&cv)[U]) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t pr = pr0 + 4 * u, px = 2 * pr + lh;
+      const int64_t pxs = (pr < p_end && px < npix) ? px : 0;
+      xv[u] = *(const f32x4*)(xbase + pxs * sld);
+      if (scm) cv[u] = *(const f32x4*)(scm + (pxs / hw) * cm_ld + cin);
+      const float* z = zbase + pxs * d.dz_ldc;
+      if constexpr (NCO == 2) { const float2 t = *(const float2*)z; zv[u][0] = t.x; zv[u][1] = t.y; }
+      else zv[u][0] = z[0];
+    }
+  };
+  auto finish = [&](int64_t pr0, f32x4 (&xv)[U], float (&zv)[U][NCO], const f32x4 (&cv)[U]) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t pr = pr0 + 4 * u, px = 2 * pr + lh;
+      const bool ok = pr < p_end && px < npix;
+      f32x4 t = xv[u];
+      if (has_sc) t = t * sc4 + sh4;
+      if (relu) { t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f); }
+      if (scm) t = t * cv[u];
+      const bool xo = ok && kok, zo = ok && cok;
+      xv[u] = f32x4{xo ? t.x : 0.f, xo ? t.y : 0.f, xo ? t.z : 0.f, xo ? t.w : 0.f};
+#pragma unroll
+      for (int jj = 0; jj < NCO; ++jj) zv[u][jj] = zo ? zv[u][jj] : 0.f;
+    }
+  };
+  f32x4 xa[U], xb[U], ca[U], cb[U];
+  float za[U][NCO], zb[U][NCO];
+  int64_t pr0 = p_begin + wave;
+  issue(pr0, xa, za, ca);
+  finish(pr0, xa, za, ca);
+  for (; pr0 < p_end; pr0 += 4 * U) {
+    issue(pr0 + 4 * U, xb, zb, cb);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int jj = 0; jj < NCO; ++jj)
+          acc[j][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[u][j], za[u][jj], acc[j][jj], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    finish(pr0 + 4 * U, xb, zb, cb);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      xa[u] = xb[u];
+#pragma unroll
+      for (int jj = 0; jj < NCO; ++jj) za[u][jj] = zb[u][jj];
+    }
+  }
+  // fold waves 1..3 into wave 0 (fixed order), one wave's tiles at a time through LDS
+  for (int w = 1; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int jj = 0; jj < NCO; ++jj)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) fold[((j * NCO + jj) * 16 + r) * 64 + lane] = acc[j][jj][r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int jj = 0; jj < NCO; ++jj)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[j][jj][r] += fold[((j * NCO + jj) * 16 + r) * 64 + lane];
+    }
+    __syncthreads();
+  }
+  if (wave) return;
+  float* part = d.partial + (size_t)split * Ktot * Cout32;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int k = kb * 128 + 4 * m + j;
+#pragma unroll
+      for (int jj = 0; jj < NCO; ++jj) {
+        const int c = ob * CW + q * NCO + jj;
+        if (k < Ktot && c < Cout32) part[(size_t)k * Cout32 + c] = acc[j][jj][r];
+      }
+    }
+}
+
+// conditions of the direct 1x1 kernel + its grid
+static bool wg_direct_1x1(const pmf_wgrad_desc_t* d) {
+  if (getenv("PMF_WGRAD_NODIRECT") || ((d->cfg >> 8) & 0xff) == 2) return false;
+  if (d->ntaps != 1 || d->gather || d->in_stride != 1 || d->tdy[0] || d->tdx[0] || (d->Cout & 1) || (d->dz_ldc & 1)) return false;
+  for (int i = 0; i < d->nsrc; ++i) {
+    const pmf_src_t& s = d->src[i];
+    if ((s.flags & PMF_SRC_BCAST) || s.H != d->OH || s.W != d->OW || (s.C & 3) || (s.ldc & 3)) return false;
+    if (s.flags & ~(PMF_SRC_RELU)) return false;
+  }
+  int Ktot = 0;
+  for (int i = 0; i < d->nsrc; ++i) Ktot += d->src[i].C;
+  if (Ktot < 96) return false;                       // a lane owns 4 of 128 channels: narrow operands idle most lanes
+  if (d->Cout > 128 && Ktot < 256) return false;     // X is re-read once per 64 output channels
+  // measured (64x2048, bs 2): 192->64 158 -> 119 us, 384->128 115 -> 92, 768->256 111 -> 95; below ~16 k pixels the
+  // tiled kernels win (fewer, larger tiles; the per-workgroup fold and slab dominate here)
+  return (int64_t)d->N * d->OH * d->OW >= 16384;
+}
+static void wg_direct_grid(const pmf_wgrad_desc_t* d, int* kblocks, int* oblocks, int* nco) {
+  int Ktot = 0;
+  for (int i = 0; i < d->nsrc; ++i) Ktot += d->src[i].C;
+  *nco = d->Cout > 32 ? 2 : 1;
+  *kblocks = cdiv(Ktot, 128);
+  *oblocks = cdiv(round_up(d->Cout, 32), 32 * *nco);
+}
+
 // stage 2: dw_oihw[(co*Cin_real + k)*KHW + widx[t]] (+)= sum_s partial[s][t][k][co]
 // 256 threads = 32 consecutive outputs x 8 split slices (independent, unrolled loads), folded through LDS in a
 // fixed order -> deterministic, and no thread walks hundreds of slabs serially.
@@ -784,6 +946,14 @@ extern "C" int pmf_conv_wgrad_nsplit(const pmf_wgrad_desc_t* d) {
     const int tiles = cdiv(d->OW, 32) * cdiv(d->OH, WG_ROWS) * d->N, ns = 256 / cdiv(d->Cout, 64);
     return tiles < ns ? tiles : (ns < 1 ? 1 : ns);
   }
+  if (wg_direct_1x1(d)) {  // two resident workgroups per CU in total; every workgroup gets >= 64 pixel pairs
+    int kb, ob, nco;
+    wg_direct_grid(d, &kb, &ob, &nco);
+    int ns = 512 / (kb * ob);
+    const int64_t pairs = ((int64_t)d->N * d->OH * d->OW + 1) / 2;
+    if (ns > pairs / 64) ns = (int)(pairs / 64);
+    return ns < 1 ? 1 : ns;
+  }
   int TB, NT, lds;
   WgGeom g;
   wg_config(d, &TB, &NT);
@@ -913,6 +1083,26 @@ static int wgrad_phases(const pmf_wgrad_desc_t* d, pmf_stream_t st, int phase) {
     if (d->src[i].C % 8 || d->src[i].ldc % 4) return PMF_E_ARG;
   if (d->gather && false) return PMF_E_ARG;
   if (wg_fewc(d)) return wg_launch_fewc(d, s, phase);
+  if (wg_direct_1x1(d)) {
+    WgGeom g;
+    int lds, kb, ob, nco;
+    wg_geometry(d, 1, 32, &g, &lds);
+    if (phase & 1) {
+      if (((uintptr_t)d->dz & 7) != 0) return PMF_E_ARG;       // float2 loads of dz
+      wg_direct_grid(d, &kb, &ob, &nco);
+      static bool attr_set = false;
+      if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)wgrad_1x1_k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        (void)hipFuncSetAttribute((const void*)wgrad_1x1_k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        attr_set = true;
+      }
+      const dim3 grid(d->nsplit, kb, ob);
+      if (nco == 2) hipLaunchKernelGGL(wgrad_1x1_k<2>, grid, dim3(256), 8 * 16 * 64 * 4, s, *d, g.Ktot, g.Cout32);
+      else hipLaunchKernelGGL(wgrad_1x1_k<1>, grid, dim3(256), 4 * 16 * 64 * 4, s, *d, g.Ktot, g.Cout32);
+      PMF_LAUNCH_CHECK();
+    }
+    return (phase & 2) ? wg_reduce(d, g, s) : 0;
+  }
   int TB, NT;
   wg_config(d, &TB, &NT);
 #define WG_CASE(tb, nt) if (TB == tb && NT == nt) return wg_launch<tb, nt>(d, s, phase)

@@ -91,6 +91,11 @@ CONVS = [
     ("c3x3d18", 1, 8, 40, [32], 32, 3, 18, 18, 1, True, "none", False),
     ("c3x3_big", 2, 4, 16, [256], 256, 3, 1, 1, 1, True, "act_bn", True),
     ("c1x1_512_cat", 1, 4, 16, [256, 512], 256, 3, 1, 1, 1, True, "act_bn", True),
+    # >= 16384 pixels and >= 96 input channels: the LDS-free 1x1 weight-gradient kernel (operands straight from global)
+    ("c1x1cat3_big", 2, 64, 128, [64, 64, 64], 64, 1, 1, 0, 1, True, "act_bn", True),
+    ("c1x1_odd_big", 1, 129, 129, [96], 32, 1, 1, 0, 1, True, "lrelu", False),
+    ("c1x1_c20_big", 1, 129, 129, [128], 20, 1, 1, 0, 1, True, "none", False),
+    ("c1x1_wide_big", 2, 64, 128, [128, 256], 128, 1, 1, 0, 1, True, "act_bn", True),
 ]
 
 
