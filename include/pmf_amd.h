@@ -124,6 +124,14 @@ int pmf_conv_wgrad(const pmf_wgrad_desc_t* d, pmf_stream_t s);
 int pmf_conv_wgrad_partial(const pmf_wgrad_desc_t* d, pmf_stream_t s);
 int pmf_conv_wgrad_reduce(const pmf_wgrad_desc_t* d, pmf_stream_t s);
 int64_t pmf_conv_wgrad_workspace(const pmf_wgrad_desc_t* d);
+/* stage 2 of many layers in ONE launch (a training plan queues the reductions of a run of layers: each needs its own
+ * `partial` workspace then).  pmf_conv_wgrad_reduce_plan fills meta8 = {0, kind, Ktot, Cout32, KB, grid x, grid y, 0} for one
+ * layer and returns its workgroup count; the caller sets meta8[0] = running sum of the counts (first workgroup of the
+ * job), uploads the descriptors and the meta rows, and launches them with pmf_conv_wgrad_reduce_multi.  Results are
+ * bit-identical to pmf_conv_wgrad_reduce per layer. */
+int pmf_conv_wgrad_reduce_plan(const pmf_wgrad_desc_t* d, int32_t* meta8);
+int pmf_conv_wgrad_reduce_multi(const pmf_wgrad_desc_t* jobs_dev, const int32_t* meta_dev, int32_t njobs,
+                                int32_t total_blocks, pmf_stream_t s);
 
 /* OIHW -> packed GEMM layout, all convs of the network in ONE launch (weights change every optimiser step).
  * Job j writes dst[t][k][n] (dst is [ntaps][K_pad][ldw], padding pre-zeroed by the caller once):
@@ -364,7 +372,7 @@ enum {
   PMF_OP_MAXPOOL, PMF_OP_MAXPOOL_BWD, PMF_OP_BILINEAR, PMF_OP_BILINEAR_BWD, PMF_OP_PSHUFFLE, PMF_OP_PSHUFFLE_BWD,
   PMF_OP_GATE, PMF_OP_GATE_BWD, PMF_OP_GMEAN, PMF_OP_GMEAN_BWD, PMF_OP_COLSUM, PMF_OP_SOFTMAX, PMF_OP_SOFTMAX_BWD,
   PMF_OP_NCHW2NHWC, PMF_OP_FILL, PMF_OP_PMASK_FROM, PMF_OP_PMASK_POOL, PMF_OP_PMASK_MUL, PMF_OP_PMASK_MUL_BWD,
-  PMF_OP_VEC_ADD, PMF_OP_WGRAD_PART, PMF_OP_WGRAD_RED
+  PMF_OP_VEC_ADD, PMF_OP_WGRAD_PART, PMF_OP_WGRAD_RED, PMF_OP_WGRAD_RED_MULTI
 };
 
 /* generic argument record for the small ops (slot meaning documented next to each dispatcher case in plan.cpp) */

@@ -17,7 +17,7 @@ SRC_RELU, SRC_BCAST = 1, 2
  OP_ADD_ACT_BWD, OP_ACT_BWD, OP_AVGPOOL, OP_AVGPOOL_BWD, OP_MAXPOOL, OP_MAXPOOL_BWD, OP_BILINEAR,
  OP_BILINEAR_BWD, OP_PSHUFFLE, OP_PSHUFFLE_BWD, OP_GATE, OP_GATE_BWD, OP_GMEAN, OP_GMEAN_BWD, OP_COLSUM,
  OP_SOFTMAX, OP_SOFTMAX_BWD, OP_NCHW2NHWC, OP_FILL, OP_PMASK_FROM, OP_PMASK_POOL, OP_PMASK_MUL, OP_PMASK_MUL_BWD,
- OP_VEC_ADD, OP_WGRAD_PART, OP_WGRAD_RED) = range(1, 35)
+ OP_VEC_ADD, OP_WGRAD_PART, OP_WGRAD_RED, OP_WGRAD_RED_MULTI) = range(1, 36)
 
 OP_NAMES = {v: k for k, v in list(globals().items()) if k.startswith("OP_")}
 
@@ -142,6 +142,10 @@ def lib():
     L.pmf_project_v2_scatter.argtypes = [C.c_void_p] * 6 + [C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
                                                              C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                                              C.c_void_p, C.c_void_p, C.c_void_p]
+    L.pmf_conv_wgrad_reduce_plan.restype = C.c_int
+    L.pmf_conv_wgrad_reduce_plan.argtypes = [C.c_void_p, C.c_void_p]
+    L.pmf_conv_wgrad_reduce_multi.restype = C.c_int
+    L.pmf_conv_wgrad_reduce_multi.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
     L.pmf_flip_rotate_crop.restype = C.c_int
     L.pmf_flip_rotate_crop.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_float)] + \
         [C.c_int32] * 6 + [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
@@ -180,7 +184,7 @@ def lib():
 
 
 EXPORTS = [
-    "pmf_conv_fwd", "pmf_conv_wgrad", "pmf_conv_wgrad_partial", "pmf_conv_wgrad_reduce", "pmf_conv_wgrad_workspace", "pmf_conv_wgrad_nsplit", "pmf_pack_tile_ci",
+    "pmf_conv_fwd", "pmf_conv_wgrad", "pmf_conv_wgrad_partial", "pmf_conv_wgrad_reduce", "pmf_conv_wgrad_reduce_plan", "pmf_conv_wgrad_reduce_multi", "pmf_conv_wgrad_workspace", "pmf_conv_wgrad_nsplit", "pmf_pack_tile_ci",
     "pmf_pack_weights_batched", "pmf_conv_fwd_stat_rows", "pmf_conv_fwd_stat_rows_max", "pmf_conv_fwd_kstages", "pmf_col_rows", "pmf_bn_finalize", "pmf_bn_eval_affine", "pmf_bn_bwd_reduce", "pmf_bn_bwd_apply",
     "pmf_add_act", "pmf_add_act_bwd", "pmf_act_bwd", "pmf_avgpool3s2", "pmf_avgpool3s2_bwd", "pmf_maxpool3s2",
     "pmf_maxpool3s2_bwd", "pmf_bilinear2x", "pmf_bilinear2x_bwd", "pmf_pixel_shuffle2", "pmf_pixel_shuffle2_bwd",

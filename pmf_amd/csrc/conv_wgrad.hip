@@ -768,12 +768,12 @@ static void wg_direct_grid(const pmf_wgrad_desc_t* d, int* kblocks, int* oblocks
 // stage 2: dw_oihw[(co*Cin_real + k)*KHW + widx[t]] (+)= sum_s partial[s][t][k][co]
 // 256 threads = 32 consecutive outputs x 8 split slices (independent, unrolled loads), folded through LDS in a
 // fixed order -> deterministic, and no thread walks hundreds of slabs serially.
-__global__ __launch_bounds__(256) void wgrad_reduce_k(const pmf_wgrad_desc_t d, int Ktot, int Cout32) {
+__device__ __forceinline__ void red_flat_body(const pmf_wgrad_desc_t& d, int Ktot, int Cout32, int bid, int nblk) {
   __shared__ float shr[8][32];
   const int64_t total = (int64_t)d.ntaps * Ktot * Cout32;
   const int64_t slab = total;
   const int ol = threadIdx.x & 31, sl = threadIdx.x >> 5;
-  for (int64_t base = (int64_t)blockIdx.x * 32; base < total; base += (int64_t)gridDim.x * 32) {
+  for (int64_t base = (int64_t)bid * 32; base < total; base += (int64_t)nblk * 32) {
     const int64_t i = base + ol;
     float s = 0.f;
     if (i < total) {
@@ -803,7 +803,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_k(const pmf_wgrad_desc_t d, 
   // (one output channel per workgroup round, rows split over the threads, LDS tree)
   if (d.dbias_rows) {
     __shared__ float shb[256];
-    for (int co = blockIdx.x; co < d.Cout; co += gridDim.x) {
+    for (int co = bid; co < d.Cout; co += nblk) {
       float s = 0.f;
       for (int r = threadIdx.x; r < d.dbias_nrows; r += blockDim.x) s += d.dbias_rows[(size_t)r * d.dbias_ld + co];
       shb[threadIdx.x] = s;
@@ -817,16 +817,20 @@ __global__ __launch_bounds__(256) void wgrad_reduce_k(const pmf_wgrad_desc_t d, 
     }
   }
 }
+__global__ __launch_bounds__(256) void wgrad_reduce_k(const pmf_wgrad_desc_t d, int Ktot, int Cout32) {
+  red_flat_body(d, Ktot, Cout32, blockIdx.x, gridDim.x);
+}
 
 // Stage 2 for layers with many weights: the slabs are [split][tap][k][co32] (co fastest) while the gradient is OIHW
 // (tap fastest), so a thread-per-output reduction scatters 4-byte writes one weight row apart.  Here a workgroup owns
 // 32 output channels x KB input channels x all taps: float4 loads along co (every split summed by the same thread, in
 // slab order), a transpose through LDS, then runs of KB*KHW contiguous floats per output channel.
 #define WGR_ROWS 128
-__global__ __launch_bounds__(256) void wgrad_reduce_tile_k(const pmf_wgrad_desc_t d, int Ktot, int Cout32, int KB) {
+__device__ __forceinline__ void red_tile_body(const pmf_wgrad_desc_t& d, int Ktot, int Cout32, int KB, int bx, int by,
+                                              int nbx, int nby) {
   __shared__ float tile[WGR_ROWS][33];
   const int T = d.ntaps, RB = T * KB;
-  const int co0 = blockIdx.x * 32, k0 = blockIdx.y * KB;
+  const int co0 = bx * 32, k0 = by * KB;
   const int q = threadIdx.x & 7, rs = threadIdx.x >> 3;
   const int64_t slab = (int64_t)T * Ktot * Cout32;
   for (int j = rs; j < RB; j += 32) {
@@ -860,8 +864,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_tile_k(const pmf_wgrad_desc_
   }
   if (d.dbias_rows) {
     __shared__ float shb[256];
-    const int nb = gridDim.x * gridDim.y;
-    for (int co = blockIdx.y * gridDim.x + blockIdx.x; co < d.Cout; co += nb) {
+    const int nb = nbx * nby;
+    for (int co = by * nbx + bx; co < d.Cout; co += nb) {
       float s = 0.f;
       for (int r = threadIdx.x; r < d.dbias_nrows; r += blockDim.x) s += d.dbias_rows[(size_t)r * d.dbias_ld + co];
       shb[threadIdx.x] = s;
@@ -874,6 +878,28 @@ __global__ __launch_bounds__(256) void wgrad_reduce_tile_k(const pmf_wgrad_desc_
       __syncthreads();
     }
   }
+}
+__global__ __launch_bounds__(256) void wgrad_reduce_tile_k(const pmf_wgrad_desc_t d, int Ktot, int Cout32, int KB) {
+  red_tile_body(d, Ktot, Cout32, KB, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y);
+}
+
+// Stage 2 of MANY layers in one launch (a training plan queues the reductions of a run of layers: every kernel of a
+// replayed graph costs >= 3.6 us, 110 reductions per iteration are mostly that).  jobs: device copies of the layers'
+// descriptors; meta[j] = {first workgroup, kind (0 flat / 1 tiled), Ktot, Cout32, KB, grid x, grid y}.  Each workgroup
+// finds its job by bisection and runs the same body as the single-layer kernels (bit-identical results).
+struct RedMeta { int32_t block_start, kind, Ktot, Cout32, KB, gx, gy, pad_; };
+__global__ __launch_bounds__(256) void wgrad_reduce_multi_k(const pmf_wgrad_desc_t* __restrict__ jobs,
+                                                            const RedMeta* __restrict__ meta, int njobs) {
+  int lo = 0, hi = njobs - 1;
+  const int b = blockIdx.x;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (meta[mid].block_start <= b) lo = mid; else hi = mid - 1;
+  }
+  const RedMeta m = meta[lo];
+  const int lb = b - m.block_start;
+  if (m.kind == 1) red_tile_body(jobs[lo], m.Ktot, m.Cout32, m.KB, lb % m.gx, lb / m.gx, m.gx, m.gy);
+  else red_flat_body(jobs[lo], m.Ktot, m.Cout32, lb, m.gx);
 }
 
 static int wg_geometry(const pmf_wgrad_desc_t* d, int TB, int BN, WgGeom* g, int* lds) {
@@ -971,19 +997,44 @@ extern "C" int64_t pmf_conv_wgrad_workspace(const pmf_wgrad_desc_t* d) {
   return (int64_t)d->nsplit * d->ntaps * Ktot * round_up(d->Cout, 32) * 4;
 }
 
-static int wg_reduce(const pmf_wgrad_desc_t* d, const WgGeom& g, hipStream_t s) {
-  const int64_t total = (int64_t)d->ntaps * g.Ktot * g.Cout32;
+// which stage-2 kernel and grid a layer gets
+static void red_plan(const pmf_wgrad_desc_t* d, int Ktot, int Cout32, int* kind, int* KB, int* gx, int* gy) {
+  const int64_t total = (int64_t)d->ntaps * Ktot * Cout32;
   if (total >= 131072 && d->nsplit <= 32 && d->ntaps <= WGR_ROWS && !getenv("PMF_WGRAD_RED_FLAT")) {
-    int KB = WGR_ROWS / d->ntaps;
-    if (KB > g.Ktot) KB = g.Ktot;
-    const int cog = g.Cout32 / 32;
-    while (KB > 4 && cog * cdiv(g.Ktot, KB) < 512) KB = (KB + 1) / 2;
-    hipLaunchKernelGGL(wgrad_reduce_tile_k, dim3(cog, cdiv(g.Ktot, KB)), dim3(256), 0, s, *d, g.Ktot, g.Cout32, KB);
-    PMF_LAUNCH_CHECK();
-    return 0;
+    int kb = WGR_ROWS / d->ntaps;
+    if (kb > Ktot) kb = Ktot;
+    const int cog = Cout32 / 32;
+    while (kb > 4 && cog * cdiv(Ktot, kb) < 512) kb = (kb + 1) / 2;
+    *kind = 1; *KB = kb; *gx = cog; *gy = cdiv(Ktot, kb);
+    return;
   }
-  int gb = (int)cdiv64(total, 32);
-  hipLaunchKernelGGL(wgrad_reduce_k, dim3(gb > 4096 ? 4096 : gb), dim3(256), 0, s, *d, g.Ktot, g.Cout32);
+  const int gb = (int)cdiv64(total, 32);
+  *kind = 0; *KB = 0; *gx = gb > 4096 ? 4096 : gb; *gy = 1;
+}
+static int wg_reduce(const pmf_wgrad_desc_t* d, const WgGeom& g, hipStream_t s) {
+  int kind, KB, gx, gy;
+  red_plan(d, g.Ktot, g.Cout32, &kind, &KB, &gx, &gy);
+  if (kind == 1) hipLaunchKernelGGL(wgrad_reduce_tile_k, dim3(gx, gy), dim3(256), 0, s, *d, g.Ktot, g.Cout32, KB);
+  else hipLaunchKernelGGL(wgrad_reduce_k, dim3(gx), dim3(256), 0, s, *d, g.Ktot, g.Cout32);
+  PMF_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int pmf_conv_wgrad_reduce_plan(const pmf_wgrad_desc_t* d, int32_t* meta8) {
+  if (!d || !meta8 || d->nsrc < 1 || d->nsrc > PMF_MAX_SRC || d->ntaps < 1 || d->ntaps > PMF_MAX_TAPS || d->nsplit < 1)
+    return PMF_E_ARG;
+  int Ktot = 0;
+  for (int i = 0; i < d->nsrc; ++i) Ktot += d->src[i].C;
+  const int Cout32 = round_up(d->Cout, 32);
+  int kind, KB, gx, gy;
+  red_plan(d, Ktot, Cout32, &kind, &KB, &gx, &gy);
+  meta8[0] = 0; meta8[1] = kind; meta8[2] = Ktot; meta8[3] = Cout32; meta8[4] = KB; meta8[5] = gx; meta8[6] = gy; meta8[7] = 0;
+  return gx * gy;
+}
+extern "C" int pmf_conv_wgrad_reduce_multi(const pmf_wgrad_desc_t* jobs_dev, const int32_t* meta_dev, int32_t njobs,
+                                           int32_t total_blocks, pmf_stream_t s) {
+  if (!jobs_dev || !meta_dev || njobs < 1 || total_blocks < 1) return PMF_E_ARG;
+  hipLaunchKernelGGL(wgrad_reduce_multi_k, dim3(total_blocks), dim3(256), 0, (hipStream_t)s, jobs_dev,
+                     (const RedMeta*)meta_dev, njobs);
   PMF_LAUNCH_CHECK();
   return 0;
 }

@@ -15,6 +15,8 @@ static int run_one(const pmf_op_t& o, pmf_stream_t s) {
     case PMF_OP_WGRAD: return pmf_conv_wgrad(&o.u.wgrad, s);
     case PMF_OP_WGRAD_PART: return pmf_conv_wgrad_partial(&o.u.wgrad, s);
     case PMF_OP_WGRAD_RED: return pmf_conv_wgrad_reduce(&o.u.wgrad, s);
+    case PMF_OP_WGRAD_RED_MULTI:  // p0 descriptors(dev)  p1 meta(dev)  i0 njobs  i1 total_blocks
+      return pmf_conv_wgrad_reduce_multi((const pmf_wgrad_desc_t*)a.p[0], (const int32_t*)a.p[1], i[0], i[1], s);
     case PMF_OP_PACK:  // p0 jobs(dev)  i0 njobs  i1 total_blocks
       return pmf_pack_weights_batched((const pmf_pack_job_t*)a.p[0], i[0], i[1], s);
     case PMF_OP_BN_FINALIZE:  // p: stats gamma beta rm rv scale shift save_mean save_invstd | f: count mom eps | i: C nrows

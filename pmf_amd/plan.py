@@ -23,6 +23,7 @@ _A = 256  # arena alignment (bytes)
 SPLITK_BYTES = 32 << 20      # shared split-K scratch
 DBIAS_LD = 2048              # floats per partial conv-bias-gradient row (max Cout)
 COL_ROWS = 512               # PMF_COL_ROWS in csrc/common.h
+RED_BATCH = 16               # weight-gradient reductions per batched stage-2 launch (flat training state)
 
 
 def _ru(a, b):
@@ -150,6 +151,9 @@ class Plan:
         self._graphs, self._graph_seen = {}, {}   # hipGraph replay cache (see run)
         self._conv_fin = {}                 # forward conv op index -> index of the BN finalize op reading its rows
         self.n_wgrad = 0                    # weight-gradient ops emitted so far (workspace / event ping-pong)
+        import os as _os
+        self.batch_reds = _os.environ.get("PMF_RED_BATCH", "1") != "0"
+        self.pending_reds, self._red_tables = [], []
         self.grad_done = {}                 # id(param) -> index (in self.bwd) of the last op writing its gradient
         self.pgrad_floats = 0
         self._pid = {}
@@ -567,20 +571,70 @@ class Plan:
                 d.dbias_rows, d.dbias_nrows, d.dbias_ld = dbr.ptr, dbias_rows, dbr_ld
                 d.dbias_out = self.pgrad_buf.at(boff)
         boff = self.pgrad(conv.bias) if dbias_rows else None
-        # two ops: the partial-slab kernel on the main stream, the reduction into OIHW on the side stream (nothing
-        # downstream needs it before the optimiser).  Partial slabs ping-pong between two workspaces; side event i % 2
-        # is recorded after reduction i and awaited by the main stream before kernel i + 2 overwrites that workspace.
         widx = self.n_wgrad
         self.n_wgrad += 1
-        self.emit(self.bwd, L.OP_WGRAD_PART, f, lane=(((widx % 2) + 1) << 2) if widx >= 2 else 0)
-        part_index = len(self.bwd) - 1
-        self.emit(self.bwd, L.OP_WGRAD_RED, f, lane=1 | (((widx % 2) + 1) << 4))
-        self.grad_done[id(conv.weight)] = len(self.bwd) - 1
-        if dbias_rows:
-            self.grad_done[id(conv.bias)] = len(self.bwd) - 1
+        if self.flat is not None and self.batch_reds:
+            # flat training state (the product path): the partial-slab kernel now, the reduction into OIHW later -- the
+            # reductions of RED_BATCH consecutive layers are ONE launch (pmf_conv_wgrad_reduce_multi); every layer keeps
+            # its own workspace until then (1.65 GB at 64x2048 bs 2: nothing next to 288 GB)
+            ws = self.act.alloc(max(L.lib().pmf_conv_wgrad_workspace(C.byref(probe)), 256))
+
+            def fb(op, f=f, ws=ws):
+                f(op)
+                op.u.wgrad.partial = ws.ptr
+            self.emit(self.bwd, L.OP_WGRAD_PART, fb)
+            part_index = len(self.bwd) - 1
+            self.pending_reds.append((fb, [conv.weight] + ([conv.bias] if dbias_rows else [])))
+            if len(self.pending_reds) >= RED_BATCH:
+                self.flush_reds()
+        else:
+            # two ops: the partial-slab kernel on the main stream, the reduction into OIHW on the side stream (nothing
+            # downstream needs it before the optimiser).  Partial slabs ping-pong between two workspaces; side event
+            # i % 2 is recorded after reduction i and awaited by the main stream before kernel i + 2 overwrites it.
+            self.emit(self.bwd, L.OP_WGRAD_PART, f, lane=(((widx % 2) + 1) << 2) if widx >= 2 else 0)
+            part_index = len(self.bwd) - 1
+            self.emit(self.bwd, L.OP_WGRAD_RED, f, lane=1 | (((widx % 2) + 1) << 4))
+            self.grad_done[id(conv.weight)] = len(self.bwd) - 1
+            if dbias_rows:
+                self.grad_done[id(conv.bias)] = len(self.bwd) - 1
         self.meta_bwd[part_index] = dict(
             family="conv_wgrad", flops=2.0 * dz.N * dz.H * dz.W * Cout * conv.in_channels * len(taps), name=name,
             shape="%dx%dx%d %d->%d t%d" % (dz.N, dz.H, dz.W, conv.in_channels, Cout, len(taps)))
+
+    def flush_reds(self):
+        """emit ONE stage-2 launch for the weight gradients queued by _wgrad (flat training state only)"""
+        pend, self.pending_reds = self.pending_reds, []
+        if not pend:
+            return
+
+        def f(op, pend=pend):
+            lib = L.lib()
+            n = len(pend)
+            descs = (L.WgradDesc * n)()
+            meta = (C.c_int32 * (8 * n))()
+            tmp = L.Op()
+            blocks = 0
+            for j, (fill, _) in enumerate(pend):
+                C.memset(C.addressof(tmp), 0, C.sizeof(tmp))      # fills only set what they use (as on a fresh op)
+                fill(tmp)
+                C.memmove(C.addressof(descs[j]), C.addressof(tmp.u.wgrad), C.sizeof(L.WgradDesc))
+                row = (C.c_int32 * 8)()
+                nb = lib.pmf_conv_wgrad_reduce_plan(C.byref(descs[j]), row)
+                if nb <= 0:
+                    raise RuntimeError("pmf_conv_wgrad_reduce_plan failed: %d" % nb)
+                row[0] = blocks
+                meta[8 * j:8 * j + 8] = row[:]
+                blocks += nb
+            jd = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(self.device)
+            md = torch.frombuffer(bytearray(bytes(meta)), dtype=torch.uint8).to(self.device)
+            self._red_tables.append((jd, md))                  # keep the device tables alive with the plan
+            a = op.u.sm
+            a.p[0], a.p[1] = jd.data_ptr(), md.data_ptr()
+            a.i[0], a.i[1] = n, blocks
+        self.emit(self.bwd, L.OP_WGRAD_RED_MULTI, f)
+        for _, params in pend:
+            for p in params:
+                self.grad_done[id(p)] = len(self.bwd) - 1
 
     # ---- element-wise primitives -----------------------------------------------------------------
     def add_act(self, a, b, act, name=""):
@@ -882,6 +936,7 @@ class Plan:
         if self.training:
             for fn in reversed(self.tape):
                 fn()
+            self.flush_reds()
         self.tape = None
         if self.dry:
             return self
