@@ -30,7 +30,7 @@ def main(db, ops_file, step, out=None):
     ops = []
     for line in open(ops_file):
         p = line.split()
-        if p[1] in ("OP_CONV", "OP_WGRAD_PART", "OP_WGRAD_RED", "OP_WGRAD"):
+        if p[1] in ("OP_CONV", "OP_WGRAD_PART", "OP_WGRAD_RED", "OP_WGRAD_RED_MULTI", "OP_WGRAD"):
             i = line.index("[") if "[" in line else -1
             shape = line[i:line.index("]") + 1] if i >= 0 else ""
             gf = float(p[-4]) if i >= 0 else 0.0
@@ -40,10 +40,10 @@ def main(db, ops_file, step, out=None):
     k = 0
     res = []
     for op in ops:
-        want = {"OP_CONV": "C", "OP_WGRAD_PART": "W", "OP_WGRAD": "W", "OP_WGRAD_RED": "R"}[op[1]]
+        want = {"OP_CONV": "C", "OP_WGRAD_PART": "W", "OP_WGRAD": "W", "OP_WGRAD_RED": "R", "OP_WGRAD_RED_MULTI": "R"}[op[1]]
         if k >= len(cls):
             break
-        if op[1] == "OP_WGRAD_RED":
+        if op[1] in ("OP_WGRAD_RED", "OP_WGRAD_RED_MULTI"):
             if cls[k][0] == "R":
                 r = cls[k][1]; k += 1
                 res.append((op, (r[1] - r[0]) / 1e3, 0.0, r))
