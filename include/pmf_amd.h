@@ -386,9 +386,9 @@ typedef struct {
 
 typedef struct {
   int32_t kind;
-  int32_t pad_;    /* scheduling bits for pmf_plan_run: bit 0 = side stream (forks from the main stream at this point, joined
-                    * at the end of the range); bits 2-3 = k+1: the MAIN stream first waits for side event k; bits 4-5 =
-                    * k+1: record side event k after this op (k = 0, 1) */
+  int32_t pad_;    /* scheduling bits for pmf_plan_run: bits 0-1 = lane (0 = the caller's stream; a side lane forks from it
+                    * at its first op of the range and is joined at the end of the range); bits 8-15 = e+1: the op's lane
+                    * first waits for plan event e; bits 16-23 = e+1: record plan event e on the op's lane after the op */
   union {
     pmf_conv_desc_t conv;
     pmf_wgrad_desc_t wgrad;

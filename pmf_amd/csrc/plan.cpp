@@ -94,71 +94,93 @@ static int run_one(const pmf_op_t& o, pmf_stream_t s) {
   }
 }
 
-// Two lanes (pmf_op_t.pad_): side-lane ops go to a private stream.  A side op waits for everything issued on the main
-// stream before it (its inputs were produced there); the main stream only waits for the side stream at the end of the
-// range, or for one of two ping-pong events where a buffer is about to be reused.  The plan puts the weight-gradient
-// REDUCTIONS there: latency-bound 11-us kernels that nothing downstream needs before the optimiser, so they now run
-// under the next layer's kernels instead of between them (the partial slabs they read ping-pong between two
-// workspaces).  Putting the whole weight-gradient op on the side lane was measured first: no gain (two machine-filling
-// kernels just share the CUs).  hipGraph capture records the fork / join / event edges; PMF_SIDE=0 disables the lane.
-static hipStream_t g_side = nullptr;
-static hipEvent_t g_fork = nullptr, g_join = nullptr;
-static int lanes_init() {
-  if (g_side) return 0;
-  hipError_t e = hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking);
-  if (e != hipSuccess) return (int)e;
-  e = hipEventCreateWithFlags(&g_fork, hipEventDisableTiming);
-  if (e != hipSuccess) return (int)e;
-  e = hipEventCreateWithFlags(&g_join, hipEventDisableTiming);
-  return (int)e;
+// Lanes (pmf_op_t.pad_): a plan may spread independent branches of the network (the camera stream and the LiDAR stream
+// of PMFNet are independent between fusion points) over up to PMF_MAX_LANES HIP streams so that the ramp-up, tail and
+// latency-bound small kernels of one branch run under the machine-filling kernels of the other.
+//   bits 0-1   lane of the op (0 = the caller's stream)
+//   bits 8-15  e+1: the op's lane first waits for plan event e      (recorded earlier in the SAME range by another lane)
+//   bits 16-23 e+1: plan event e is recorded on the op's lane after the op
+// A side lane forks from the main stream at its first op of the range (it sees everything issued on the main stream up to
+// that point) and is joined to the main stream at the end of the range.  Events never reach across ranges.  hipGraph
+// capture records the fork / join / event edges, so a replayed range is a DAG with one branch per lane.
+// PMF_LANES=0 runs everything on the caller's stream.
+#define PMF_MAX_LANES 4
+#define PMF_MAX_EVENTS 255
+static hipStream_t g_lane[PMF_MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
+static hipEvent_t g_fork = nullptr, g_join[PMF_MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
+static hipEvent_t g_ev[PMF_MAX_EVENTS];
+static int g_nev = 0;
+static int lane_stream(int lane, hipStream_t* out) {
+  if (!g_lane[lane]) {
+    hipError_t e = hipStreamCreateWithFlags(&g_lane[lane], hipStreamNonBlocking);
+    if (e != hipSuccess) return (int)e;
+    e = hipEventCreateWithFlags(&g_join[lane], hipEventDisableTiming);
+    if (e != hipSuccess) return (int)e;
+  }
+  if (!g_fork) {
+    hipError_t e = hipEventCreateWithFlags(&g_fork, hipEventDisableTiming);
+    if (e != hipSuccess) return (int)e;
+  }
+  *out = g_lane[lane];
+  return 0;
+}
+static int plan_event(int e, hipEvent_t* out) {
+  while (g_nev <= e) {
+    hipError_t r = hipEventCreateWithFlags(&g_ev[g_nev], hipEventDisableTiming);
+    if (r != hipSuccess) return (int)r;
+    ++g_nev;
+  }
+  *out = g_ev[e];
+  return 0;
 }
 static bool lanes_enabled() {
   static int on = -1;
-  if (on < 0) { const char* e = getenv("PMF_SIDE"); on = (e && e[0] == '1') ? 1 : 0; }   // opt-in: measured 27.5 vs 25.5 ms/step -- 110 fork/join pairs cost more than the reductions they hide
+  if (on < 0) { const char* e = getenv("PMF_LANES"); on = (e && e[0] == '0') ? 0 : 1; }
   return on == 1;
 }
 
-static hipEvent_t g_ev[2] = {nullptr, nullptr};
-
 static int run_range(const pmf_op_t* ops, int32_t begin, int32_t end, hipStream_t main_s, int32_t* failed_at) {
-  bool side_used = false;
   const bool lanes = lanes_enabled();
-  bool ev_valid[2] = {false, false};     // side events recorded inside THIS range (a wait never reaches back further)
-  for (int32_t k = begin; k < end; ++k) {
-    const int bits = lanes ? ops[k].pad_ : 0;
-    int rc = 0;
-    if (bits) {
-      rc = lanes_init();
-      if (rc == 0 && !g_ev[0]) {
-        rc = (int)hipEventCreateWithFlags(&g_ev[0], hipEventDisableTiming);
-        if (rc == 0) rc = (int)hipEventCreateWithFlags(&g_ev[1], hipEventDisableTiming);
-      }
+  bool used[PMF_MAX_LANES] = {true, false, false, false};
+  bool ev_valid[PMF_MAX_EVENTS] = {};      // events recorded inside THIS range (a wait never reaches back further)
+  hipStream_t st[PMF_MAX_LANES] = {main_s, nullptr, nullptr, nullptr};
+  int rc = 0;
+  int32_t k = begin;
+  for (; k < end && rc == 0; ++k) {
+    const int bits = ops[k].pad_;
+    const int lane = lanes ? (bits & 3) : 0;
+    const int wait_e = ((bits >> 8) & 0xff) - 1, rec_e = ((bits >> 16) & 0xff) - 1;
+    if (lane && !used[lane]) {             // fork: the lane starts from the main stream's current position
+      rc = lane_stream(lane, &st[lane]);
+      if (rc == 0) rc = (int)hipEventRecord(g_fork, main_s);
+      if (rc == 0) rc = (int)hipStreamWaitEvent(st[lane], g_fork, 0);
+      if (rc) break;
+      used[lane] = true;
     }
-    const int wait_k = ((bits >> 2) & 3) - 1, rec_k = ((bits >> 4) & 3) - 1;
-    if (rc == 0 && wait_k >= 0 && ev_valid[wait_k]) rc = (int)hipStreamWaitEvent(main_s, g_ev[wait_k], 0);
-    if (rc == 0) {
-      if (bits & 1) {
-        rc = (int)hipEventRecord(g_fork, main_s);
-        if (rc == 0) rc = (int)hipStreamWaitEvent(g_side, g_fork, 0);
-        if (rc == 0) rc = run_one(ops[k], (pmf_stream_t)g_side);
-        side_used = true;
-        if (rc == 0 && rec_k >= 0) { rc = (int)hipEventRecord(g_ev[rec_k], g_side); ev_valid[rec_k] = true; }
-      } else {
-        rc = run_one(ops[k], (pmf_stream_t)main_s);
-      }
+    if (lanes && wait_e >= 0 && ev_valid[wait_e]) {
+      hipEvent_t ev;
+      rc = plan_event(wait_e, &ev);
+      if (rc == 0) rc = (int)hipStreamWaitEvent(st[lane], ev, 0);
+      if (rc) break;
     }
-    if (rc != 0) {
-      if (failed_at) *failed_at = k;
-      if (side_used) { (void)hipEventRecord(g_join, g_side); (void)hipStreamWaitEvent(main_s, g_join, 0); }
-      return rc;
+    rc = run_one(ops[k], (pmf_stream_t)st[lane]);
+    if (rc) break;
+    if (lanes && rec_e >= 0) {
+      hipEvent_t ev;
+      rc = plan_event(rec_e, &ev);
+      if (rc == 0) rc = (int)hipEventRecord(ev, st[lane]);
+      if (rc) break;
+      ev_valid[rec_e] = true;
     }
   }
-  if (side_used) {
-    hipError_t e = hipEventRecord(g_join, g_side);
-    if (e == hipSuccess) e = hipStreamWaitEvent(main_s, g_join, 0);
-    if (e != hipSuccess) return (int)e;
+  if (rc != 0 && failed_at) *failed_at = k;
+  for (int l = 1; l < PMF_MAX_LANES; ++l) {      // join (also on failure: never leave a forked capture behind)
+    if (!used[l]) continue;
+    hipError_t e = hipEventRecord(g_join[l], st[l]);
+    if (e == hipSuccess) e = hipStreamWaitEvent(main_s, g_join[l], 0);
+    if (e != hipSuccess && rc == 0) rc = (int)e;
   }
-  return 0;
+  return rc;
 }
 
 extern "C" int pmf_plan_run(const pmf_op_t* ops, int32_t n, pmf_stream_t s, int32_t* failed_at) {

@@ -266,6 +266,9 @@ class SalsaNextFusion(SalsaNext):
         self.aspp = ASPP(c * 8, c * 8)
 
     def _fuse(self, P, i, x, feats):
+        ready = getattr(P, "feat_ready", None)
+        if ready:                            # the camera features come from another lane
+            P.wait_event(P.fwd, ready[i - 1])
         return getattr(self, "fusionblock_%d" % i).emit(P, x, feats[i - 1], "fusion%d" % i)
 
     def _bottleneck(self, P, x):
@@ -367,7 +370,9 @@ class ResNet(_Holder):
         if pretrained:
             _try_load_imagenet(self, backbone, in_channels)
 
-    def emit(self, P, x, M):
+    def emit(self, P, x, M, ready=None):
+        """ready (optional list): receives one plan event per feature map, recorded on the emitting lane once the
+        feature is complete -- consumers on another lane wait for it (Plan.wait_event)."""
         c1 = P.conv([x], self.conv1, L.ACT_NONE, self.bn1, "bn_act", True, name="enc.stem")
         y = V(P.maxpool(c1, name="enc.maxpool"))
         feats = []
@@ -377,6 +382,8 @@ class ResNet(_Holder):
             if li >= 2 and M is not None:    # Dropout2d on layer3 / layer4 outputs (one module, two masks)
                 y = y.with_cmul(M["enc.f%d" % li], y.t.C)
             feats.append(y)
+            if ready is not None:
+                ready.append(P.record_event(P.fwd))
         return feats
 
 
@@ -451,11 +458,18 @@ class PMFNet(nn.Module):
     def _build(self, N, H, W, training, device, dry=False):
         P = Plan(device, training, getattr(self, "_flat", None), dry)
         M = _alloc_masks(P, self, N, device) if training else None
+        # two lanes (csrc/plan.cpp): the camera stream (encoder + decoder) runs on lane 1, the LiDAR stream on lane 0; the
+        # only forward edges between them are the four feature maps the fusion blocks read (pmf_net.py:160-176)
         pcd = V(P.input_nchw("pcd", N, self.pcd_channels, H, W, "pcd"))
+        P.lane = 1
         rgb = V(P.input_nchw("rgb", N, self.img_channels, H, W, "rgb"))
-        feats = self.camera_stream_encoder.emit(P, rgb, M)
+        P.feat_ready = []
+        feats = self.camera_stream_encoder.emit(P, rgb, M, P.feat_ready)
+        P.lane = 0
         self.lidar_stream.emit_trunk(P, pcd, feats, M)
+        P.lane = 1
         self.camera_stream_decoder.emit(P, feats)
+        P.lane = 0
         return P.finalise()
 
     def _mask_sites(self):

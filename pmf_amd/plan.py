@@ -105,6 +105,7 @@ class T:
         self.g = None            # gradient tensor (same geometry)
         self.g_written = False
         self.needs_grad = True
+        self.lane = plan.lane    # lane of the op that produces it (its backward runs there too)
 
     @property
     def npix(self):
@@ -152,11 +153,20 @@ class Plan:
         self.params = []                    # (param, grad Buf float offset)
         self._graphs, self._graph_seen = {}, {}   # hipGraph replay cache (see run)
         self._conv_fin = {}                 # forward conv op index -> index of the BN finalize op reading its rows
-        self.n_wgrad = 0                    # weight-gradient ops emitted so far (workspace / event ping-pong)
+        self.n_wgrad = 0                    # weight-gradient ops emitted so far
+        # lanes: independent branches of the network on separate HIP streams (csrc/plan.cpp); ``lane`` is the lane ops
+        # are being emitted on; cross-lane edges are plan events (record after one op, wait before another)
+        self.lane = 0
+        self.n_lanes = 2
+        self.n_events = 0
+        self._event_pos = {}                # event -> list position of its record op
+        self._last_op = {}                  # (id(op list), lane) -> last entry emitted on that lane
+        self._pending_wait = {}             # (id(op list), lane) -> (event, position of its record op)
+        self._touched = None                # gradient tensors touched by the tape entry being emitted
         import os as _os
         self.red_batch = int(_os.environ.get("PMF_RED_BATCH", str(RED_BATCH)))     # 0: one reduction op per layer
         self.batch_reds = self.red_batch > 0
-        self.pending_reds, self._red_tables = [], []
+        self.pending_reds, self._red_tables = {}, []     # lane -> queued stage-2 reductions
         self.grad_done = {}                 # id(param) -> index (in self.bwd) of the last op writing its gradient
         self.pgrad_floats = 0
         self._pid = {}
@@ -181,11 +191,84 @@ class Plan:
         return self._pid[id(p)][1]
 
     # ------------------------------------------------------------------ op emission helpers
-    def emit(self, lst, kind, fill, lane=0):
-        """fill(op) populates a zeroed L.Op at finalise time (pointers are known only then).
-        lane 1 = side stream: the op only waits for what was issued before it and is joined at the end of the range
-        (weight gradients: off the critical path, they overlap the latency-bound BatchNorm / finish kernels)."""
-        lst.append((kind, fill) if lane == 0 else (kind, fill, lane))    # lane: the pad_ scheduling bits (pmf_amd.h)
+    def emit(self, lst, kind, fill):
+        """fill(op) populates a zeroed L.Op at finalise time (pointers are known only then).  The op runs on the
+        current lane; a wait registered for this lane (wait_event) is attached to it."""
+        ent = [kind, fill, self.lane]       # [kind, fill, scheduling bits (pmf_amd.h)]
+        key = (id(lst), self.lane)
+        w = self._pending_wait.pop(key, None)
+        if w is not None:
+            ent[2] |= (w[0] + 1) << 8
+        lst.append(ent)
+        ent.append(len(lst) - 1)            # [3]: position at emission time (orders record points of one lane)
+        self._last_op[key] = ent
+
+    def record_event(self, lst, lane=None):
+        """plan event recorded after the last op emitted so far on ``lane`` (default: the current lane); None when the
+        lane has not emitted anything into ``lst`` yet (nothing to wait for: a side lane forks from the main stream)."""
+        ent = self._last_op.get((id(lst), self.lane if lane is None else lane))
+        return None if ent is None else self._event_after(ent)
+
+    def _event_after(self, ent):
+        e = ((ent[2] >> 16) & 0xff) - 1
+        if e < 0:
+            e = self.n_events
+            self.n_events += 1
+            if e >= 255:
+                raise RuntimeError("plan: more than 255 cross-lane events")
+            ent[2] |= (e + 1) << 16
+            self._event_pos[e] = ent[3]
+        return (e, ent[3])
+
+    def wait_event(self, lst, ev):
+        """the NEXT op emitted on the current lane first waits for ``ev`` (from record_event).  Two lanes only: of
+        several waits for the other lane the latest record point subsumes the others."""
+        if ev is None:
+            return
+        key = (id(lst), self.lane)
+        cur = self._pending_wait.get(key)
+        if cur is None or ev[1] > cur[1]:
+            self._pending_wait[key] = ev
+
+    def on_backward(self, fn):
+        """register the backward of the op(s) just emitted; it is emitted on the lane of its forward."""
+        self.tape.append((self.lane, fn))
+
+    def _emit_tape(self):
+        """walk the tape in reverse.  Gradient tensors touched by an entry (grad_of / tgrad) are tracked per entry: when
+        the previous entry that touched one of them ran on the other lane, the entry's first op waits for an event
+        recorded after that entry's last op -- accumulation order and read-after-write across lanes stay exactly those
+        of the single-stream order."""
+        lst = self.bwd
+        for lane, fn in reversed(self.tape):
+            self.lane = lane
+            a = len(lst)
+            self._touched = []
+            fn()
+            touched, self._touched = self._touched, None
+            b = len(lst)
+            if b == a:
+                continue
+            first, last, wait = lst[a], lst[b - 1], None
+            for g in touched:
+                lw = getattr(g, "_last_touch", None)
+                if lw is not None and lw[0] != lane:
+                    ev = self._event_after(lw[1])
+                    if wait is None or ev[1] > wait[1]:
+                        wait = ev
+            if wait is not None:
+                cur = ((first[2] >> 8) & 0xff) - 1
+                if cur < 0 or wait[1] > self._event_pos[cur]:
+                    first[2] = (first[2] & ~0xff00) | ((wait[0] + 1) << 8)
+            for g in touched:
+                g._last_touch = (lane, last)
+        for lane in sorted(self.pending_reds):
+            self.flush_reds(lane)
+        self.lane = 0
+
+    def _touch(self, g):
+        if self._touched is not None and g is not None:
+            self._touched.append(g)
 
     def view_struct(self, v, dst):
         dst.x = v.t.buf.ptr
@@ -206,25 +289,65 @@ class Plan:
 
     # gradient targets ------------------------------------------------------------------
     def grad_of(self, v):
-        """(tensor receiving dL/dy of view v, accumulate flag); allocates lazily."""
+        """(tensor receiving dL/dy of view v, accumulate flag); allocates lazily.
+        A consumer on another lane than the producer accumulates into a PRIVATE tensor of its lane; the producer's
+        backward folds it in before it reads the gradient (_fold_side).  The two lanes then only meet where the data
+        dependency is (the fold), not at every accumulation into the shared tensor."""
         r = v.root()
+        if self.lane != r.t.lane:
+            holder = r if r.bn is not None else r.t
+            side = holder.__dict__.setdefault("_side", {})
+            ent = side.get(self.lane)
+            if ent is None:
+                ent = side[self.lane] = [T(self, r.t.N, r.t.H, r.t.W, r.t.C, r.t.name + ".gside%d" % self.lane,
+                                           ldc=r.t.ldc), False]
+            acc, ent[1] = ent[1], True
+            self._touch(ent[0])
+            return ent[0], int(acc)
         if r.bn is not None:
             if r.gy is None:
                 r.gy = T(self, r.t.N, r.t.H, r.t.W, r.t.C, r.t.name + ".gy", ldc=r.t.ldc)
             acc = r.gy_written
             r.gy_written = True
+            self._touch(r.gy)
             return r.gy, int(acc)
         t = r.t
         if t.g is None:
             t.g = T(self, t.N, t.H, t.W, t.C, t.name + ".g", ldc=t.ldc)
         acc = t.g_written
         t.g_written = True
+        self._touch(t.g)
         return t.g, int(acc)
+
+    def _fold_side(self, holder, g, written):
+        """g (+)= the private accumulators other lanes kept for this gradient (grad_of); returns True when g holds a
+        gradient afterwards.  Emitted on the current lane = the producer's lane, at the start of its backward."""
+        for lane, (sg, w) in sorted(getattr(holder, "_side", {}).items()):
+            if not w:
+                continue
+            self._touch(sg)
+
+            def f(op, sg=sg, g=g, both=written):
+                s = op.u.sm
+                for k, t in enumerate((sg, g) if both else (sg,)):
+                    s.v[k].x, s.v[k].ldc = t.buf.ptr, t.ldc
+                s.p[0] = g.buf.ptr
+                s.i[0], s.i[1], s.i[2], s.i[3], s.i[4] = L.ACT_NONE, g.ldc, g.H * g.W, int(both), _ru(g.C, 4)
+                s.l[0] = g.npix
+            self.emit(self.bwd, L.OP_ADD_ACT, f)
+            written = True
+        return written
 
     def tgrad(self, t):
         """the gradient tensor of a materialised T that this op is about to CONSUME."""
+        if getattr(t, "_side", None):
+            if t.g is None:
+                t.g = T(self, t.N, t.H, t.W, t.C, t.name + ".g", ldc=t.ldc)
+            t.g_written = self._fold_side(t, t.g, t.g_written)
+            t._side = None
         if t.g is None or not t.g_written:
             raise RuntimeError("plan: gradient of %s consumed before any producer wrote it" % t.name)
+        self._touch(t.g)
         return t.g
 
     # ------------------------------------------------------------------ primitives
@@ -313,6 +436,8 @@ class Plan:
             max_rows = max(stat_rows, L.lib().pmf_conv_fwd_stat_rows_max(C.byref(probe)))
         stats = self.act.alloc(16 * Cout * max_rows) if train_bn else None   # float64 [rows][2][Cout] partials
 
+        lane = self.lane
+
         def f(op, srcs=srcs):
             d = op.u.conv
             shape_fill(d)
@@ -325,7 +450,7 @@ class Plan:
             d.out_sy = d.out_sx = 1
             d.stats = stats.ptr if stats is not None else None
             d.ep_pmask = pmask.buf.ptr if pmask is not None else None
-            d.splitk_ws, d.splitk_ws_bytes = self.sk_buf.ptr, self.sk_buf.nbytes
+            d.splitk_ws, d.splitk_ws_bytes = self.sk_bufs[lane].ptr, self.sk_bufs[lane].nbytes
         self.emit(self.fwd, L.OP_CONV, f)
         conv_fwd_index = len(self.fwd) - 1
         conv_flops = 2.0 * N * OH * OW * Cout * conv.in_channels * len(taps)   # algorithmic (SURVEY.md 8d rule)
@@ -374,6 +499,11 @@ class Plan:
             dbr_ld = _ru(Cout, 4)
             dbr = self.act.alloc(COL_ROWS * dbr_ld * 4) if (has_bias and pmask is None) else None
             if bn is not None:
+                if getattr(view, "_side", None):
+                    if view.gy is None:
+                        view.gy = T(self, N, OH, OW, Cout, name + ".gy", ldc=out.ldc)
+                    view.gy_written = self._fold_side(view, view.gy, view.gy_written)
+                    view._side = None
                 if view.gy is None:
                     raise RuntimeError("plan: no gradient reached BN output of %s" % name)
                 if out.g is None:
@@ -382,12 +512,14 @@ class Plan:
                 coef = self.act.alloc(12 * Cout)                  # [3][Cout] per-channel backward coefficients
                 dgam, dbet = self.pgrad(bn.weight), self.pgrad(bn.bias)
                 gyt, dz = view.gy, out.g
+                self._touch(gyt)
+                self._touch(dz)
                 self.colrows_max = max(self.colrows_max, _ru(Cout, 4))
 
                 def r1(op):
                     a = op.u.sm
                     ps = (gyt.buf.ptr, out.buf.ptr, info["mean"].ptr, bn.weight.data_ptr(), info["invstd"].ptr,
-                          self.bnpart_buf.ptr, coef.ptr, self.pgrad_buf.at(dgam), self.pgrad_buf.at(dbet))
+                          self.bnpart_bufs[lane].ptr, coef.ptr, self.pgrad_buf.at(dgam), self.pgrad_buf.at(dbet))
                     for i, p in enumerate(ps):
                         a.p[i] = p
                     a.i[0], a.i[1], a.i[2], a.i[3] = gyt.ldc, out.ldc, Cout, 1
@@ -449,7 +581,7 @@ class Plan:
                         self.grad_done[id(extra_bias)] = len(self.bwd) - 1
             self._dgrad(srcs, conv, dz, taps, stride, gather, name)
             self._wgrad(srcs, conv, dz, taps, stride, gather, name, dbias_rows, dbr, dbr_ld)
-        self.tape.append(backward)
+        self.on_backward(backward)
         return view
 
     def _dgrad(self, srcs, conv, dz, taps, stride, gather, name):
@@ -462,6 +594,7 @@ class Plan:
         if not any(s.t.needs_grad for s in srcs):
             return
         ldwT = _ru(Cin_tot, 64) + 64
+        lane = self.lane
         if stride == 1:
             classes = [(0, 0, [(-dy, -dx, wi) for (dy, dx, wi) in taps])]
         else:
@@ -485,6 +618,7 @@ class Plan:
                     if r.t.g is None:
                         r.t.g = T(self, r.t.N, 1, 1, r.t.C, r.t.name + ".g", arena=self.zero_bwd, ldc=r.t.ldc)
                     r.t.g_written = True
+                    self._touch(r.t.g)
                     tgt, acc = tmp, 0
                 else:
                     tgt, acc = self.grad_of(s)
@@ -514,7 +648,7 @@ class Plan:
                         d.out_sy = d.out_sx = stride
                         d.out_oy, d.out_ox = py, px
                         d.accumulate = acc
-                        d.splitk_ws, d.splitk_ws_bytes = self.sk_buf.ptr, self.sk_buf.nbytes
+                        d.splitk_ws, d.splitk_ws_bytes = self.sk_bufs[lane].ptr, self.sk_bufs[lane].nbytes
                         if s.cmul is not None:
                             d.ep_cmul, d.ep_cmul_ld = self.masks_ptr + 4 * s.cmul, s.cmul_ld
                         if relu_x is not None:
@@ -566,7 +700,7 @@ class Plan:
             for i, s in enumerate(srcs):
                 self.src_struct(s, d.src[i])
             d.dz, d.dz_ldc = dz.buf.ptr, dz.ldc
-            d.partial = self.wg_bufs[widx % 2].ptr
+            d.partial = self.wg_bufs[lane].ptr
             d.nsplit = nsplit
             d.dw_oihw = self.pgrad_buf.at(goff)
             d.accumulate = 0
@@ -574,7 +708,7 @@ class Plan:
                 d.dbias_rows, d.dbias_nrows, d.dbias_ld = dbr.ptr, dbias_rows, dbr_ld
                 d.dbias_out = self.pgrad_buf.at(boff)
         boff = self.pgrad(conv.bias) if dbias_rows else None
-        widx = self.n_wgrad
+        lane = self.lane
         self.n_wgrad += 1
         if self.flat is not None and self.batch_reds:
             # flat training state (the product path): the partial-slab kernel now, the reduction into OIHW later -- the
@@ -587,16 +721,16 @@ class Plan:
                 op.u.wgrad.partial = ws.ptr
             self.emit(self.bwd, L.OP_WGRAD_PART, fb)
             part_index = len(self.bwd) - 1
-            self.pending_reds.append((fb, [conv.weight] + ([conv.bias] if dbias_rows else [])))
-            if len(self.pending_reds) >= self.red_batch:
-                self.flush_reds()
+            pend = self.pending_reds.setdefault(lane, [])
+            pend.append((fb, [conv.weight] + ([conv.bias] if dbias_rows else [])))
+            if len(pend) >= self.red_batch:
+                self.flush_reds(lane)
         else:
-            # two ops: the partial-slab kernel on the main stream, the reduction into OIHW on the side stream (nothing
-            # downstream needs it before the optimiser).  Partial slabs ping-pong between two workspaces; side event
-            # i % 2 is recorded after reduction i and awaited by the main stream before kernel i + 2 overwrites it.
-            self.emit(self.bwd, L.OP_WGRAD_PART, f, lane=(((widx % 2) + 1) << 2) if widx >= 2 else 0)
+            # per-tensor gradients (tests, stock DistributedDataParallel): partial slabs, then the reduction into OIHW,
+            # back to back on the op's lane through that lane's workspace
+            self.emit(self.bwd, L.OP_WGRAD_PART, f)
             part_index = len(self.bwd) - 1
-            self.emit(self.bwd, L.OP_WGRAD_RED, f, lane=1 | (((widx % 2) + 1) << 4))
+            self.emit(self.bwd, L.OP_WGRAD_RED, f)
             self.grad_done[id(conv.weight)] = len(self.bwd) - 1
             if dbias_rows:
                 self.grad_done[id(conv.bias)] = len(self.bwd) - 1
@@ -604,11 +738,12 @@ class Plan:
             family="conv_wgrad", flops=2.0 * dz.N * dz.H * dz.W * Cout * conv.in_channels * len(taps), name=name,
             shape="%dx%dx%d %d->%d t%d" % (dz.N, dz.H, dz.W, conv.in_channels, Cout, len(taps)))
 
-    def flush_reds(self):
-        """emit ONE stage-2 launch for the weight gradients queued by _wgrad (flat training state only)"""
-        pend, self.pending_reds = self.pending_reds, []
+    def flush_reds(self, lane):
+        """emit ONE stage-2 launch for the weight gradients queued on ``lane`` by _wgrad (flat training state only)"""
+        pend = self.pending_reds.pop(lane, [])
         if not pend:
             return
+        prev, self.lane = self.lane, lane
 
         def f(op, pend=pend):
             lib = L.lib()
@@ -635,6 +770,7 @@ class Plan:
             a.p[0], a.p[1] = jd.data_ptr(), md.data_ptr()
             a.i[0], a.i[1] = n, blocks
         self.emit(self.bwd, L.OP_WGRAD_RED_MULTI, f)
+        self.lane = prev
         for _, params in pend:
             for p in params:
                 self.grad_done[id(p)] = len(self.bwd) - 1
@@ -672,7 +808,7 @@ class Plan:
                     s.i[7] = _ru(t.C, 4)
                     s.l[0] = out.npix
                 self.emit(self.bwd, L.OP_ADD_ACT_BWD, fb)
-            self.tape.append(backward)
+            self.on_backward(backward)
         return out
 
     # ---- per-pixel validity masks (EPMF) ---------------------------------------------------------------
@@ -732,7 +868,7 @@ class Plan:
                     s.i[0], s.i[1], s.i[2], s.i[3] = g.ldc, _ru(t.C, 4), gin.ldc, acc
                     s.l[0] = t.npix
                 self.emit(self.bwd, L.OP_PMASK_MUL_BWD, fb)
-            self.tape.append(backward)
+            self.on_backward(backward)
         else:
             out.needs_grad = False
         return out
@@ -769,7 +905,7 @@ class Plan:
                         s.i[0], s.i[1], s.i[2], s.i[3], s.i[4] = g.ldc, t.N, t.H, t.W, _ru(t.C, 4)
                         s.i[5], s.i[6], s.i[7] = v.cmul_ld, gin.ldc, acc
                 self.emit(self.bwd, kind_b, fb)
-            self.tape.append(backward)
+            self.on_backward(backward)
         return out
 
     def avgpool(self, v, name=""):
@@ -799,7 +935,7 @@ class Plan:
                     s.i[0], s.i[1], s.i[2], s.i[3], s.i[4] = g.ldc, t.N, t.H, t.W, _ru(t.C, 4)
                     s.i[5], s.i[6] = gin.ldc, acc
                 self.emit(self.bwd, L.OP_BILINEAR_BWD, fb)
-            self.tape.append(backward)
+            self.on_backward(backward)
         return out
 
     def pixel_shuffle(self, v, out_cmul=None, out_cmul_ld=0, name=""):
@@ -828,7 +964,7 @@ class Plan:
                     for i, x in enumerate((g.ldc, t.N, t.H, t.W, Co, out_cmul_ld, v.cmul_ld, gin.ldc, acc)):
                         s.i[i] = x
                 self.emit(self.bwd, L.OP_PSHUFFLE_BWD, fb)
-            self.tape.append(backward)
+            self.on_backward(backward)
         return out
 
     def gate(self, f_v, att_v, pcd, name=""):
@@ -859,7 +995,7 @@ class Plan:
                         s.i[i] = x
                     s.l[0] = out.npix
                 self.emit(self.bwd, L.OP_GATE_BWD, fb)
-            self.tape.append(backward)
+            self.on_backward(backward)
         return out
 
     def global_mean(self, v, name=""):
@@ -884,7 +1020,7 @@ class Plan:
                     for i, x in enumerate((t.N, t.H * t.W, _ru(t.C, 4), v.cmul_ld, gin.ldc, acc)):
                         s.i[i] = x
                 self.emit(self.bwd, L.OP_GMEAN_BWD, fb)
-            self.tape.append(backward)
+            self.on_backward(backward)
         return out
 
     def softmax_out(self, logits, slot, name=""):
@@ -903,6 +1039,7 @@ class Plan:
                 if t.g is None:
                     t.g = T(self, t.N, t.H, t.W, t.C, name + ".dlogits", ldc=t.ldc)
                 t.g_written = True
+                self._touch(t.g)
 
                 def fb(op):
                     s = op.u.sm
@@ -911,7 +1048,7 @@ class Plan:
                     s.i[0], s.i[1], s.i[2], s.i[3] = t.N, t.H * t.W, t.C, t.ldc
                 self.emit(self.bwd, L.OP_SOFTMAX_BWD, fb)
                 self.out_slots[slot]["bwd_index"] = len(self.bwd) - 1
-            self.tape.append(backward)
+            self.on_backward(backward)
 
     def external_grad(self, v):
         """tests: declare that dL/d(view) is supplied from outside (written into the returned T before backward)."""
@@ -937,9 +1074,7 @@ class Plan:
         # backward ops are emitted by walking the tape in reverse; gradients of the flat parameter buffer and
         # the BN reduction scratch live in zero_bwd (one fill at the start of the backward pass)
         if self.training:
-            for fn in reversed(self.tape):
-                fn()
-            self.flush_reds()
+            self._emit_tape()
         self.tape = None
         if self.dry:
             return self
@@ -948,10 +1083,12 @@ class Plan:
             self.pgrad_floats = self.flat.grad.numel()
         else:
             self.pgrad_buf = self.zero_bwd.alloc(4 * max(self.pgrad_floats, 64)) if self.training else None
-        self.wg_bufs = [self.act.alloc(max(self.wg_scratch, 256)) for _ in range(2)] if self.training else None
-        self.wg_buf = self.wg_bufs[0] if self.training else None
-        self.sk_buf = self.act.alloc(SPLITK_BYTES)   # shared split-K scratch (small maps only; ops run in stream order)
-        self.bnpart_buf = self.act.alloc(COL_ROWS * 2 * max(self.colrows_max, 4) * 8)   # float64 partial rows
+        # scratch shared by the ops of ONE lane (they run in stream order): weight-gradient slabs of the per-tensor path,
+        # split-K slabs (small maps only), float64 partial rows of the BatchNorm backward reduction
+        nl = self.n_lanes
+        self.wg_bufs = [self.act.alloc(max(self.wg_scratch, 256)) for _ in range(nl)] if self.training else None
+        self.sk_bufs = [self.act.alloc(SPLITK_BYTES) for _ in range(nl)]
+        self.bnpart_bufs = [self.act.alloc(COL_ROWS * 2 * max(self.colrows_max, 4) * 8) for _ in range(nl)]
         for a, zero in ((self.act, False), (self.zero_fwd, True), (self.zero_bwd, True), (self.persist, True)):
             a.materialise(dev, zero)
         self.masks_ptr = self.masks.data_ptr() if self.masks is not None else 0
@@ -984,7 +1121,7 @@ class Plan:
             for ent in prologue + lst:
                 kind, fill = ent[0], ent[1]
                 arr[k].kind = kind
-                arr[k].pad_ = ent[2] if len(ent) > 2 else 0
+                arr[k].pad_ = ent[2] if len(ent) > 2 else 0     # lane / wait / record bits (pmf_amd.h)
                 fill(arr[k])
                 k += 1
             return arr, n

@@ -116,11 +116,25 @@ def test_plan_builds_and_is_consistent(training):
     if training:
         bk = [L.OP_NAMES[k] for k in P.bwd_kinds]
         assert bk.count("OP_WGRAD_PART") == bk.count("OP_WGRAD_RED") == 110 and bk.count("OP_BN_BWD_APPLY") == 94
-        # scheduling bits: reductions on the side lane recording ping-pong events that the kernel two ops later awaits
-        sched = [(k, P.bwd_ops[i].pad_) for i, k in enumerate(bk) if k.startswith("OP_WGRAD")]
-        parts, reds = [b for k, b in sched if k == "OP_WGRAD_PART"], [b for k, b in sched if k == "OP_WGRAD_RED"]
-        assert all(b & 1 and ((b >> 4) & 3) - 1 == i % 2 for i, b in enumerate(reds))
-        assert parts[0] == parts[1] == 0 and all(((b >> 2) & 3) - 1 == i % 2 for i, b in enumerate(parts) if i >= 2)
+        # scheduling bits: the camera stream on lane 1, the LiDAR stream on lane 0; forward: one event per encoder
+        # feature map awaited by the fusion block that reads it; backward: the four fusion blocks' image gradients go to
+        # private tensors that the encoder's backward folds in (one ADD_ACT per feature map, waiting for its event)
+        fl = [P.fwd_ops[i].pad_ for i in range(P.n_fwd)]
+        assert {b & 3 for b in fl} == {0, 1}
+        rec = {((b >> 16) & 0xff) - 1 for b in fl if (b >> 16) & 0xff}
+        wait = [(((b >> 8) & 0xff) - 1, b & 3) for b in fl if (b >> 8) & 0xff]
+        assert len(wait) == 4 and all(l == 0 for _, l in wait) and {e for e, _ in wait} == rec
+        bl = [(bk[i], P.bwd_ops[i].pad_) for i in range(P.n_bwd)]
+        bwait = [(k, b & 3) for k, b in bl if (b >> 8) & 0xff]
+        assert bwait == [("OP_ADD_ACT", 1)] * 4
+        for ops, n in ((P.fwd_ops, P.n_fwd), (P.bwd_ops, P.n_bwd)):      # an event is recorded before it is awaited
+            seen = set()
+            for i in range(n):
+                b = ops[i].pad_
+                if (b >> 8) & 0xff:
+                    assert ((b >> 8) & 0xff) - 1 in seen
+                if (b >> 16) & 0xff:
+                    seen.add(((b >> 16) & 0xff) - 1)
         # every parameter has a slot in the flat gradient buffer
         assert {id(p) for p in m.parameters()} == {id(p) for p in P.params}
         offs = sorted((P._pid[id(p)][1], p.numel()) for p in P.params)
