@@ -335,6 +335,15 @@ int pmf_flip_rotate_crop(const float* src, int32_t C, int32_t h, int32_t w, int3
                          int32_t top, int32_t left, int32_t crop_h, int32_t crop_w, int32_t pad_top, int32_t pad_left,
                          float* dst, int32_t oh, int32_t ow, pmf_stream_t s);
 
+/* torchvision ColorJitter on the PIL image (perspective_view_loader.py:46-49,84-85; perspective_view_loader_v2.py:19-23,
+ * 46-47), applied in place to the uint8 [h][w][3] frame on the device, bit for bit what Pillow computes (ImageEnhance =
+ * Image.blend with a degenerate image; hue through Pillow's HSV conversion), each operation on the uint8 result of the
+ * previous one.  HOST arrays: order4 = the drawn permutation of {0 brightness, 1 contrast, 2 saturation, 3 hue};
+ * factor4[op] / enabled4[op] = the drawn factor of operation op / whether it is applied (a zero-width range draws
+ * nothing).  scratch: one device uint64 (luma sum of the contrast step). */
+int pmf_color_jitter(uint8_t* image, int32_t h, int32_t w, const int32_t* order4, const double* factor4,
+                     const int32_t* enabled4, uint64_t* scratch, pmf_stream_t s);
+
 /* ---- loss-side kernels ------------------------------------------------------------------------------------ */
 /* Lovasz-softmax Jaccard gradient (pc_processor/loss/lovasz_softmax.py:56-68) for C class rows at once.
  * fg_sorted f32[C][P]: 0/1 foreground indicator, each row ordered by DESCENDING error with ignored pixels last;

@@ -531,10 +531,122 @@ def trainer_trace(R):
     print("g7_trace: %d arrays" % len(out))
 
 
+def _torchvision_transform_standins(tvt):
+    """functional stand-ins for the torchvision.transforms classes the training path of the perspective loaders APPLIES
+    (torchvision is absent).  ColorJitter: torchvision's published get_params draw order, pixel operations by Pillow
+    itself (ImageEnhance / HSV convert -- what torchvision's PIL backend calls).  Flip / rotate / crop / pad / compose:
+    oracle/tensor_aug_ref.py (torch's own grid_sample).  => the fixture pins the reference LOADER code + Pillow; the
+    torchvision layer is restated (unpinned)."""
+    from PIL import Image, ImageEnhance
+    from oracle import color_jitter_ref as CJ
+    from oracle import tensor_aug_ref as TA
+
+    class ColorJitter:
+        def __init__(self, brightness=0, contrast=0, saturation=0, hue=0):
+            self.ranges = CJ.jitter_ranges(brightness, contrast, saturation, hue)
+
+        def __call__(self, img):
+            order, fac = CJ.draw_params(self.ranges)
+            for fn_id in order:
+                f = fac[fn_id]
+                if f is None:
+                    continue
+                if fn_id == 0:
+                    img = ImageEnhance.Brightness(img).enhance(f)
+                elif fn_id == 1:
+                    img = ImageEnhance.Contrast(img).enhance(f)
+                elif fn_id == 2:
+                    img = ImageEnhance.Color(img).enhance(f)
+                else:
+                    h, s_, v = img.convert("HSV").split()
+                    np_h = np.array(h, dtype=np.uint8)
+                    with np.errstate(over="ignore"):
+                        np_h += np.uint8(int(f * 255) & 0xff)
+                    img = Image.merge("HSV", (Image.fromarray(np_h, "L"), s_, v)).convert("RGB")
+            return img
+
+    class Compose:
+        def __init__(self, ts):
+            self.ts = ts
+
+        def __call__(self, x):
+            for t in self.ts:
+                x = t(x)
+            return x
+
+    class RandomHorizontalFlip:
+        def __init__(self, p=0.5):
+            self.p = p
+
+        def __call__(self, x):
+            return x.flip(-1) if torch.rand(1) < self.p else x
+
+    class RandomRotation:
+        def __init__(self, degrees):
+            self.d = float(degrees)
+
+        def __call__(self, x):
+            angle = float(torch.empty(1).uniform_(-self.d, self.d).item())
+            return TA.rotate_nearest(x, angle)
+
+    class RandomCrop:
+        def __init__(self, size):
+            self.size = size
+
+        def __call__(self, x):
+            h, w = x.shape[-2:]
+            th, tw = self.size
+            if h < th or w < tw:
+                raise ValueError("Required crop size {} is larger than input image size {}".format((th, tw), (h, w)))
+            if (h, w) == (th, tw):
+                return x
+            i = int(torch.randint(0, h - th + 1, size=(1,)).item())
+            j = int(torch.randint(0, w - tw + 1, size=(1,)).item())
+            return x[..., i:i + th, j:j + tw]
+
+    class Pad:
+        def __init__(self, padding):
+            self.p = padding
+
+        def __call__(self, x):
+            return torch.nn.functional.pad(x, (self.p[0], self.p[0], self.p[1], self.p[1]))
+
+    for c in (ColorJitter, Compose, RandomHorizontalFlip, RandomRotation, RandomCrop, Pad):
+        setattr(tvt, c.__name__, c)
+
+
+def loader_train(R):
+    """G13: the reference PerspectiveViewLoader's TRAINING item exactly as tasks/pmf/trainer.py:139-142 builds it
+    (is_train=True, pcd_aug=False, img_aug=True, use_padding=True), torch seeded per case."""
+    from PIL import Image
+    _torchvision_transform_standins(sys.modules["torchvision.transforms"])
+    out = {}
+    for tag, seed, npts, h, w, ht, wt, hp, wp in (("a", 2, 6000, 96, 320, 80, 256, 4, 8),
+                                                 ("b", 7, 9000, 64, 208, 64, 208, 2, 4)):
+        M, pts, sem, img, lut = loader_ref.synthetic_frame(seed, npts, h, w)
+        ds = object.__new__(R.parser.SemanticKitti)
+        ds.has_image = True
+        ds.proj_matrix = {"00": M}
+        ds.class_map_lut = lut
+        ds.loadDataByIndex = lambda i: (pts, sem, np.zeros_like(sem))
+        ds.loadImage = lambda i: Image.fromarray(img)
+        ds.parsePathInfoByIndex = lambda i: ("00", "000000")
+        ds.pointcloud_files = [None]
+        cfg = {"augmentation": {"img_jitter": [0.4, 0.4, 0.4, 0.1]},
+               "sensor": {"proj_h": h, "proj_w": w, "proj_ht": ht, "proj_wt": wt, "h_pad": hp, "w_pad": wp}}
+        ld = R.loader.PerspectiveViewLoader(ds, cfg, is_train=True, pcd_aug=False, img_aug=True, use_padding=True)
+        for rep in range(2):
+            torch.manual_seed(100 * seed + rep)
+            feat, mask, label = ld[0]
+            out["train.%s.%d" % (tag, rep)] = np.concatenate([feat.numpy(), mask.numpy()[None], label.numpy()[None]], 0)
+    np.savez_compressed(os.path.join(OUT, "g13_loader_train.npz"), **out)
+    print("g13_loader_train: %d arrays" % len(out))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     R = import_reference()
-    which = sys.argv[1:] or ["blocks", "whole_net", "losses_metrics", "knn", "loader", "trainer_trace", "epmf", "loader_v2", "range_loader", "kitti_formats", "merge"]
+    which = sys.argv[1:] or ["blocks", "whole_net", "losses_metrics", "knn", "loader", "trainer_trace", "epmf", "loader_v2", "range_loader", "kitti_formats", "merge", "loader_train"]
     for name in which:
         globals()[name](R)

@@ -347,3 +347,121 @@ extern "C" int pmf_flip_rotate_crop(const float* src, int32_t C, int32_t h, int3
   PMF_LAUNCH_CHECK();
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Image jitter (perspective_view_loader.py:46-49,84-85; perspective_view_loader_v2.py:19-23,46-47: torchvision
+// ColorJitter on the PIL image) on the uint8 [h*w][3] frame, in place, bit for bit what Pillow computes:
+//   brightness / contrast / saturation = Image.blend(degenerate, image, f): float32  d + f * (x - d), truncated (clipped to
+//   [0, 255] when f is outside [0, 1]); degenerate = 0 / the rounded mean luma of the whole image / the pixel's luma
+//   (luma = (19595 R + 38470 G + 7471 B + 0x8000) >> 16);
+//   hue = RGB -> HSV (Convert.c: float32 ratios, float64 hue arithmetic, truncation), H += shift (uint8 wrap), HSV -> RGB.
+// Each operation reads the uint8 result of the previous one, as the PIL pipeline does.
+__device__ __forceinline__ int cj_luma(int r, int g, int b) { return (r * 19595 + g * 38470 + b * 7471 + 0x8000) >> 16; }
+
+__device__ __forceinline__ uint8_t cj_blend1(int d, int x, float a, bool interp) {
+  // plain operators under `fp contract(off)`: the __fmul_rn / __fadd_rn header inlines carry the contract flag and
+  // fuse into one FMA (128 + 0.6f * -125 then truncates to 52 where Pillow's two roundings give 53)
+  const float m = a * (float)(x - d);
+  const float t = (float)d + m;
+  if (interp) return (uint8_t)(int)t;
+  return t <= 0.f ? (uint8_t)0 : (t >= 255.f ? (uint8_t)255 : (uint8_t)(int)t);
+}
+
+__global__ __launch_bounds__(256) void cj_lsum_k(const uint8_t* __restrict__ img, int64_t npix,
+                                                 unsigned long long* __restrict__ sum) {
+  unsigned long long acc = 0;
+  for (int64_t p = blockIdx.x * (int64_t)256 + threadIdx.x; p < npix; p += (int64_t)gridDim.x * 256)
+    acc += (unsigned)cj_luma(img[p * 3], img[p * 3 + 1], img[p * 3 + 2]);
+  for (int o = 32; o; o >>= 1) acc += __shfl_xor(acc, o);
+  __shared__ unsigned long long sh[4];
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(sum, sh[0] + sh[1] + sh[2] + sh[3]);     // integer sum: order-independent
+}
+
+// mode 0 brightness, 1 contrast (degenerate = int(mean luma + 0.5) from *sum), 2 saturation
+__global__ __launch_bounds__(256) void cj_blend_k(uint8_t* __restrict__ img, int64_t npix, int mode, float a,
+                                                  const unsigned long long* __restrict__ sum) {
+  const int64_t p = blockIdx.x * (int64_t)256 + threadIdx.x;
+  if (p >= npix) return;
+  const bool interp = a >= 0.f && a <= 1.f;
+  int d = 0;
+  if (mode == 1) d = (int)((double)*sum / (double)npix + 0.5);
+  const int r = img[p * 3], g = img[p * 3 + 1], b = img[p * 3 + 2];
+  if (mode == 2) d = cj_luma(r, g, b);
+  img[p * 3] = cj_blend1(d, r, a, interp);
+  img[p * 3 + 1] = cj_blend1(d, g, a, interp);
+  img[p * 3 + 2] = cj_blend1(d, b, a, interp);
+}
+
+__global__ __launch_bounds__(256) void cj_hue_k(uint8_t* __restrict__ img, int64_t npix, int shift) {
+  const int64_t p = blockIdx.x * (int64_t)256 + threadIdx.x;
+  if (p >= npix) return;
+  const int r = img[p * 3], g = img[p * 3 + 1], b = img[p * 3 + 2];
+  const int maxc = max(r, max(g, b)), minc = min(r, min(g, b));
+  int uh = 0, us = 0;
+  const int uv = maxc;
+  if (minc != maxc) {
+    const float cr = (float)(maxc - minc);
+    const float s = cr / (float)maxc;        // float32 divisions are correctly rounded (hipcc default)
+    const float rc = (float)(maxc - r) / cr, gc = (float)(maxc - g) / cr, bc = (float)(maxc - b) / cr;
+    float h;
+    if (r == maxc) h = bc - gc;
+    else if (g == maxc) h = (float)(2.0 + (double)rc - (double)bc);
+    else h = (float)(4.0 + (double)gc - (double)rc);
+    const double hh = (double)h / 6.0 + 1.0;
+    h = (float)(hh - floor(hh));                       // fmod(x, 1.0) for x >= 0
+    uh = min(max((int)((double)h * 255.0), 0), 255);
+    us = min(max((int)((double)s * 255.0), 0), 255);
+  }
+  uh = (uh + shift) & 0xff;
+  int ro = uv, go = uv, bo = uv;
+  if (us != 0) {
+    const double h6 = (double)(float)uh * 6.0 / 255.0;
+    const int i = (int)floor(h6);
+    const double f = (double)(float)(h6 - (double)(float)i);
+    const double fs = (double)(float)((double)(float)us / 255.0);
+    const double vf = (double)(float)uv;
+    const int pp = min(max((int)floor(vf * (1.0 - fs) + 0.5), 0), 255);
+    const int q = min(max((int)floor(vf * (1.0 - fs * f) + 0.5), 0), 255);
+    const int t = min(max((int)floor(vf * (1.0 - fs * (1.0 - f)) + 0.5), 0), 255);
+    switch (i % 6) {
+      case 0: ro = uv; go = t; bo = pp; break;
+      case 1: ro = q; go = uv; bo = pp; break;
+      case 2: ro = pp; go = uv; bo = t; break;
+      case 3: ro = pp; go = q; bo = uv; break;
+      case 4: ro = t; go = pp; bo = uv; break;
+      default: ro = uv; go = pp; bo = q; break;
+    }
+  }
+  img[p * 3] = (uint8_t)ro; img[p * 3 + 1] = (uint8_t)go; img[p * 3 + 2] = (uint8_t)bo;
+}
+
+extern "C" int pmf_color_jitter(uint8_t* image, int32_t h, int32_t w, const int32_t* order4, const double* factor4,
+                                const int32_t* enabled4, uint64_t* scratch, pmf_stream_t st) {
+  hipStream_t s = (hipStream_t)st;
+  if (!image || !order4 || !factor4 || !enabled4 || !scratch || h < 1 || w < 1) return PMF_E_ARG;
+  const int64_t npix = (int64_t)h * w;
+  const unsigned grid = (unsigned)cdiv64(npix, 256);
+  for (int k = 0; k < 4; ++k) {
+    const int op = order4[k];
+    if (op < 0 || op > 3) return PMF_E_ARG;
+    if (!enabled4[op]) continue;
+    if (op == 3) {
+      if (!(factor4[3] >= -0.5 && factor4[3] <= 0.5)) return PMF_E_ARG;
+      hipLaunchKernelGGL(cj_hue_k, dim3(grid), dim3(256), 0, s, image, npix, (int)(factor4[3] * 255.0) & 0xff);
+    } else {
+      if (op == 1) {
+        hipError_t e = hipMemsetAsync(scratch, 0, sizeof(uint64_t), s);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(cj_lsum_k, dim3(grid < 1024 ? grid : 1024), dim3(256), 0, s, image, npix,
+                           (unsigned long long*)scratch);
+        PMF_LAUNCH_CHECK();
+      }
+      hipLaunchKernelGGL(cj_blend_k, dim3(grid), dim3(256), 0, s, image, npix, op, (float)factor4[op],
+                         (const unsigned long long*)scratch);
+    }
+    PMF_LAUNCH_CHECK();
+  }
+  return 0;
+}

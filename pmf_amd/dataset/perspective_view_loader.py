@@ -12,7 +12,11 @@ perspective_view_loader.py:63-69,138-141) are ONE HIP gather (pmf_flip_rotate_cr
 come from torch's global RNG in torchvision's order (seeding torch reproduces its parameters), the rotation is
 nearest-neighbour about the image centre with zero fill.  torchvision itself is absent here: the restatement follows its
 published tensor path and is checked against torch's own grid_sample (oracle/tensor_aug_ref.py), unpinned.  The point
-augmentation (``pcd_aug``, augmentor.py) runs on the GPU before the projection; ``img_aug`` (ColorJitter) is not built.
+augmentation (``pcd_aug``, augmentor.py) runs on the GPU before the projection.  ``img_aug`` (perspective_view_loader.py:
+46-49,84-85: torchvision ColorJitter(*img_jitter) on the PIL image) is ``ColorJitter`` below: the draws follow
+torchvision's get_params order on torch's RNG, the four pixel operations run as HIP kernels on the uint8 frame
+(pmf_color_jitter) and reproduce Pillow's ImageEnhance / HSV arithmetic bit for bit (oracle/color_jitter_ref.py is pinned
+to Pillow exhaustively).
 """
 import ctypes as C
 
@@ -21,6 +25,63 @@ import torch
 from torch.utils.data import Dataset
 
 from .. import _lib as L
+
+
+def image_to_device(image_u8, device):
+    """uint8 [h, w, 3] PIL image / numpy array / tensor -> contiguous device tensor."""
+    if isinstance(image_u8, torch.Tensor):
+        return image_u8.to(device, torch.uint8).contiguous()
+    return torch.from_numpy(np.array(image_u8, dtype=np.uint8, order="C")).to(device)
+
+
+class ColorJitter(object):
+    """torchvision.transforms.ColorJitter(brightness, contrast, saturation, hue) for the uint8 camera frame on the device.
+    Parameter ranges and draws as torchvision 0.14.1 (transforms.py ColorJitter._check_input / get_params): a number v
+    means [max(0, 1 - v), 1 + v] (hue: [-v, v], |v| <= 0.5), a zero-width range draws nothing; per call
+    torch.randperm(4), then one torch.empty(1).uniform_ per active range in the order brightness, contrast, saturation,
+    hue.  ``draw`` / ``apply`` are split for tests."""
+
+    def __init__(self, brightness=0, contrast=0, saturation=0, hue=0):
+        self.ranges = (self._range(brightness, "brightness"), self._range(contrast, "contrast"),
+                       self._range(saturation, "saturation"),
+                       self._range(hue, "hue", center=0.0, bound=(-0.5, 0.5), clip_first_on_zero=False))
+
+    @staticmethod
+    def _range(value, name, center=1.0, bound=(0.0, float("inf")), clip_first_on_zero=True):
+        if isinstance(value, (int, float)):
+            if value < 0:
+                raise ValueError("If {} is a single number, it must be non negative.".format(name))
+            value = [center - float(value), center + float(value)]
+            if clip_first_on_zero:
+                value[0] = max(value[0], 0.0)
+        elif isinstance(value, (tuple, list)) and len(value) == 2:
+            value = [float(value[0]), float(value[1])]
+        else:
+            raise TypeError("{} should be a single number or a list/tuple with length 2.".format(name))
+        if not bound[0] <= value[0] <= value[1] <= bound[1]:
+            raise ValueError("{} values should be between {}".format(name, bound))
+        return None if value[0] == value[1] == center else tuple(value)
+
+    def draw(self):
+        order = torch.randperm(4).tolist()
+        factors = [None if r is None else float(torch.empty(1).uniform_(r[0], r[1])) for r in self.ranges]
+        return order, factors
+
+    def apply(self, img, order, factors):
+        """img: uint8 [h, w, 3] DEVICE tensor, jittered in place (and returned)."""
+        if not (isinstance(img, torch.Tensor) and img.is_cuda and img.dtype == torch.uint8 and img.is_contiguous()):
+            raise RuntimeError("ColorJitter runs on a contiguous uint8 GPU tensor only (no CPU fallback)")
+        scratch = torch.empty(1, dtype=torch.int64, device=img.device)
+        o = (C.c_int32 * 4)(*order)
+        f = (C.c_double * 4)(*[0.0 if x is None else x for x in factors])
+        e = (C.c_int32 * 4)(*[int(x is not None) for x in factors])
+        L.check(L.lib().pmf_color_jitter(img.data_ptr(), img.shape[0], img.shape[1], o, f, e, scratch.data_ptr(),
+                                         C.c_void_p(torch.cuda.current_stream(img.device).cuda_stream)),
+                "pmf_color_jitter")
+        return img
+
+    def __call__(self, img):
+        return self.apply(img, *self.draw())
 
 
 def project_frame_gpu(points, sem_label, image_u8, proj_matrix, label_lut, device="cuda"):
@@ -32,7 +93,7 @@ def project_frame_gpu(points, sem_label, image_u8, proj_matrix, label_lut, devic
     else:
         pts = torch.as_tensor(np.ascontiguousarray(points, np.float32)).to(dev)
     sem = torch.as_tensor(np.ascontiguousarray(sem_label, np.int32)).to(dev)
-    img = torch.as_tensor(np.ascontiguousarray(image_u8, np.uint8)).to(dev)
+    img = image_to_device(image_u8, dev)
     mat = torch.as_tensor(np.ascontiguousarray(proj_matrix, np.float64).reshape(12)).to(dev)
     lut = torch.as_tensor(np.ascontiguousarray(label_lut, np.int32)).to(dev)
     P = pts.shape[0]
@@ -122,9 +183,8 @@ class PerspectiveViewLoader(Dataset):
         self.use_padding, self.return_uproj = use_padding, return_uproj
         self.device = device
         self.aug_ops = aug_ops
-        if img_aug and is_train:
-            raise NotImplementedError("img_aug (torchvision ColorJitter: third-party random photometric jitter) is not "
-                                      "built; tasks/pmf trains with it off")
+        self.img_aug = bool(img_aug and is_train)                  # perspective_view_loader.py:19-21,46-49
+        self.img_jitter = ColorJitter(*config["augmentation"]["img_jitter"]) if self.img_aug else None
         self.pcd_aug = bool(pcd_aug and is_train)
         self.augmentor = None
         if self.pcd_aug:                    # perspective_view_loader.py:24-41
@@ -150,7 +210,9 @@ class PerspectiveViewLoader(Dataset):
         pointcloud, sem_label, _ = self.dataset.loadDataByIndex(index)
         if self.pcd_aug:
             pointcloud = self.augmentor.doAugmentation(pointcloud)
-        image = np.asarray(self.dataset.loadImage(index))
+        image = image_to_device(self.dataset.loadImage(index), self.device)
+        if self.img_aug:
+            image = self.img_jitter(image)
         seq_id, _ = self.dataset.parsePathInfoByIndex(index)
         proj, xd, yd, depth, _ = project_frame_gpu(pointcloud, sem_label, image, self.dataset.proj_matrix[seq_id],
                                                    self.dataset.class_map_lut, self.device)

@@ -8,7 +8,9 @@ are HIP kernels (pmf_project_v2_index / pmf_project_v2_scatter); the frame size 
 optionally fov_left / fov_right (defaults: +-45 degrees, parser.py:36-37).
 Training path (:25-34,50-57,142-153): random image rescale in [1, 1.2] (numpy RNG draw, PIL bilinear resize on the host
 as in the reference), coordinates scaled with it inside the projection kernel, bottom / centred horizontal zero padding
-to (proj_ht, proj_wt), then flip / rotate(15) / crop as one HIP gather (FlipRotateCrop).  img_aug (ColorJitter) is not built."""
+to (proj_ht, proj_wt), then flip / rotate(15) / crop as one HIP gather (FlipRotateCrop).  img_aug (:19-23,46-47,
+ColorJitter(*PVconfig.img_jitter) before the rescale) runs on the device (perspective_view_loader.ColorJitter ->
+pmf_color_jitter, bit-exact Pillow arithmetic); the jittered uint8 frame comes back once for the host-side PIL resize."""
 import ctypes as C
 import math
 
@@ -27,7 +29,8 @@ def project_frame_v2_gpu(points, sem_label, image_u8, proj_matrix, label_lut, fo
     dev = torch.device(device)
     pts = torch.as_tensor(np.ascontiguousarray(points, np.float32)).to(dev)
     sem = torch.as_tensor(np.ascontiguousarray(sem_label, np.int32)).to(dev)
-    img = torch.as_tensor(np.ascontiguousarray(image_u8, np.uint8)).to(dev)
+    from .perspective_view_loader import image_to_device
+    img = image_to_device(image_u8, dev)
     mat = torch.as_tensor(np.ascontiguousarray(proj_matrix, np.float64).reshape(12)).to(dev)
     lut = torch.as_tensor(np.ascontiguousarray(label_lut, np.int32)).to(dev)
     P = pts.shape[0]
@@ -64,8 +67,10 @@ class PerspectiveViewLoaderV2(Dataset):
         self.is_train, self.img_aug, self.data_len = is_train, img_aug, data_len
         self.pv_config = config["PVconfig"]
         self.return_uproj, self.device = return_uproj, device
-        if img_aug:
-            raise NotImplementedError("img_aug (torchvision ColorJitter) is outside the accelerated path")
+        self.img_jitter = None
+        if img_aug:                       # :19-23 (the reference jitters whenever img_aug is set, train or not)
+            from .perspective_view_loader import ColorJitter
+            self.img_jitter = ColorJitter(*self.pv_config["img_jitter"])
         self.aug_ops = None
         if is_train:                      # :25-34 flip / rotate(15) / crop to (proj_ht, proj_wt) as one HIP gather
             from .perspective_view_loader import FlipRotateCrop
@@ -73,6 +78,11 @@ class PerspectiveViewLoaderV2(Dataset):
 
     def __getitem__(self, index):
         image = self.dataset.loadImage(index)
+        if self.img_jitter is not None:
+            from .perspective_view_loader import image_to_device
+            image = self.img_jitter(image_to_device(image, self.device))
+            if self.is_train:
+                image = image.cpu().numpy()           # the rescale below is PIL's (host), as in the reference
         img_scale = 1.0
         if self.is_train:
             # :50-57 random rescale of the camera image: numpy's global RNG, PIL's bilinear resize (what
@@ -83,7 +93,8 @@ class PerspectiveViewLoaderV2(Dataset):
             img_w, img_h = image.size
             img_scale = np.random.uniform(low=1.0, high=1.2)
             image = image.resize((int(img_w * img_scale), int(img_h * img_scale)), Image.BILINEAR)
-        image = np.asarray(image)
+        if not isinstance(image, torch.Tensor):
+            image = np.asarray(image)
         pointcloud, sem_label, _ = self.dataset.loadDataByIndex(index)
         seq_id, _ = self.dataset.parsePathInfoByIndex(index)
         fl = getattr(self.dataset, "fov_left", -45 / 180.0 * math.pi)

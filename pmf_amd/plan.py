@@ -154,16 +154,20 @@ class Plan:
         self._graphs, self._graph_seen = {}, {}   # hipGraph replay cache (see run)
         self._conv_fin = {}                 # forward conv op index -> index of the BN finalize op reading its rows
         self.n_wgrad = 0                    # weight-gradient ops emitted so far
+        import os as _os
         # lanes: independent branches of the network on separate HIP streams (csrc/plan.cpp); ``lane`` is the lane ops
         # are being emitted on; cross-lane edges are plan events (record after one op, wait before another)
         self.lane = 0
-        self.n_lanes = 2
+        self.n_lanes = 3
+        # weight gradients are leaves of the backward graph (only the optimiser / the gradient all-reduce reads them):
+        # PMF_WGRAD_LANE=2 runs them on their own lane behind an event of the op that produced dz.  Measured slower
+        # (25.1 vs 23.3 ms per step: 110 cross-queue edges cost more than the tails they fill), so off by default.
+        self.wgrad_lane = int(_os.environ.get("PMF_WGRAD_LANE", "0"))
         self.n_events = 0
         self._event_pos = {}                # event -> list position of its record op
         self._last_op = {}                  # (id(op list), lane) -> last entry emitted on that lane
         self._pending_wait = {}             # (id(op list), lane) -> (event, position of its record op)
         self._touched = None                # gradient tensors touched by the tape entry being emitted
-        import os as _os
         self.red_batch = int(_os.environ.get("PMF_RED_BATCH", str(RED_BATCH)))     # 0: one reduction op per layer
         self.batch_reds = self.red_batch > 0
         self.pending_reds, self._red_tables = {}, []     # lane -> queued stage-2 reductions
@@ -249,7 +253,10 @@ class Plan:
             b = len(lst)
             if b == a:
                 continue
-            first, last, wait = lst[a], lst[b - 1], None
+            own = [e for e in lst[a:b] if (e[2] & 3) == lane]      # (weight gradients sit on their own lane)
+            if not own:
+                continue
+            first, last, wait = own[0], own[-1], None
             for g in touched:
                 lw = getattr(g, "_last_touch", None)
                 if lw is not None and lw[0] != lane:
@@ -708,6 +715,11 @@ class Plan:
                 d.dbias_rows, d.dbias_nrows, d.dbias_ld = dbr.ptr, dbias_rows, dbr_ld
                 d.dbias_out = self.pgrad_buf.at(boff)
         boff = self.pgrad(conv.bias) if dbias_rows else None
+        home = self.lane
+        if self.wgrad_lane and self.wgrad_lane != home:
+            ready = self.record_event(self.bwd)           # dz (and the bias-gradient rows) are complete after this op
+            self.lane = self.wgrad_lane
+            self.wait_event(self.bwd, ready)
         lane = self.lane
         self.n_wgrad += 1
         if self.flat is not None and self.batch_reds:
@@ -734,6 +746,7 @@ class Plan:
             self.grad_done[id(conv.weight)] = len(self.bwd) - 1
             if dbias_rows:
                 self.grad_done[id(conv.bias)] = len(self.bwd) - 1
+        self.lane = home
         self.meta_bwd[part_index] = dict(
             family="conv_wgrad", flops=2.0 * dz.N * dz.H * dz.W * Cout * conv.in_channels * len(taps), name=name,
             shape="%dx%dx%d %d->%d t%d" % (dz.N, dz.H, dz.W, conv.in_channels, Cout, len(taps)))
