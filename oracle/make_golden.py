@@ -510,6 +510,10 @@ def trainer_trace(R):
     foc = R.focal.FocalSoftmaxLoss(20, gamma=2, alpha=alpha.numpy(), softmax=False)
     pcd, rgb, label, _ = synthetic_batch(1, 64, 512, 20, seed=1)
     vals = []
+    keys = ["lidar_stream.downCntx.conv1.weight", "lidar_stream.resBlock3.conv3.weight",
+            "lidar_stream.logits.bias", "camera_stream_encoder.conv1.weight",
+            "camera_stream_encoder.layer3.2.conv1.weight", "camera_stream_decoder.conv.weight",
+            "lidar_stream.fusionblock_2.attention.4.weight"]
     for step in range(2):
         lp, cp = m(pcd, rgb)
         total, terms = reference_loss(lov, foc, lp, cp, label)
@@ -519,13 +523,16 @@ def trainer_trace(R):
         adam.step()
         sgd.step()
         vals.append([total.item()] + [terms[k].item() for k in ("foc", "lov", "foc_cam", "lov_cam", "per")])
+        if step == 0:      # after ONE step (Adam's first update is lr * sign(g): well conditioned) ...
+            sd = m.state_dict()
+            for k in keys:
+                out["trace.param1." + k] = np.array([sd[k].double().sum().item(), sd[k].double().abs().sum().item()])
+            for k in ("lidar_stream.downCntx.bn1.running_mean", "lidar_stream.downCntx.bn1.running_var",
+                      "camera_stream_encoder.bn1.running_mean", "camera_stream_encoder.layer2.0.bn1.running_var"):
+                out["trace.buf1." + k] = sd[k].double().numpy().copy()
     out["trace.losses"] = np.array(vals)
-    keys = ["lidar_stream.downCntx.conv1.weight", "lidar_stream.resBlock3.conv3.weight",
-            "lidar_stream.logits.bias", "camera_stream_encoder.conv1.weight",
-            "camera_stream_encoder.layer3.2.conv1.weight", "camera_stream_decoder.conv.weight",
-            "lidar_stream.fusionblock_2.attention.4.weight"]
     sd = m.state_dict()
-    for k in keys:
+    for k in keys:             # ... and after two
         out["trace.param." + k] = np.array([sd[k].double().sum().item(), sd[k].double().abs().sum().item()])
     np.savez_compressed(os.path.join(OUT, "g7_trace.npz"), **out)
     print("g7_trace: %d arrays" % len(out))

@@ -90,3 +90,170 @@ def test_reference_trainer_loader_call(case, golden):
                                                      use_padding=True)
     f, m, l = val[0]
     assert f.shape == (8, h, w) and val.img_jitter is None
+
+
+def _ones_masks(model, n):
+    return {name: torch.ones(n, ch, device="cuda") for name, ch in model._mask_sites()}
+
+
+def _checksum(t):
+    return np.array([t.double().sum().item(), t.double().abs().sum().item()])
+
+
+def test_train_engine_matches_reference_trace(golden):
+    """g7 (two optimisation steps driven with the REFERENCE's modules on config-1 shapes: 1 x 64 x 512, deterministic init,
+    dropout off) replayed on the HIP model through TrainEngine (flat state, fused objective, fused AdamW / SGD-Nesterov):
+    losses and their five terms per step, parameter checksums and BatchNorm running statistics after step 1, parameter
+    checksums after step 2"""
+    from pmf_amd.engine import TrainEngine
+    from pmf_amd.models import PMFNet
+    from pmf_amd.utils.detinit import deterministic_init, synthetic_batch
+    g = golden("g7_trace")
+    m = deterministic_init(PMFNet(5, 3, 20, 32, imagenet_pretrained=False, image_backbone="resnet34")).cuda()
+    m.set_dropout_masks(_ones_masks(m, 1))
+    alpha = np.linspace(0.2, 1.0, 20).astype(np.float32)
+    alpha[0] = 0
+    eng = TrainEngine(m, 20, lr=1e-3, momentum=0.9, weight_decay=1e-5, alpha=alpha, warmup_steps=1, max_steps=10 ** 9)
+    pcd, rgb, label, mask = synthetic_batch(1, 64, 512, 20, seed=1)
+    feat = torch.cat((pcd, rgb), 1).cuda()
+    vals, worst1 = [], 0.0
+    for step in range(2):
+        total, t = eng.train_step(feat.clone(), torch.ones_like(mask).cuda(), label.cuda())
+        vals.append([total.item()] + [t[k].item() for k in ("foc", "lov", "foc_cam", "lov_cam", "per")])
+        if step == 0:
+            sd = m.state_dict()
+            for k in [k for k in g.files if k.startswith("trace.param1.")]:
+                want = g[k]
+                err = np.abs(_checksum(sd[k[len("trace.param1."):]]) - want).max() / max(abs(want[1]), 1e-3)
+                worst1 = max(worst1, err)
+                assert err < 1e-4, (k, err)
+            for k in [k for k in g.files if k.startswith("trace.buf1.")]:
+                got = sd[k[len("trace.buf1."):]].double().cpu().numpy()
+                assert np.abs(got - g[k]).max() <= 1e-4 * max(np.abs(g[k]).max(), 1.0), k
+    vals, want = np.array(vals), g["trace.losses"]
+    assert np.abs(vals[:, :5] - want[:, :5]).max() < 1e-3 * np.abs(want).max(), (vals, want)
+    assert np.abs(vals[:, 5] - want[:, 5]).max() < 1e-3 * max(np.abs(want[:, 5]).max(), 1e-4)
+    sd = m.state_dict()
+    for k in [k for k in g.files if k.startswith("trace.param.")]:
+        want = g[k]
+        assert np.abs(_checksum(sd[k[len("trace.param."):]]) - want).max() <= 1e-3 * max(abs(want[1]), 1e-3), k
+    print("g7 on the HIP model: worst checksum error after step 1 = %.2e (relative to sum |w|)" % worst1)
+
+
+def test_reference_trainer_call_sequence_stock_ddp():
+    """the reference Trainer's own call sequence against the shim, nothing adapted: _initOptimizer on the bare model
+    (tasks/pmf/trainer.py:80-98), replaceBN -> .cuda() -> stock nn.parallel.DistributedDataParallel(device_ids=[gpu])
+    (:33-39; world 1 over RCCL), criterion dict (:191-207), IOUEval on device cpu (:49-59), WarmupCosineLR x2 (:61-75),
+    then two iterations of run("Train") (:289-341,383-396): in-place normalisation, strided channel-slice inputs,
+    torch-op losses, zero_grad / backward / step x2, scheduler steps, argmax metrics.  Checked against TrainEngine
+    (flat state + fused objective) on the same data: same losses, same parameters after two steps."""
+    import math
+    import os
+    import torch.distributed as dist
+    import torch.nn as nn
+    import pc_processor
+    from pmf_amd.engine import TrainEngine
+    from pmf_amd.utils.detinit import deterministic_init, synthetic_batch
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1)
+        created = True
+    try:
+        nclasses, lr, momentum, wd, lam, gam, tau = 20, 1e-3, 0.9, 1e-5, 1.0, 0.5, 0.7
+        mean = [12.12, 10.88, 0.23, -1.04, 0.21]
+        stds = [12.32, 11.47, 6.91, 0.86, 0.16]
+        pcd, rgb, label, mask = synthetic_batch(2, 32, 64, nclasses, seed=4, fill=0.6)
+        feat0 = torch.cat((pcd * torch.tensor(stds).view(1, 5, 1, 1) + torch.tensor(mean).view(1, 5, 1, 1), rgb), 1)
+        alpha = np.log(1 + 1 / (np.linspace(0.01, 0.3, nclasses) + 1e-3))
+        alpha = alpha / alpha.max()
+        alpha[0] = 0
+
+        def make_model():
+            m = pc_processor.models.PMFNet(pcd_channels=5, img_channels=3, nclasses=nclasses, base_channels=32,
+                                           image_backbone="resnet34", imagenet_pretrained=False)
+            m = deterministic_init(m).cuda()
+            m.set_dropout_masks(_ones_masks(m, 2))
+            return m
+
+        # ---------------- the reference's sequence
+        model = make_model()
+        adam_opt = torch.optim.AdamW(params=[{"params": model.lidar_stream.parameters()}], lr=lr)
+        sgd_opt = torch.optim.SGD(params=[{"params": model.camera_stream_encoder.parameters()},
+                                          {"params": model.camera_stream_decoder.parameters()}],
+                                  lr=lr, nesterov=True, momentum=momentum, weight_decay=wd)
+        raw = model
+        model = pc_processor.layers.sync_bn.replaceBN(model).cuda()
+        model = nn.parallel.DistributedDataParallel(model, device_ids=[0])
+        criterion = {"lovasz": pc_processor.loss.Lovasz_softmax(ignore=0), "kl_loss": nn.KLDivLoss(reduction="none"),
+                     "focal_loss": pc_processor.loss.FocalSoftmaxLoss(nclasses, gamma=2, alpha=alpha, softmax=False)}
+        for v in criterion.values():
+            v.cuda()
+        metrics = pc_processor.metrics.IOUEval(n_classes=nclasses, device=torch.device("cpu"), ignore=[0],
+                                               is_distributed=True)
+        metrics.reset()
+        sched = [pc_processor.utils.WarmupCosineLR(optimizer=o, lr=lr, warmup_steps=2, momentum=momentum, max_steps=10)
+                 for o in (adam_opt, sgd_opt)]
+        feature_mean = torch.Tensor(mean).unsqueeze(0).unsqueeze(2).unsqueeze(2).cuda()
+        feature_std = torch.Tensor(stds).unsqueeze(0).unsqueeze(2).unsqueeze(2).cuda()
+        model.train()
+        ref_losses = []
+        for it in range(2):
+            input_feature, input_mask, input_label = feat0.clone().cuda(), mask.clone().cuda(), label.clone().float()
+            input_feature[:, 0:5] = (input_feature[:, 0:5] - feature_mean) / feature_std * \
+                input_mask.unsqueeze(1).expand_as(input_feature[:, 0:5])
+            pcd_feature, img_feature = input_feature[:, 0:5], input_feature[:, 5:8]
+            input_label = input_label.cuda().long()
+            label_mask = input_label.gt(0)
+            lidar_pred, camera_pred = model(pcd_feature, img_feature)
+            lidar_pred_log = torch.log(lidar_pred.clamp(min=1e-8))
+            pcd_entropy = -(lidar_pred * lidar_pred_log).sum(1) / math.log(nclasses)
+            loss_foc = criterion["focal_loss"](lidar_pred, input_label, mask=label_mask)
+            loss_lov = criterion["lovasz"](lidar_pred, input_label)
+            camera_pred_log = torch.log(camera_pred.clamp(min=1e-8))
+            img_entropy = -(camera_pred * camera_pred_log).sum(1) / math.log(nclasses)
+            loss_foc_cam = criterion["focal_loss"](camera_pred, input_label, mask=label_mask)
+            loss_lov_cam = criterion["lovasz"](camera_pred, input_label)
+            pcd_conf, img_conf = 1 - pcd_entropy, 1 - img_entropy
+            imp = pcd_conf - img_conf
+            pcd_w = imp.gt(0).float() * imp.abs() * pcd_conf.ge(tau).float()
+            img_w = imp.lt(0).float() * imp.abs() * img_conf.ge(tau).float()
+            loss_per = (criterion["kl_loss"](lidar_pred_log, camera_pred) * img_w.unsqueeze(1)).mean() + \
+                (criterion["kl_loss"](camera_pred_log, lidar_pred) * pcd_w.unsqueeze(1)).mean()
+            total_loss = loss_foc + loss_lov * lam + loss_foc_cam + loss_lov_cam * lam + loss_per * gam
+            total_loss = total_loss.mean()
+            adam_opt.zero_grad()
+            sgd_opt.zero_grad()
+            total_loss.backward()
+            adam_opt.step()
+            sgd_opt.step()
+            for s in sched:
+                s.step()
+            with torch.no_grad():
+                metrics.addBatch(lidar_pred.argmax(dim=1), input_label)
+                mean_iou, _ = metrics.getIoU()
+                mean_acc, _ = metrics.getAcc()
+                mean_recall, _ = metrics.getRecall()
+            ref_losses.append(total_loss.item())
+            assert all(np.isfinite(v.item()) for v in (mean_iou, mean_acc, mean_recall))
+        assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in raw.parameters())
+        ref_state = {k: v.detach().clone() for k, v in raw.state_dict().items()}
+
+        # ---------------- the engine bench.py times
+        m2 = make_model()
+        eng = TrainEngine(m2, nclasses, lr=lr, momentum=momentum, weight_decay=wd, lambda_=lam, gamma=gam, tau=tau,
+                          alpha=alpha.astype(np.float32), warmup_steps=2, max_steps=10, feature_mean=mean,
+                          feature_std=stds)
+        eng_losses = [eng.train_step(feat0.clone().cuda(), mask.clone().cuda(), label.clone().cuda())[0].item()
+                      for _ in range(2)]
+        assert np.abs(np.array(ref_losses) - np.array(eng_losses)).max() < 2e-4 * max(ref_losses), (ref_losses, eng_losses)
+        st = m2.state_dict()
+        worst = 0.0
+        for k, v in ref_state.items():
+            if v.dtype.is_floating_point:
+                worst = max(worst, ((st[k] - v).norm() / v.norm().clamp_min(1e-6)).item())
+        assert worst < 2e-3, worst
+    finally:
+        if created:
+            dist.destroy_process_group()
