@@ -187,6 +187,9 @@ def main():
     ap.add_argument("--model", default="pmf", choices=["pmf", "epmf", "salsanext"],
                     help="pmf = the headline workload (BASELINE configs[2]); epmf = configs[4] (EPMF-R34), reported "
                          "under its own metric name, no CPU baseline")
+    ap.add_argument("--fresh-inputs", action="store_true",
+                    help="hand the step a batch at a NEW device address every iteration (what DataLoader + .cuda() does, "
+                         "tasks/pmf/trainer.py:289-303): the captured graphs must keep replaying")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--profile-out", default=None, help="write the per-launch HIP-event profile (one line per op)")
@@ -219,7 +222,15 @@ def main():
                       distributed=multi, device_ids=[local] if multi else None)
     feat0, mask, label = make_batch(args.bs, args.height, args.width, 1 + rank, dev, args.nclasses)   # per-rank data
 
+    ring = []
+
     def step():
+        if args.fresh_inputs:                 # keep the last three batches alive: the allocator must rotate addresses
+            batch = (feat0.clone(), mask.clone(), label.clone())
+            ring.append(batch)
+            if len(ring) > 3:
+                ring.pop(0)
+            return eng.train_step(*batch)
         return eng.train_step(feat0.clone(), mask, label)     # clone: the trainer normalises in place
 
     if args.mode == "infer":
@@ -317,7 +328,9 @@ def main():
                                       ", S_A" if (args.height, args.width) == (64, 2048) else "", args.bs,
                                       args.nclasses),
                        "global_batch": world * args.bs, "parallelism": "dp%d" % world,
-                       "samples_per_s": world * args.bs * args.steps / dt, "final_loss": loss_val},
+                       "samples_per_s": world * args.bs * args.steps / dt, "final_loss": loss_val,
+                       "fresh_input_addresses": bool(args.fresh_inputs),
+                       "graphs_captured": len(next(iter(model._plans.values()))._graphs)},
             "roofline": roof, "cpu_baseline": cpu, "kernel_time_breakdown": detail,
         }
         try:       # RCCL prints its version banner through C stdio (buffered when piped): push it out first so that the

@@ -214,8 +214,9 @@ class PerspectiveViewLoader(Dataset):
         if self.img_aug:
             image = self.img_jitter(image)
         seq_id, _ = self.dataset.parsePathInfoByIndex(index)
-        proj, xd, yd, depth, _ = project_frame_gpu(pointcloud, sem_label, image, self.dataset.proj_matrix[seq_id],
-                                                   self.dataset.class_map_lut, self.device)
+        proj, xd, yd, depth, keep = project_frame_gpu(pointcloud, sem_label, image, self.dataset.proj_matrix[seq_id],
+                                                      self.dataset.class_map_lut, self.device)
+        self.last_keep = keep            # bool[P]: the points behind x_data / y_data, in file order
         if self.return_uproj:
             return proj[:8], proj[8], proj[9], xd, yd, depth
         if self.is_train:

@@ -1,1 +1,1 @@
-from .parser import SemanticKitti, write_prediction  # noqa: F401
+from .parser import SemanticKitti, write_prediction, DEFAULT_CONFIG  # noqa: F401

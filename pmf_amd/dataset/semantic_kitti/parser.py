@@ -13,6 +13,26 @@ import os
 import numpy as np
 import yaml
 
+DEFAULT_CONFIG = os.path.join(os.path.dirname(os.path.abspath(__file__)), "semantic-kitti.yaml")
+
+
+def label_tables(cfg):
+    """the dictionaries the reference parser reads (parser.py:100-133) from either layout of the label file: the
+    semantic-kitti-api one (labels / color_map / content / learning_map / learning_map_inv / learning_ignore /
+    mapped_class_name / color_map_inv) or this package's two tables (raw / train rows)."""
+    if "raw" not in cfg:
+        return cfg
+    out = {"name": cfg.get("name", ""), "split": cfg.get("split", {})}
+    out["labels"] = {r["id"]: r["name"] for r in cfg["raw"]}
+    out["color_map"] = {r["id"]: list(r["color"]) for r in cfg["raw"]}
+    out["content"] = {r["id"]: r["content"] for r in cfg["raw"]}
+    out["learning_map"] = {r["id"]: r["train"] for r in cfg["raw"]}
+    out["learning_map_inv"] = {r["id"]: r["raw"] for r in cfg["train"]}
+    out["learning_ignore"] = {r["id"]: bool(r["ignore"]) for r in cfg["train"]}
+    out["mapped_class_name"] = {r["id"]: r["name"] for r in cfg["train"]}
+    out["color_map_inv"] = {r["id"]: list(r["color"]) for r in cfg["train"]}
+    return out
+
 
 class SemanticKitti(object):
     def __init__(self, root, sequences, config_path, has_image=True, has_pcd=True, has_label=True):
@@ -22,7 +42,7 @@ class SemanticKitti(object):
         if not os.path.isfile(config_path):
             raise ValueError("config file not found: {}".format(config_path))
         with open(config_path, "r") as f:
-            self.data_config = yaml.safe_load(f)
+            self.data_config = label_tables(yaml.safe_load(f))
         if not os.path.isdir(self.root):
             raise ValueError("dataset not found: {}".format(self.root))
         self.pointcloud_files, self.label_files, self.image_files = [], [], []

@@ -5,8 +5,9 @@
     -> confusion-matrix update for both heads.
 
 Used by tasks/pmf/trainer.py (real loop) and bench.py (synthetic, device-resident batches) so the benchmark
-times exactly what the trainer runs.  Metrics are reduced across ranks every ``metrics_sync_every`` steps
-(the reference reduces 6x per iteration) -- epoch-end numbers are identical."""
+times exactly what the trainer runs.  The confusion matrices are rank-local until somebody reads a statistic
+(IOUEval.getIoU / getAcc / getRecall: one cached all-reduce per read; the reference reduces 6x per iteration, SURVEY.md
+5.8) -- the trainer reads at its print frequency and at the end of the epoch, so epoch-end numbers are identical."""
 import numpy as np
 import torch
 import torch.nn as nn
@@ -28,10 +29,97 @@ def kitti_focal_alpha(cls_freq, learning_ignore):
     return a.astype(np.float32), [c for c in range(len(w)) if w[c] < 1e-10]
 
 
+class FlatOptimizerView(object):
+    """What a trainer sees as ``trainer.optimizer`` when the engine runs on the flat training state: ``step`` /
+    ``zero_grad`` / ``param_groups`` are the fused optimiser's own (the LR schedulers act on them), while ``state_dict``
+    / ``load_state_dict`` speak the REFERENCE's per-parameter layout (tasks/pmf/main.py:72-83,104-127): parameter ids in
+    the order of the reference's parameter lists (trainer.py:80-98: AdamW over lidar_stream.parameters(); SGD over the
+    camera encoder's and the decoder's parameters as two groups), one state entry per parameter.  A checkpoint.pth
+    written by the reference loads here and vice versa, and the file does not depend on the plan's emission order."""
+
+    _PER_PARAM = ("exp_avg", "exp_avg_sq", "max_exp_avg_sq", "momentum_buffer")
+
+    def __init__(self, optimizer, flat, ref_groups):
+        self.optimizer, self.flat = optimizer, flat
+        self.ref_groups = [list(g) for g in ref_groups]
+        self.flat_param = optimizer.param_groups[0]["params"][0]
+
+    # ---- what the training loop and the schedulers use
+    @property
+    def param_groups(self):
+        return self.optimizer.param_groups
+
+    def step(self, *a, **k):
+        return self.optimizer.step(*a, **k)
+
+    def zero_grad(self, set_to_none=True):
+        self.flat_param.grad.zero_()        # the gradient buffer is owned by the FlatState: never dropped
+
+    # ---- checkpoint layout
+    def _slice(self, t, p):
+        base = self.flat.offset[id(p)] - self._group_start
+        return t[base:base + p.numel()].view(p.shape)
+
+    @property
+    def _group_start(self):
+        return min(self.flat.offset[id(p)] for g in self.ref_groups for p in g)
+
+    def state_dict(self):
+        st = self.optimizer.state.get(self.flat_param, {})
+        state, groups, idx = {}, [], 0
+        hyper = {k: v for k, v in self.optimizer.param_groups[0].items() if k != "params"}
+        for g in self.ref_groups:
+            ids = []
+            for p in g:
+                ent = {}
+                for k, v in st.items():
+                    if k in self._PER_PARAM and torch.is_tensor(v) and v.numel() == self.flat_param.numel():
+                        ent[k] = self._slice(v, p).clone()
+                    elif k == "step":
+                        ent[k] = v.clone() if torch.is_tensor(v) else v
+                if ent:
+                    state[idx] = ent
+                ids.append(idx)
+                idx += 1
+            groups.append(dict(hyper, params=ids))
+        return {"state": state, "param_groups": groups}
+
+    def load_state_dict(self, sd):
+        n = sum(len(g) for g in self.ref_groups)
+        ids = [i for g in sd["param_groups"] for i in g["params"]]
+        if len(ids) != n:
+            raise ValueError("optimizer checkpoint holds %d parameters, this model has %d" % (len(ids), n))
+        params = [p for g in self.ref_groups for p in g]
+        fp = self.flat_param
+        st = self.optimizer.state[fp]
+        step = None
+        for i, p in zip(ids, params):
+            ent = sd["state"].get(i, sd["state"].get(str(i)))
+            if not ent:
+                continue
+            for k, v in ent.items():
+                if k == "step":
+                    step = v if step is None else step
+                elif k in self._PER_PARAM and v is not None:
+                    if tuple(v.shape) != tuple(p.shape):
+                        raise ValueError("optimizer checkpoint: state %r of parameter %d has shape %s, expected %s"
+                                         % (k, i, tuple(v.shape), tuple(p.shape)))
+                    if k not in st:
+                        st[k] = torch.zeros_like(fp.data)
+                    self._slice(st[k], p).copy_(v.to(fp.device, fp.dtype))
+        if step is not None:
+            st["step"] = torch.as_tensor(float(step), dtype=torch.float32, device=fp.device) \
+                if self.optimizer.param_groups[0].get("fused") else torch.as_tensor(float(step))
+        src = sd["param_groups"][0]
+        for k, v in src.items():                # hyper-parameters (lr, betas, momentum, weight decay ...) as saved
+            if k != "params" and k in self.optimizer.param_groups[0] and k not in ("fused", "foreach", "capturable"):
+                self.optimizer.param_groups[0][k] = v
+
+
 class TrainEngine:
     def __init__(self, model, nclasses, lr=1e-3, momentum=0.9, weight_decay=1e-5, lambda_=1.0, gamma=0.5, tau=0.7,
                  alpha=None, ignore_class=(0,), warmup_steps=1, max_steps=1, feature_mean=None, feature_std=None,
-                 distributed=False, device_ids=None, metrics_sync_every=0, flat_state=True):
+                 distributed=False, device_ids=None, flat_state=True):
         self.raw_model = model
         dev = next(model.parameters()).device
         self.device = dev
@@ -49,7 +137,7 @@ class TrainEngine:
             groups = [list(model.lidar_stream.parameters()),
                       list(model.camera_stream_encoder.parameters()) + list(model.camera_stream_decoder.parameters())]
             self.flat = flatten_training_state(model, groups, dev)
-            lidar_params, camera_params = [self.flat.group_params[0]], [self.flat.group_params[1]]
+            lidar_params, camera_groups = [self.flat.group_params[0]], [{"params": [self.flat.group_params[1]]}]
             if distributed:
                 import torch.distributed as dist
                 self._pending, self._frontier = [], None
@@ -60,15 +148,23 @@ class TrainEngine:
                     dist.broadcast(b, 0)
         else:
             lidar_params = list(model.lidar_stream.parameters())
-            camera_params = list(model.camera_stream_encoder.parameters()) + list(model.camera_stream_decoder.parameters())
+            camera_groups = [{"params": list(model.camera_stream_encoder.parameters())},      # two groups, as
+                             {"params": list(model.camera_stream_decoder.parameters())}]      # trainer.py:88-90
             if distributed:
                 self.model = nn.parallel.DistributedDataParallel(
                     model, device_ids=device_ids, gradient_as_bucket_view=True)   # local-stat BN: layers/sync_bn.py
         # trainer.py:80-98: AdamW over the LiDAR stream (torch defaults incl. weight_decay 0.01),
         # SGD-Nesterov over camera encoder + decoder
         self.optimizer = torch.optim.AdamW([{"params": lidar_params}], lr=lr, **fused)
-        self.aux_optimizer = torch.optim.SGD([{"params": camera_params}], lr=lr, nesterov=True, momentum=momentum,
+        self.aux_optimizer = torch.optim.SGD(camera_groups, lr=lr, nesterov=True, momentum=momentum,
                                              weight_decay=weight_decay, **fused)
+        # what a trainer / main.py holds as trainer.optimizer / trainer.aux_optimizer: reference checkpoint layout
+        self.optimizer_view, self.aux_optimizer_view = self.optimizer, self.aux_optimizer
+        if self.flat is not None:
+            self.optimizer_view = FlatOptimizerView(self.optimizer, self.flat, [list(model.lidar_stream.parameters())])
+            self.aux_optimizer_view = FlatOptimizerView(
+                self.aux_optimizer, self.flat, [list(model.camera_stream_encoder.parameters()),
+                                                list(model.camera_stream_decoder.parameters())])
         if alpha is None:
             alpha = np.ones(nclasses, np.float32)
             alpha[0] = 0
@@ -80,7 +176,6 @@ class TrainEngine:
         self.aux_scheduler = WarmupCosineLR(self.aux_optimizer, lr, warmup_steps, momentum, max_steps)
         self.mean = None if feature_mean is None else torch.tensor(feature_mean, device=dev).view(1, -1, 1, 1).float()
         self.std = None if feature_std is None else torch.tensor(feature_std, device=dev).view(1, -1, 1, 1).float()
-        self.metrics_sync_every = metrics_sync_every
         self.iteration = 0
 
     # ---- data parallel over the flat gradient buffer ---------------------------------------------------------
@@ -101,6 +196,24 @@ class TrainEngine:
         for h in self._pending:
             h.wait()
         self._pending, self._frontier = [], None
+
+    def sync_buffers(self):
+        """rank 0's BatchNorm running statistics / counters to every rank, as two coalesced broadcasts.
+        DistributedDataParallel (broadcast_buffers=True, the reference's default: trainer.py:38-39) does this at every
+        forward; since rank 0's buffers are never written by another rank and train-mode BatchNorm normalises with batch
+        statistics, doing it once before anything READS the running statistics (validation, checkpoint) leaves every
+        observable identical -- eval_step calls it automatically after training steps."""
+        self._buffers_dirty = False
+        if not self.distributed:
+            return
+        import torch.distributed as dist
+        for want_float in (True, False):
+            bufs = [b for b in self.raw_model.buffers() if b.is_floating_point() == want_float]
+            if not bufs:
+                continue
+            flat = torch.cat([b.reshape(-1) for b in bufs])
+            dist.broadcast(flat, 0)
+            torch._foreach_copy_(bufs, [c.view(b.shape) for c, b in zip(flat.split([b.numel() for b in bufs]), bufs)])
 
     def prepare(self, input_feature, input_mask):
         """trainer.py:291-297: normalise the 5 LiDAR channels in place, return the two channel-slice views."""
@@ -130,6 +243,7 @@ class TrainEngine:
     def train_step(self, input_feature, input_mask, input_label):
         """one full iteration; everything stays on the device (no .item())."""
         self.model.train()
+        self._buffers_dirty = True
         pcd, rgb = self.prepare(input_feature, input_mask)
         label = input_label.long()
         total, terms, lidar_pred, camera_pred, metrics_done = self.forward_loss(pcd, rgb, label)
@@ -158,6 +272,8 @@ class TrainEngine:
     @torch.no_grad()
     def eval_step(self, input_feature, input_mask, input_label):
         self.model.eval()
+        if self.distributed and getattr(self, "_buffers_dirty", True) and self.flat is not None:
+            self.sync_buffers()
         pcd, rgb = self.prepare(input_feature, input_mask)
         label = input_label.long()
         total, terms, lidar_pred, camera_pred, metrics_done = self.forward_loss(pcd, rgb, label)

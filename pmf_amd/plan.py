@@ -404,7 +404,9 @@ class Plan:
         # very large dilations: per-tap staging (the halo tile would not fit LDS)
         span = max(max(t[0] for t in taps) - min(t[0] for t in taps), max(t[1] for t in taps) - min(t[1] for t in taps))
         gather = 1 if (8 * stride + span) * (32 * stride + span) * 80 > 110 * 1024 else 0
-        train_bn = bn is not None and self.training
+        # a BatchNorm module in eval mode inside a training plan (frozen statistics, torch semantics): running statistics in
+        # the forward pass, no statistics update, backward through the fixed affine map (dgamma / dbeta still flow)
+        train_bn = bn is not None and self.training and bn.training
         has_bias = conv.bias is not None
         k_act = act if order == "act_bn" else L.ACT_NONE
         # EPMF SparseVariantConv: (conv + conv.bias + extra bias) * dilated mask; the mask multiplies after the
@@ -442,6 +444,7 @@ class Plan:
             # the autotuner (Plan.autotune) may pick another tile configuration: size the rows for any of them
             max_rows = max(stat_rows, L.lib().pmf_conv_fwd_stat_rows_max(C.byref(probe)))
         stats = self.act.alloc(16 * Cout * max_rows) if train_bn else None   # float64 [rows][2][Cout] partials
+        bn_train_flag = int(train_bn)
 
         lane = self.lane
 
@@ -493,7 +496,8 @@ class Plan:
                 self.emit(self.fwd, L.OP_BN_EVAL, fb)
             info = dict(mean=smean, invstd=sinv, module=bn)
             view = V(out, scale, shift, relu=relu_view, bn=info)
-            self.bn_modules.append(bn)
+            if train_bn:
+                self.bn_modules.append(bn)
         if name:
             self.views[name] = view
         if not self.training:
@@ -529,7 +533,7 @@ class Plan:
                           self.bnpart_bufs[lane].ptr, coef.ptr, self.pgrad_buf.at(dgam), self.pgrad_buf.at(dbet))
                     for i, p in enumerate(ps):
                         a.p[i] = p
-                    a.i[0], a.i[1], a.i[2], a.i[3] = gyt.ldc, out.ldc, Cout, 1
+                    a.i[0], a.i[1], a.i[2], a.i[3] = gyt.ldc, out.ldc, Cout, bn_train_flag
                     a.l[0] = out.npix
                 self.emit(self.bwd, L.OP_BN_BWD_REDUCE, r1)
                 self.grad_done[id(bn.weight)] = self.grad_done[id(bn.bias)] = len(self.bwd) - 1
@@ -1344,9 +1348,10 @@ class Plan:
     # ------------------------------------------------------------------ running
     def run(self, ops, n, what, begin=0, end=None, sig=None):
         """launch ops[begin:end) on torch's current stream.  ``sig``: hashable summary of every pointer patched into
-        the op array for this call (inputs, outputs, upstream gradients).  With a signature the range is replayed
-        from a hipGraph captured for exactly these pointers (first sighting: eager run; second: capture); in steady
-        state the caching allocator hands out the same addresses every iteration, so every launch is a replay."""
+        the op array for this call; None = never capture.  With a signature the range is replayed from a hipGraph
+        captured for exactly these pointers (first sighting: eager run; second: capture).  The model front end
+        (models/pmf_net.py _bind_io) stages inputs, outputs and upstream gradients in plan-owned buffers, so its
+        signature is constant and ONE graph per range serves every call, wherever the caller's tensors live."""
         import os
         stream = torch.cuda.current_stream(self.device).cuda_stream
         failed = C.c_int32(-1)

@@ -23,7 +23,6 @@ class Option(object):
         self.img_backbone, self.base_channels = c["img_backbone"], c["base_channels"]
         self.imagenet_pretrained = c["imagenet_pretrained"]
         self.checkpoint, self.pretrained_model = c["checkpoint"], c["pretrained_model"]
-        self.metrics_sync_every = c.get("metrics_sync_every", self.print_frequency)
         self.save_path = os.path.join(self.save_path, "log_{}_PMFNet-{}_bs{}-lr{}_{}".format(
             self.dataset, self.img_backbone, self.batch_size[0] * self.n_gpus, self.lr, self.experiment_id))
 

@@ -1,10 +1,21 @@
 """Trainer for tasks/pmf (counterpart of the reference's tasks/pmf/trainer.py:13-537).
 
-Same responsibilities -- data loaders, criterion, AdamW(lidar)+SGD(camera), WarmupCosineLR x2, DDP, two IOUEval,
-run(epoch, "Train"|"Validation") returning the epoch summary -- with the per-iteration work delegated to
-pmf_amd.engine.TrainEngine (the unit bench.py times).  dataset: "Synthetic" needs no files (no SemanticKITTI here);
-"SemanticKitti" expects the reference's parser object to be importable by the user."""
+Same responsibilities and the same constructor / ``run(epoch, mode)`` contract: data loaders (SemanticKitti / nuScenes
+through PerspectiveViewLoader exactly as trainer.py:100-147 builds them, plus a file-free "Synthetic" set), class weights
+-> focal alpha (:108-114,194-199), AdamW(lidar) + SGD-Nesterov(camera) (:80-98), two WarmupCosineLR (:61-75), data
+parallelism (:33-39), two IOUEval (:49-59); ``run`` returns {"Acc", "IOU", "Recall", "last"} (:531-537).  The
+per-iteration work (:289-341) is pmf_amd.engine.TrainEngine -- the unit bench.py times.
+
+Differences that do not change results:
+  * the perspective loaders run HIP kernels and return DEVICE tensors, so their DataLoader runs in the main process
+    (num_workers=0: a forked worker cannot initialise the GPU); file reading / PNG decoding of the next batches is
+    overlapped by a small prefetch thread instead (``n_threads`` > 0 switches it on);
+  * loss terms are accumulated on the device every iteration and read at the print frequency (one host sync per
+    print instead of nine .item() calls per iteration); metrics are all-reduced when read."""
 import datetime
+import os
+import queue
+import threading
 import time
 
 import numpy as np
@@ -14,6 +25,8 @@ from torch.utils.data import DataLoader, Dataset
 import pc_processor
 from pmf_amd.engine import TrainEngine, kitti_focal_alpha
 from pmf_amd.utils.detinit import synthetic_batch
+
+TERMS = ("foc", "lov", "foc_cam", "lov_cam", "per")
 
 
 class SyntheticPV(Dataset):
@@ -28,6 +41,39 @@ class SyntheticPV(Dataset):
     def __getitem__(self, i):
         pcd, rgb, label, mask = synthetic_batch(1, self.h, self.w, self.nclasses, seed=self.seed + i)
         return torch.cat((pcd[0], rgb[0]), 0), mask[0], label[0].float()
+
+
+class Prefetcher(object):
+    """iterates a DataLoader from a background thread, ``depth`` batches ahead (HIP calls are thread-safe; the thread
+    uses the loader's device and its own stream is not needed: the loader kernels are tiny next to a training step)."""
+
+    def __init__(self, loader, depth=2):
+        self.loader, self.depth = loader, depth
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __iter__(self):
+        q = queue.Queue(maxsize=self.depth)
+        dev = torch.cuda.current_device() if torch.cuda.is_available() else None
+
+        def work():
+            try:
+                if dev is not None:
+                    torch.cuda.set_device(dev)
+                for item in self.loader:
+                    q.put(("item", item))
+                q.put(("end", None))
+            except BaseException as e:            # surfaces in the consumer
+                q.put(("error", e))
+        threading.Thread(target=work, daemon=True).start()
+        while True:
+            kind, item = q.get()
+            if kind == "end":
+                return
+            if kind == "error":
+                raise item
+            yield item
 
 
 class Trainer(object):
@@ -46,33 +92,70 @@ class Trainer(object):
             feature_mean=sensor["img_mean"], feature_std=sensor["img_stds"],
             distributed=settings.distributed and settings.world_size > 1,
             device_ids=[settings.gpu] if settings.distributed else None)
-        self.optimizer, self.aux_optimizer = self.engine.optimizer, self.engine.aux_optimizer
+        # main.py reads / restores these two (:72-83,104-127): reference checkpoint layout on top of the flat state
+        self.optimizer, self.aux_optimizer = self.engine.optimizer_view, self.engine.aux_optimizer_view
         self.metrics, self.metrics_img = self.engine.metrics, self.engine.metrics_img
         self.scheduler, self.aux_scheduler = self.engine.scheduler, self.engine.aux_scheduler
+        self.last_summary = {}
 
+    # ------------------------------------------------------------------ data
     def _initDataloader(self):
         s = self.settings
         sensor = s.config["sensor"]
-        if s.dataset == "Synthetic":
-            nfr = s.config.get("synthetic_frames", [16, 4])
-            trainset = SyntheticPV(nfr[0], sensor["proj_ht"], sensor["proj_wt"], s.nclasses, seed=s.seed)
-            valset = SyntheticPV(nfr[1], sensor["proj_h"], sensor["proj_w"], s.nclasses, seed=s.seed + 10000)
+        device_side = True
+        if s.dataset == "SemanticKitti":                                       # trainer.py:101-125
+            cfg_path = s.config.get("data_config_path") or pc_processor.dataset.semantic_kitti.DEFAULT_CONFIG
+            seqs = s.config.get("sequences", {})
+            trainset = pc_processor.dataset.semantic_kitti.SemanticKitti(
+                root=s.data_root, sequences=list(seqs.get("train", [0, 1, 2, 3, 4, 5, 6, 7, 9, 10])), config_path=cfg_path)
+            valset = pc_processor.dataset.semantic_kitti.SemanticKitti(
+                root=s.data_root, sequences=list(seqs.get("valid", [8])), config_path=cfg_path)
+            li = trainset.data_config.get("learning_ignore", {})
+            ignore = [bool(li.get(c, False)) for c in range(len(trainset.cls_freq))]
+            self.alpha, self.ignore_class = kitti_focal_alpha(trainset.cls_freq, ignore)
+            self.cls_weight = np.where(np.asarray(ignore), 0.0, 1.0 / (trainset.cls_freq + 1e-3))
+            if self.recorder is not None:
+                self.recorder.logger.info("weight: {}".format(self.cls_weight))
+                self.recorder.logger.info("focal_loss alpha: {}".format(self.alpha))
+            self.mapped_cls_name = trainset.mapped_cls_name
+        elif s.dataset == "nuScenes":                                          # trainer.py:127-136
+            trainset = pc_processor.dataset.nuScenes.Nuscenes(root=s.data_root, version="v1.0-trainval", split="train")
+            valset = pc_processor.dataset.nuScenes.Nuscenes(root=s.data_root, version="v1.0-trainval", split="val")
+            self.cls_weight = np.ones((s.nclasses))
             self.alpha = np.ones(s.nclasses, np.float32)
             self.alpha[0] = 0
             self.ignore_class = [0]
-            self.mapped_cls_name = ["class_%d" % i for i in range(s.nclasses)]
+            self.mapped_cls_name = trainset.mapped_cls_name
+        elif s.dataset == "Synthetic":
+            nfr = s.config.get("synthetic_frames", [16, 4])
+            train_pv = SyntheticPV(nfr[0], sensor["proj_ht"], sensor["proj_wt"], s.nclasses, seed=s.seed)
+            val_pv = SyntheticPV(nfr[1], sensor["proj_h"], sensor["proj_w"], s.nclasses, seed=s.seed + 10000)
+            trainset, valset, device_side = train_pv, val_pv, False
+            self.alpha = np.ones(s.nclasses, np.float32)
+            self.alpha[0] = 0
+            self.ignore_class = [0]
+            self.mapped_cls_name = {i: "class_%d" % i for i in range(s.nclasses)}
         else:
-            raise NotImplementedError("dataset {}: plug the reference's SemanticKitti parser into "
-                                      "pmf_amd.dataset.PerspectiveViewLoader (INTEGRATION.md)".format(s.dataset))
+            raise ValueError("invalid dataset: {}".format(s.dataset))
+        if device_side:                                                        # trainer.py:139-147, verbatim arguments
+            train_pv = pc_processor.dataset.PerspectiveViewLoader(
+                dataset=trainset, config=s.config, is_train=True, pcd_aug=False, img_aug=True, use_padding=True)
+            val_pv = pc_processor.dataset.PerspectiveViewLoader(
+                dataset=valset, config=s.config, is_train=False, use_padding=True)
         tsamp = vsamp = None
         if s.distributed and s.world_size > 1:
             tsamp = torch.utils.data.distributed.DistributedSampler(trainset, shuffle=True, drop_last=True)
             vsamp = torch.utils.data.distributed.DistributedSampler(valset, shuffle=False, drop_last=False)
-        tl = DataLoader(trainset, batch_size=s.batch_size[0], num_workers=s.n_threads, shuffle=tsamp is None,
-                        sampler=tsamp, drop_last=True)
-        vl = DataLoader(valset, batch_size=s.batch_size[1], num_workers=s.n_threads, shuffle=False, sampler=vsamp)
+        workers = 0 if device_side else s.n_threads
+        tl = DataLoader(train_pv, batch_size=s.batch_size[0], num_workers=workers, shuffle=tsamp is None, sampler=tsamp,
+                        drop_last=True)
+        vl = DataLoader(val_pv, batch_size=s.batch_size[1], num_workers=workers, shuffle=False, sampler=vsamp,
+                        drop_last=False)
+        if device_side and s.n_threads > 0:
+            tl, vl = Prefetcher(tl), Prefetcher(vl)
         return tl, vl, tsamp, vsamp
 
+    # ------------------------------------------------------------------ one epoch
     def run(self, epoch, mode="Train"):
         s, eng = self.settings, self.engine
         if mode == "Train":
@@ -80,46 +163,57 @@ class Trainer(object):
             if self.train_sampler is not None:
                 self.train_sampler.set_epoch(epoch)
         elif mode == "Validation":
-            loader = self.val_loader
+            loader = self.val_loader     # (the engine broadcasts rank 0's BN statistics before the first eval step)
         else:
             raise ValueError("invalid mode: {}".format(mode))
         self.metrics.reset()
         self.metrics_img.reset()
-        meters = {k: pc_processor.utils.AverageMeter() for k in ("loss", "foc", "lov", "foc_cam", "lov_cam", "per")}
+        sums = torch.zeros(1 + len(TERMS), dtype=torch.float64, device="cuda")     # sum of (loss x batch) per term
+        count = 0
         total_iter = len(loader)
         t_start = time.time()
+        lr = self.optimizer.param_groups[0]["lr"]
         for i, (feat, mask, label) in enumerate(loader):
             t0 = time.time()
             feat, mask, label = feat.cuda(non_blocking=True), mask.cuda(non_blocking=True), label.cuda(non_blocking=True)
             step = eng.train_step if mode == "Train" else eng.eval_step
             total, terms = step(feat, mask, label)
-            last = (i + 1) % max(s.print_frequency, 1) == 0 or i + 1 == total_iter
-            if last:                                      # host syncs only when something is printed
-                vals = torch.stack([total] + [terms[k] for k in ("foc", "lov", "foc_cam", "lov_cam", "per")]).tolist()
-                for k, v in zip(meters, vals):
-                    meters[k].update(v, feat.size(0))
+            sums += torch.stack([total.detach()] + [terms[k].detach() for k in TERMS]).double() * feat.size(0)
+            count += feat.size(0)
+            if (i + 1) % max(s.print_frequency, 1) == 0 or i + 1 == total_iter:    # the only host syncs of the loop
+                avg = (sums / count).tolist()
                 miou, _ = self.metrics.getIoU()
                 macc, _ = self.metrics.getAcc()
                 mrec, _ = self.metrics.getRecall()
                 miou_i, _ = self.metrics_img.getIoU()
                 self.remain_time.update(cost_time=(time.time() - t_start), mode=mode)
                 rt = datetime.timedelta(seconds=int(self.remain_time.getRemainTime(epoch, i, total_iter, mode)))
+                lr = self.optimizer.param_groups[0]["lr"]
                 if self.recorder is not None:
                     self.recorder.logger.info(
                         ">>> {} E[{:03d}|{:03d}] I[{:04d}|{:04d}] DT[{:.3f}] PT[{:.3f}] LR {:0.5f} Loss {:0.4f} Acc {:0.4f} "
                         "IOU {:0.4f} Recall {:0.4f} ImgIOU {:0.4f} RT {}".format(
-                            mode, s.n_epochs, epoch + 1, total_iter, i + 1, t0 - t_start, time.time() - t0,
-                            self.optimizer.param_groups[0]["lr"], meters["loss"].avg, macc.item(), miou.item(),
-                            mrec.item(), miou_i.item(), rt))
+                            mode, s.n_epochs, epoch + 1, total_iter, i + 1, t0 - t_start, time.time() - t0, lr, avg[0],
+                            macc.item(), miou.item(), mrec.item(), miou_i.item(), rt))
             t_start = time.time()
             if s.is_debug:
                 break
+        avg = (sums / max(count, 1)).tolist()
         miou, ciou = self.metrics.getIoU()
-        macc, _ = self.metrics.getAcc()
-        mrec, _ = self.metrics.getRecall()
+        macc, cacc = self.metrics.getAcc()
+        mrec, crec = self.metrics.getRecall()
+        miou_i, _ = self.metrics_img.getIoU()
         if self.recorder is not None:
-            for k, m in meters.items():
-                self.recorder.tensorboard.add_scalar("{}_{}".format(mode, k), m.avg, epoch)
-            self.recorder.tensorboard.add_scalar("{}_IOU".format(mode), miou.item(), epoch)
-        return {"Loss": meters["loss"].avg, "Acc": macc.item(), "IOU": miou.item(), "Recall": mrec.item(),
-                "class_IOU": ciou.tolist()}
+            tb = self.recorder.tensorboard
+            for k, v in zip(("Loss", "LossFocal", "LossLovasz", "LossImageFocal", "LossImageLovasz", "LossPerception"), avg):
+                tb.add_scalar("{}_{}".format(mode, k), v, epoch)
+            tb.add_scalar("{}_lr".format(mode), lr, epoch)
+            for k, v in (("meanAcc", macc), ("meanIOU", miou), ("meanRecall", mrec), ("Image_meanIOU", miou_i)):
+                tb.add_scalar("{}_{}".format(mode, k), v.item(), epoch)
+            for c, name in self.mapped_cls_name.items():
+                tb.add_scalar("{}_{:02d}_{}_IOU".format(mode, c, name), ciou[c].item(), epoch)
+            self.recorder.logger.info(">>> {} Loss {:0.4f} Acc {:0.4f} IOU {:0.4f} Recall {:0.4f}".format(
+                mode, avg[0], macc.item(), miou.item(), mrec.item()))
+        self.last_summary = {"Loss": avg[0], "terms": dict(zip(TERMS, avg[1:])), "class_IOU": ciou.tolist(),
+                             "ImgIOU": miou_i.item()}
+        return {"Acc": macc.item(), "IOU": miou.item(), "Recall": mrec.item(), "last": 0}

@@ -257,3 +257,153 @@ def test_reference_trainer_call_sequence_stock_ddp():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_checkpoint_roundtrip_in_reference_layout():
+    """checkpoint.pth as tasks/pmf/main.py:104-127 writes it ({"model", "optimizer", "aux_optimizer"} with per-parameter
+    optimizer state in the reference's parameter order) from the flat training state: restore into (a) a second flat
+    engine and (b) plain per-parameter torch optimisers -- the layout a reference checkpoint has -- and (c) back from
+    those into a flat engine; the next step is bit-identical in all of them"""
+    import io
+    from pmf_amd.engine import TrainEngine
+    from pmf_amd.models import PMFNet
+    from pmf_amd.utils.detinit import deterministic_init, synthetic_batch
+    pcd, rgb, label, mask = synthetic_batch(2, 32, 64, 20, seed=9, fill=0.5)
+    feat = torch.cat((pcd, rgb), 1).cuda()
+    mask, label = mask.cuda(), label.cuda()
+
+    def engine(flat, seed_init=True):
+        m = PMFNet(5, 3, 20, 32, imagenet_pretrained=False, image_backbone="resnet34")
+        if seed_init:
+            deterministic_init(m)
+        m = m.cuda()
+        m.set_dropout_masks(_ones_masks(m, 2))
+        return m, TrainEngine(m, 20, lr=1e-3, warmup_steps=2, max_steps=50, flat_state=flat)
+
+    def save(m, e):
+        buf = io.BytesIO()
+        torch.save({"model": m.state_dict(), "optimizer": e.optimizer_view.state_dict(),
+                    "aux_optimizer": e.aux_optimizer_view.state_dict(), "epoch": 0}, buf)
+        buf.seek(0)
+        return torch.load(buf, map_location="cpu")
+
+    def restore(m, e, ck, it):
+        m.load_state_dict(ck["model"])
+        e.optimizer_view.load_state_dict(ck["optimizer"])
+        e.aux_optimizer_view.load_state_dict(ck["aux_optimizer"])
+        for sch in (e.scheduler, e.aux_scheduler):          # (the reference restarts its schedule on resume; here the
+            for _ in range(it):                             #  comparison wants the same learning rate on both sides)
+                sch.step()
+
+    def step(e):
+        return e.train_step(feat.clone(), mask, label)[0].item()
+
+    mA, eA = engine(True)
+    for _ in range(2):
+        step(eA)
+    ck = save(mA, eA)
+    lossA = step(eA)
+    wantA = {k: v.clone() for k, v in mA.state_dict().items()}
+    # layout: reference parameter order, per-parameter tensors
+    lidar = list(mA.lidar_stream.parameters())
+    assert len(ck["optimizer"]["param_groups"]) == 1 and len(ck["aux_optimizer"]["param_groups"]) == 2
+    assert ck["optimizer"]["param_groups"][0]["params"] == list(range(len(lidar)))
+    assert all(tuple(ck["optimizer"]["state"][i]["exp_avg"].shape) == tuple(p.shape) for i, p in enumerate(lidar))
+    n_enc = len(list(mA.camera_stream_encoder.parameters()))
+    assert ck["aux_optimizer"]["param_groups"][1]["params"][0] == n_enc
+    assert "momentum_buffer" in ck["aux_optimizer"]["state"][0]
+
+    def same(m, loss):
+        assert loss == lossA, (loss, lossA)
+        for k, v in m.state_dict().items():
+            assert torch.equal(v, wantA[k]), k
+
+    mB, eB = engine(True, seed_init=False)                 # (a) flat <- checkpoint
+    restore(mB, eB, ck, 2)
+    same(mB, step(eB))
+    mC, eC = engine(False, seed_init=False)                # (b) per-parameter torch optimisers <- checkpoint
+    restore(mC, eC, ck, 2)
+    ckC = save(mC, eC)                                     #     ... and their own state dict is the same layout
+    assert ckC["optimizer"]["param_groups"][0]["params"] == ck["optimizer"]["param_groups"][0]["params"]
+    same(mC, step(eC))
+    mD, eD = engine(True, seed_init=False)                 # (c) flat <- a checkpoint written by per-parameter optimisers
+    restore(mD, eD, ckC, 2)
+    same(mD, step(eD))
+    with pytest.raises(ValueError):
+        bad = {"state": {}, "param_groups": [{"params": [0, 1, 2]}]}
+        eD.optimizer_view.load_state_dict(bad)
+
+
+def test_tasks_pmf_train_resume_and_infer(tmp_path):
+    """the task scripts end to end on a synthetic on-disk SemanticKITTI tree: tasks/pmf/main.py (SemanticKitti branch of the
+    trainer: parser -> PerspectiveViewLoader(is_train, img_aug, use_padding) -> engine, validation schedule, best_* and
+    checkpoint.pth), a second run resuming from that checkpoint, then tasks/pmf_eval_semantickitti/infer.py (pad ->
+    forward -> crop -> argmax -> KNN -> inverse label map -> .label files) checked against the frame's point count"""
+    import os
+    import subprocess
+    import sys
+    import yaml
+    from oracle.cases import kitti_tree
+    root = str(tmp_path / "sequences")
+    cfg_path, data = kitti_tree(root, seqs=(0, 8), frames=4, npts=3000, h=48, w=160)
+    with open(cfg_path) as f:
+        lab = yaml.safe_load(f)
+    lab["learning_ignore"] = {k: k == 0 for k in lab["learning_map_inv"]}
+    with open(cfg_path, "w") as f:
+        yaml.safe_dump(lab, f)
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(repo, "tasks", "pmf", "config_server_kitti.yaml")) as f:
+        cfg = yaml.safe_load(f)
+    cfg.update(save_path=str(tmp_path / "exp"), gpu="0", n_threads=1, n_epochs=2, batch_size=[2, 2], nclasses=6,
+               data_root=root, data_config_path=cfg_path, sequences={"train": [0], "valid": [8]},
+               imagenet_pretrained=False, print_frequency=1)
+    cfg["sensor"].update(proj_h=48, proj_w=160, proj_ht=32, proj_wt=128, h_pad=0, w_pad=0)
+    train_cfg = str(tmp_path / "train.yaml")
+    with open(train_cfg, "w") as f:
+        yaml.safe_dump(cfg, f)
+    env = dict(os.environ, PMF_AUTOTUNE="0")
+    env.pop("RANK", None), env.pop("WORLD_SIZE", None)
+
+    def run(script, conf):
+        r = subprocess.run([sys.executable, os.path.basename(script), conf], cwd=os.path.dirname(script), env=env,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        return r.stdout
+    main = os.path.join(repo, "tasks", "pmf", "main.py")
+    out = run(main, train_cfg)
+    assert "===init env success===" in out and ">>> Validation" in out
+    exp = [d for d in os.listdir(cfg["save_path"])]
+    assert len(exp) == 1
+    ckdir = os.path.join(cfg["save_path"], exp[0], "checkpoint")
+    files = set(os.listdir(ckdir))
+    assert {"checkpoint.pth", "best_IOU_model.pth", "best_Acc_model.pth", "best_Recall_model.pth"} <= files
+    ck = torch.load(os.path.join(ckdir, "checkpoint.pth"), map_location="cpu")
+    assert ck["epoch"] == 1 and len(ck["aux_optimizer"]["param_groups"]) == 2
+    cfg.update(checkpoint=os.path.join(ckdir, "checkpoint.pth"), n_epochs=3, experiment_id="resume")
+    with open(train_cfg, "w") as f:
+        yaml.safe_dump(cfg, f)
+    out = run(main, train_cfg)
+    assert "E[003|003]" in out and "E[003|001]" not in out        # resumed at epoch 2 (0-based): only the third epoch ran
+    # inference
+    with open(os.path.join(repo, "tasks", "pmf_eval_semantickitti", "config_server_kitti.yaml")) as f:
+        icfg = yaml.safe_load(f)
+    icfg.update(save_path=str(tmp_path / "eval"), data_root=root, data_config_path=cfg_path, nclasses=6,
+                sequences={"valid": [8]}, pretrained_model=os.path.join(ckdir, "best_IOU_model.pth"))
+    icfg["sensor"].update(proj_h=48, proj_w=160, h_pad=8, w_pad=0)
+    infer_cfg = str(tmp_path / "infer.yaml")
+    with open(infer_cfg, "w") as f:
+        yaml.safe_dump(icfg, f)
+    out = run(os.path.join(repo, "tasks", "pmf_eval_semantickitti", "infer.py"), infer_cfg)
+    assert "Point-wise Evaluation Results" in out and "Pixel-wise Evaluation Results" in out
+    edir = os.path.join(icfg["save_path"], os.listdir(icfg["save_path"])[0], "preds", "sequences", "08", "predictions")
+    preds = sorted(os.listdir(edir))
+    assert preds == ["%06d.label" % i for i in range(4)]
+    from oracle import loader_ref
+    from pmf_amd.dataset.semantic_kitti import SemanticKitti
+    ds = SemanticKitti(root, [8], cfg_path)
+    for i, name in enumerate(preds):
+        lab_out = np.fromfile(os.path.join(edir, name), dtype=np.int32)
+        pts, raw, img = data[("08", "%06d" % i)]
+        _, keep = loader_ref.map_lidar_to_camera(ds.proj_matrix["08"], pts[:, :3], img.shape[1], img.shape[0])
+        assert lab_out.shape[0] == int(keep.sum())                 # one label per point inside the camera frustum
+        assert set(np.unique(lab_out)) <= set(lab["learning_map_inv"].values())

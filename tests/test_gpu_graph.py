@@ -1,0 +1,51 @@
+"""hipGraph replay does not depend on where the caller's tensors live (tasks/pmf/trainer.py:289-303 hands the model a
+fresh batch from DataLoader + .cuda() every iteration)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_graph_replay_with_fresh_input_addresses():
+    from pmf_amd.engine import TrainEngine
+    from pmf_amd.models import PMFNet
+    from pmf_amd.utils.detinit import deterministic_init, synthetic_batch
+
+    def run(fresh):
+        m = deterministic_init(PMFNet(5, 3, 20, 32, imagenet_pretrained=False, image_backbone="resnet34")).cuda()
+        eng = TrainEngine(m, 20, lr=1e-3, warmup_steps=2, max_steps=20)
+        pcd, rgb, label, mask = synthetic_batch(2, 32, 64, 20, seed=11, fill=0.5)
+        feat = torch.cat((pcd, rgb), 1).cuda()
+        mask, label = mask.cuda(), label.cuda()
+        torch.manual_seed(5)
+        torch.cuda.manual_seed(5)
+        ring, addrs, losses = [], set(), []
+        for _ in range(8):
+            if fresh:
+                batch = (feat.clone(), mask.clone(), label.clone())
+                ring.append(batch)              # three batches stay alive: the caching allocator must rotate addresses
+                if len(ring) > 3:
+                    ring.pop(0)
+            else:
+                batch = (feat.clone(), mask, label)
+            addrs.add(batch[0].data_ptr())
+            losses.append(eng.train_step(*batch)[0].item())
+        plan = next(iter(m._plans.values()))
+        return losses, len(addrs), len(plan._graphs), {k: v.clone() for k, v in m.state_dict().items()}
+
+    l0, a0, g0, s0 = run(False)
+    l1, a1, g1, s1 = run(True)
+    assert a1 >= 3 and a0 <= 2                      # the fresh run really saw different input addresses
+    assert g0 == g1 == 2                            # one forward graph + one backward graph, captured once
+    assert l0 == l1
+    for k in s0:
+        assert torch.equal(s0[k], s1[k]), k
+    # eval: outputs are the caller's own tensors (not views of plan memory that the next call overwrites)
+    m = deterministic_init(PMFNet(5, 3, 20, 32, imagenet_pretrained=False, image_backbone="resnet34")).cuda().eval()
+    pcd, rgb, _, _ = synthetic_batch(1, 32, 64, 20, seed=2)
+    pcd2, rgb2, _, _ = synthetic_batch(1, 32, 64, 20, seed=3)
+    with torch.no_grad():
+        a = m(pcd.cuda(), rgb.cuda())[0]
+        keep = a.clone()
+        b = m(pcd2.cuda(), rgb2.cuda())[0]
+    assert torch.equal(a, keep) and not torch.equal(a, b)
