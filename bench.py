@@ -11,12 +11,16 @@ statistics, fp32 arithmetic (fp32 MFMA).  Nothing is skipped inside the timed re
 N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (one rank per GPU,
 RCCL); weak scaling (bs=2 per GPU); value = N*K iterations / max-over-ranks wall time.
 
-Extra objects on the JSON line:
-  roofline     -- the conv MFMA kernel (conv_fwd_k: forward + input-gradient launches): algorithmic FLOPs of those
-                  launches / their summed duration, measured with HIP events on the plan's stream in one extra
-                  profiled iteration after the timed region; peak = 157.3 TFLOP/s fp32 MFMA (MI355X_MICROARCH.md).
-  cpu_baseline -- the CPU oracle (oracle/pmf_torch.py, a port pinned to reference-run fixtures) doing the same
-                  iteration on the host cores (rank 0, N=1 only, one timed iteration after one warm-up).
+Extra objects on the JSON line (every mode: --mode infer, --backbone resnet50 ..., --model epmf carry them too):
+  roofline     -- the dominant kernel, the conv MFMA kernel (conv_fwd_k: forward + input-gradient launches): algorithmic
+                  FLOPs of those launches / their summed duration, measured with HIP events on the plan's stream in one
+                  extra op-by-op iteration after the timed region; peak = 157.3 TFLOP/s fp32 MFMA (MI355X_MICROARCH.md).
+  roofline_hbm -- the bandwidth-bound kernel families (BatchNorm backward, residual adds, pools, bilinear, softmax, fusion
+                  gate, fused objective; KNN in --mode infer): SURVEY.md 8d algorithmic bytes / measured duration against
+                  8 TB/s.
+  cpu_baseline -- the CPU oracle (oracle/*.py, a port pinned to reference-run fixtures) doing the same step at the SAME
+                  configuration on the host cores (rank 0, N=1 only: one timed iteration after one warm-up, all cores;
+                  plus a single-thread number from a bounded slice).
 """
 import argparse
 import json
@@ -76,6 +80,20 @@ def infer_bench(args, model, dev):
         out = step()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    roof = hbm = cpu = None
+    if not args.no_roofline:
+        plan = next(p for k, p in model._plans.items() if not k[3])
+        roof, hbm, _ = plan_rooflines(plan, plan.run_profiled("forward"), args.model)
+        am = model(feat[:, 0:5], feat[:, 5:8])[0].argmax(1)
+        pr, ur, px, py = frames[0]
+        ms = timed_ms(lambda: knn(pr, ur, am[0], px, py), 20)
+        nb = 12.0 * args.height * args.width + 28.0 * ur.numel()            # 12 H W + 28 P bytes per call
+        hbm.insert(0, {"kernel": "knn_k (5x5 window, k=5 vote per point)", "bound": "hbm", "launches": bs,
+                       "achieved": round(nb / ms / 1e6, 1), "peak": PEAK_HBM, "unit": "GB/s",
+                       "frac": round(nb / ms / 1e6 / PEAK_HBM, 5), "algorithmic_mb_per_iter": round(bs * nb / 1e6, 2),
+                       "ms_per_iter": round(bs * ms, 4), "points": ur.numel()})
+    if not args.no_cpu_baseline:
+        cpu = cpu_baseline(bs, args.height, args.width, args.model, args.backbone, args.nclasses, mode="infer")
     print(json.dumps({
         "metric": "inference frames/sec PMF-ResNet34 64x2048 bs=%d (eval forward + KNN post-processing)" % bs,
         "value": bs * args.steps / dt, "unit": "frame/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -83,7 +101,7 @@ def infer_bench(args, model, dev):
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "PMF-ResNet34 inference, both streams %dx%d (BASELINE configs[1]), bs=%d, KNN 5/5/1.0/1.0 "
                                "on %d points per frame" % (args.height, args.width, bs, frames[0][1].numel())},
-        "roofline": None, "cpu_baseline": None}))
+        "roofline": roof, "roofline_hbm": hbm, "cpu_baseline": cpu}))
 
 
 def salsanext_bench(args, dev, multi, rank, world):
@@ -110,7 +128,7 @@ def salsanext_bench(args, dev, multi, rank, world):
         feat = torch.stack([i[0] for i in items])
         label = torch.stack([i[1] for i in items])
         mask = torch.stack([i[2] for i in items])
-        return eng.train_step(feat, mask, label)
+        return eng.train_step(feat, label, mask)
     for _ in range(args.warmup):
         step()
     if multi:
@@ -143,30 +161,116 @@ def salsanext_bench(args, dev, multi, rank, world):
         dist.destroy_process_group()
 
 
-def cpu_baseline(bs, h, w):
-    """the oracle port on the host cores.  Bounded sample: the same full iteration on a 1/8-area slice of the
-    workload (bs=1, H x W/4), 1 warm-up + 2 timed steps, scaled by pixel count (every term of the step is linear
-    in N*H*W: convs, BN, losses; the optimiser part is size-independent and left unscaled -> slightly favours the CPU)."""
+def _oracle_model(model, backbone, nclasses):
     from oracle import pmf_torch as O
+    if model == "epmf":
+        from oracle import epmf_torch as E
+        return E.EPMFNet(5, 3, nclasses, 32, False, backbone)
+    return O.PMFNet(5, 3, nclasses, 32, False, backbone)
+
+
+def cpu_baseline(bs, h, w, model="pmf", backbone="resnet34", nclasses=20, mode="train"):
+    """the CPU oracle (oracle/*.py: the port pinned to reference-run fixtures) doing the SAME step at the SAME
+    configuration on the host cores: 1 warm-up + 1 timed iteration with every core torch will use, plus -- for scaling
+    context -- one single-thread iteration of a 1/16-area slice (bs=1, W/8) scaled by pixel count."""
     from pmf_amd.engine import TrainEngine
     torch.manual_seed(1)
-    threads = min(32, os.cpu_count() or 1)      # oneDNN conv does not scale past a few dozen threads at this size
+    threads = os.cpu_count() or 1
     torch.set_num_threads(threads)
-    sb, sw = 1, max(w // 4, 64)
-    model = O.PMFNet(5, 3, 20, 32, False, "resnet34")
-    eng = TrainEngine(model, 20, feature_mean=KITTI_MEAN, feature_std=KITTI_STD, warmup_steps=10, max_steps=100)
-    feat, mask, label = make_batch(sb, h, sw, 1, "cpu")
+    net = _oracle_model(model, backbone, nclasses)
+    feat, mask, label = make_batch(bs, h, w, 1, "cpu", nclasses)
+    if mode == "infer":
+        from oracle import knn_ref
+        net.eval()
+        pr = torch.where(mask[0] > 0, feat[0, 0].abs() + 2.0, torch.full_like(feat[0, 0], -1.0)).numpy()
+        occ = np.argwhere(mask[0].numpy() > 0)
+        sel = np.random.default_rng(3).integers(0, occ.shape[0], int(occ.shape[0] * 1.3))
+        py, px = occ[sel, 0].astype(np.int64), occ[sel, 1].astype(np.int64)
+        ur = (pr[py, px] + 0.1).astype(np.float32)
+
+        def one():
+            with torch.no_grad():
+                lp, _ = net(feat[:, 0:5], feat[:, 5:8])
+                am = lp.argmax(1).numpy()
+            for b in range(bs):
+                knn_ref.knn_vote(pr, ur, am[b], px, py)
+        one()
+        t0 = time.time()
+        one()
+        dt = time.time() - t0
+        return {"value": bs / dt, "unit": "frame/s", "cores": threads, "kind": "port",
+                "sample": "1 timed pass (after 1 warm-up) of the full configuration: eval forward of bs=%d at %dx%d + KNN "
+                          "vote per frame; oracle/pmf_torch.py + oracle/knn_ref.py, torch %s, %d host threads, %.2f s"
+                          % (bs, h, w, torch.__version__, threads, dt)}
+    eng = TrainEngine(net, nclasses, feature_mean=KITTI_MEAN, feature_std=KITTI_STD, warmup_steps=10, max_steps=100)
     eng.train_step(feat.clone(), mask, label)
     t0 = time.time()
-    n = 2
-    for _ in range(n):
-        eng.train_step(feat.clone(), mask, label)
-    dt = (time.time() - t0) / n
-    scale = (bs * h * w) / float(sb * h * sw)
-    return {"value": 1.0 / (dt * scale), "unit": "iter/s", "cores": threads, "kind": "port",
-            "sample": "%d timed full train iterations at bs=%d %dx%d (1/%g of the workload's pixels, %.2f s each) after "
-                      "1 warm-up, scaled by pixel count; oracle/pmf_torch.py + torch %s, %d host threads"
-                      % (n, sb, h, sw, scale, dt, torch.__version__, threads)}
+    eng.train_step(feat.clone(), mask, label)
+    dt = time.time() - t0
+    # single thread, bounded: 1/16 of the pixels
+    torch.set_num_threads(1)
+    sw = max(w // 8, 64)
+    f1, m1, l1 = make_batch(1, h, sw, 1, "cpu", nclasses)
+    net1 = _oracle_model(model, backbone, nclasses)
+    eng1 = TrainEngine(net1, nclasses, feature_mean=KITTI_MEAN, feature_std=KITTI_STD, warmup_steps=10, max_steps=100)
+    t1 = time.time()
+    eng1.train_step(f1.clone(), m1, l1)
+    d1 = (time.time() - t1) * (bs * h * w) / float(h * sw)
+    torch.set_num_threads(threads)
+    return {"value": 1.0 / dt, "unit": "iter/s", "cores": threads, "kind": "port",
+            "sample": "1 timed full train iteration (after 1 warm-up) at the full configuration bs=%d %dx%d: %.2f s; "
+                      "oracle + torch %s on %d host threads (os.cpu_count)" % (bs, h, w, dt, torch.__version__, threads),
+            "single_thread": {"value": 1.0 / d1, "unit": "iter/s", "cores": 1,
+                              "sample": "1 iteration at bs=1 %dx%d on one thread, scaled by pixel count to the full "
+                                        "configuration (%.1f s)" % (h, sw, d1)}}
+
+
+PEAK_HBM = 8000.0      # GB/s, MI355X_MICROARCH.md (6.3 TB/s is what a float4 copy reaches)
+
+
+def plan_rooflines(plan, prof, model_tag):
+    """(mfma roofline of the conv kernel, per-family HBM rooflines, kernel-time breakdown) from one op-by-op profile"""
+    fam = {}
+    for kind, family, flops, ms, _, nbytes in prof:
+        a = fam.setdefault(family or kind, [0, 0.0, 0.0, 0.0])
+        a[0] += 1
+        a[1] += flops
+        a[2] += ms
+        a[3] += nbytes
+    convs = [k for k in ("conv_fwd", "conv_dgrad") if k in fam]
+    mfma_ms = sum(fam[k][2] for k in convs)
+    mfma_fl = sum(fam[k][1] for k in convs)
+    n_launch = sum(fam[k][0] for k in convs)
+    achieved = mfma_fl / (mfma_ms * 1e-3) / 1e12
+    roof = {"bound": "mfma", "kernel": "conv_fwd_k (forward%s launches, fp32 MFMA 32x32x2)" % (
+                " + input-gradient" if "conv_dgrad" in fam else ""),
+            "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA, "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_FP32_MFMA, 4), "traffic": None, "traffic_source": None,
+            "launches_per_iter": n_launch, "avg_launch_us": round(1e3 * mfma_ms / n_launch, 2),
+            "algorithmic_gflop_per_iter": round(mfma_fl / 1e9, 1)}
+    hbm = []
+    for k, v in sorted(fam.items(), key=lambda kv: -kv[1][3]):
+        if v[3] > 0 and v[2] > 0:
+            gbs = v[3] / (v[2] * 1e-3) / 1e9
+            hbm.append({"kernel": k, "bound": "hbm", "launches": v[0], "achieved": round(gbs, 1), "peak": PEAK_HBM,
+                        "unit": "GB/s", "frac": round(gbs / PEAK_HBM, 4), "algorithmic_mb_per_iter": round(v[3] / 1e6, 1),
+                        "ms_per_iter": round(v[2], 4)})
+    detail = {k: {"launches": v[0], "gflop": round(v[1] / 1e9, 1), "ms": round(v[2], 3),
+                  "tflops": round(v[1] / max(v[2], 1e-9) / 1e9, 2) if v[1] else None}
+              for k, v in sorted(fam.items(), key=lambda kv: -kv[1][2])}
+    return roof, hbm, detail
+
+
+def timed_ms(fn, reps=5):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / reps
 
 
 def main():
@@ -257,7 +361,7 @@ def main():
     if not np.isfinite(loss_val):
         raise SystemExit("bench.py: non-finite loss %r" % loss_val)
 
-    roof, detail = None, None
+    roof, detail, hbm = None, None, None
     if rank == 0 and not args.no_roofline:
         # one extra iteration with a HIP event pair around every launch of the forward and backward plans
         plan = next(iter(model._plans.values()))
@@ -268,48 +372,47 @@ def main():
         pcd, rgb = eng.prepare(feat0.clone(), mask)
         total = eng.forward_loss(pcd, rgb, label.long())[0]
         prof_f = plan.run_profiled("forward")       # re-runs the forward plan op by op (same inputs)
-        total.backward()                             # normal backward (needed to patch gradient pointers) ...
+        total.backward()                             # normal backward (stages the upstream gradients) ...
         prof_b = plan.run_profiled("backward")      # ... then the backward plan again, op by op
         model._bwd_segment_hook = hook
         if args.profile_out:
             with open(args.profile_out, "w") as f:
                 for ph, prof in (("fwd", prof_f), ("bwd", prof_b)):
-                    for kind, family, flops, ms, name in prof:
+                    for kind, family, flops, ms, name, _ in prof:
                         f.write("%s %-18s %-12s %-28s %9.1f us %8.2f GF %7.2f TF/s\n" % (
                             ph, kind, family or "-", name, ms * 1e3, flops / 1e9, flops / max(ms, 1e-9) / 1e9))
-        fam = {}
-        for kind, family, flops, ms, _ in prof_f + prof_b:
-            key = family or kind
-            a = fam.setdefault(key, [0, 0.0, 0.0])
-            a[0] += 1
-            a[1] += flops
-            a[2] += ms
-        mfma_ms = fam["conv_fwd"][2] + fam["conv_dgrad"][2]
-        mfma_fl = fam["conv_fwd"][1] + fam["conv_dgrad"][1]
-        n_launch = fam["conv_fwd"][0] + fam["conv_dgrad"][0]
-        achieved = mfma_fl / (mfma_ms * 1e-3) / 1e12
-        # HBM-side bytes per launch come from a separate rocprofv3 --pmc run of this command (counters cannot be read
-        # from inside the process); tools/pmc_traffic.py wrote the summary that is committed under profiles/
-        traffic, tsrc = None, None
-        tp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+        roof, hbm, detail = plan_rooflines(plan, prof_f + prof_b, args.model)
+        # the fused objective runs outside the plans (loss/fused.py): two probability maps read, two gradient maps
+        # written, 2 x C x N x H x W sort keys written and read back permuted
+        from pmf_amd.loss import pmf_total_loss_fused
+        lp = torch.softmax(torch.randn(args.bs, args.nclasses, args.height, args.width, device=dev), 1).requires_grad_(True)
+        cp = torch.softmax(torch.randn(args.bs, args.nclasses, args.height, args.width, device=dev), 1).requires_grad_(True)
+
+        def loss_step():
+            t, _ = pmf_total_loss_fused(lp, cp, label.long(), eng.focal.alpha, 1.0, 0.5, 0.7, eng.focal.gamma)
+            t.backward()
+        ms = timed_ms(loss_step)
+        nb = 4.0 * lp.numel() * (2 + 2 + 2 * 3)
+        hbm.append({"kernel": "fused objective (loss_pixel_k + Lovasz sort + gradient scatter, both heads, fwd+bwd)",
+                    "bound": "hbm", "launches": None, "achieved": round(nb / ms / 1e6, 1), "peak": PEAK_HBM, "unit": "GB/s",
+                    "frac": round(nb / ms / 1e6 / PEAK_HBM, 4), "algorithmic_mb_per_iter": round(nb / 1e6, 1),
+                    "ms_per_iter": round(ms, 4)})
+        # HBM-side bytes per conv launch come from a separate rocprofv3 --pmc run of this command (counters cannot be
+        # read from inside the process); tools/pmc_traffic.py wrote the summary that is committed under profiles/
         headline = args.model == "pmf" and args.backbone == "resnet34" and args.nclasses == 20 and \
             (args.height, args.width, args.bs) == (64, 2048, 2)
-        if headline and os.path.exists(tp):
-            with open(tp) as f:
-                tj = json.load(f)
-            traffic, tsrc = round(tj["hbm_bytes_per_launch"]), "profiles/r01_pmc_traffic.json (" + tj["method"] + ")"
-        roof = {"bound": "mfma", "kernel": "conv_fwd_k (forward + input-gradient launches, fp32 MFMA 32x32x2)",
-                "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_FP32_MFMA, 4), "traffic": traffic, "traffic_source": tsrc,
-                "launches_per_iter": n_launch, "avg_launch_us": round(1e3 * mfma_ms / n_launch, 2),
-                "algorithmic_gflop_per_iter": round(mfma_fl / 1e9, 1)}
-        detail = {k: {"launches": v[0], "gflop": round(v[1] / 1e9, 1), "ms": round(v[2], 3),
-                      "tflops": round(v[1] / max(v[2], 1e-9) / 1e9, 2) if v[1] else None}
-                  for k, v in sorted(fam.items(), key=lambda kv: -kv[1][2])}
+        for tp in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+            tp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", tp)
+            if headline and os.path.exists(tp):
+                with open(tp) as f:
+                    tj = json.load(f)
+                roof["traffic"] = round(tj["hbm_bytes_per_launch"])
+                roof["traffic_source"] = "profiles/%s (%s)" % (os.path.basename(tp), tj["method"])
+                break
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.model == "pmf":
-        cpu = cpu_baseline(args.bs, args.height, args.width)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.bs, args.height, args.width, args.model, args.backbone, args.nclasses)
 
     if rank == 0:
         iters = world * args.steps
@@ -328,10 +431,11 @@ def main():
                                       ", S_A" if (args.height, args.width) == (64, 2048) else "", args.bs,
                                       args.nclasses),
                        "global_batch": world * args.bs, "parallelism": "dp%d" % world,
+                       "rccl_ranks": (dist.get_world_size() if multi else 0),
                        "samples_per_s": world * args.bs * args.steps / dt, "final_loss": loss_val,
                        "fresh_input_addresses": bool(args.fresh_inputs),
                        "graphs_captured": len(next(iter(model._plans.values()))._graphs)},
-            "roofline": roof, "cpu_baseline": cpu, "kernel_time_breakdown": detail,
+            "roofline": roof, "roofline_hbm": hbm, "cpu_baseline": cpu, "kernel_time_breakdown": detail,
         }
         try:       # RCCL prints its version banner through C stdio (buffered when piped): push it out first so that the
             import ctypes           # JSON line is the LAST line of stdout

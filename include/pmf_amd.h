@@ -413,6 +413,9 @@ int pmf_plan_run_range(const pmf_op_t* ops, int32_t begin, int32_t end, pmf_stre
  * executable graph is bound to the pointer values inside `ops` at capture time. */
 int pmf_plan_capture(const pmf_op_t* ops, int32_t begin, int32_t end, void** graph_exec, int32_t* failed_at);
 int pmf_graph_launch(void* graph_exec, pmf_stream_t s);
+/* lanes (pmf_op_t.pad_): on = 0 run every op on the caller's stream, 1 honour the lane bits (default; PMF_LANES=0 in the
+ * environment starts with 0), < 0 query only; returns the previous setting */
+int pmf_plan_lanes(int on);
 int pmf_graph_destroy(void* graph_exec);
 /* pixel splits pmf_conv_wgrad will use for this descriptor (sizes `partial`) */
 int pmf_conv_wgrad_nsplit(const pmf_wgrad_desc_t* d);

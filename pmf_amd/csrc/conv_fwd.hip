@@ -47,6 +47,12 @@ extern "C" int pmf_conv_trace_set(void* p) { return (int)hipMemcpyToSymbol(HIP_S
 #define TR_END() do { } while (0)
 #endif
 
+// Kernel-argument fields travel through the scalar cache.  Left alone, hipcc sinks every s_load to its first use and
+// waits for it there: 9 tap offsets + 6 operand fields were 15 dependent scalar-cache round trips (~5.5k cycles, 2.6 us)
+// at the start of EVERY workgroup, before its first global load was issued.  Naming the values in one empty asm
+// statement makes the compiler fetch them as one batch with a single wait.
+#define PMF_SGPR_BATCH(...) asm volatile("" ::__VA_ARGS__)
+
 // NTAPS taps x 16 channels of one staged chunk, fully unrolled and branch-free.  The LDS operands of step i+1 (one
 // ds_read_b128 per M tile + 4 ds_read_b32 per N tile) are issued BEFORE the 4*MT*NT MFMAs of step i (explicit double
 // buffer + sched_barrier): left alone hipcc emits read -> wait -> 2 mfma groups, four exposed LDS round trips per step.
@@ -175,6 +181,7 @@ __device__ __forceinline__ void conv_kloop_pipe(const pmf_conv_desc_t& d, const 
     gA[j] = ok ? (n * sH + iy) * sW + ix : -1;   // -1: negative byte offset = out of range = the buffer load returns 0
     okA |= ok ? (1u << j) : 0u;
   }
+  TR();   // (trace) slot table done
   int offB[NDMA];   // per-lane source offset (floats) of DMA instruction wave + 4*jj, relative to the half's first row
 #pragma unroll
   for (int jj = 0; jj < NDMA; ++jj) {
@@ -182,10 +189,18 @@ __device__ __forceinline__ void conv_kloop_pipe(const pmf_conv_desc_t& d, const 
     offB[jj] = ((row >> 3) * (VT > 1 ? KC : g.Ktot) + (row & 7)) * d.ldw + (lane % (BN / 4)) * 4;
   }
   int aoff[TAPG];
+  {
+    int ty[TAPG], tx[TAPG];                                // the first TAPG table entries, fetched as one batch
 #pragma unroll
-  for (int t = 0; t < TAPG; ++t) {
-    if (VT > 1) aoff[t] = t < VT ? t * g.a_floats : 0;     // virtual tap t = 16-channel chunk t of the stage
-    else aoff[t] = t < d.ntaps ? (((int)d.tdy[t] - g.dy_min) * in_cols + ((int)d.tdx[t] - g.dx_min)) * APITCH : 0;
+    for (int t = 0; t < TAPG; ++t) { ty[t] = d.tdy[t]; tx[t] = d.tdx[t]; }
+    PMF_SGPR_BATCH("s"(ty[0]), "s"(ty[1]), "s"(ty[2]), "s"(ty[3]), "s"(ty[4]), "s"(ty[5]), "s"(ty[6]), "s"(ty[7]),
+                   "s"(ty[8]), "s"(tx[0]), "s"(tx[1]), "s"(tx[2]), "s"(tx[3]), "s"(tx[4]), "s"(tx[5]), "s"(tx[6]),
+                   "s"(tx[7]), "s"(tx[8]));
+#pragma unroll
+    for (int t = 0; t < TAPG; ++t) {
+      if (VT > 1) aoff[t] = t < VT ? t * g.a_floats : 0;   // virtual tap t = 16-channel chunk t of the stage
+      else aoff[t] = t < d.ntaps ? ((ty[t] - g.dy_min) * in_cols + (tx[t] - g.dx_min)) * APITCH : 0;
+    }
   }
   int abase[MT];
 #pragma unroll
@@ -208,18 +223,24 @@ __device__ __forceinline__ void conv_kloop_pipe(const pmf_conv_desc_t& d, const 
   int nld = 0, ncch = 0;
   const float* __restrict__ nw = nullptr;   // first weight row of the stage being fetched (uniform)
   auto head = [&]() {   // per-stage scalars + the channel transform of stage (si, c0)
-    nrs = __builtin_amdgcn_make_buffer_rsrc((void*)d.src[si].x, 0, d.N * sH * sW * d.src[si].ldc * 4, 0x00020000);
-    nld = d.src[si].ldc; ncch = c0 + q * 4;
-    cur_flags = d.src[si].flags;
-    cur_aff = d.src[si].scale != nullptr;
+    const float* sx = d.src[si].x;
+    const float* ssc = d.src[si].scale;
+    const float* ssh = d.src[si].shift;
+    const float* scm = d.src[si].cmul;
+    const int sld = d.src[si].ldc, sfl = d.src[si].flags, scl = d.src[si].cmul_ld;
+    PMF_SGPR_BATCH("s"(sx), "s"(ssc), "s"(ssh), "s"(scm), "s"(sld), "s"(sfl), "s"(scl));   // one scalar-cache round trip
+    nrs = __builtin_amdgcn_make_buffer_rsrc((void*)sx, 0, d.N * sH * sW * sld * 4, 0x00020000);
+    nld = sld; ncch = c0 + q * 4;
+    cur_flags = sfl;
+    cur_aff = ssc != nullptr;
 #pragma unroll
     for (int v = 0; v < VT; ++v) {      // channel transform of virtual tap v (channels ncch + 16 v ...)
       sc4[v] = f32x4{1.f, 1.f, 1.f, 1.f}; sh4[v] = f32x4{0.f, 0.f, 0.f, 0.f}; cm4[v] = f32x4{1.f, 1.f, 1.f, 1.f};
       if (cur_aff) {
-        sc4[v] = *(const f32x4*)(d.src[si].scale + ncch + KC * v);
-        sh4[v] = *(const f32x4*)(d.src[si].shift + ncch + KC * v);
+        sc4[v] = *(const f32x4*)(ssc + ncch + KC * v);
+        sh4[v] = *(const f32x4*)(ssh + ncch + KC * v);
       }
-      if (d.src[si].cmul) cm4[v] = *(const f32x4*)(d.src[si].cmul + (size_t)n * d.src[si].cmul_ld + ncch + KC * v);
+      if (scm) cm4[v] = *(const f32x4*)(scm + (size_t)n * scl + ncch + KC * v);
     }
     nw = d.w + (size_t)(kb + c0) * d.ldw + n0;
   };
@@ -237,10 +258,12 @@ __device__ __forceinline__ void conv_kloop_pipe(const pmf_conv_desc_t& d, const 
         __builtin_amdgcn_global_load_lds(wsrc + offB[jj], (lds_ptr_t)(dst + i * 256), 16, 0, 0);
     }
   };
+  TR();   // (trace) tap / weight offsets done
   bool have = settle();
   const float* __restrict__ wcur = nullptr;
   if (have) {
     head();
+    TR();   // (trace) stage scalars + channel transform loaded
 #pragma unroll
     for (int j = 0; j < ASL; ++j) loadA(j);
     dma_half(nw, Bs);
@@ -317,6 +340,12 @@ __device__ __forceinline__ void conv_kloop_pipe(const pmf_conv_desc_t& d, const 
 template <int BN, int MT, int PIPE>   // PIPE: 0 generic K loop, 1 pipelined, 4 pipelined with 64-channel stages (1x1 convs)
 __global__ __launch_bounds__(256) void conv_fwd_k(const pmf_conv_desc_t d, const ConvGeom g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  {  // everything the prologue reads from the two argument structs, as ONE scalar-cache batch (see PMF_SGPR_BATCH)
+    PMF_SGPR_BATCH("s"(d.N), "s"(d.OH), "s"(d.OW), "s"(d.nsrc), "s"(d.ntaps), "s"(d.in_stride), "s"(d.w), "s"(d.ldw),
+                   "s"(d.src[0].C), "s"(d.src[0].H), "s"(d.src[0].W), "s"(g.segs_x_log2), "s"(g.th), "s"(g.tw),
+                   "s"(g.tiles_x), "s"(g.in_rows), "s"(g.in_cols), "s"(g.dy_min), "s"(g.dx_min), "s"(g.Ktot),
+                   "s"(g.kc_alloc), "s"(g.a_floats), "s"(g.ksplit));
+  }
   float* __restrict__ As = smem;
   float* __restrict__ Bs = smem + g.a_floats * (PIPE > 1 ? PIPE : 1);
   constexpr int NT = BN / 32;
@@ -542,6 +571,10 @@ __global__ __launch_bounds__(256) void conv_fwd_k(const pmf_conv_desc_t d, const
   double ssum[NT], ssq[NT];
 #pragma unroll
   for (int u = 0; u < NT; ++u) ssum[u] = ssq[u] = 0.0;
+  PMF_SGPR_BATCH("s"(d.out), "s"(d.bias), "s"(d.act), "s"(d.Cout), "s"(d.out_ldc), "s"(d.out_H), "s"(d.out_W), "s"(d.out_sy),
+                 "s"(d.out_sx), "s"(d.out_oy), "s"(d.out_ox), "s"(d.accumulate), "s"(d.ep_cmul), "s"(d.ep_cmul_ld),
+                 "s"(d.ep_relu_x), "s"(d.ep_relu_scale), "s"(d.ep_relu_shift), "s"(d.ep_relu_ldc), "s"(d.stats),
+                 "s"(d.ep_pmask));
   {
     const __amdgpu_buffer_rsrc_t orr = __builtin_amdgcn_make_buffer_rsrc((void*)d.out, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t xrr =

@@ -133,10 +133,17 @@ static int plan_event(int e, hipEvent_t* out) {
   *out = g_ev[e];
   return 0;
 }
+static int g_lanes_on = -1;
 static bool lanes_enabled() {
-  static int on = -1;
-  if (on < 0) { const char* e = getenv("PMF_LANES"); on = (e && e[0] == '0') ? 0 : 1; }
-  return on == 1;
+  if (g_lanes_on < 0) { const char* e = getenv("PMF_LANES"); g_lanes_on = (e && e[0] == '0') ? 0 : 1; }
+  return g_lanes_on == 1;
+}
+// on = 0 / 1: run every op on the caller's stream / honour the lane bits; on < 0: query.  Returns the previous setting.
+// (Per-op profiling switches the lanes off so that an event pair on the caller's stream brackets exactly one kernel.)
+extern "C" int pmf_plan_lanes(int on) {
+  const int prev = lanes_enabled() ? 1 : 0;
+  if (on >= 0) g_lanes_on = on ? 1 : 0;
+  return prev;
 }
 
 static int run_range(const pmf_op_t* ops, int32_t begin, int32_t end, hipStream_t main_s, int32_t* failed_at) {

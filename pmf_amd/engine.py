@@ -325,7 +325,9 @@ class SalsaNextEngine:
     _allreduce_ready_ranges = TrainEngine._allreduce_ready_ranges
     _finish_allreduce = TrainEngine._finish_allreduce
 
-    def forward_loss(self, feature, mask, label):
+    def forward_loss(self, feature, label, mask):
+        """(feature, label, mask): the order SalsaNextLoader yields and the reference loop unpacks
+        (salsanext_loader.py:84, tasks/salsanext/trainer.py:186) -- ``eng.train_step(*batch)`` is right by construction."""
         label = label.long()
         label = label * label.ge(1).long()
         mask = mask.to(feature.dtype) * label.ge(1).to(feature.dtype)
@@ -334,9 +336,9 @@ class SalsaNextEngine:
         loss_lovasz = self.lovasz(output, label)
         return loss_lovasz + loss_s, {"focal": loss_s.detach(), "lovasz": loss_lovasz.detach()}, output, label
 
-    def train_step(self, feature, mask, label):
+    def train_step(self, feature, label, mask):
         self.model.train()
-        total, terms, output, label = self.forward_loss(feature, mask, label)
+        total, terms, output, label = self.forward_loss(feature, label, mask)
         if self.flat is None:
             self.optimizer.zero_grad(set_to_none=True)
         if self.flat is not None and self.distributed:
@@ -353,8 +355,8 @@ class SalsaNextEngine:
         return total.detach(), terms
 
     @torch.no_grad()
-    def eval_step(self, feature, mask, label):
+    def eval_step(self, feature, label, mask):
         self.model.eval()
-        total, terms, output, label = self.forward_loss(feature, mask, label)
+        total, terms, output, label = self.forward_loss(feature, label, mask)
         self.metrics.addBatch(output.argmax(dim=1), label)
         return total, terms

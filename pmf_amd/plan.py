@@ -163,6 +163,8 @@ class Plan:
         # PMF_WGRAD_LANE=2 runs them on their own lane behind an event of the op that produced dz.  Measured slower
         # (25.1 vs 23.3 ms per step: 110 cross-queue edges cost more than the tails they fill), so off by default.
         self.wgrad_lane = int(_os.environ.get("PMF_WGRAD_LANE", "0"))
+        self.wgrad_batch = int(_os.environ.get("PMF_WGRAD_BATCH", "8"))
+        self._wg_deferred = {}
         self.n_events = 0
         self._event_pos = {}                # event -> list position of its record op
         self._last_op = {}                  # (id(op list), lane) -> last entry emitted on that lane
@@ -206,6 +208,12 @@ class Plan:
         lst.append(ent)
         ent.append(len(lst) - 1)            # [3]: position at emission time (orders record points of one lane)
         self._last_op[key] = ent
+
+    def note_bytes(self, lst, family, nbytes):
+        """algorithmic HBM bytes (every operand read once, every result written once) of the op just
+        emitted -- what bench.py divides by the measured duration for the bandwidth-bound families"""
+        meta = self.meta_fwd if lst is self.fwd else self.meta_bwd
+        meta[len(lst) - 1] = dict(family=family, flops=0.0, bytes=float(nbytes))
 
     def record_event(self, lst, lane=None):
         """plan event recorded after the last op emitted so far on ``lane`` (default: the current lane); None when the
@@ -269,6 +277,8 @@ class Plan:
                     first[2] = (first[2] & ~0xff00) | ((wait[0] + 1) << 8)
             for g in touched:
                 g._last_touch = (lane, last)
+        for home in sorted(self._wg_deferred):
+            self.flush_wgrads(home)
         for lane in sorted(self.pending_reds):
             self.flush_reds(lane)
         self.lane = 0
@@ -536,6 +546,7 @@ class Plan:
                     a.i[0], a.i[1], a.i[2], a.i[3] = gyt.ldc, out.ldc, Cout, bn_train_flag
                     a.l[0] = out.npix
                 self.emit(self.bwd, L.OP_BN_BWD_REDUCE, r1)
+                self.note_bytes(self.bwd, "bn_bwd_reduce", 8.0 * out.npix * Cout)
                 self.grad_done[id(bn.weight)] = self.grad_done[id(bn.bias)] = len(self.bwd) - 1
 
                 def r2(op):
@@ -547,6 +558,7 @@ class Plan:
                     a.i[0], a.i[1], a.i[2], a.i[3], a.i[4], a.i[5] = gyt.ldc, out.ldc, Cout, k_act, dz.ldc, dbr_ld
                     a.l[0] = out.npix
                 self.emit(self.bwd, L.OP_BN_BWD_APPLY, r2)
+                self.note_bytes(self.bwd, "bn_bwd_apply", 12.0 * out.npix * Cout)
                 dbias_rows = L.lib().pmf_col_rows(out.npix, Cout) if (has_bias and pmask is None) else 0
             else:
                 dz = self.tgrad(out)
@@ -559,6 +571,7 @@ class Plan:
                         a.i[0], a.i[1], a.i[2], a.i[3], a.i[4] = dz.ldc, out.ldc, k_act, _ru(Cout, 4), dbr_ld
                         a.l[0] = out.npix
                     self.emit(self.bwd, L.OP_ACT_BWD, r3)
+                    self.note_bytes(self.bwd, "act_bwd", 12.0 * out.npix * Cout)
                     dbias_rows = L.lib().pmf_col_rows(out.npix, _ru(Cout, 4)) if (has_bias and pmask is None) else 0
             dz = out.g
             if pmask is not None:
@@ -720,40 +733,58 @@ class Plan:
                 d.dbias_out = self.pgrad_buf.at(boff)
         boff = self.pgrad(conv.bias) if dbias_rows else None
         home = self.lane
-        if self.wgrad_lane and self.wgrad_lane != home:
-            ready = self.record_event(self.bwd)           # dz (and the bias-gradient rows) are complete after this op
-            self.lane = self.wgrad_lane
-            self.wait_event(self.bwd, ready)
-        lane = self.lane
+        lane = self.wgrad_lane if (self.wgrad_lane and self.wgrad_lane != home) else home
         self.n_wgrad += 1
+        meta = dict(family="conv_wgrad", flops=2.0 * dz.N * dz.H * dz.W * Cout * conv.in_channels * len(taps), name=name,
+                    shape="%dx%dx%d %d->%d t%d" % (dz.N, dz.H, dz.W, conv.in_channels, Cout, len(taps)))
+        ws = None
         if self.flat is not None and self.batch_reds:
             # flat training state (the product path): the partial-slab kernel now, the reduction into OIHW later -- the
             # reductions of RED_BATCH consecutive layers are ONE launch (pmf_conv_wgrad_reduce_multi); every layer keeps
             # its own workspace until then (1.65 GB at 64x2048 bs 2: nothing next to 288 GB)
             ws = self.act.alloc(max(L.lib().pmf_conv_wgrad_workspace(C.byref(probe)), 256))
 
-            def fb(op, f=f, ws=ws):
-                f(op)
-                op.u.wgrad.partial = ws.ptr
-            self.emit(self.bwd, L.OP_WGRAD_PART, fb)
-            part_index = len(self.bwd) - 1
-            pend = self.pending_reds.setdefault(lane, [])
-            pend.append((fb, [conv.weight] + ([conv.bias] if dbias_rows else [])))
-            if len(pend) >= self.red_batch:
-                self.flush_reds(lane)
+        def emit_ops():          # on the current lane
+            if ws is not None:
+                def fb(op, f=f, ws=ws):
+                    f(op)
+                    op.u.wgrad.partial = ws.ptr
+                self.emit(self.bwd, L.OP_WGRAD_PART, fb)
+                self.meta_bwd[len(self.bwd) - 1] = meta
+                pend = self.pending_reds.setdefault(lane, [])
+                pend.append((fb, [conv.weight] + ([conv.bias] if dbias_rows else [])))
+                if len(pend) >= self.red_batch:
+                    self.flush_reds(lane)
+            else:
+                # per-tensor gradients (tests, stock DistributedDataParallel): partial slabs, then the reduction into
+                # OIHW, back to back on the op's lane through that lane's workspace
+                self.emit(self.bwd, L.OP_WGRAD_PART, f)
+                self.meta_bwd[len(self.bwd) - 1] = meta
+                self.emit(self.bwd, L.OP_WGRAD_RED, f)
+                self.grad_done[id(conv.weight)] = len(self.bwd) - 1
+                if dbias_rows:
+                    self.grad_done[id(conv.bias)] = len(self.bwd) - 1
+        if lane == home:
+            emit_ops()
         else:
-            # per-tensor gradients (tests, stock DistributedDataParallel): partial slabs, then the reduction into OIHW,
-            # back to back on the op's lane through that lane's workspace
-            self.emit(self.bwd, L.OP_WGRAD_PART, f)
-            part_index = len(self.bwd) - 1
-            self.emit(self.bwd, L.OP_WGRAD_RED, f)
-            self.grad_done[id(conv.weight)] = len(self.bwd) - 1
-            if dbias_rows:
-                self.grad_done[id(conv.bias)] = len(self.bwd) - 1
-        self.lane = home
-        self.meta_bwd[part_index] = dict(
-            family="conv_wgrad", flops=2.0 * dz.N * dz.H * dz.W * Cout * conv.in_channels * len(taps), name=name,
-            shape="%dx%dx%d %d->%d t%d" % (dz.N, dz.H, dz.W, conv.in_channels, Cout, len(taps)))
+            # weight-gradient lane: the ops are DEFERRED and emitted in batches behind ONE event of the home lane (every
+            # dz stays alive in the arena until the end of the pass, so running a weight gradient late is always legal)
+            q = self._wg_deferred.setdefault(home, [])
+            q.append(emit_ops)
+            if len(q) >= self.wgrad_batch:
+                self.flush_wgrads(home)
+
+    def flush_wgrads(self, home):
+        q = self._wg_deferred.pop(home, [])
+        if not q:
+            return
+        prev = self.lane
+        ready = self.record_event(self.bwd, lane=home)      # everything the batch reads is complete after this op
+        self.lane = self.wgrad_lane
+        self.wait_event(self.bwd, ready)
+        for fn in q:
+            fn()
+        self.lane = prev
 
     def flush_reds(self, lane):
         """emit ONE stage-2 launch for the weight gradients queued on ``lane`` by _wgrad (flat training state only)"""
@@ -808,6 +839,7 @@ class Plan:
             s.i[0], s.i[1], s.i[2], s.i[3], s.i[4] = act, out.ldc, t.H * t.W, int(b is not None), _ru(t.C, 4)
             s.l[0] = out.npix
         self.emit(self.fwd, L.OP_ADD_ACT, f)
+        self.note_bytes(self.fwd, "add_act", (12.0 if b is not None else 8.0) * out.npix * t.C)
         if self.training:
             def backward():
                 g = self.tgrad(out)
@@ -825,6 +857,8 @@ class Plan:
                     s.i[7] = _ru(t.C, 4)
                     s.l[0] = out.npix
                 self.emit(self.bwd, L.OP_ADD_ACT_BWD, fb)
+                self.note_bytes(self.bwd, "add_act_bwd", 4.0 * out.npix * t.C * (2 + (ga is not None) * (1 + acca) +
+                                                                                 (gb is not None) * (1 + accb)))
             self.on_backward(backward)
         return out
 
@@ -904,6 +938,7 @@ class Plan:
                 s.p[1] = idx.ptr if idx is not None else None
             s.i[0], s.i[1], s.i[2], s.i[3], s.i[4] = t.N, t.H, t.W, _ru(t.C, 4), out.ldc
         self.emit(self.fwd, kind_f, f)
+        self.note_bytes(self.fwd, "pool", 4.0 * t.C * (t.npix + out.npix) + (out.npix * t.C if with_idx else 0))
         if self.training and t.needs_grad:
             def backward():
                 g = self.tgrad(out)
@@ -922,6 +957,7 @@ class Plan:
                         s.i[0], s.i[1], s.i[2], s.i[3], s.i[4] = g.ldc, t.N, t.H, t.W, _ru(t.C, 4)
                         s.i[5], s.i[6], s.i[7] = v.cmul_ld, gin.ldc, acc
                 self.emit(self.bwd, kind_b, fb)
+                self.note_bytes(self.bwd, "pool_bwd", 4.0 * t.C * (t.npix * (1 + acc) + out.npix))
             self.on_backward(backward)
         return out
 
@@ -941,6 +977,7 @@ class Plan:
             s.p[0] = out.buf.ptr
             s.i[0], s.i[1], s.i[2], s.i[3], s.i[4] = t.N, t.H, t.W, _ru(t.C, 4), out.ldc
         self.emit(self.fwd, L.OP_BILINEAR, f)
+        self.note_bytes(self.fwd, "bilinear", 4.0 * t.C * (t.npix + out.npix))
         if self.training:
             def backward():
                 g = self.tgrad(out)
@@ -952,6 +989,7 @@ class Plan:
                     s.i[0], s.i[1], s.i[2], s.i[3], s.i[4] = g.ldc, t.N, t.H, t.W, _ru(t.C, 4)
                     s.i[5], s.i[6] = gin.ldc, acc
                 self.emit(self.bwd, L.OP_BILINEAR_BWD, fb)
+                self.note_bytes(self.bwd, "bilinear_bwd", 4.0 * t.C * (t.npix * (1 + acc) + out.npix))
             self.on_backward(backward)
         return out
 
@@ -967,6 +1005,7 @@ class Plan:
             s.p[1] = out.buf.ptr
             s.i[0], s.i[1], s.i[2], s.i[3], s.i[4], s.i[5] = t.N, t.H, t.W, Co, out_cmul_ld, out.ldc
         self.emit(self.fwd, L.OP_PSHUFFLE, f)
+        self.note_bytes(self.fwd, "pixel_shuffle", 8.0 * t.C * t.npix)
         if self.training:
             def backward():
                 g = self.tgrad(out)
@@ -981,6 +1020,7 @@ class Plan:
                     for i, x in enumerate((g.ldc, t.N, t.H, t.W, Co, out_cmul_ld, v.cmul_ld, gin.ldc, acc)):
                         s.i[i] = x
                 self.emit(self.bwd, L.OP_PSHUFFLE_BWD, fb)
+                self.note_bytes(self.bwd, "pixel_shuffle_bwd", 4.0 * t.C * t.npix * (2 + acc))
             self.on_backward(backward)
         return out
 
@@ -996,6 +1036,7 @@ class Plan:
             s.i[0], s.i[1], s.i[2] = pcd.ldc, out.ldc, _ru(t.C, 4)
             s.l[0] = out.npix
         self.emit(self.fwd, L.OP_GATE, f)
+        self.note_bytes(self.fwd, "fusion_gate", 16.0 * t.C * t.npix)
         if self.training:
             def backward():
                 g = self.tgrad(out)
@@ -1012,6 +1053,7 @@ class Plan:
                         s.i[i] = x
                     s.l[0] = out.npix
                 self.emit(self.bwd, L.OP_GATE_BWD, fb)
+                self.note_bytes(self.bwd, "fusion_gate_bwd", 4.0 * t.C * t.npix * (7 + accf + accp))
             self.on_backward(backward)
         return out
 
@@ -1050,6 +1092,7 @@ class Plan:
             s.p[1] = None   # patched per call
             s.i[0], s.i[1], s.i[2], s.i[3] = t.ldc, t.N, t.H * t.W, t.C
         self.emit(self.fwd, L.OP_SOFTMAX, f)
+        self.note_bytes(self.fwd, "softmax", 8.0 * t.C * t.npix)
         self.out_slots[slot] = dict(fwd_index=len(self.fwd) - 1, shape=(t.N, t.C, t.H, t.W))
         if self.training:
             def backward():
@@ -1064,6 +1107,7 @@ class Plan:
                     s.p[2] = t.g.buf.ptr
                     s.i[0], s.i[1], s.i[2], s.i[3] = t.N, t.H * t.W, t.C, t.ldc
                 self.emit(self.bwd, L.OP_SOFTMAX_BWD, fb)
+                self.note_bytes(self.bwd, "softmax_bwd", 12.0 * t.C * t.npix)
                 self.out_slots[slot]["bwd_index"] = len(self.bwd) - 1
             self.on_backward(backward)
 
@@ -1082,6 +1126,7 @@ class Plan:
             s.p[1] = t.buf.ptr
             s.i[0], s.i[1], s.i[2], s.i[3] = N, C, H * W, t.ldc
         self.emit(self.fwd, L.OP_NCHW2NHWC, f)
+        self.note_bytes(self.fwd, "nchw_to_nhwc", 8.0 * N * C * H * W)
         self.in_slots[slot] = len(self.fwd) - 1
         return t
 
@@ -1322,8 +1367,9 @@ class Plan:
         return out
 
     def run_profiled(self, what):
-        """run one pass op by op with a HIP event pair around every launch (on the stream the plan uses);
-        returns [(op kind name, family or None, algorithmic flops, milliseconds)].  Measurement only."""
+        """run one pass op by op with a HIP event pair around every launch (on the stream the plan uses, lanes off);
+        returns [(op kind name, family or None, algorithmic flops, milliseconds, label, algorithmic bytes)].
+        Measurement only."""
         ops, n = (self.fwd_ops, self.n_fwd) if what == "forward" else (self.bwd_ops, self.n_bwd)
         kinds = self.fwd_kinds if what == "forward" else self.bwd_kinds
         meta = self.meta_fwd if what == "forward" else self.meta_bwd
@@ -1331,18 +1377,22 @@ class Plan:
         stream = torch.cuda.current_stream(self.device).cuda_stream
         failed = C.c_int32(-1)
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
-        for k in range(n):
-            evs[k][0].record()
-            rc = L.lib().pmf_plan_run_range(C.addressof(ops), k, k + 1, C.c_void_p(stream), C.byref(failed))
-            evs[k][1].record()
-            if rc != 0:
-                raise RuntimeError("pmf_amd %s plan failed at op #%d: code %d" % (what, k, rc))
-        torch.cuda.synchronize(self.device)
+        lanes = L.lib().pmf_plan_lanes(0)
+        try:
+            for k in range(n):
+                evs[k][0].record()
+                rc = L.lib().pmf_plan_run_range(C.addressof(ops), k, k + 1, C.c_void_p(stream), C.byref(failed))
+                evs[k][1].record()
+                if rc != 0:
+                    raise RuntimeError("pmf_amd %s plan failed at op #%d: code %d" % (what, k, rc))
+            torch.cuda.synchronize(self.device)
+        finally:
+            L.lib().pmf_plan_lanes(lanes)
         out = []
         for k in range(n):
             m = meta.get(k - shift, {})
             out.append((L.OP_NAMES.get(kinds[k], "?"), m.get("family"), m.get("flops", 0.0), evs[k][0].elapsed_time(evs[k][1]),
-                        m.get("name", "") + ("  [" + m["shape"] + "]" if "shape" in m else "")))
+                        m.get("name", "") + ("  [" + m["shape"] + "]" if "shape" in m else ""), m.get("bytes", 0.0)))
         return out
 
     # ------------------------------------------------------------------ running

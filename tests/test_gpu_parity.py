@@ -744,8 +744,20 @@ def test_loader_v2_matches_oracle_and_fixture(golden):
         pu = PerspectiveViewLoaderV2(DS(), tcfg, is_train=True, return_uproj=True)
         np.random.seed(40 + seed)
         assert np.array_equal(pu[0][1].cpu().numpy(), txy)              # scaled float64 (row, col), bit for bit
-    with pytest.raises(NotImplementedError):
-        PerspectiveViewLoaderV2(DS(), cfg, is_train=True, img_aug=True)
+    # img_aug (perspective_view_loader_v2.py:19-23,46-47): ColorJitter(*PVconfig.img_jitter) before everything else
+    from oracle import color_jitter_ref as CJ
+    jcfg = {"PVconfig": dict(cfg["PVconfig"], img_jitter=[0.4, 0.4, 0.4, 0.1])}
+    torch.manual_seed(77)
+    got = PerspectiveViewLoaderV2(DS(), jcfg, is_train=False, img_aug=True)[0]
+    torch.manual_seed(77)
+    order, fac = CJ.draw_params(CJ.jitter_ranges(0.4, 0.4, 0.4, 0.1))
+    jp = loader_v2_ref.project_frame_v2(pts, sem, CJ.color_jitter(img, order, fac), M, lut)[0]
+    assert np.array_equal(got.cpu().numpy(), loader_v2_ref.pad_center_crop(jp, h, w, h, w))
+    torch.manual_seed(78)
+    np.random.seed(78)
+    tj = PerspectiveViewLoaderV2(DS(), dict(PVconfig=dict(tcfg["PVconfig"], img_jitter=[0.4, 0.4, 0.4, 0.1])),
+                                 is_train=True, img_aug=True)[0]
+    assert tj.shape == (10, h - 16, w - 32) and torch.isfinite(tj).all()
 
 
 @pytest.mark.gpu
@@ -820,6 +832,70 @@ def test_two_rank_data_parallel_on_one_gpu():
     ret = mgr.dict()
     mp.spawn(_dp_worker, args=(2, 29551, ret), nprocs=2, join=True)
     assert ret["finite"] and ret["same"], dict(ret)
+
+
+def _dp_worker_rccl(rank, world, port, ret):
+    """two ranks, ONE device, backend nccl (= RCCL): either the real N>1 RCCL path runs end to end or RCCL's refusal
+    is recorded verbatim"""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_IGNORE_DISABLED_P2P="1")
+    torch.cuda.set_device(0)
+    try:
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+        t = torch.full((1024,), float(rank + 1), device="cuda")
+        dist.all_reduce(t)
+        torch.cuda.synchronize()
+        assert float(t[0]) == 3.0
+    except Exception as e:                                            # RCCL refuses duplicate devices: keep the text
+        ret["rccl_error_%d" % rank] = "%s: %s" % (type(e).__name__, str(e)[:600])
+        return
+    from pmf_amd.engine import TrainEngine
+    from pmf_amd.models import PMFNet
+    torch.manual_seed(100 + rank)
+    m = PMFNet(5, 3, 20, 32, imagenet_pretrained=False, image_backbone="resnet34").cuda()
+    eng = TrainEngine(m, 20, lr=1e-3, warmup_steps=2, max_steps=10, distributed=True, device_ids=[0])
+    pcd, rgb, label, mask = synthetic_batch(2, 32, 64, 20, seed=20 + rank, fill=0.5)
+    feat = torch.cat((pcd, rgb), 1).cuda()
+    torch.manual_seed(5)
+    torch.cuda.manual_seed(5)
+    losses = [float(eng.train_step(feat.clone(), mask.cuda(), label.cuda())[0]) for _ in range(3)]
+    eng.eval_step(feat.clone(), mask.cuda(), label.cuda())            # broadcasts rank 0's BN statistics first
+    flat = eng.flat.param.detach().clone()
+    bufs = torch.cat([b.reshape(-1).float() for b in m.buffers()])
+    gp = [torch.zeros_like(flat) for _ in range(world)]
+    gb = [torch.zeros_like(bufs) for _ in range(world)]
+    dist.all_gather(gp, flat)
+    dist.all_gather(gb, bufs)
+    if rank == 0:
+        ret["same"] = bool(all(torch.equal(gp[0], g) for g in gp))
+        ret["same_buffers"] = bool(all(torch.equal(gb[0], g) for g in gb))
+        ret["finite"] = bool(all(np.isfinite(l) for l in losses))
+        ret["world"] = dist.get_world_size()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_rank_data_parallel_on_one_gpu_rccl():
+    """the N>1 path over RCCL with two ranks sharing the one GPU of the test box.  RCCL may refuse two ranks on one
+    device ("Duplicate GPU detected"): then the test records the refusal in gpurun_out/rccl_two_ranks.txt and the gloo
+    variant above remains the N>1 coverage; when it runs, parameters AND BatchNorm buffers must agree across ranks"""
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    try:
+        mp.spawn(_dp_worker_rccl, args=(2, 29557, ret), nprocs=2, join=True)
+    except Exception as e:
+        ret["spawn_error"] = "%s: %s" % (type(e).__name__, str(e)[:600])
+    out = dict(ret)
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(os.path.join("gpurun_out", "rccl_two_ranks.txt"), "w") as f:
+        for k in sorted(out):
+            f.write("%s: %s\n" % (k, out[k]))
+    if any(k.startswith("rccl_error") or k == "spawn_error" for k in out):
+        pytest.skip("RCCL refuses two ranks on one device here: " + "; ".join("%s=%s" % kv for kv in out.items())[:400])
+    assert out.get("finite") and out.get("same") and out.get("same_buffers") and out.get("world") == 2, out
 
 
 # ---------------------------------------------------------------------------------------------- SalsaNext range loader
@@ -964,7 +1040,7 @@ def test_salsanext_engine_train_steps_match_oracle():
         want.backward()
         opt.step()
         sched.step()
-        got, terms = eng.train_step(pcd.cuda(), mask.cuda(), label.cuda())
+        got, terms = eng.train_step(pcd.cuda(), label.cuda(), mask.cuda())
         trace.append((it, got.item(), want.item(), terms["focal"].item(), terms["lovasz"].item()))
         if it == 0:
             # the optimiser step is compared after ONE iteration: from the second AdamW step on, m / sqrt(v) of a

@@ -73,9 +73,10 @@ def main(filt, with_stats):
         print("   distinct (xcc,se,sh,cu): %d" % len(set(zip(xcc.tolist(), se.tolist(), sh.tolist(), cu.tolist()))))
         d_ = np.diff(t[:, :cnt], axis=1)
         med = np.median(d_, axis=0); p90 = np.percentile(d_, 90, axis=0)
-        labels = ["prologue(slots+first loads)"]
-        # stamps: start, after-first-issue, [X, stored+Y, half0+Z, half1]*nch, epilogue-start, stored, end
-        nch = (cnt - 5) // 4
+        labels = ["acc zero + slot table (gA)", "tap / weight offsets", "settle + head (stage scalars)",
+                  "first loads + DMA issue"]
+        # stamps: start, 3 prologue stamps, after-first-issue, [X, stored+Y, half0+Z, half1]*nch, epilogue-start, stored, end
+        nch = (cnt - 8) // 4
         for c in range(nch): labels += ["c%d barrier X" % c, "c%d store A + barrier Y" % c, "c%d mfma h0 (+loads) + barrier Z" % c, "c%d mfma h1" % c]
         labels += ["(to epilogue)", "epilogue stores", "stats reduce"]
         for i in range(cnt - 1):
