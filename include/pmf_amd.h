@@ -305,6 +305,11 @@ int pmf_crop_pad(const float* src, int32_t C, int32_t h, int32_t w, int32_t top,
 int pmf_merge_pred(int32_t n_cams, const int64_t* const* point_idx, const float* const* conf,
                    const int64_t* const* label, const int64_t* counts, int64_t pc_size, uint64_t* keys, int64_t* merged,
                    pmf_stream_t s);
+/* the same with a per-point fallback label (int64[pc_size], e.g. the argmax of a LiDAR-only SalsaNext) for the points
+ * no camera sees, instead of -1 (more_experiment_config.md:10) */
+int pmf_merge_pred_fallback(int32_t n_cams, const int64_t* const* point_idx, const float* const* conf,
+                            const int64_t* const* label, const int64_t* counts, int64_t pc_size, const int64_t* fallback,
+                            uint64_t* keys, int64_t* merged, pmf_stream_t s);
 /* SalsaNext range-image loader (replaces pc_processor/dataset/preprocess/projection.py:31-86 RangeProjection.doProjection,
  * salsanext_loader.py:48-84 and augmentor.py:97-180).
  * pmf_points_transform: in place on points f32[P][C] -- flips (x <- -x, y <- -y), float32 translation, then
@@ -363,7 +368,11 @@ int pmf_lovasz_grad(const float* fg_sorted, int32_t C, int64_t P, const int64_t*
  * Step 2, pmf_loss_lovasz: Jaccard first differences along the permutation, value = dot(sorted errors, grad) per
  *   class, gradient lambda / n_present * grad * d|fg-p|/dp added to grad_* through the permutation (no atomics);
  *   bsum f32[2C][pmf_loss_chunks(P)], dots f64[2C][pmf_loss_chunks(P)] scratch;
- *   out6 = {total, foc, lov, foc_cam, lov_cam, per}.  Deterministic (fixed summation order). */
+ *   out8 = {total, foc, lov, foc_cam, lov_cam, per, per_p, per_q} (per = per_p + per_q: the two KL halves of
+ *   trainer.py:247-250).  Deterministic (fixed summation order).
+ * The *_w variants take the weights of the six terms from DEVICE memory, w6 = {foc, lov, foc_cam, lov_cam, per_p,
+ * per_q}: total = sum_i w6[i] * term_i -- the EPMF multi-task objective (tasks/epmf/trainer.py:409-430 with
+ * pc_processor/loss/multi_task_loss.py: w_i = 1 / (2 sigma_i^2)) without a host round trip for the learned sigmas. */
 int pmf_loss_rows(int64_t P);
 int pmf_loss_chunks(int64_t P);
 int pmf_loss_pixel(const float* lidar_prob, const float* camera_prob, const int64_t* label, const float* alpha,
@@ -372,7 +381,14 @@ int pmf_loss_pixel(const float* lidar_prob, const float* camera_prob, const int6
                    unsigned long long* conf_lidar, unsigned long long* conf_camera, pmf_stream_t s);
 int pmf_loss_lovasz(const int64_t* perm, const float* key_sorted, const int64_t* label, int32_t N, int32_t C, int64_t HW,
                     const unsigned long long* cnt, float lambda, float gamma_per, float* bsum, double* dots,
-                    const double* rows, float* grad_lidar, float* grad_camera, float* out6, pmf_stream_t s);
+                    const double* rows, float* grad_lidar, float* grad_camera, float* out8, pmf_stream_t s);
+int pmf_loss_pixel_w(const float* lidar_prob, const float* camera_prob, const int64_t* label, const float* alpha,
+                     int32_t N, int32_t C, int64_t HW, float focal_gamma, float tau, const float* w6,
+                     unsigned long long* cnt, float* grad_lidar, float* grad_camera, float* key, double* rows,
+                     unsigned long long* conf_lidar, unsigned long long* conf_camera, pmf_stream_t s);
+int pmf_loss_lovasz_w(const int64_t* perm, const float* key_sorted, const int64_t* label, int32_t N, int32_t C, int64_t HW,
+                      const unsigned long long* cnt, const float* w6, float* bsum, double* dots, const double* rows,
+                      float* grad_lidar, float* grad_camera, float* out8, pmf_stream_t s);
 
 /* ---- plan executor: a whole forward (or backward) pass = one call --------------------------------------- */
 enum {

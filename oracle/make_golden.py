@@ -650,10 +650,77 @@ def loader_train(R):
     print("g13_loader_train: %d arrays" % len(out))
 
 
+def epmf_trace(R):
+    """G14: two optimisation steps of the EPMF task (tasks/epmf/trainer.py, PMFNet branch, use_mtloss): the reference's
+    EPMFNet, MultiTaskLoss(6), FocalSoftmaxLoss, Lovasz_softmax and KLDivLoss driven exactly as trainer.py:376-430
+    assembles them ([foc_img, lov_img, per_img, per, foc, lov] -> mt_loss), AdamW over lidar_stream + mt_loss
+    (weight_decay = settings.weight_decay, :95-109), SGD-Nesterov over the camera stream; 64x128, bs 2, dropout p=0."""
+    import math
+    out = {}
+    E = _load("refpc.models.epmf_net", "pc_processor/models/epmf_net.py")
+    mt = _load("refpc_mtloss", "pc_processor/loss/multi_task_loss.py")
+    m = deterministic_init(E.EPMFNet(pcd_channels=5, img_channels=3, nclasses=20, base_channels=32,
+                                     imagenet_pretrained=False, image_backbone="resnet34"))
+    set_p0(m)
+    m.train()
+    mtl = mt.MultiTaskLoss(6)
+    lr, wd, tau = 0.001, 1e-5, 0.7
+    adam = torch.optim.AdamW([{"params": m.lidar_stream.parameters()}, {"params": mtl.parameters()}], lr=lr, weight_decay=wd)
+    sgd = torch.optim.SGD([{"params": m.camera_stream_encoder.parameters()},
+                           {"params": m.camera_stream_decoder.parameters()}],
+                          lr=lr, nesterov=True, momentum=0.9, weight_decay=wd)
+    alpha = torch.linspace(0.2, 1.0, 20)
+    alpha[0] = 0
+    lov = R.lovasz.Lovasz_softmax(ignore=0)
+    foc = R.focal.FocalSoftmaxLoss(20, gamma=2, alpha=alpha.numpy(), softmax=False)
+    kl = torch.nn.KLDivLoss(reduction="none")
+    pcd, rgb, label, _ = synthetic_batch(2, 64, 128, 20, seed=1, fill=0.3)
+    label_mask = label.gt(0)
+    vals, sig = [], []
+    for step in range(2):
+        lidar_pred, camera_pred = m(pcd, rgb)
+        lidar_pred_log = torch.log(lidar_pred.clamp(min=1e-8))
+        pcd_entropy = -(lidar_pred * lidar_pred_log).sum(1) / math.log(20)
+        camera_pred_log = torch.log(camera_pred.clamp(min=1e-8))
+        img_entropy = -(camera_pred * camera_pred_log).sum(1) / math.log(20)
+        pcd_conf, img_conf = 1 - pcd_entropy, 1 - img_entropy
+        imp = pcd_conf - img_conf
+        pcd_w = imp.gt(0).float() * imp.abs() * pcd_conf.ge(tau).float()
+        img_w = imp.lt(0).float() * imp.abs() * img_conf.ge(tau).float()
+        loss_per = (kl(lidar_pred_log, camera_pred) * img_w.unsqueeze(1)).mean()
+        loss_per_img = (kl(camera_pred_log, lidar_pred) * pcd_w.unsqueeze(1)).mean()
+        loss_foc_img = foc(camera_pred, label, mask=label_mask)
+        loss_lov_img = lov(camera_pred, label)
+        loss_foc = foc(lidar_pred, label, mask=label_mask)
+        loss_lov = lov(lidar_pred, label)
+        loss_list = [loss_foc_img.unsqueeze(0), loss_lov_img.unsqueeze(0), loss_per_img.unsqueeze(0),
+                     loss_per.unsqueeze(0), loss_foc.unsqueeze(0), loss_lov.unsqueeze(0)]
+        total = mtl(loss_list)
+        adam.zero_grad()
+        sgd.zero_grad()
+        total.backward()
+        if step == 0:
+            out["etrace.gsigma0"] = mtl.sigma.grad.double().numpy().copy()
+        adam.step()
+        sgd.step()
+        vals.append([total.item()] + [x.item() for x in loss_list])
+        sig.append(mtl.sigma.detach().double().numpy().copy())
+        if step == 0:
+            sd = m.state_dict()
+            for k in ("lidar_stream.downCntx.conv1.conv.weight", "lidar_stream.resBlock3.conv3.weight",
+                      "lidar_stream.logits.bias", "camera_stream_encoder.conv1.weight",
+                      "camera_stream_decoder.conv.weight", "lidar_stream.extraUpSample.0.weight"):
+                out["etrace.param1." + k] = np.array([sd[k].double().sum().item(), sd[k].double().abs().sum().item()])
+    out["etrace.losses"] = np.array(vals)            # rows: [total, foc_img, lov_img, per_img, per, foc, lov]
+    out["etrace.sigma"] = np.array(sig)
+    np.savez_compressed(os.path.join(OUT, "g14_epmf_trace.npz"), **out)
+    print("g14_epmf_trace: %d arrays" % len(out))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     R = import_reference()
-    which = sys.argv[1:] or ["blocks", "whole_net", "losses_metrics", "knn", "loader", "trainer_trace", "epmf", "loader_v2", "range_loader", "kitti_formats", "merge", "loader_train"]
+    which = sys.argv[1:] or ["blocks", "whole_net", "losses_metrics", "knn", "loader", "trainer_trace", "epmf", "loader_v2", "range_loader", "kitti_formats", "merge", "loader_train", "epmf_trace"]
     for name in which:
         globals()[name](R)

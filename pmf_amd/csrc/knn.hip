@@ -106,15 +106,19 @@ __global__ __launch_bounds__(256) void merge_init_k(unsigned long long* __restri
   const int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x;
   if (i < pc_size) keys[i] = (unsigned long long)(n_cams - 1) << 16;
 }
+// fallback (optional): label of a LiDAR-only model for every point; it replaces the -1 of points no camera sees
+// (more_experiment_config.md:10: "For LiDAR points that are outside the camera view, we use predictions of SalsaNext")
 __global__ __launch_bounds__(256) void merge_final_k(const unsigned long long* __restrict__ keys, int64_t pc_size,
-                                                     int64_t* __restrict__ out) {
+                                                     const int64_t* __restrict__ fallback, int64_t* __restrict__ out) {
   const int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x;
-  if (i < pc_size) out[i] = (int64_t)(keys[i] & 0xffffull) - 1;
+  if (i >= pc_size) return;
+  const int64_t lab = (int64_t)(keys[i] & 0xffffull) - 1;
+  out[i] = (lab < 0 && fallback) ? fallback[i] : lab;
 }
 
-extern "C" int pmf_merge_pred(int32_t n_cams, const int64_t* const* point_idx, const float* const* conf,
-                              const int64_t* const* label, const int64_t* counts, int64_t pc_size, uint64_t* keys,
-                              int64_t* merged, pmf_stream_t s) {
+static int merge_impl(int32_t n_cams, const int64_t* const* point_idx, const float* const* conf,
+                      const int64_t* const* label, const int64_t* counts, int64_t pc_size, const int64_t* fallback,
+                      uint64_t* keys, int64_t* merged, pmf_stream_t s) {
   if (n_cams < 1 || n_cams > 255 || pc_size < 0 || !counts || (pc_size > 0 && (!keys || !merged))) return PMF_E_ARG;
   for (int j = 0; j < n_cams; ++j)
     if (counts[j] < 0 || (counts[j] > 0 && (!point_idx || !conf || !label || !point_idx[j] || !conf[j] || !label[j])))
@@ -128,7 +132,18 @@ extern "C" int pmf_merge_pred(int32_t n_cams, const int64_t* const* point_idx, c
       hipLaunchKernelGGL(merge_scatter_k, dim3((unsigned)cdiv64(counts[j], 256)), dim3(256), 0, st, point_idx[j], conf[j],
                          label[j], counts[j], j, n_cams, pc_size, (unsigned long long*)keys);
   hipLaunchKernelGGL(merge_final_k, dim3((unsigned)cdiv64(pc_size, 256)), dim3(256), 0, st,
-                     (const unsigned long long*)keys, pc_size, merged);
+                     (const unsigned long long*)keys, pc_size, fallback, merged);
   PMF_LAUNCH_CHECK();
   return 0;
+}
+extern "C" int pmf_merge_pred(int32_t n_cams, const int64_t* const* point_idx, const float* const* conf,
+                              const int64_t* const* label, const int64_t* counts, int64_t pc_size, uint64_t* keys,
+                              int64_t* merged, pmf_stream_t s) {
+  return merge_impl(n_cams, point_idx, conf, label, counts, pc_size, nullptr, keys, merged, s);
+}
+extern "C" int pmf_merge_pred_fallback(int32_t n_cams, const int64_t* const* point_idx, const float* const* conf,
+                                       const int64_t* const* label, const int64_t* counts, int64_t pc_size,
+                                       const int64_t* fallback, uint64_t* keys, int64_t* merged, pmf_stream_t s) {
+  if (pc_size > 0 && !fallback) return PMF_E_ARG;
+  return merge_impl(n_cams, point_idx, conf, label, counts, pc_size, fallback, keys, merged, s);
 }

@@ -136,10 +136,11 @@ struct LossPixelArgs {
   int64_t HW, P;
   int C;
   float fgamma, tau, gamma_per;
+  const float* w6;                           // device weights {foc_l, lov_l, foc_c, lov_c, per_p, per_q} or null
 };
 
 __global__ __launch_bounds__(LP_BLOCK) void loss_pixel_k(const LossPixelArgs a) {
-  __shared__ double red[3][LP_BLOCK];
+  __shared__ double red[4][LP_BLOCK];
   __shared__ unsigned int hist[2][LP_MAXC * LP_MAXC];
   const int C = a.C;
   const bool want_conf = a.conf_l != nullptr;
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(LP_BLOCK) void loss_pixel_k(const LossPixelArgs a) 
     __syncthreads();
   }
   const int64_t i = (int64_t)blockIdx.x * LP_BLOCK + threadIdx.x;
-  double s_fl = 0.0, s_fc = 0.0, s_per = 0.0;
+  double s_fl = 0.0, s_fc = 0.0, s_per = 0.0, s_per2 = 0.0;
   if (i < a.P) {
     const int64_t n = i / a.HW, hw = i - n * a.HW;
     const float* pl = a.pl + n * C * a.HW + hw;
@@ -177,8 +178,12 @@ __global__ __launch_bounds__(LP_BLOCK) void loss_pixel_k(const LossPixelArgs a) 
     const float gate_q = (d < 0.f && conf_q >= a.tau) ? 1.f : 0.f;   // w_img = gate_q * |d|
     const float w_pcd = gate_p * fabsf(d), w_img = gate_q * fabsf(d);
     const double M = (double)a.P * C;
-    s_per = ((double)w_img * Lp + (double)w_pcd * Lq) / M;
-    const float sper = a.gamma_per / (float)M;
+    s_per = (double)w_img * Lp / M;            // per_p: KL(q || p) weighted by w_img   (trainer.py:247-248)
+    s_per2 = (double)w_pcd * Lq / M;           // per_q: KL(p || q) weighted by w_pcd   (trainer.py:249-250)
+    // weights of the six terms in the total: the PMF objective (1, lambda, 1, lambda, gamma, gamma) or, for the EPMF
+    // multi-task objective (tasks/epmf/trainer.py:409-430), 1 / (2 sigma_i^2) read from device memory
+    const float w_fl = a.w6 ? a.w6[0] : 1.f, w_fc = a.w6 ? a.w6[2] : 1.f;
+    const float spa = (a.w6 ? a.w6[4] : a.gamma_per) / (float)M, spb = (a.w6 ? a.w6[5] : a.gamma_per) / (float)M;
     // focal
     const bool valid = t > 0 && t < C;
     const double msum = (double)a.P - (double)a.cnt[0];
@@ -192,12 +197,12 @@ __global__ __launch_bounds__(LP_BLOCK) void loss_pixel_k(const LossPixelArgs a) 
       s_fl = (double)(-pwl * ll * al) / msum;
       s_fc = (double)(-pwc * lc * al) / msum;
       const float pwl1 = a.fgamma == 1.f ? 1.f : powf(ol, a.fgamma - 1.f), pwc1 = a.fgamma == 1.f ? 1.f : powf(oc, a.fgamma - 1.f);
-      dfl = al * (a.fgamma * pwl1 * ll - (ptl >= 1e-6f ? pwl / ptl : 0.f)) / (float)msum;
-      dfc = al * (a.fgamma * pwc1 * lc - (ptc >= 1e-6f ? pwc / ptc : 0.f)) / (float)msum;
+      dfl = w_fl * al * (a.fgamma * pwl1 * ll - (ptl >= 1e-6f ? pwl / ptl : 0.f)) / (float)msum;
+      dfc = w_fc * al * (a.fgamma * pwc1 * lc - (ptc >= 1e-6f ? pwc / ptc : 0.f)) / (float)msum;
     }
     float* gl = a.gl + n * C * a.HW + hw;
     float* gc = a.gc + n * C * a.HW + hw;
-    const float cw = Lq * gate_p - Lp * gate_q;    // d(w_pcd Lq + w_img Lp)/dd through the weights: sign folded in
+    // d(w_pcd Lq)/dd = Lq gate_p and d(w_img Lp)/dd = -Lp gate_q through the (not detached) weights
     const bool lov_valid = t != 0;                  // Lovasz ignore label 0
 #pragma unroll 4
     for (int c = 0; c < C; ++c) {
@@ -206,9 +211,10 @@ __global__ __launch_bounds__(LP_BLOCK) void loss_pixel_k(const LossPixelArgs a) 
       const float ip = pv >= 1e-8f ? 1.f : 0.f, iq = qv >= 1e-8f ? 1.f : 0.f;
       const float ddp = (plog + ip) * ilogC;       // dd/dp_c
       const float ddq = -(qlog + iq) * ilogC;      // dd/dq_c
-      float g1 = -w_img * qv * (ip > 0.f ? 1.f / pv : 0.f) + w_pcd * (logf(fmaxf(pv, 1e-38f)) + 1.f - qlog) + cw * ddp;
-      float g2 = -w_pcd * pv * (iq > 0.f ? 1.f / qv : 0.f) + w_img * (logf(fmaxf(qv, 1e-38f)) + 1.f - plog) + cw * ddq;
-      g1 *= sper; g2 *= sper;
+      float g1 = spa * (-w_img * qv * (ip > 0.f ? 1.f / pv : 0.f) - Lp * gate_q * ddp) +
+                 spb * (w_pcd * (logf(fmaxf(pv, 1e-38f)) + 1.f - qlog) + Lq * gate_p * ddp);
+      float g2 = spa * (w_img * (logf(fmaxf(qv, 1e-38f)) + 1.f - plog) - Lp * gate_q * ddq) +
+                 spb * (-w_pcd * pv * (iq > 0.f ? 1.f / qv : 0.f) + Lq * gate_p * ddq);
       if (c == t) { g1 += dfl; g2 += dfc; }
       gl[c * a.HW] = g1;
       gc[c * a.HW] = g2;
@@ -221,19 +227,20 @@ __global__ __launch_bounds__(LP_BLOCK) void loss_pixel_k(const LossPixelArgs a) 
       atomicAdd(&hist[1][am_c * C + t], 1u);
     }
   }
-  red[0][threadIdx.x] = s_fl; red[1][threadIdx.x] = s_fc; red[2][threadIdx.x] = s_per;
+  red[0][threadIdx.x] = s_fl; red[1][threadIdx.x] = s_fc; red[2][threadIdx.x] = s_per; red[3][threadIdx.x] = s_per2;
   __syncthreads();
   for (int o = LP_BLOCK / 2; o > 0; o >>= 1) {
     if ((int)threadIdx.x < o) {
       red[0][threadIdx.x] += red[0][threadIdx.x + o];
       red[1][threadIdx.x] += red[1][threadIdx.x + o];
       red[2][threadIdx.x] += red[2][threadIdx.x + o];
+      red[3][threadIdx.x] += red[3][threadIdx.x + o];
     }
     __syncthreads();
   }
   if (threadIdx.x == 0) {
     double* r = a.rows + (size_t)blockIdx.x * 4;
-    r[0] = red[0][0]; r[1] = red[1][0]; r[2] = red[2][0]; r[3] = 0.0;
+    r[0] = red[0][0]; r[1] = red[1][0]; r[2] = red[2][0]; r[3] = red[3][0];
   }
   if (want_conf) {
     for (int k = threadIdx.x; k < C * C; k += LP_BLOCK) {
@@ -271,8 +278,8 @@ __global__ __launch_bounds__(LV_BLOCK) void lovasz2_grad_k(const int64_t* __rest
                                                            const int64_t* __restrict__ label, int64_t P, int64_t HW, int C,
                                                            int nb, const float* __restrict__ bsum,
                                                            const unsigned long long* __restrict__ cnt, float lambda,
-                                                           float* __restrict__ gl, float* __restrict__ gc,
-                                                           double* __restrict__ dots) {
+                                                           const float* __restrict__ w6, float* __restrict__ gl,
+                                                           float* __restrict__ gc, double* __restrict__ dots) {
   __shared__ float sh[LV_BLOCK];
   __shared__ double shd[LV_BLOCK];
   __shared__ float carry_s, total_s;
@@ -285,7 +292,8 @@ __global__ __launch_bounds__(LV_BLOCK) void lovasz2_grad_k(const int64_t* __rest
   }
   int npresent = 0;
   for (int c = 1; c < C; ++c) npresent += cnt[c] > 0 ? 1 : 0;
-  const float wcls = (cls != 0 && cnt[cls] > 0) ? lambda / (float)(npresent > 0 ? npresent : 1) : 0.f;
+  const float lam = w6 ? w6[head == 0 ? 1 : 3] : lambda;
+  const float wcls = (cls != 0 && cnt[cls] > 0) ? lam / (float)(npresent > 0 ? npresent : 1) : 0.f;
   const int64_t base = (int64_t)b * LV_CHUNK + (int64_t)threadIdx.x * LV_PER_THREAD;
   const int64_t* row = perm + (int64_t)r * P;
   const float* krow = key_sorted + (int64_t)r * P;
@@ -347,13 +355,15 @@ __global__ __launch_bounds__(LV_BLOCK) void lovasz2_grad_k(const int64_t* __rest
   if (threadIdx.x == 0) dots[r * nb + b] = shd[0];
 }
 
-// out[6] = {total, foc, lov, foc_cam, lov_cam, per}; single workgroup, fixed summation order
+// out[8] = {total, foc, lov, foc_cam, lov_cam, per (= per_p + per_q), per_p, per_q}; single workgroup, fixed summation order
 __global__ __launch_bounds__(256) void loss_fold_k(const double* __restrict__ rows, int nrows, const double* __restrict__ dots,
                                                    int C, int nb, const unsigned long long* __restrict__ cnt, float lambda,
-                                                   float gamma_per, float* __restrict__ out) {
-  __shared__ double sh[5][256];
-  double a0 = 0, a1 = 0, a2 = 0;
-  for (int i = threadIdx.x; i < nrows; i += 256) { a0 += rows[(size_t)i * 4]; a1 += rows[(size_t)i * 4 + 1]; a2 += rows[(size_t)i * 4 + 2]; }
+                                                   float gamma_per, const float* __restrict__ w6, float* __restrict__ out) {
+  __shared__ double sh[6][256];
+  double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+  for (int i = threadIdx.x; i < nrows; i += 256) {
+    a0 += rows[(size_t)i * 4]; a1 += rows[(size_t)i * 4 + 1]; a2 += rows[(size_t)i * 4 + 2]; a3 += rows[(size_t)i * 4 + 3];
+  }
   // Lovasz: per-class dot products, classes present only
   double l0 = 0, l1 = 0;
   for (int idx = threadIdx.x; idx < 2 * C * nb; idx += 256) {
@@ -361,29 +371,32 @@ __global__ __launch_bounds__(256) void loss_fold_k(const double* __restrict__ ro
     if (cls != 0 && cnt[cls] > 0) { if (r < C) l0 += dots[idx]; else l1 += dots[idx]; }
   }
   sh[0][threadIdx.x] = a0; sh[1][threadIdx.x] = a1; sh[2][threadIdx.x] = a2; sh[3][threadIdx.x] = l0; sh[4][threadIdx.x] = l1;
+  sh[5][threadIdx.x] = a3;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
     if ((int)threadIdx.x < o)
-      for (int k = 0; k < 5; ++k) sh[k][threadIdx.x] += sh[k][threadIdx.x + o];
+      for (int k = 0; k < 6; ++k) sh[k][threadIdx.x] += sh[k][threadIdx.x + o];
     __syncthreads();
   }
   if (threadIdx.x == 0) {
     int npresent = 0;
     for (int c = 1; c < C; ++c) npresent += cnt[c] > 0 ? 1 : 0;
     const double np = npresent > 0 ? npresent : 1;
-    const double foc = sh[0][0], focc = sh[1][0], per = sh[2][0], lov = sh[3][0] / np, lovc = sh[4][0] / np;
-    out[1] = (float)foc; out[2] = (float)lov; out[3] = (float)focc; out[4] = (float)lovc; out[5] = (float)per;
-    out[0] = (float)(foc + focc + lambda * (lov + lovc) + gamma_per * per);
+    const double foc = sh[0][0], focc = sh[1][0], perp = sh[2][0], perq = sh[5][0], lov = sh[3][0] / np, lovc = sh[4][0] / np;
+    out[1] = (float)foc; out[2] = (float)lov; out[3] = (float)focc; out[4] = (float)lovc; out[5] = (float)(perp + perq);
+    out[6] = (float)perp; out[7] = (float)perq;
+    if (w6) out[0] = (float)(w6[0] * foc + w6[1] * lov + w6[2] * focc + w6[3] * lovc + w6[4] * perp + w6[5] * perq);
+    else out[0] = (float)(foc + focc + lambda * (lov + lovc) + gamma_per * (perp + perq));
   }
 }
 
 extern "C" int pmf_loss_rows(int64_t P) { return (int)cdiv64(P, LP_BLOCK); }
 extern "C" int pmf_loss_chunks(int64_t P) { return (int)cdiv64(P, LV_CHUNK); }
 
-extern "C" int pmf_loss_pixel(const float* lidar_prob, const float* camera_prob, const int64_t* label, const float* alpha,
-                              int32_t N, int32_t C, int64_t HW, float focal_gamma, float tau, float gamma_per,
-                              unsigned long long* cnt, float* grad_lidar, float* grad_camera, float* key, double* rows,
-                              unsigned long long* conf_lidar, unsigned long long* conf_camera, pmf_stream_t s) {
+static int loss_pixel_impl(const float* lidar_prob, const float* camera_prob, const int64_t* label, const float* alpha,
+                           int32_t N, int32_t C, int64_t HW, float focal_gamma, float tau, float gamma_per,
+                           const float* w6, unsigned long long* cnt, float* grad_lidar, float* grad_camera, float* key,
+                           double* rows, unsigned long long* conf_lidar, unsigned long long* conf_camera, pmf_stream_t s) {
   if (C < 2 || C > LP_MAXC || N < 1 || HW < 1) return PMF_E_ARG;
   const int64_t P = (int64_t)N * HW;
   hipStream_t st = (hipStream_t)s;
@@ -394,25 +407,54 @@ extern "C" int pmf_loss_pixel(const float* lidar_prob, const float* camera_prob,
   LossPixelArgs a;
   a.pl = lidar_prob; a.pc = camera_prob; a.label = label; a.alpha = alpha; a.cnt = cnt;
   a.gl = grad_lidar; a.gc = grad_camera; a.key = key; a.rows = rows; a.conf_l = conf_lidar; a.conf_c = conf_camera;
-  a.HW = HW; a.P = P; a.C = C; a.fgamma = focal_gamma; a.tau = tau; a.gamma_per = gamma_per;
+  a.HW = HW; a.P = P; a.C = C; a.fgamma = focal_gamma; a.tau = tau; a.gamma_per = gamma_per; a.w6 = w6;
   hipLaunchKernelGGL(loss_pixel_k, dim3((unsigned)cdiv64(P, LP_BLOCK)), dim3(LP_BLOCK), 0, st, a);
   PMF_LAUNCH_CHECK();
   return 0;
 }
+extern "C" int pmf_loss_pixel(const float* lidar_prob, const float* camera_prob, const int64_t* label, const float* alpha,
+                              int32_t N, int32_t C, int64_t HW, float focal_gamma, float tau, float gamma_per,
+                              unsigned long long* cnt, float* grad_lidar, float* grad_camera, float* key, double* rows,
+                              unsigned long long* conf_lidar, unsigned long long* conf_camera, pmf_stream_t s) {
+  return loss_pixel_impl(lidar_prob, camera_prob, label, alpha, N, C, HW, focal_gamma, tau, gamma_per, nullptr, cnt,
+                         grad_lidar, grad_camera, key, rows, conf_lidar, conf_camera, s);
+}
+extern "C" int pmf_loss_pixel_w(const float* lidar_prob, const float* camera_prob, const int64_t* label, const float* alpha,
+                                int32_t N, int32_t C, int64_t HW, float focal_gamma, float tau, const float* w6,
+                                unsigned long long* cnt, float* grad_lidar, float* grad_camera, float* key, double* rows,
+                                unsigned long long* conf_lidar, unsigned long long* conf_camera, pmf_stream_t s) {
+  if (!w6) return PMF_E_ARG;
+  return loss_pixel_impl(lidar_prob, camera_prob, label, alpha, N, C, HW, focal_gamma, tau, 0.f, w6, cnt, grad_lidar,
+                         grad_camera, key, rows, conf_lidar, conf_camera, s);
+}
 
-extern "C" int pmf_loss_lovasz(const int64_t* perm, const float* key_sorted, const int64_t* label, int32_t N, int32_t C,
-                               int64_t HW, const unsigned long long* cnt, float lambda, float gamma_per, float* bsum,
-                               double* dots, const double* rows, float* grad_lidar, float* grad_camera, float* out6,
-                               pmf_stream_t s) {
+static int loss_lovasz_impl(const int64_t* perm, const float* key_sorted, const int64_t* label, int32_t N, int32_t C,
+                            int64_t HW, const unsigned long long* cnt, float lambda, float gamma_per, const float* w6,
+                            float* bsum, double* dots, const double* rows, float* grad_lidar, float* grad_camera,
+                            float* out6, pmf_stream_t s) {
   if (C < 2 || C > LP_MAXC || N < 1 || HW < 1) return PMF_E_ARG;
   const int64_t P = (int64_t)N * HW;
   const int nb = (int)cdiv64(P, LV_CHUNK);
   hipStream_t st = (hipStream_t)s;
   hipLaunchKernelGGL(lovasz2_sums_k, dim3(nb, 2 * C), dim3(LV_BLOCK), 0, st, perm, label, P, C, nb, bsum);
   hipLaunchKernelGGL(lovasz2_grad_k, dim3(nb, 2 * C), dim3(LV_BLOCK), 0, st, perm, key_sorted, label, P, HW, C, nb,
-                     (const float*)bsum, cnt, lambda, grad_lidar, grad_camera, dots);
+                     (const float*)bsum, cnt, lambda, w6, grad_lidar, grad_camera, dots);
   hipLaunchKernelGGL(loss_fold_k, dim3(1), dim3(256), 0, st, rows, (int)cdiv64(P, LP_BLOCK), (const double*)dots, C, nb, cnt,
-                     lambda, gamma_per, out6);
+                     lambda, gamma_per, w6, out6);
   PMF_LAUNCH_CHECK();
   return 0;
+}
+extern "C" int pmf_loss_lovasz(const int64_t* perm, const float* key_sorted, const int64_t* label, int32_t N, int32_t C,
+                               int64_t HW, const unsigned long long* cnt, float lambda, float gamma_per, float* bsum,
+                               double* dots, const double* rows, float* grad_lidar, float* grad_camera, float* out8,
+                               pmf_stream_t s) {
+  return loss_lovasz_impl(perm, key_sorted, label, N, C, HW, cnt, lambda, gamma_per, nullptr, bsum, dots, rows, grad_lidar,
+                          grad_camera, out8, s);
+}
+extern "C" int pmf_loss_lovasz_w(const int64_t* perm, const float* key_sorted, const int64_t* label, int32_t N, int32_t C,
+                                 int64_t HW, const unsigned long long* cnt, const float* w6, float* bsum, double* dots,
+                                 const double* rows, float* grad_lidar, float* grad_camera, float* out8, pmf_stream_t s) {
+  if (!w6) return PMF_E_ARG;
+  return loss_lovasz_impl(perm, key_sorted, label, N, C, HW, cnt, 0.f, 0.f, w6, bsum, dots, rows, grad_lidar, grad_camera,
+                          out8, s);
 }

@@ -12,7 +12,8 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .loss import FocalSoftmaxLoss, Lovasz_softmax, pmf_total_loss, pmf_total_loss_fused
+from .loss import (FocalSoftmaxLoss, Lovasz_softmax, MultiTaskLoss, pmf_total_loss, pmf_total_loss_fused,
+                   epmf_total_loss, weighted_loss_fused, EPMF_TERMS)
 from .metrics import IOUEval
 from .utils import WarmupCosineLR
 
@@ -119,7 +120,7 @@ class FlatOptimizerView(object):
 class TrainEngine:
     def __init__(self, model, nclasses, lr=1e-3, momentum=0.9, weight_decay=1e-5, lambda_=1.0, gamma=0.5, tau=0.7,
                  alpha=None, ignore_class=(0,), warmup_steps=1, max_steps=1, feature_mean=None, feature_std=None,
-                 distributed=False, device_ids=None, flat_state=True):
+                 distributed=False, device_ids=None, flat_state=True, adam_weight_decay=None, extra_adam_params=None):
         self.raw_model = model
         dev = next(model.parameters()).device
         self.device = dev
@@ -155,7 +156,11 @@ class TrainEngine:
                     model, device_ids=device_ids, gradient_as_bucket_view=True)   # local-stat BN: layers/sync_bn.py
         # trainer.py:80-98: AdamW over the LiDAR stream (torch defaults incl. weight_decay 0.01),
         # SGD-Nesterov over camera encoder + decoder
-        self.optimizer = torch.optim.AdamW([{"params": lidar_params}], lr=lr, **fused)
+        adam_groups = [{"params": lidar_params}]
+        if extra_adam_params:                               # EPMF: the MultiTaskLoss sigmas (tasks/epmf/trainer.py:105-106)
+            adam_groups.append({"params": list(extra_adam_params)})
+        adam_kw = {} if adam_weight_decay is None else {"weight_decay": adam_weight_decay}
+        self.optimizer = torch.optim.AdamW(adam_groups, lr=lr, **adam_kw, **fused)
         self.aux_optimizer = torch.optim.SGD(camera_groups, lr=lr, nesterov=True, momentum=momentum,
                                              weight_decay=weight_decay, **fused)
         # what a trainer / main.py holds as trainer.optimizer / trainer.aux_optimizer: reference checkpoint layout
@@ -281,6 +286,55 @@ class TrainEngine:
             self.metrics.addBatch(lidar_pred.argmax(dim=1), label)
             self.metrics_img.addBatch(camera_pred.argmax(dim=1), label)
         return total, terms
+
+
+class EPMFEngine(TrainEngine):
+    """One EPMF optimisation step (tasks/epmf/trainer.py:27-33,95-122,340-437 of the reference, PMFNet branch with
+    ``use_mtloss``): six separately weighted terms [foc_img, lov_img, per_img, per, foc, lov] through MultiTaskLoss(6)
+    (learned sigmas, optimised by the AdamW that also owns the LiDAR stream, weight_decay = settings.weight_decay),
+    SGD-Nesterov over the camera stream.  On the GPU the six terms, the gradient of their sigma-weighted sum w.r.t. both
+    probability maps and the confusion matrices are one fused HIP pass (loss/fused.py weighted_loss_fused: the weights
+    1 / (2 sigma_i^2) are read on the device); the sigma gradients come from autograd through those weights.  Under data
+    parallelism the sigma gradient is averaged like every other gradient (the reference wraps mt_loss in its own
+    DistributedDataParallel, :44-49)."""
+
+    def __init__(self, model, nclasses, weight_decay=1e-5, **kw):
+        dev = next(model.parameters()).device
+        self.mt_loss = MultiTaskLoss(6).to(dev)
+        super().__init__(model, nclasses, weight_decay=weight_decay, adam_weight_decay=weight_decay,
+                         extra_adam_params=self.mt_loss.parameters(), **kw)
+        if self.distributed:
+            import torch.distributed as dist
+            dist.broadcast(self.mt_loss.sigma.data, 0)
+        if self.flat is not None:                       # checkpoint view: lidar parameters, then the sigmas (group 2)
+            self.optimizer_view = self.optimizer
+
+    def forward_loss(self, pcd, rgb, label):
+        if self.flat is not None:
+            self.mt_loss.sigma.grad = None              # (the flat buffer is re-zeroed by the backward plan itself)
+        lidar_pred, camera_pred = self.model(pcd, rgb)
+        if lidar_pred.is_cuda:
+            for m in (self.metrics, self.metrics_img):
+                if m.conf_matrix.device != lidar_pred.device:
+                    m.conf_matrix = m.conf_matrix.to(lidar_pred.device)
+            sg2 = self.mt_loss.sigma.pow(2)
+            w = 1.0 / (2.0 * sg2)                                             # multi_task_loss.py:17-18
+            # fused term order (foc, lov, foc_cam, lov_cam, per, per_img) <- sigma order of EPMF_TERMS
+            order = [EPMF_TERMS.index(k) for k in ("foc", "lov", "foc_cam", "lov_cam", "per", "per_img")]
+            total, terms = weighted_loss_fused(lidar_pred, camera_pred, label, self.focal.alpha, w[order], self.tau,
+                                               self.focal.gamma, self.metrics.conf_matrix, self.metrics_img.conf_matrix)
+            total = total + (sg2 + 1.0).log().sum()
+            self.metrics.external_update()
+            self.metrics_img.external_update()
+            return total, terms, lidar_pred, camera_pred, True
+        total, terms = epmf_total_loss(lidar_pred, camera_pred, label, self.focal, self.lovasz, self.mt_loss, self.tau)
+        return total, terms, lidar_pred, camera_pred, False
+
+    def _finish_allreduce(self):
+        super()._finish_allreduce()
+        if self.distributed and self.mt_loss.sigma.grad is not None:
+            import torch.distributed as dist
+            dist.all_reduce(self.mt_loss.sigma.grad)      # (1 / world rides on the upstream gradient already)
 
 
 class SalsaNextEngine:

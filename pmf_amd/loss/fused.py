@@ -32,7 +32,7 @@ class _FusedPMFLoss(torch.autograd.Function):
         nb = lib.pmf_loss_chunks(p)
         bsum = torch.empty((2 * c, nb), dtype=torch.float32, device=dev)
         dots = torch.empty((2 * c, nb), dtype=torch.float64, device=dev)
-        out6 = torch.empty(6, dtype=torch.float32, device=dev)
+        out6 = torch.empty(8, dtype=torch.float32, device=dev)
         st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         a = alpha.to(dev, torch.float32).contiguous()
         L.check(lib.pmf_loss_pixel(pl.data_ptr(), pc.data_ptr(), lab.data_ptr(), a.data_ptr(), n, c, hw,
@@ -52,6 +52,60 @@ class _FusedPMFLoss(torch.autograd.Function):
     def backward(ctx, g_total, _g_terms):
         gl, gc = ctx.saved_tensors
         return gl * g_total, gc * g_total, None, None, None, None, None, None, None, None
+
+
+class _FusedWeightedLoss(torch.autograd.Function):
+    """total = sum_i w_i * term_i over (foc, lov, foc_cam, lov_cam, per_p, per_q) with the weights read on the device;
+    gradients w.r.t. both probability maps (analytic, HIP) and w.r.t. the weights (= the term values)."""
+
+    @staticmethod
+    def forward(ctx, lidar_prob, camera_prob, label, alpha, w6, tau, focal_gamma, conf_l, conf_c):
+        lib = L.lib()
+        if not (lidar_prob.is_cuda and camera_prob.is_cuda and label.is_cuda and w6.is_cuda):
+            raise RuntimeError("pmf_amd fused loss: tensors must live on the GPU (no CPU fallback)")
+        pl, pc = lidar_prob.detach().contiguous().float(), camera_prob.detach().contiguous().float()
+        lab = label.contiguous().long()
+        w = w6.detach().contiguous().float()
+        n, c, h, wd = pl.shape
+        hw, p = h * wd, n * h * wd
+        dev = pl.device
+        gl, gc = torch.empty_like(pl), torch.empty_like(pc)
+        key = torch.empty((2 * c, p), dtype=torch.float32, device=dev)
+        rows = torch.empty((lib.pmf_loss_rows(p), 4), dtype=torch.float64, device=dev)
+        cnt = torch.empty(c, dtype=torch.int64, device=dev)
+        nb = lib.pmf_loss_chunks(p)
+        bsum = torch.empty((2 * c, nb), dtype=torch.float32, device=dev)
+        dots = torch.empty((2 * c, nb), dtype=torch.float64, device=dev)
+        out8 = torch.empty(8, dtype=torch.float32, device=dev)
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        a = alpha.to(dev, torch.float32).contiguous()
+        L.check(lib.pmf_loss_pixel_w(pl.data_ptr(), pc.data_ptr(), lab.data_ptr(), a.data_ptr(), n, c, hw,
+                                     float(focal_gamma), float(tau), w.data_ptr(), cnt.data_ptr(), gl.data_ptr(),
+                                     gc.data_ptr(), key.data_ptr(), rows.data_ptr(),
+                                     conf_l.data_ptr() if conf_l is not None else None,
+                                     conf_c.data_ptr() if conf_c is not None else None, st), "pmf_loss_pixel_w")
+        vals, perm = torch.sort(key, dim=1, descending=True)
+        L.check(lib.pmf_loss_lovasz_w(perm.data_ptr(), vals.data_ptr(), lab.data_ptr(), n, c, hw, cnt.data_ptr(),
+                                      w.data_ptr(), bsum.data_ptr(), dots.data_ptr(), rows.data_ptr(), gl.data_ptr(),
+                                      gc.data_ptr(), out8.data_ptr(), st), "pmf_loss_lovasz_w")
+        terms = torch.stack([out8[1], out8[2], out8[3], out8[4], out8[6], out8[7]])
+        ctx.save_for_backward(gl, gc, terms)
+        ctx.mark_non_differentiable(out8)
+        return out8[0].clone(), out8
+
+    @staticmethod
+    def backward(ctx, g_total, _g_terms):
+        gl, gc, terms = ctx.saved_tensors
+        return gl * g_total, gc * g_total, None, None, terms * g_total, None, None, None, None
+
+
+def weighted_loss_fused(lidar_prob, camera_prob, label, alpha, w6, tau=0.7, focal_gamma=2.0, conf_lidar=None,
+                        conf_camera=None):
+    """total = w6 . (foc, lov, foc_cam, lov_cam, per_p, per_q); w6: device tensor [6] (may require grad).
+    returns (total, dict of the six terms)."""
+    total, o = _FusedWeightedLoss.apply(lidar_prob, camera_prob, label, alpha, w6, tau, focal_gamma, conf_lidar,
+                                        conf_camera)
+    return total, {"foc": o[1], "lov": o[2], "foc_cam": o[3], "lov_cam": o[4], "per": o[6], "per_img": o[7]}
 
 
 def pmf_total_loss_fused(lidar_prob, camera_prob, label, alpha, lambda_=1.0, gamma_=0.5, tau=0.7, focal_gamma=2.0,

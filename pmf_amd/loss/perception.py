@@ -37,3 +37,26 @@ def pmf_total_loss(lidar_prob, camera_prob, label, focal, lovasz, lambda_=1.0, g
     t["pcd_entropy"], t["img_entropy"] = pe, ie
     total = t["foc"] + t["lov"] * lambda_ + t["foc_cam"] + t["lov_cam"] * lambda_ + t["per"] * gamma_
     return total, t
+
+
+def epmf_total_loss(lidar_prob, camera_prob, label, focal, lovasz, mt_loss, tau=0.7):
+    """the EPMF multi-task objective with torch ops (tasks/epmf/trainer.py:376-430, use_mtloss): the six terms
+    [foc_img, lov_img, per_img, per, foc, lov] through MultiTaskLoss in THAT order (sigma index = list position).
+    returns (total, dict of terms)."""
+    mask = label.gt(0)
+    pe, plog = normalized_entropy(lidar_prob)
+    ie, ilog = normalized_entropy(camera_prob)
+    pc, ic = 1 - pe, 1 - ie
+    d = pc - ic
+    w_pcd = d.gt(0).to(d.dtype) * d.abs() * pc.ge(tau).to(d.dtype)
+    w_img = d.lt(0).to(d.dtype) * d.abs() * ic.ge(tau).to(d.dtype)
+    per = (F.kl_div(plog, camera_prob, reduction="none") * w_img.unsqueeze(1)).mean()        # loss_per (pcd)
+    per_img = (F.kl_div(ilog, lidar_prob, reduction="none") * w_pcd.unsqueeze(1)).mean()     # loss_per_img
+    t = {"foc_cam": focal(camera_prob, label, mask=mask), "lov_cam": lovasz(camera_prob, label),
+         "per_img": per_img, "per": per,
+         "foc": focal(lidar_prob, label, mask=mask), "lov": lovasz(lidar_prob, label)}
+    total = mt_loss([t[k].reshape(1) for k in EPMF_TERMS]).squeeze()
+    return total, t
+
+
+EPMF_TERMS = ("foc_cam", "lov_cam", "per_img", "per", "foc", "lov")      # the reference's loss_list order

@@ -11,8 +11,10 @@ import torch
 from .. import _lib as L
 
 
-def getMergePred(point_idx_list, pred_conf_list, pred_argmax_list, pc_size):
-    """-> int64 [pc_size] on the inputs' device (-1 = no view decides; same values as the reference)"""
+def getMergePred(point_idx_list, pred_conf_list, pred_argmax_list, pc_size, fallback=None):
+    """-> int64 [pc_size] on the inputs' device (-1 = no view decides; same values as the reference).
+    fallback (optional, int64 [pc_size]): labels of a LiDAR-only model (SalsaNext) taken for the points outside every
+    camera view instead of -1 -- the test-split protocol of more_experiment_config.md:10, in the same launch."""
     n = len(point_idx_list)
     if not (n == len(pred_conf_list) == len(pred_argmax_list)) or n == 0:
         raise ValueError("getMergePred: need the same, non-zero number of index / confidence / label lists")
@@ -30,6 +32,14 @@ def getMergePred(point_idx_list, pred_conf_list, pred_argmax_list, pc_size):
     out = torch.empty(pc_size, dtype=torch.int64, device=dev)
     ptrs = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
     counts = (C.c_int64 * n)(*[t.numel() for t in idx])
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    if fallback is not None:
+        fb = fallback.to(dev).long().contiguous()
+        if fb.numel() != pc_size:
+            raise ValueError("getMergePred: fallback needs one label per point (%d), got %d" % (pc_size, fb.numel()))
+        L.check(L.lib().pmf_merge_pred_fallback(n, ptrs(idx), ptrs(conf), ptrs(lab), counts, pc_size, fb.data_ptr(),
+                                                keys.data_ptr(), out.data_ptr(), st), "pmf_merge_pred_fallback")
+        return out
     L.check(L.lib().pmf_merge_pred(n, ptrs(idx), ptrs(conf), ptrs(lab), counts, pc_size, keys.data_ptr(), out.data_ptr(),
-                                   C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "pmf_merge_pred")
+                                   st), "pmf_merge_pred")
     return out

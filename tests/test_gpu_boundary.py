@@ -407,3 +407,48 @@ def test_tasks_pmf_train_resume_and_infer(tmp_path):
         _, keep = loader_ref.map_lidar_to_camera(ds.proj_matrix["08"], pts[:, :3], img.shape[1], img.shape[0])
         assert lab_out.shape[0] == int(keep.sum())                 # one label per point inside the camera frustum
         assert set(np.unique(lab_out)) <= set(lab["learning_map_inv"].values())
+
+
+def test_epmf_engine_matches_reference_trace(golden):
+    """g14 (two optimisation steps of tasks/epmf driven with the REFERENCE's modules: EPMFNet, MultiTaskLoss(6), the six
+    terms in the reference's order, AdamW over lidar stream + sigmas, SGD-Nesterov camera) replayed on the HIP model
+    through EPMFEngine: the fused six-term objective with device-side sigma weights, sigma gradients, sigmas and
+    parameter checksums after step 1, losses of both steps"""
+    from pmf_amd.engine import EPMFEngine
+    from pmf_amd.loss import EPMF_TERMS
+    from pmf_amd.models import EPMFNet
+    from pmf_amd.utils.detinit import deterministic_init, synthetic_batch
+    g = golden("g14_epmf_trace")
+    m = deterministic_init(EPMFNet(5, 3, 20, 32, imagenet_pretrained=False, image_backbone="resnet34")).cuda()
+    m.set_dropout_masks(_ones_masks(m, 2))
+    alpha = np.linspace(0.2, 1.0, 20).astype(np.float32)
+    alpha[0] = 0
+    eng = EPMFEngine(m, 20, lr=1e-3, momentum=0.9, weight_decay=1e-5, alpha=alpha, warmup_steps=1, max_steps=10 ** 9)
+    pcd, rgb, label, mask = synthetic_batch(2, 64, 128, 20, seed=1, fill=0.3)
+    feat = torch.cat((pcd, rgb), 1).cuda()
+    for step in range(2):
+        if step == 0:            # the sigma gradient of the first step, before the optimiser consumes it
+            p_, r_ = eng.prepare(feat.clone(), torch.ones_like(mask).cuda())
+            tot = eng.forward_loss(p_, r_, label.cuda().long())[0]
+            tot.backward()
+            gs = eng.mt_loss.sigma.grad.double().cpu().numpy()
+            want = g["etrace.gsigma0"]
+            assert np.abs(gs - want).max() < 2e-3 * np.abs(want).max(), (gs, want)
+            m._plans = {}        # fresh plan state for the timed path (BN statistics were updated once: rebuild model)
+            m = deterministic_init(EPMFNet(5, 3, 20, 32, imagenet_pretrained=False, image_backbone="resnet34")).cuda()
+            m.set_dropout_masks(_ones_masks(m, 2))
+            eng = EPMFEngine(m, 20, lr=1e-3, momentum=0.9, weight_decay=1e-5, alpha=alpha, warmup_steps=1,
+                             max_steps=10 ** 9)
+        total, t = eng.train_step(feat.clone(), torch.ones_like(mask).cuda(), label.cuda())
+        got = np.array([total.item()] + [t[k].item() for k in EPMF_TERMS])
+        want = g["etrace.losses"][step]
+        assert np.abs(got[:3] - want[:3]).max() < 1e-3 * np.abs(want[:3]).max(), (step, got, want)
+        assert np.abs(got[5:] - want[5:]).max() < 1e-3 * np.abs(want[5:]).max(), (step, got, want)
+        assert np.abs(got[3:5] - want[3:5]).max() < 2e-2 * max(np.abs(want[3:5]).max(), 1e-6), (step, got, want)
+        assert np.abs(eng.mt_loss.sigma.detach().double().cpu().numpy() - g["etrace.sigma"][step]).max() < 5e-6
+        if step == 0:
+            sd = m.state_dict()
+            for k in [k for k in g.files if k.startswith("etrace.param1.")]:
+                name = k[len("etrace.param1."):]
+                err = np.abs(_checksum(sd[name]) - g[k]).max() / max(abs(g[k][1]), 1e-3)
+                assert err < 1e-4, (name, err)

@@ -1112,6 +1112,14 @@ def test_camera_merge_exact(tag, seed, pc, golden):
     np.testing.assert_array_equal(got, merge_ref.get_merge_pred(idx, conf, lab, pc))
     if tag:
         np.testing.assert_array_equal(got, golden("g12_merge")["merge." + tag])
+    # points outside every camera view take the label of the LiDAR-only model (more_experiment_config.md:10)
+    fb = np.random.default_rng(seed).integers(0, 17, pc).astype(np.int64)
+    got_fb = getMergePred(t(idx), t(conf), t(lab), pc, fallback=torch.from_numpy(fb).cuda()).cpu().numpy()
+    want = merge_ref.get_merge_pred(idx, conf, lab, pc)
+    assert (want == -1).any()
+    np.testing.assert_array_equal(got_fb, np.where(want == -1, fb, want))
+    with pytest.raises(ValueError):
+        getMergePred(t(idx), t(conf), t(lab), pc, fallback=torch.from_numpy(fb[:-1]).cuda())
     # a view that sees nothing, a single view, no points at all
     e = torch.zeros(0, dtype=torch.int64).cuda()
     one = getMergePred([torch.tensor([2, 0]).cuda(), e], [torch.tensor([0.5, 0.25]).cuda(), e.float()],

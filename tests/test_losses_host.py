@@ -96,3 +96,38 @@ def test_epmf_surface_and_no_cpu_fallback():
         m(torch.zeros(1, 5, 48, 64), torch.zeros(1, 3, 48, 64))
     with pytest.raises(NotImplementedError):
         pc_processor.models.EPMFNet(image_backbone="vgg16")
+
+
+def test_epmf_engine_two_steps_match_reference_trace(golden):
+    """G14: EPMFEngine (six terms through MultiTaskLoss in the reference's order, AdamW over lidar stream + sigmas with
+    weight_decay, SGD-Nesterov camera) against two optimisation steps driven with the reference's modules; the CPU
+    oracle network stands in for the HIP model (the GPU test replays the same fixture on the HIP model)."""
+    from oracle import epmf_torch as E
+    from oracle import pmf_torch as O
+    from pmf_amd.engine import EPMFEngine
+    from pmf_amd.loss import EPMF_TERMS
+    from pmf_amd.utils.detinit import deterministic_init
+    g = golden("g14_epmf_trace")
+    m = deterministic_init(E.EPMFNet(5, 3, 20, 32, False, "resnet34"))
+    for x in m.modules():
+        if isinstance(x, O.DropSite):
+            x.p = 0.0
+    alpha = np.linspace(0.2, 1.0, 20).astype(np.float32)
+    alpha[0] = 0
+    eng = EPMFEngine(m, 20, lr=1e-3, momentum=0.9, weight_decay=1e-5, alpha=alpha, warmup_steps=1, max_steps=10 ** 9)
+    assert len(eng.optimizer.param_groups) == 2 and eng.optimizer.param_groups[1]["params"][0] is eng.mt_loss.sigma
+    assert eng.optimizer.param_groups[0]["weight_decay"] == 1e-5
+    pcd, rgb, label, mask = synthetic_batch(2, 64, 128, 20, seed=1, fill=0.3)
+    feat = torch.cat((pcd, rgb), 1)
+    for step in range(2):
+        total, t = eng.train_step(feat.clone(), torch.ones_like(mask), label)
+        got = np.array([total.item()] + [t[k].item() for k in EPMF_TERMS])
+        want = g["etrace.losses"][step]
+        assert np.abs(got - want).max() < 1e-3 * np.abs(want).max(), (step, got, want)
+        assert np.abs(eng.mt_loss.sigma.detach().double().numpy() - g["etrace.sigma"][step]).max() < 2e-6
+        if step == 0:
+            sd = m.state_dict()
+            for k in [k for k in g.files if k.startswith("etrace.param1.")]:
+                name = k[len("etrace.param1."):]
+                gotc = np.array([sd[name].double().sum().item(), sd[name].double().abs().sum().item()])
+                assert np.abs(gotc - g[k]).max() <= 1e-4 * max(abs(g[k][1]), 1e-3), name
