@@ -58,6 +58,19 @@ extern "C" int pmf_conv_trace_set(void* p) { return (int)hipMemcpyToSymbol(HIP_S
 // buffer + sched_barrier): left alone hipcc emits read -> wait -> 2 mfma groups, four exposed LDS round trips per step.
 struct NoFill { __device__ __forceinline__ void operator()(int, int) const {} };
 
+// scheduling recipe of one MFMA step: MFMA i is followed by its share of the NR LDS reads of the NEXT step (and, behind
+// the first two, one global load of the staging slice): the builtin wants literal counts, hence the recursion
+template <int I, int NM, int NR>
+__device__ __forceinline__ void pmf_sgb_seq() {
+  if constexpr (I < NM) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    constexpr int k = (NR * (I + 1)) / NM - (NR * I) / NM;
+    if constexpr (k > 0) __builtin_amdgcn_sched_group_barrier(0x100, k, 0);
+    if constexpr (I < 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    pmf_sgb_seq<I + 1, NM, NR>();
+  }
+}
+
 template <int BN, int MT, int NTAPS, class Fill = NoFill>
 __device__ __forceinline__ void conv_steps(f32x16 (&acc)[MT][BN / 32], const float* __restrict__ As,
                                            const float* __restrict__ Bs, const int (&abase)[MT],
@@ -138,7 +151,6 @@ __device__ __forceinline__ void conv_half(f32x16 (&acc)[MT][BN / 32], const floa
         for (int q = 0; q < 4; ++q) b[nxt][u][q] = bp[q * BN + u * 32];
     }
     fill(st, NTAPS);
-    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -146,6 +158,9 @@ __device__ __forceinline__ void conv_half(f32x16 (&acc)[MT][BN / 32], const floa
 #pragma unroll
         for (int u = 0; u < NT; ++u)
           acc[m][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][m][q], b[cur][u][q], acc[m][u], 0, 0, 0);
+    // the next step's LDS reads (and this step's slice of global loads) go INTO the 64-cycle gaps behind the MFMAs
+    // instead of in front of the block (hipcc otherwise waits lgkmcnt(0) right behind the reads it has just issued)
+    pmf_sgb_seq<0, 4 * MT * NT, MT + 4 * NT>();
     __builtin_amdgcn_sched_barrier(0);
   }
 }
@@ -347,9 +362,13 @@ __device__ __forceinline__ void conv_kloop_pipe(const pmf_conv_desc_t& d, const 
 }
 
 // PIPE: 0 generic K loop, 1 pipelined, 4 pipelined with 64-channel stages (1x1 convs).
-// (A variant with a second input tile in LDS -- two barriers per chunk instead of three, no separate staging phase -- was
-// built and measured: 49.2 vs 47.8 us on 64->64 3x3 at 32x1024, 23.60 vs 23.23 ms per training step.  The barrier count
-// is not what limits this loop.)
+// Measured and rejected on this loop (kept out of the code): a second input tile in LDS (two barriers per chunk instead
+// of three: 49.2 vs 47.8 us on 64->64 3x3 at 32x1024, 23.60 vs 23.23 ms per training step); a start delay for the
+// workgroup in the odd wave slots (de-phasing the co-resident pair: monotonically slower, 47.6 -> 50.2 us at 16k cycles);
+// a 512-thread "paired" form with two pixel tiles per workgroup whose MFMA / staging phases are complementary by
+// construction (one group multiplies while the other stages; shared, double-buffered weight slabs: 53.3 vs 47.3 us,
+// 24.13 vs 23.18 ms per step).  Two waves per SIMD that interleave freely fill each other's gaps better than any
+// enforced schedule here; what did help is placing the next step's LDS reads inside the MFMA gaps (pmf_sgb_seq).
 template <int BN, int MT, int PIPE>
 __global__ __launch_bounds__(256) void conv_fwd_k(const pmf_conv_desc_t d, const ConvGeom g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
