@@ -42,6 +42,21 @@ __device__ __forceinline__ f32x4 pmf_view_load4(const float* __restrict__ x, con
   return v;
 }
 
+// Scheduling recipe of one MFMA step (device code): MFMA i is followed by its share of the NR LDS reads that fetch the
+// NEXT step's operands (and, behind the first NV MFMAs, one global load each).  Left alone -- or fenced into
+// [reads][MFMAs] blocks with sched_barrier -- hipcc waits lgkmcnt(0) right behind reads it has just issued; inside the
+// 64-cycle MFMA gaps the reads are free.  The builtin wants literal counts, hence the recursion.
+template <int I, int NM, int NR, int NV>
+__device__ __forceinline__ void pmf_sgb_seq() {
+  if constexpr (I < NM) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    constexpr int k = (NR * (I + 1)) / NM - (NR * I) / NM;
+    if constexpr (k > 0) __builtin_amdgcn_sched_group_barrier(0x100, k, 0);
+    if constexpr (I < NV) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    pmf_sgb_seq<I + 1, NM, NR, NV>();
+  }
+}
+
 // geometry shared by conv forward / weight-gradient host code
 struct ConvGeom {
   int segs_x_log2;  // 32-pixel segments across the tile (log2)

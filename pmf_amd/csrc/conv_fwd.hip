@@ -58,6 +58,10 @@ extern "C" int pmf_conv_trace_set(void* p) { return (int)hipMemcpyToSymbol(HIP_S
 // buffer + sched_barrier): left alone hipcc emits read -> wait -> 2 mfma groups, four exposed LDS round trips per step.
 struct NoFill { __device__ __forceinline__ void operator()(int, int) const {} };
 
+// NTAPS taps x 16 channels of one staged chunk, fully unrolled and branch-free.  The LDS operands of step i+1 (one
+// ds_read_b128 per M tile + 4 ds_read_b32 per N tile) are issued BEFORE the 4*MT*NT MFMAs of step i (explicit double
+// buffer + sched_barrier): left alone hipcc emits read -> wait -> 2 mfma groups, four exposed LDS round trips per step.
+
 // scheduling recipe of one MFMA step: MFMA i is followed by its share of the NR LDS reads of the NEXT step (and, behind
 // the first two, one global load of the staging slice): the builtin wants literal counts, hence the recursion
 template <int I, int NM, int NR>
@@ -160,7 +164,7 @@ __device__ __forceinline__ void conv_half(f32x16 (&acc)[MT][BN / 32], const floa
           acc[m][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][m][q], b[cur][u][q], acc[m][u], 0, 0, 0);
     // the next step's LDS reads (and this step's slice of global loads) go INTO the 64-cycle gaps behind the MFMAs
     // instead of in front of the block (hipcc otherwise waits lgkmcnt(0) right behind the reads it has just issued)
-    pmf_sgb_seq<0, 4 * MT * NT, MT + 4 * NT>();
+    pmf_sgb_seq<0, 4 * MT * NT, MT + 4 * NT, 2>();
     __builtin_amdgcn_sched_barrier(0);
   }
 }
