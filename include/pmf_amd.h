@@ -85,8 +85,13 @@ typedef struct {
   int64_t splitk_ws_bytes;
   int32_t cfg;               /* 0 = built-in heuristics; else tile configuration chosen by the caller's autotuner:
                               * BN (32|64) | MT (1|2) << 8 | K splits (1 = none) << 16, see pmf_conv_fwd_stat_rows */
-  int32_t cfg_pad_;
+  int32_t ep_flags;          /* PMF_EP_STAT_X_ONLY: ep_relu_x feeds ep_stat_mean only (no ReLU mask) */
+  const float* ep_stat_mean; /* optional [Cout], needs stats + ep_relu_x: the second statistics column becomes
+                              * sum out * (ep_relu_x - mean) instead of sum out^2 -- the BatchNorm-backward reduction
+                              * (pmf_bn_bwd_reduce) of an input-gradient launch that is the LAST writer of that
+                              * gradient map, folded by pmf_bn_bwd_fold */
 } pmf_conv_desc_t;
+#define PMF_EP_STAT_X_ONLY 1
 
 int pmf_conv_fwd(const pmf_conv_desc_t* d, pmf_stream_t s);
 
@@ -173,6 +178,10 @@ int pmf_col_rows(int64_t npix, int32_t C);
 int pmf_bn_bwd_reduce(const float* gy, int32_t gy_ldc, const float* a, int32_t a_ldc, int64_t npix, int32_t C,
                       const float* save_mean, const float* gamma, const float* save_invstd, int32_t train,
                       double* part, float* coef, float* dgamma, float* dbeta, pmf_stream_t s);
+/* the fold step of pmf_bn_bwd_reduce alone, over `nrows` partial rows [nrows][2][C] that an input-gradient launch with
+ * ep_stat_mean wrote (pmf_conv_fwd_stat_rows rows): same dgamma / dbeta / coef results without re-reading gy and a */
+int pmf_bn_bwd_fold(const double* part, int32_t nrows, int32_t C, int64_t npix, int32_t train, const float* gamma,
+                    const float* save_invstd, float* coef, float* dgamma, float* dbeta, pmf_stream_t s);
 /* backward pass 2: dz = coef0 * ((gy - coef2) - (a - mean) * coef1) * act'(a)   (act LRELU: slope from the sign of
  * a = lrelu(z); NONE for conv -> BN -> ReLU ordering).  dbias_rows (optional): partial column sums of dz
  * [pmf_col_rows(npix, C)][dbias_ld] for pmf_conv_wgrad to fold into the conv-bias gradient. */
@@ -397,7 +406,7 @@ enum {
   PMF_OP_MAXPOOL, PMF_OP_MAXPOOL_BWD, PMF_OP_BILINEAR, PMF_OP_BILINEAR_BWD, PMF_OP_PSHUFFLE, PMF_OP_PSHUFFLE_BWD,
   PMF_OP_GATE, PMF_OP_GATE_BWD, PMF_OP_GMEAN, PMF_OP_GMEAN_BWD, PMF_OP_COLSUM, PMF_OP_SOFTMAX, PMF_OP_SOFTMAX_BWD,
   PMF_OP_NCHW2NHWC, PMF_OP_FILL, PMF_OP_PMASK_FROM, PMF_OP_PMASK_POOL, PMF_OP_PMASK_MUL, PMF_OP_PMASK_MUL_BWD,
-  PMF_OP_VEC_ADD, PMF_OP_WGRAD_PART, PMF_OP_WGRAD_RED, PMF_OP_WGRAD_RED_MULTI
+  PMF_OP_VEC_ADD, PMF_OP_WGRAD_PART, PMF_OP_WGRAD_RED, PMF_OP_WGRAD_RED_MULTI, PMF_OP_BN_BWD_FOLD
 };
 
 /* generic argument record for the small ops (slot meaning documented next to each dispatcher case in plan.cpp) */

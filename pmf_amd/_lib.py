@@ -12,12 +12,13 @@ LIB_PATH = os.path.join(_HERE, "libpmf_amd.so")
 MAX_SRC, MAX_TAPS = 5, 49
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
 SRC_RELU, SRC_BCAST = 1, 2
+EP_STAT_X_ONLY = 1
 
 (OP_CONV, OP_WGRAD, OP_PACK, OP_BN_FINALIZE, OP_BN_EVAL, OP_BN_BWD_REDUCE, OP_BN_BWD_APPLY, OP_ADD_ACT,
  OP_ADD_ACT_BWD, OP_ACT_BWD, OP_AVGPOOL, OP_AVGPOOL_BWD, OP_MAXPOOL, OP_MAXPOOL_BWD, OP_BILINEAR,
  OP_BILINEAR_BWD, OP_PSHUFFLE, OP_PSHUFFLE_BWD, OP_GATE, OP_GATE_BWD, OP_GMEAN, OP_GMEAN_BWD, OP_COLSUM,
  OP_SOFTMAX, OP_SOFTMAX_BWD, OP_NCHW2NHWC, OP_FILL, OP_PMASK_FROM, OP_PMASK_POOL, OP_PMASK_MUL, OP_PMASK_MUL_BWD,
- OP_VEC_ADD, OP_WGRAD_PART, OP_WGRAD_RED, OP_WGRAD_RED_MULTI) = range(1, 36)
+ OP_VEC_ADD, OP_WGRAD_PART, OP_WGRAD_RED, OP_WGRAD_RED_MULTI, OP_BN_BWD_FOLD) = range(1, 37)
 
 OP_NAMES = {v: k for k, v in list(globals().items()) if k.startswith("OP_")}
 
@@ -39,7 +40,8 @@ class ConvDesc(C.Structure):
                 ("ep_cmul", C.c_void_p), ("ep_cmul_ld", C.c_int32), ("ep_relu_x", C.c_void_p),
                 ("ep_relu_scale", C.c_void_p), ("ep_relu_shift", C.c_void_p), ("ep_relu_ldc", C.c_int32),
                 ("stats", C.c_void_p), ("ep_pmask", C.c_void_p), ("splitk_ws", C.c_void_p),
-                ("splitk_ws_bytes", C.c_int64), ("cfg", C.c_int32), ("cfg_pad_", C.c_int32)]
+                ("splitk_ws_bytes", C.c_int64), ("cfg", C.c_int32), ("ep_flags", C.c_int32),
+                ("ep_stat_mean", C.c_void_p)]
 
 
 class WgradDesc(C.Structure):
@@ -199,7 +201,7 @@ def lib():
 
 EXPORTS = [
     "pmf_conv_fwd", "pmf_conv_wgrad", "pmf_conv_wgrad_partial", "pmf_conv_wgrad_reduce", "pmf_conv_wgrad_reduce_plan", "pmf_conv_wgrad_reduce_multi", "pmf_conv_wgrad_workspace", "pmf_conv_wgrad_nsplit", "pmf_pack_tile_ci",
-    "pmf_pack_weights_batched", "pmf_conv_fwd_stat_rows", "pmf_conv_fwd_stat_rows_max", "pmf_conv_fwd_kstages", "pmf_col_rows", "pmf_bn_finalize", "pmf_bn_eval_affine", "pmf_bn_bwd_reduce", "pmf_bn_bwd_apply",
+    "pmf_pack_weights_batched", "pmf_conv_fwd_stat_rows", "pmf_conv_fwd_stat_rows_max", "pmf_conv_fwd_kstages", "pmf_col_rows", "pmf_bn_finalize", "pmf_bn_eval_affine", "pmf_bn_bwd_reduce", "pmf_bn_bwd_fold", "pmf_bn_bwd_apply",
     "pmf_add_act", "pmf_add_act_bwd", "pmf_act_bwd", "pmf_avgpool3s2", "pmf_avgpool3s2_bwd", "pmf_maxpool3s2",
     "pmf_maxpool3s2_bwd", "pmf_bilinear2x", "pmf_bilinear2x_bwd", "pmf_pixel_shuffle2", "pmf_pixel_shuffle2_bwd",
     "pmf_fusion_gate", "pmf_fusion_gate_bwd", "pmf_global_mean", "pmf_global_mean_bwd", "pmf_colsum",

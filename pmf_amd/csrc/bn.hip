@@ -151,6 +151,16 @@ extern "C" int pmf_bn_bwd_reduce(const float* gy, int32_t gy_ldc, const float* a
   return 0;
 }
 
+extern "C" int pmf_bn_bwd_fold(const double* part, int32_t nrows, int32_t C, int64_t npix, int32_t train,
+                               const float* gamma, const float* save_invstd, float* coef, float* dgamma, float* dbeta,
+                               pmf_stream_t s) {
+  if (nrows < 1) return PMF_E_ARG;
+  hipLaunchKernelGGL(bn_bwd_fold_k, dim3(C), dim3(64), 0, (hipStream_t)s, part, (int)nrows, C, 1.f / (float)npix, train,
+                     gamma, save_invstd, coef, dgamma, dbeta);
+  PMF_LAUNCH_CHECK();
+  return 0;
+}
+
 __global__ void bn_bwd_apply_k(const float* __restrict__ gy, int gy_ldc, const float* __restrict__ a, int a_ldc,
                                int64_t npix, int Q, int C, const float* __restrict__ coef,
                                const float* __restrict__ save_mean, int act, float* __restrict__ dz, int dz_ldc,

@@ -610,7 +610,7 @@ __global__ __launch_bounds__(256) void conv_fwd_k(const pmf_conv_desc_t d, const
   PMF_SGPR_BATCH("s"(d.out), "s"(d.bias), "s"(d.act), "s"(d.Cout), "s"(d.out_ldc), "s"(d.out_H), "s"(d.out_W), "s"(d.out_sy),
                  "s"(d.out_sx), "s"(d.out_oy), "s"(d.out_ox), "s"(d.accumulate), "s"(d.ep_cmul), "s"(d.ep_cmul_ld),
                  "s"(d.ep_relu_x), "s"(d.ep_relu_scale), "s"(d.ep_relu_shift), "s"(d.ep_relu_ldc), "s"(d.stats),
-                 "s"(d.ep_pmask));
+                 "s"(d.ep_pmask), "s"(d.ep_flags), "s"(d.ep_stat_mean));
   {
     const __amdgpu_buffer_rsrc_t orr = __builtin_amdgcn_make_buffer_rsrc((void*)d.out, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t xrr =
@@ -618,12 +618,16 @@ __global__ __launch_bounds__(256) void conv_fwd_k(const pmf_conv_desc_t d, const
     const float slope = d.act == PMF_ACT_LRELU ? 0.01f : (d.act == PMF_ACT_RELU ? 0.f : 1.f);
     const bool sig = d.act == PMF_ACT_SIGMOID, has_rx = d.ep_relu_x != nullptr, accum = d.accumulate != 0;
     const bool want_stats = d.stats != nullptr;
+    // BatchNorm-backward reduction riding on the last input-gradient launch into a gradient map: second column
+    // sum v*(x - mean) instead of sum v^2 (x = the BN input, the same tensor the ReLU mask reads when there is one)
+    const bool stat_bwd = d.ep_stat_mean != nullptr, x_only = (d.ep_flags & PMF_EP_STAT_X_ONLY) != 0;
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
       const int co = n0 + u * 32 + li;
       const bool cok = co < d.Cout;
       const float bias = (cok && d.bias) ? d.bias[co] : 0.f;
       const float ecm = (cok && d.ep_cmul) ? d.ep_cmul[(size_t)n * d.ep_cmul_ld + co] : 1.f;
+      const float smu = (cok && stat_bwd) ? d.ep_stat_mean[co] : 0.f;
       float rs = 1.f, rt = 0.f;
       if (cok && has_rx && d.ep_relu_scale) { rs = d.ep_relu_scale[co]; rt = d.ep_relu_shift[co]; }
 #pragma unroll
@@ -654,7 +658,7 @@ __global__ __launch_bounds__(256) void conv_fwd_k(const pmf_conv_desc_t d, const
           for (int r = 0; r < 16; ++r) {
             const int dx = (r & 3) + 8 * (r >> 2);
             const unsigned xo = off[r] == 0xffffffffu ? 0xffffffffu : (unsigned)(xbase + dx * xstep);
-            xr[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrr, xo, 0, 0)) * rs + rt;
+            xr[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrr, xo, 0, 0));
           }
         }
         if (accum) {
@@ -668,12 +672,12 @@ __global__ __launch_bounds__(256) void conv_fwd_k(const pmf_conv_desc_t d, const
           if (sig) v = 1.f / (1.f + __expf(-v));
           else v = v > 0.f ? v : v * slope;
           v *= ecm * pm[r];
-          if (!(xr[r] > 0.f)) v = 0.f;
+          if (!(xr[r] * rs + rt > 0.f) && !x_only) v = 0.f;
           v += old[r];
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), orr, off[r], 0, 0);
           if (want_stats && off[r] != 0xffffffffu) {
             ssum[u] += (double)v;
-            ssq[u] += (double)v * (double)v;
+            ssq[u] += (double)v * (double)(stat_bwd ? xr[r] - smu : v);
           }
         }
       }
@@ -755,15 +759,16 @@ __global__ void conv_finish_k(const pmf_conv_desc_t d, int ksplit, const float* 
         float x = pmf_act(v[k], d.act);
         if (d.ep_cmul) x *= d.ep_cmul[(size_t)n * d.ep_cmul_ld + c + k];
         if (d.ep_pmask) x *= d.ep_pmask[opix];
+        float xraw = 0.f;
         if (d.ep_relu_x) {
-          float xr = d.ep_relu_x[opix * d.ep_relu_ldc + c + k];
+          float xr = xraw = d.ep_relu_x[opix * d.ep_relu_ldc + c + k];
           if (d.ep_relu_scale) xr = xr * d.ep_relu_scale[c + k] + d.ep_relu_shift[c + k];
-          if (!(xr > 0.f)) x = 0.f;
+          if (!(xr > 0.f) && !(d.ep_flags & PMF_EP_STAT_X_ONLY)) x = 0.f;
         }
         if (d.accumulate) x += op[k];
         if (vec) xo[k] = x; else op[k] = x;
         s1[k] += (double)x;
-        s2[k] += (double)x * (double)x;
+        s2[k] += (double)x * (double)(d.ep_stat_mean ? xraw - d.ep_stat_mean[c + k] : x);
       }
       if (vec) *(f32x4*)op = xo;
     }
@@ -912,6 +917,8 @@ static int launch(const pmf_conv_desc_t* d, hipStream_t s) {
   // 32-bit byte offsets in the epilogue (buffer stores): every tensor it touches must stay below 2 GiB
   if ((int64_t)d->N * d->out_H * d->out_W * d->out_ldc * 4 >= (1ll << 31)) return PMF_E_UNSUPPORTED;
   if (d->ep_relu_x && (int64_t)d->N * d->out_H * d->out_W * d->ep_relu_ldc * 4 >= (1ll << 31)) return PMF_E_UNSUPPORTED;
+  if (d->ep_stat_mean && (!d->stats || !d->ep_relu_x)) return PMF_E_ARG;
+  if ((d->ep_flags & PMF_EP_STAT_X_ONLY) && !d->ep_stat_mean) return PMF_E_ARG;
   g.Ktot = Ktot;
   pmf_conv_desc_t dd = *d;
   dd.gather = gather;

@@ -14,6 +14,7 @@ Graph conventions
   tape turns them into the gradient w.r.t. the conv pre-activation (``T.g``), which feeds dgrad / wgrad.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -152,6 +153,8 @@ class Plan:
         self.wg_scratch = 0                 # bytes of the shared wgrad partial-sum workspace
         self.params = []                    # (param, grad Buf float offset)
         self._graphs, self._graph_seen = {}, {}   # hipGraph replay cache (see run)
+        self._conv_fold = {}                # backward conv op index -> index of the BN-backward fold op reading its rows
+        self.bn_bwd_fused = os.environ.get("PMF_BN_BWD_FUSED", "1") != "0"
         self._conv_fin = {}                 # forward conv op index -> index of the BN finalize op reading its rows
         self.n_wgrad = 0                    # weight-gradient ops emitted so far
         import os as _os
@@ -326,6 +329,7 @@ class Plan:
                 r.gy = T(self, r.t.N, r.t.H, r.t.W, r.t.C, r.t.name + ".gy", ldc=r.t.ldc)
             acc = r.gy_written
             r.gy_written = True
+            r._gy_last = None       # (_dgrad re-arms it when this writer can carry the BN-backward reduction)
             self._touch(r.gy)
             return r.gy, int(acc)
         t = r.t
@@ -384,7 +388,7 @@ class Plan:
     def add_pack(self, weight, taps_widx, transpose, K_pad, ldw):
         """register a pack job; returns the Buf of the packed slab [ntaps][K_pad][ldw]."""
         buf = self.persist.alloc(4 * len(taps_widx) * K_pad * ldw)
-        self.pack_jobs.append((weight, buf, list(taps_widx), transpose, K_pad, ldw))
+        self.pack_jobs.append((weight, buf, list(taps_widx), transpose, K_pad, ldw, self.lane))
         return buf
 
     def conv(self, srcs, conv, act=L.ACT_NONE, bn=None, order="act_bn", relu_view=False, name="", pmask=None,
@@ -525,6 +529,7 @@ class Plan:
                         view.gy = T(self, N, OH, OW, Cout, name + ".gy", ldc=out.ldc)
                     view.gy_written = self._fold_side(view, view.gy, view.gy_written)
                     view._side = None
+                    view._gy_last = None
                 if view.gy is None:
                     raise RuntimeError("plan: no gradient reached BN output of %s" % name)
                 if out.g is None:
@@ -537,16 +542,37 @@ class Plan:
                 self._touch(dz)
                 self.colrows_max = max(self.colrows_max, _ru(Cout, 4))
 
-                def r1(op):
-                    a = op.u.sm
-                    ps = (gyt.buf.ptr, out.buf.ptr, info["mean"].ptr, bn.weight.data_ptr(), info["invstd"].ptr,
-                          self.bnpart_bufs[lane].ptr, coef.ptr, self.pgrad_buf.at(dgam), self.pgrad_buf.at(dbet))
-                    for i, p in enumerate(ps):
-                        a.p[i] = p
-                    a.i[0], a.i[1], a.i[2], a.i[3] = gyt.ldc, out.ldc, Cout, bn_train_flag
-                    a.l[0] = out.npix
-                self.emit(self.bwd, L.OP_BN_BWD_REDUCE, r1)
-                self.note_bytes(self.bwd, "bn_bwd_reduce", 8.0 * out.npix * Cout)
+                lw = getattr(view, "_gy_last", None)
+                if lw is not None and lw["lane"] == lane:
+                    # the last writer of gy was an input-gradient launch on this lane: it carried the reduction
+                    # (sum gy, sum gy*(a - mean) per tile row) in its epilogue; only the fold is left
+                    probe = L.ConvDesc()
+                    lw["shape"](probe)
+                    nrows = L.lib().pmf_conv_fwd_stat_rows(C.byref(probe))
+                    rows = self.act.alloc(16 * Cout * max(nrows, L.lib().pmf_conv_fwd_stat_rows_max(C.byref(probe))))
+                    lw["hook"].update(rows=rows, mean=info["mean"])
+
+                    def r1(op):
+                        a = op.u.sm
+                        ps = (rows.ptr, bn.weight.data_ptr(), info["invstd"].ptr, coef.ptr, self.pgrad_buf.at(dgam),
+                              self.pgrad_buf.at(dbet))
+                        for i, p in enumerate(ps):
+                            a.p[i] = p
+                        a.i[0], a.i[1], a.i[2] = Cout, nrows, bn_train_flag
+                        a.l[0] = out.npix
+                    self.emit(self.bwd, L.OP_BN_BWD_FOLD, r1)
+                    self._conv_fold[lw["index"]] = len(self.bwd) - 1
+                else:
+                    def r1(op):
+                        a = op.u.sm
+                        ps = (gyt.buf.ptr, out.buf.ptr, info["mean"].ptr, bn.weight.data_ptr(), info["invstd"].ptr,
+                              self.bnpart_bufs[lane].ptr, coef.ptr, self.pgrad_buf.at(dgam), self.pgrad_buf.at(dbet))
+                        for i, p in enumerate(ps):
+                            a.p[i] = p
+                        a.i[0], a.i[1], a.i[2], a.i[3] = gyt.ldc, out.ldc, Cout, bn_train_flag
+                        a.l[0] = out.npix
+                    self.emit(self.bwd, L.OP_BN_BWD_REDUCE, r1)
+                    self.note_bytes(self.bwd, "bn_bwd_reduce", 8.0 * out.npix * Cout)
                 self.grad_done[id(bn.weight)] = self.grad_done[id(bn.bias)] = len(self.bwd) - 1
 
                 def r2(op):
@@ -653,19 +679,29 @@ class Plan:
                         acc = 1
                 relu_x = r.t if r.relu else None
                 for (py, px, sub), wT in zip(classes, packs):
-                    def f(op, s=s, r=r, sub=sub, wT=wT, tgt=tgt, acc=acc, coloff=coloff, py=py, px=px,
-                          relu_x=relu_x):
-                        d = op.u.conv
+                    def shape_only(d, s=s, sub=sub, tgt=tgt, py=py, px=px):
                         H, W = tgt.H, tgt.W
                         d.N = dz.N
                         d.OH, d.OW = (H, W) if stride == 1 else ((H - py + 1) // 2, (W - px + 1) // 2)
                         d.Cout, d.nsrc = s.t.C, 1
                         sv = d.src[0]
-                        sv.x, sv.C, sv.ldc, sv.H, sv.W = dz.buf.ptr, Kd, dz.ldc, dz.H, dz.W
+                        sv.C, sv.ldc, sv.H, sv.W = Kd, dz.ldc, dz.H, dz.W
                         d.ntaps = len(sub)
                         for i, (dy, dx, _) in enumerate(sub):
                             d.tdy[i], d.tdx[i] = dy, dx
                         d.in_stride, d.gather = 1, gather
+                        d.out_sy = d.out_sx = stride
+                        d.splitk_ws, d.splitk_ws_bytes = 1, SPLITK_BYTES
+                    # filled in by the BatchNorm backward of the layer that produced this operand when THIS launch is
+                    # the last writer of its output gradient: the launch then also writes the BN-backward partial sums
+                    hook = {}
+
+                    def f(op, s=s, r=r, sub=sub, wT=wT, tgt=tgt, acc=acc, coloff=coloff, py=py, px=px,
+                          relu_x=relu_x, shape_only=shape_only, hook=hook):
+                        d = op.u.conv
+                        shape_only(d)
+                        H, W = tgt.H, tgt.W
+                        d.src[0].x = dz.buf.ptr
                         d.w, d.ldw = wT.at(coloff), ldwT
                         d.act = L.ACT_NONE
                         d.out, d.out_ldc, d.out_H, d.out_W = tgt.buf.ptr, tgt.ldc, H, W
@@ -679,7 +715,13 @@ class Plan:
                             d.ep_relu_x, d.ep_relu_ldc = relu_x.buf.ptr, relu_x.ldc
                             d.ep_relu_scale = r.scale.ptr if r.scale is not None else None
                             d.ep_relu_shift = r.shift.ptr if r.shift is not None else None
+                        if hook:
+                            d.stats, d.ep_stat_mean = hook["rows"].ptr, hook["mean"].ptr
+                            if relu_x is None:
+                                d.ep_relu_x, d.ep_relu_ldc, d.ep_flags = r.t.buf.ptr, r.t.ldc, L.EP_STAT_X_ONLY
                     self.emit(self.bwd, L.OP_CONV, f)
+                    if (stride == 1 and tmp is None and r.bn is not None and tgt is r.gy and self.bn_bwd_fused):
+                        r._gy_last = dict(hook=hook, index=len(self.bwd) - 1, shape=shape_only, lane=lane)
                     mh = tgt.H if stride == 1 else (tgt.H - py + 1) // 2
                     mw = tgt.W if stride == 1 else (tgt.W - px + 1) // 2
                     self.meta_bwd[len(self.bwd) - 1] = dict(
@@ -1155,26 +1197,29 @@ class Plan:
             a.materialise(dev, zero)
         self.masks_ptr = self.masks.data_ptr() if self.masks is not None else 0
         lib = L.lib()
-        # pack job table (device) --------------------------------------------------------------
-        njobs = len(self.pack_jobs)
-        jobs = (L.PackJob * max(njobs, 1))()
-        blocks = 0
-        for j, (w, buf, tap_idx, transpose, K_pad, ldw) in enumerate(self.pack_jobs):
-            Cout, Cin, KHW = w.shape[0], w.shape[1], w.shape[2] * w.shape[3]
-            ct = lib.pmf_pack_tile_ci(Cin, KHW)
-            J = jobs[j]
-            J.w, J.dst = w.data_ptr(), buf.ptr
-            J.Cout, J.Cin, J.KHW, J.ntaps, J.transpose = Cout, Cin, KHW, len(tap_idx), transpose
-            J.K_pad, J.ldw, J.CT = K_pad, ldw, ct
-            J.tiles_ci = (Cin + ct - 1) // ct
-            J.block_start = blocks
-            for i, ti in enumerate(tap_idx):
-                J.tap_idx[i] = ti
-            blocks += J.tiles_ci * ((Cout + 31) // 32)
-        raw = bytes(jobs)
-        self.jobs_dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
-        self.n_pack_jobs, self.n_pack_blocks = njobs, blocks
-        self.pack_is_bwd = [bool(j[3]) for j in self.pack_jobs]
+        # pack job tables (device), one per lane: every lane re-packs the weights of its own layers at the start of the
+        # forward pass (they change every step), concurrently with the other lane's ---------------------------------
+        self.pack_tables = []
+        for lane in sorted({j[6] for j in self.pack_jobs}):
+            mine = [j for j in self.pack_jobs if j[6] == lane]
+            jobs = (L.PackJob * len(mine))()
+            blocks = 0
+            for j, (w, buf, tap_idx, transpose, K_pad, ldw, _) in enumerate(mine):
+                Cout, Cin, KHW = w.shape[0], w.shape[1], w.shape[2] * w.shape[3]
+                ct = lib.pmf_pack_tile_ci(Cin, KHW)
+                J = jobs[j]
+                J.w, J.dst = w.data_ptr(), buf.ptr
+                J.Cout, J.Cin, J.KHW, J.ntaps, J.transpose = Cout, Cin, KHW, len(tap_idx), transpose
+                J.K_pad, J.ldw, J.CT = K_pad, ldw, ct
+                J.tiles_ci = (Cin + ct - 1) // ct
+                J.block_start = blocks
+                for i, ti in enumerate(tap_idx):
+                    J.tap_idx[i] = ti
+                blocks += J.tiles_ci * ((Cout + 31) // 32)
+            dev_tab = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(dev)
+            self.pack_tables.append((lane, dev_tab, len(mine), blocks))
+        self.n_pack_jobs = len(self.pack_jobs)
+        self.n_pack_blocks = sum(t[3] for t in self.pack_tables)
 
         def build(lst, prologue):
             n = len(lst) + len(prologue)
@@ -1188,10 +1233,12 @@ class Plan:
                 k += 1
             return arr, n
 
-        def pack_op(op):
-            a = op.u.sm
-            a.p[0] = self.jobs_dev.data_ptr()
-            a.i[0], a.i[1] = njobs, blocks
+        def pack_op(tab, n, blocks):
+            def f(op):
+                a = op.u.sm
+                a.p[0] = tab.data_ptr()
+                a.i[0], a.i[1] = n, blocks
+            return f
 
         def zero_arena(arena):
             def z(op):
@@ -1199,9 +1246,10 @@ class Plan:
                 a.p[0], a.f[0], a.l[0] = arena.base, 0.0, arena.size // 4
             return z
 
-        pro_f = [(L.OP_PACK, pack_op)] if njobs else []
+        # lane 0 first: a side lane forks from the main stream at its first op and must not wait for lane 0's packing
+        pro_f = [(L.OP_PACK, pack_op(tab, n, blocks), lane) for lane, tab, n, blocks in sorted(self.pack_tables, key=lambda t: -t[0])]
         if self.zero_fwd.size:
-            pro_f.append((L.OP_FILL, zero_arena(self.zero_fwd)))
+            pro_f.insert(0, (L.OP_FILL, zero_arena(self.zero_fwd)))
         self.fwd_shift = len(pro_f)
         self.fwd_ops, self.n_fwd = build(self.fwd, pro_f)
         if self.training:
@@ -1230,7 +1278,7 @@ class Plan:
         0 = heuristics) -- each configuration the autotuner may choose is pinned against float64 this way."""
         lib = L.lib()
         for ops, n, kinds, shift, fins in ((self.fwd_ops, self.n_fwd, self.fwd_kinds, self.fwd_shift, self._conv_fin),
-                                           (self.bwd_ops, self.n_bwd, self.bwd_kinds, self.bwd_shift, {})):
+                                           (self.bwd_ops, self.n_bwd, self.bwd_kinds, self.bwd_shift, self._conv_fold)):
             for k in range(n):
                 if kinds[k] != L.OP_CONV:
                     continue
@@ -1276,10 +1324,10 @@ class Plan:
                           for i in range(d.nsrc)),
                     d.ntaps, tuple(d.tdy[i] for i in range(d.ntaps)), tuple(d.tdx[i] for i in range(d.ntaps)),
                     d.in_stride, d.gather, d.act, d.out_sy, d.out_sx, d.accumulate, bool(d.bias), bool(d.ep_cmul),
-                    bool(d.ep_relu_x), bool(d.stats), bool(d.ep_pmask))
+                    bool(d.ep_relu_x), bool(d.stats), bool(d.ep_pmask), bool(d.ep_stat_mean), d.ep_flags)
 
         for ops, n, kinds, shift, fins in ((self.fwd_ops, self.n_fwd, self.fwd_kinds, self.fwd_shift, self._conv_fin),
-                                           (self.bwd_ops, self.n_bwd, self.bwd_kinds, self.bwd_shift, {})):
+                                           (self.bwd_ops, self.n_bwd, self.bwd_kinds, self.bwd_shift, self._conv_fold)):
             for k in range(n):
                 if kinds[k] != L.OP_CONV:
                     continue
