@@ -90,8 +90,15 @@ typedef struct {
                               * sum out * (ep_relu_x - mean) instead of sum out^2 -- the BatchNorm-backward reduction
                               * (pmf_bn_bwd_reduce) of an input-gradient launch that is the LAST writer of that
                               * gradient map, folded by pmf_bn_bwd_fold */
+  const void* w_s3;          /* optional, instead of w: the weights split into three bf16 planes in MFMA B-fragment order
+                              * [ntaps][Ktot/16][ldw/32][3][64 lanes][8 bf16] (pmf_pack_job_t.format 1).  The launch then
+                              * runs fp32 arithmetic on the bf16 matrix pipe (six split products, fp32 accumulate: see
+                              * conv_fwd.hip PIPE 5); only for descriptors with pmf_conv_s3_eligible() != 0 */
 } pmf_conv_desc_t;
 #define PMF_EP_STAT_X_ONLY 1
+/* 1 when every tile configuration of this descriptor runs the software-pipelined K loop (stride 1, one halo tile,
+ * every operand a multiple of 16 channels, same H x W, no broadcast): the class pmf_conv_fwd accepts w_s3 for */
+int pmf_conv_s3_eligible(const pmf_conv_desc_t* d);
 
 int pmf_conv_fwd(const pmf_conv_desc_t* d, pmf_stream_t s);
 
@@ -149,6 +156,7 @@ typedef struct {
   float* dst;
   int32_t Cout, Cin, KHW, ntaps, transpose, K_pad, ldw, CT, tiles_ci, block_start;
   int8_t tap_idx[PMF_MAX_TAPS + 3];
+  int32_t format;            /* 0: fp32 slabs [tap][K_pad][ldw]; 1: split-bf16 fragments (pmf_conv_desc_t.w_s3) */
 } pmf_pack_job_t;
 int pmf_pack_tile_ci(int32_t Cin, int32_t KHW);
 int pmf_pack_weights_batched(const pmf_pack_job_t* jobs_dev, int32_t njobs, int32_t total_blocks, pmf_stream_t s);

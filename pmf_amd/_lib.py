@@ -41,7 +41,7 @@ class ConvDesc(C.Structure):
                 ("ep_relu_scale", C.c_void_p), ("ep_relu_shift", C.c_void_p), ("ep_relu_ldc", C.c_int32),
                 ("stats", C.c_void_p), ("ep_pmask", C.c_void_p), ("splitk_ws", C.c_void_p),
                 ("splitk_ws_bytes", C.c_int64), ("cfg", C.c_int32), ("ep_flags", C.c_int32),
-                ("ep_stat_mean", C.c_void_p)]
+                ("ep_stat_mean", C.c_void_p), ("w_s3", C.c_void_p)]
 
 
 class WgradDesc(C.Structure):
@@ -78,7 +78,7 @@ class PackJob(C.Structure):
     _fields_ = [("w", C.c_void_p), ("dst", C.c_void_p), ("Cout", C.c_int32), ("Cin", C.c_int32), ("KHW", C.c_int32),
                 ("ntaps", C.c_int32), ("transpose", C.c_int32), ("K_pad", C.c_int32), ("ldw", C.c_int32),
                 ("CT", C.c_int32), ("tiles_ci", C.c_int32), ("block_start", C.c_int32),
-                ("tap_idx", C.c_int8 * (MAX_TAPS + 3))]
+                ("tap_idx", C.c_int8 * (MAX_TAPS + 3)), ("format", C.c_int32)]
 
 
 _lib = None
@@ -201,7 +201,7 @@ def lib():
 
 EXPORTS = [
     "pmf_conv_fwd", "pmf_conv_wgrad", "pmf_conv_wgrad_partial", "pmf_conv_wgrad_reduce", "pmf_conv_wgrad_reduce_plan", "pmf_conv_wgrad_reduce_multi", "pmf_conv_wgrad_workspace", "pmf_conv_wgrad_nsplit", "pmf_pack_tile_ci",
-    "pmf_pack_weights_batched", "pmf_conv_fwd_stat_rows", "pmf_conv_fwd_stat_rows_max", "pmf_conv_fwd_kstages", "pmf_col_rows", "pmf_bn_finalize", "pmf_bn_eval_affine", "pmf_bn_bwd_reduce", "pmf_bn_bwd_fold", "pmf_bn_bwd_apply",
+    "pmf_pack_weights_batched", "pmf_conv_fwd_stat_rows", "pmf_conv_s3_eligible", "pmf_conv_fwd_stat_rows_max", "pmf_conv_fwd_kstages", "pmf_col_rows", "pmf_bn_finalize", "pmf_bn_eval_affine", "pmf_bn_bwd_reduce", "pmf_bn_bwd_fold", "pmf_bn_bwd_apply",
     "pmf_add_act", "pmf_add_act_bwd", "pmf_act_bwd", "pmf_avgpool3s2", "pmf_avgpool3s2_bwd", "pmf_maxpool3s2",
     "pmf_maxpool3s2_bwd", "pmf_bilinear2x", "pmf_bilinear2x_bwd", "pmf_pixel_shuffle2", "pmf_pixel_shuffle2_bwd",
     "pmf_fusion_gate", "pmf_fusion_gate_bwd", "pmf_global_mean", "pmf_global_mean_bwd", "pmf_colsum",

@@ -365,6 +365,265 @@ __device__ __forceinline__ void conv_kloop_pipe(const pmf_conv_desc_t& d, const 
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// PIPE 5: fp32 convolution on the bf16 matrix pipe by operand splitting (the pipelined class only).
+// Every fp32 operand x is written as x = h1 + h2 + h3 with h1 = bf16(x), h2 = bf16(x - h1), h3 = bf16(x - h1 - h2)
+// (round-to-nearest-even; both subtractions are exact in fp32 and 3 x 8 significand bits cover the 24 of fp32, so the
+// split itself is exact up to 2^-25 |x|).  A product a*b is then the sum of the SIX bf16 products of order <= 2^-16
+//      a1 b1 + (a1 b2 + a2 b1) + (a1 b3 + a2 b2 + a3 b1),
+// each exact in the fp32 accumulator of v_mfma_f32_32x32x16_bf16; what is dropped (a2 b3 + a3 b2 + a3 b3) is below
+// 2^-23 |a b| -- the size of ONE fp32 rounding of the product, so the result carries fp32-class error (pinned against the
+// float64 oracle by the same tests and tolerances as the v_mfma_f32_32x32x2_f32 path; PMF_CONV_F32=1 selects that path).
+// Six 32-cycle MFMAs cover 16 channels of a 32x32 tile where the fp32 pipe needs eight 64-cycle ones (2.67x).
+//   * input tile: staged exactly like PIPE 1 (slot tables, loads a chunk ahead, BatchNorm-apply / ReLU / mask folded
+//     in), then split while it is written to LDS as [pixel][plane][16 bf16], pixel pitch 112 B (an odd number of 16-B
+//     slots: the 16-lane groups of ds_read_b128 hit 16 distinct slots);
+//   * weights: split ONCE per optimiser step by the pack kernel and stored in MFMA B-fragment order
+//     [tap][K/16][Cout/32][plane][lane][8 bf16]: one fragment = 1 KiB contiguous = one LDS-DMA wave instruction, and
+//     its LDS image is lane-linear (conflict-free reads).  The taps of a chunk are split into two halves that ping-pong
+//     like the channel halves of PIPE 1.
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+#define S3_APB 112
+
+__device__ __forceinline__ unsigned s3_pk(f32x2 v) { return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2)); }
+__device__ __forceinline__ f32x2 s3_unpk(unsigned u) {
+  return f32x2{__builtin_bit_cast(float, u << 16), __builtin_bit_cast(float, u & 0xffff0000u)};
+}
+// two floats -> their three bf16 planes (packed pairs)
+__device__ __forceinline__ void s3_split2(float a, float b, unsigned& p0, unsigned& p1, unsigned& p2) {
+  f32x2 r = {a, b};
+  p0 = s3_pk(r);
+  r = r - s3_unpk(p0);
+  p1 = s3_pk(r);
+  r = r - s3_unpk(p1);
+  p2 = s3_pk(r);
+}
+
+// NTH taps of one half: A fragments (MT x 3 planes) and B fragments (NT x 3 planes) of tap i+1 are read while the
+// 6 MT NT MFMAs of tap i run
+template <int BN, int MT, int NTH, class Fill = NoFill>
+__device__ __forceinline__ void s3_half(f32x16 (&acc)[MT][BN / 32], const char* __restrict__ As,
+                                        const char* __restrict__ Bh, const int (&abase)[MT], const int (&aoff)[TAPG],
+                                        int t0, int lane, Fill fill = Fill()) {
+  constexpr int NT = BN / 32;
+  bf16x8 a[2][MT][3], b[2][NT][3];
+  const char* bp0 = Bh + lane * 16;
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int p = 0; p < 3; ++p) a[0][m][p] = *(const bf16x8*)(As + abase[m] + aoff[t0] + p * 32);
+#pragma unroll
+  for (int u = 0; u < NT; ++u)
+#pragma unroll
+    for (int p = 0; p < 3; ++p) b[0][u][p] = *(const bf16x8*)(bp0 + (u * 3 + p) * 1024);
+#pragma unroll
+  for (int st = 0; st < NTH; ++st) {
+    const int cur = st & 1, nxt = cur ^ 1;
+    if (st + 1 < NTH) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) a[nxt][m][p] = *(const bf16x8*)(As + abase[m] + aoff[t0 + st + 1] + p * 32);
+#pragma unroll
+      for (int u = 0; u < NT; ++u)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) b[nxt][u][p] = *(const bf16x8*)(bp0 + (((st + 1) * NT + u) * 3 + p) * 1024);
+    }
+    fill(st, NTH);
+    // smallest terms first
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int u = 0; u < NT; ++u) {
+        acc[m][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][m][0], b[cur][u][2], acc[m][u], 0, 0, 0);
+        acc[m][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][m][1], b[cur][u][1], acc[m][u], 0, 0, 0);
+        acc[m][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][m][2], b[cur][u][0], acc[m][u], 0, 0, 0);
+        acc[m][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][m][0], b[cur][u][1], acc[m][u], 0, 0, 0);
+        acc[m][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][m][1], b[cur][u][0], acc[m][u], 0, 0, 0);
+        acc[m][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][m][0], b[cur][u][0], acc[m][u], 0, 0, 0);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int BN, int MT>
+__device__ __forceinline__ void conv_kloop_s3(const pmf_conv_desc_t& d, const ConvGeom& g, f32x16 (&acc)[MT][BN / 32],
+                                              char* __restrict__ As, char* __restrict__ Bs, const int (&segrow)[MT],
+                                              const int (&segcol)[MT], int tid, int li, int lh, int n, int n0, int ks,
+                                              int oy0, int ox0, int& tri_) {
+  constexpr int NT = BN / 32;
+  constexpr int ASL = MT == 2 ? 7 : 5;            // float4 slots per thread for the input tile
+  constexpr int NF = 5 * NT * 3;                  // fragments of the larger half (<= 5 taps)
+  constexpr int NDMA = (NF + 3) / 4;              // DMA instructions per wave per half
+  const int in_cols = g.in_cols;
+  const int sH = d.src[0].H, sW = d.src[0].W;
+  const int q = tid & 3;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int totalA = g.in_rows * in_cols * 4;
+  const int nt0 = (d.ntaps + 1) >> 1, nt1 = d.ntaps - nt0;   // taps of half 0 / half 1
+  char* __restrict__ Bh1 = Bs + nt0 * NT * 3 * 1024;
+  const int KS = g.Ktot >> 4, CT = d.ldw >> 5;
+  int gA[ASL];
+  unsigned okA = 0u;
+#pragma unroll
+  for (int j = 0; j < ASL; ++j) {
+    const int f = tid + 256 * j, pix = f >> 2;
+    const int r = pix / in_cols, c = pix - r * in_cols;
+    const int iy = oy0 + g.dy_min + r, ix = ox0 + g.dx_min + c;
+    const bool ok = f < totalA && iy >= 0 && iy < sH && ix >= 0 && ix < sW;
+    gA[j] = ok ? (n * sH + iy) * sW + ix : -1;
+    okA |= ok ? (1u << j) : 0u;
+  }
+  TR();
+  int aoff[TAPG];
+  {
+    int ty[TAPG], tx[TAPG];
+#pragma unroll
+    for (int t = 0; t < TAPG; ++t) { ty[t] = d.tdy[t]; tx[t] = d.tdx[t]; }
+    PMF_SGPR_BATCH("s"(ty[0]), "s"(ty[1]), "s"(ty[2]), "s"(ty[3]), "s"(ty[4]), "s"(ty[5]), "s"(ty[6]), "s"(ty[7]),
+                   "s"(ty[8]), "s"(tx[0]), "s"(tx[1]), "s"(tx[2]), "s"(tx[3]), "s"(tx[4]), "s"(tx[5]), "s"(tx[6]),
+                   "s"(tx[7]), "s"(tx[8]));
+#pragma unroll
+    for (int t = 0; t < TAPG; ++t)
+      aoff[t] = t < d.ntaps ? ((ty[t] - g.dy_min) * in_cols + (tx[t] - g.dx_min)) * S3_APB : 0;
+  }
+  int abase[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) abase[m] = (segrow[m] * in_cols + segcol[m] * 32 + li) * S3_APB + lh * 16;
+
+  int si = 0, c0 = 0, kb = 0, cn = 0;
+  auto settle = [&]() {
+    for (;;) {
+      if (si >= d.nsrc) return false;
+      if (c0 >= d.src[si].C) { kb += d.src[si].C; ++si; c0 = 0; continue; }
+      if ((cn % g.ksplit) == ks) return true;
+      ++cn; c0 += KC;
+    }
+  };
+  f32x4 rA[ASL], sc4, sh4, cm4;
+  int cur_flags = 0;
+  bool cur_aff = false;
+  __amdgpu_buffer_rsrc_t nrs;
+  int nld = 0, ncch = 0;
+  const char* __restrict__ nw = nullptr;   // fragment (tap 0, plane 0) of the stage being fetched, first output tile (uniform)
+  const size_t tap_stride = (size_t)KS * CT * 3 * 1024;
+  auto head = [&]() {
+    const float* sx = d.src[si].x;
+    const float* ssc = d.src[si].scale;
+    const float* ssh = d.src[si].shift;
+    const float* scm = d.src[si].cmul;
+    const int sld = d.src[si].ldc, sfl = d.src[si].flags, scl = d.src[si].cmul_ld;
+    PMF_SGPR_BATCH("s"(sx), "s"(ssc), "s"(ssh), "s"(scm), "s"(sld), "s"(sfl), "s"(scl));
+    nrs = __builtin_amdgcn_make_buffer_rsrc((void*)sx, 0, d.N * sH * sW * sld * 4, 0x00020000);
+    nld = sld; ncch = c0 + q * 4;
+    cur_flags = sfl;
+    cur_aff = ssc != nullptr;
+    sc4 = f32x4{1.f, 1.f, 1.f, 1.f}; sh4 = f32x4{0.f, 0.f, 0.f, 0.f}; cm4 = f32x4{1.f, 1.f, 1.f, 1.f};
+    if (cur_aff) { sc4 = *(const f32x4*)(ssc + ncch); sh4 = *(const f32x4*)(ssh + ncch); }
+    if (scm) cm4 = *(const f32x4*)(scm + (size_t)n * scl + ncch);
+    nw = (const char*)d.w_s3 + ((size_t)((kb + c0) >> 4) * CT + (n0 >> 5)) * 3 * 1024;
+  };
+  auto loadA = [&](int j) {
+    rA[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(nrs, (gA[j] * nld + ncch) * 4, 0, 0));
+  };
+  // fragments ((t - ta) NT + u) 3 + p of taps [ta, ta + nth) -> dst, one 1-KiB DMA instruction each
+  auto dma_half = [&](const char* __restrict__ wsrc, char* __restrict__ dst, int ta, int nth) {
+#pragma unroll
+    for (int jj = 0; jj < NDMA; ++jj) {
+      const int f = wave + 4 * jj;                 // wave-uniform
+      if (f < nth * NT * 3) {
+        const int tl = f / (NT * 3), up = f - tl * (NT * 3);
+        __builtin_amdgcn_global_load_lds((const float*)(wsrc + (size_t)(ta + tl) * tap_stride + up * 1024 + lane * 16),
+                                         (lds_ptr_t)(dst + f * 1024), 16, 0, 0);
+      }
+    }
+  };
+  TR();
+  bool have = settle();
+  const char* __restrict__ wcur = nullptr;
+  if (have) {
+    head();
+    TR();
+#pragma unroll
+    for (int j = 0; j < ASL; ++j) loadA(j);
+    dma_half(nw, Bs, 0, nt0);
+  }
+  TR();
+  auto storeA = [&](char* __restrict__ dst) {
+#pragma unroll
+    for (int j = 0; j < ASL; ++j) {
+      const int f = tid + 256 * j;
+      if (f < totalA) {
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+        if ((okA >> j) & 1u) {
+          t = rA[j];
+          if (cur_aff) t = t * sc4 + sh4;
+          if (cur_flags & PMF_SRC_RELU) {
+            t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f);
+          }
+          t = t * cm4;
+        }
+        unsigned l0, l1, l2, h0, h1, h2;
+        s3_split2(t.x, t.y, l0, l1, l2);
+        s3_split2(t.z, t.w, h0, h1, h2);
+        char* o = dst + (f >> 2) * S3_APB + q * 8;
+        *(u32x2*)(o) = u32x2{l0, h0};
+        *(u32x2*)(o + 32) = u32x2{l1, h1};
+        *(u32x2*)(o + 64) = u32x2{l2, h2};
+      }
+    }
+  };
+  auto fill = [&](int st, int ns) {
+    constexpr int per = 2;
+#pragma unroll
+    for (int j = 0; j < ASL; ++j)
+      if (j >= st * per && j < (st + 1) * per) loadA(j);
+    if (st == ns - 1) {
+#pragma unroll
+      for (int j = 0; j < ASL; ++j)
+        if (j >= ns * per) loadA(j);
+    }
+  };
+  auto mfma_half = [&](const char* __restrict__ Bt, int t0, int nth, bool with_fill) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) asm volatile("" : "+v"(abase[m]));
+    __builtin_amdgcn_sched_barrier(0);
+    if (with_fill) {
+      if (nth == 5) s3_half<BN, MT, 5>(acc, As, Bt, abase, aoff, t0, lane, fill);
+      else if (nth == 2) s3_half<BN, MT, 2>(acc, As, Bt, abase, aoff, t0, lane, fill);
+      else s3_half<BN, MT, 1>(acc, As, Bt, abase, aoff, t0, lane, fill);
+    } else {
+      if (nth == 4) s3_half<BN, MT, 4>(acc, As, Bt, abase, aoff, t0, lane);
+      else if (nth == 2) s3_half<BN, MT, 2>(acc, As, Bt, abase, aoff, t0, lane);
+      else if (nth == 1) s3_half<BN, MT, 1>(acc, As, Bt, abase, aoff, t0, lane);
+    }
+  };
+  while (have) {
+    __syncthreads();                       // X: everyone finished the MFMAs of the previous chunk
+    TR();
+    storeA(As);
+    wcur = nw;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of B(half 0) has landed in LDS
+    __syncthreads();                       // Y: input tile + half 0 visible
+    TR();
+    ++cn; c0 += KC;
+    have = settle();
+    if (have) head();
+    else nrs = __builtin_amdgcn_make_buffer_rsrc((void*)d.src[0].x, 0, 0, 0x00020000);
+    if (nt1) dma_half(wcur, Bh1, nt0, nt1);
+    mfma_half(Bs, 0, nt0, true);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // B(half 1) (and the next input tile) landed
+    __syncthreads();                       // Z: everyone finished reading half 0
+    TR();
+    if (have) dma_half(nw, Bs, 0, nt0);
+    if (nt1) mfma_half(Bh1, nt0, nt1, false);
+    TR();
+  }
+}
+
 // PIPE: 0 generic K loop, 1 pipelined, 4 pipelined with 64-channel stages (1x1 convs).
 // Measured and rejected on this loop (kept out of the code): a second input tile in LDS (two barriers per chunk instead
 // of three: 49.2 vs 47.8 us on 64->64 3x3 at 32x1024, 23.60 vs 23.23 ms per training step); a start delay for the
@@ -383,7 +642,7 @@ __global__ __launch_bounds__(256) void conv_fwd_k(const pmf_conv_desc_t d, const
                    "s"(g.kc_alloc), "s"(g.a_floats), "s"(g.ksplit));
   }
   float* __restrict__ As = smem;
-  float* __restrict__ Bs = smem + g.a_floats * (PIPE > 1 ? PIPE : 1);
+  float* __restrict__ Bs = smem + g.a_floats * ((PIPE > 1 && PIPE < 5) ? PIPE : 1);
   constexpr int NT = BN / 32;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
@@ -425,7 +684,9 @@ __global__ __launch_bounds__(256) void conv_fwd_k(const pmf_conv_desc_t d, const
     segcol[m] = s & ((1 << g.segs_x_log2) - 1);
   }
 
-  if constexpr (PIPE != 0) {
+  if constexpr (PIPE == 5) {
+    conv_kloop_s3<BN, MT>(d, g, acc, (char*)smem, (char*)(smem + g.a_floats), segrow, segcol, tid, li, lh, n, n0, ks, oy0, ox0, tri_);
+  } else if constexpr (PIPE != 0) {
     conv_kloop_pipe<BN, MT, (PIPE > 1 ? PIPE : 1)>(d, g, acc, As, Bs, segrow, segcol, tid, li, lh, n, n0, ks, oy0, ox0, tri_);
   } else {
   const int ngroups = d.gather ? d.ntaps : 1;
@@ -928,10 +1189,21 @@ static int launch(const pmf_conv_desc_t* d, hipStream_t s) {
     (void)hipFuncSetAttribute((const void*)conv_fwd_k<BN, MT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if constexpr (MT == 1)
       (void)hipFuncSetAttribute((const void*)conv_fwd_k<BN, 1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_fwd_k<BN, MT, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   const int co_tiles = cdiv(d->Cout, BN);
-  const int mode = conv_pipe_mode(d, g, gather, MT);
+  int mode = conv_pipe_mode(d, g, gather, MT);
+  if (d->w_s3) {             // split-bf16 weights: the pipelined class only (pmf_conv_s3_eligible)
+    if (mode == 0 || (d->ldw & 31)) return PMF_E_UNSUPPORTED;
+    mode = 5;
+    g.a_floats = round_up(g.in_rows * g.in_cols * (S3_APB / 4), 4);
+    lds = g.a_floats * 4 + d->ntaps * (BN / 32) * 3 * 1024;
+    if (lds < 2 * 4 * 64 * 2 * 8) lds = 2 * 4 * 64 * 2 * 8;
+    if (lds > 160 * 1024) return PMF_E_UNSUPPORTED;
+  } else if (!d->w) {
+    return PMF_E_ARG;
+  }
   if (mode == 4) {           // 64-channel stages
     nchunks = 0;
     for (int i = 0; i < d->nsrc; ++i) nchunks += d->src[i].C / (KC * 4);
@@ -941,7 +1213,9 @@ static int launch(const pmf_conv_desc_t* d, hipStream_t s) {
   g.ws = d->splitk_ws;
   g.ws_ld = round_up(d->Cout, 4);
   dim3 grid(g.tiles_x * g.tiles_y, co_tiles * g.ksplit, d->N);
-  if (mode == 4) {
+  if (mode == 5) {
+    hipLaunchKernelGGL((conv_fwd_k<BN, MT, 5>), grid, dim3(256), lds, s, dd, g);
+  } else if (mode == 4) {
     if constexpr (MT == 1) hipLaunchKernelGGL((conv_fwd_k<BN, 1, 4>), grid, dim3(256), lds, s, dd, g);
   } else if (mode == 1) {
     g.kc_alloc = KC;   // the pipelined loop lays the weight slab out as [tap][16][BN]
@@ -971,12 +1245,26 @@ extern "C" int pmf_conv_fwd_stat_rows(const pmf_conv_desc_t* d) {
   pmf_conv_geometry(d->OH, d->OW, d->ntaps, d->tdy, d->tdx, d->in_stride, d->gather, BN, MT, cmax < KC ? cmax : KC, &g,
                     &gather);
   const int tiles = g.tiles_x * g.tiles_y;
-  if (conv_pipe_mode(d, g, gather, MT) == 4) {      // same stage count as launch<>()
+  if (!d->w_s3 && conv_pipe_mode(d, g, gather, MT) == 4) {      // same stage count as launch<>()
     nchunks = 0;
     for (int i = 0; i < d->nsrc; ++i) nchunks += d->src[i].C / (KC * 4);
   }
   if (choose_ksplit(d, tiles * d->N * cdiv(d->Cout, BN), nchunks, d->ntaps * 8 * MT * (BN / 32)) > 1) return finish_rows(d);
   return tiles * d->N;
+}
+
+extern "C" int pmf_conv_s3_eligible(const pmf_conv_desc_t* d) {
+  int cmax = 0;
+  for (int i = 0; i < d->nsrc; ++i) cmax = d->src[i].C > cmax ? d->src[i].C : cmax;
+  for (int MT = 1; MT <= 2; ++MT) {
+    ConvGeom g;
+    int gather;
+    pmf_conv_geometry(d->OH, d->OW, d->ntaps, d->tdy, d->tdx, d->in_stride, d->gather, 64, MT, cmax < KC ? cmax : KC, &g,
+                      &gather);
+    if (conv_pipe_mode(d, g, gather, MT) == 0) return 0;
+    if (g.in_rows * g.in_cols * S3_APB + d->ntaps * 2 * 3 * 1024 > 160 * 1024) return 0;
+  }
+  return 1;
 }
 
 extern "C" int pmf_conv_fwd_stat_rows_max(const pmf_conv_desc_t* d) {
@@ -996,7 +1284,7 @@ extern "C" int pmf_conv_fwd_kstages(const pmf_conv_desc_t* d) {
   ConvGeom g;
   pmf_conv_geometry(d->OH, d->OW, d->ntaps, d->tdy, d->tdx, d->in_stride, d->gather, BN, MT, cmax < KC ? cmax : KC, &g,
                     &gather);
-  if (conv_pipe_mode(d, g, gather, MT) == 4) {
+  if (!d->w_s3 && conv_pipe_mode(d, g, gather, MT) == 4) {
     nchunks = 0;
     for (int i = 0; i < d->nsrc; ++i) nchunks += d->src[i].C / (KC * 4);
   }

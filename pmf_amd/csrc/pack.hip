@@ -24,6 +24,28 @@ __global__ __launch_bounds__(256) void pack_k(const pmf_pack_job_t* __restrict__
     T[col][j] = J.w[((size_t)(co0 + col) * J.Cin + ci0) * J.KHW + j];
   }
   __syncthreads();
+  if (J.format == 1) {
+    // split-bf16 fragments: GEMM element (tap t, k, n) -> plane p of fragment (t, k/16, n/32) at lane (n%32) + 32 ((k%16)/8),
+    // element k%8 (the B-operand layout of v_mfma_f32_32x32x16_bf16); planes are 512 bf16 apart
+    unsigned short* __restrict__ dst = (unsigned short*)J.dst;
+    const int KS = J.K_pad >> 4, CTL = J.ldw >> 5;
+    const int total = J.ntaps * nco * ct;
+    for (int i = threadIdx.x; i < total; i += 256) {
+      int col, cil, t;
+      if (!J.transpose) { col = i % nco; const int r = i / nco; cil = r % ct; t = r / ct; }
+      else { cil = i % ct; const int r = i / ct; col = r % nco; t = r / nco; }
+      const float x = T[col][cil * J.KHW + J.tap_idx[t]];
+      const int k = J.transpose ? co0 + col : ci0 + cil, nn = J.transpose ? ci0 + cil : co0 + col;
+      const unsigned u0 = __builtin_bit_cast(unsigned short, (__bf16)x);
+      const float r1 = x - __builtin_bit_cast(float, u0 << 16);
+      const unsigned u1 = __builtin_bit_cast(unsigned short, (__bf16)r1);
+      const float r2 = r1 - __builtin_bit_cast(float, u1 << 16);
+      const unsigned u2 = __builtin_bit_cast(unsigned short, (__bf16)r2);
+      const size_t e = ((((size_t)t * KS + (k >> 4)) * CTL + (nn >> 5)) * 3) * 512 + ((nn & 31) + 32 * ((k & 15) >> 3)) * 8 + (k & 7);
+      dst[e] = (unsigned short)u0; dst[e + 512] = (unsigned short)u1; dst[e + 1024] = (unsigned short)u2;
+    }
+    return;
+  }
   if (!J.transpose) {
     const int total = J.ntaps * ct * 32;
     for (int i = threadIdx.x; i < total; i += 256) {

@@ -153,6 +153,8 @@ class Plan:
         self.wg_scratch = 0                 # bytes of the shared wgrad partial-sum workspace
         self.params = []                    # (param, grad Buf float offset)
         self._graphs, self._graph_seen = {}, {}   # hipGraph replay cache (see run)
+        # fp32 convolutions on the bf16 matrix pipe (three-way operand split, six products; PMF_CONV_F32=1: fp32 MFMA only)
+        self.s3 = os.environ.get("PMF_CONV_F32", "0") != "1"
         self._conv_fold = {}                # backward conv op index -> index of the BN-backward fold op reading its rows
         self.bn_bwd_fused = os.environ.get("PMF_BN_BWD_FUSED", "1") != "0"
         self._conv_fin = {}                 # forward conv op index -> index of the BN finalize op reading its rows
@@ -385,11 +387,20 @@ class Plan:
                 out.append((ky * dil - pad, kx * dil - pad, ky * kw + kx))
         return out
 
-    def add_pack(self, weight, taps_widx, transpose, K_pad, ldw):
-        """register a pack job; returns the Buf of the packed slab [ntaps][K_pad][ldw]."""
-        buf = self.persist.alloc(4 * len(taps_widx) * K_pad * ldw)
-        self.pack_jobs.append((weight, buf, list(taps_widx), transpose, K_pad, ldw, self.lane))
+    def add_pack(self, weight, taps_widx, transpose, K_pad, ldw, fmt=0):
+        """register a pack job; returns the Buf of the packed slab [ntaps][K_pad][ldw] (fmt 0, fp32) or of the split-bf16
+        fragments [ntaps][K_pad/16][ldw/32][3][64][8] (fmt 1, 6 bytes per weight; pmf_conv_desc_t.w_s3)."""
+        buf = self.persist.alloc((6 if fmt else 4) * len(taps_widx) * K_pad * ldw)
+        self.pack_jobs.append((weight, buf, list(taps_widx), transpose, K_pad, ldw, self.lane, fmt))
         return buf
+
+    def s3_ok(self, shape_fill):
+        """True when this conv launch may run on the bf16 matrix pipe with split operands (conv_fwd.hip PIPE 5)."""
+        if not self.s3:
+            return False
+        probe = L.ConvDesc()
+        shape_fill(probe)
+        return bool(L.lib().pmf_conv_s3_eligible(C.byref(probe)))
 
     def conv(self, srcs, conv, act=L.ACT_NONE, bn=None, order="act_bn", relu_view=False, name="", pmask=None,
              extra_bias=None):
@@ -414,7 +425,6 @@ class Plan:
                 if dy < inH and dy + (OH - 1) * stride >= 0 and dx < inW and dx + (OW - 1) * stride >= 0] or all_taps[:1]
         Ktot = sum(_ru(s.t.C, 8) for s in srcs)
         ldw = _ru(Cout, 64)
-        wbuf = self.add_pack(conv.weight, [t[2] for t in taps], 0, Ktot, ldw)
         # very large dilations: per-tap staging (the halo tile would not fit LDS)
         span = max(max(t[0] for t in taps) - min(t[0] for t in taps), max(t[1] for t in taps) - min(t[1] for t in taps))
         gather = 1 if (8 * stride + span) * (32 * stride + span) * 80 > 110 * 1024 else 0
@@ -450,10 +460,13 @@ class Plan:
             d.in_stride, d.gather = stride, gather
             d.out_sy = d.out_sx = 1
             d.splitk_ws, d.splitk_ws_bytes = 1, SPLITK_BYTES      # non-NULL: same split decision as the real launch
+        fwd_s3 = self.s3_ok(shape_fill)
+        wbuf = self.add_pack(conv.weight, [t[2] for t in taps], 0, Ktot, ldw, int(fwd_s3))
         stat_rows = 0
         if train_bn:
             probe = L.ConvDesc()
             shape_fill(probe)
+            probe.w_s3 = 1 if fwd_s3 else None
             stat_rows = L.lib().pmf_conv_fwd_stat_rows(C.byref(probe))
             # the autotuner (Plan.autotune) may pick another tile configuration: size the rows for any of them
             max_rows = max(stat_rows, L.lib().pmf_conv_fwd_stat_rows_max(C.byref(probe)))
@@ -467,7 +480,11 @@ class Plan:
             shape_fill(d)
             for i, s in enumerate(srcs):
                 self.src_struct(s, d.src[i])
-            d.w, d.ldw = wbuf.ptr, ldw
+            d.ldw = ldw
+            if fwd_s3:
+                d.w_s3 = wbuf.ptr
+            else:
+                d.w = wbuf.ptr
             d.bias = (bsum.ptr if bsum is not None else conv.bias.data_ptr()) if has_bias else None
             d.act = k_act
             d.out, d.out_ldc, d.out_H, d.out_W = out.buf.ptr, out.ldc, OH, OW
@@ -655,7 +672,31 @@ class Plan:
                            if (py - dy) % 2 == 0 and (px - dx) % 2 == 0]
                     if sub:
                         classes.append((py, px, sub))
-        packs = [self.add_pack(conv.weight, [t[2] for t in sub], 1, Kd, ldwT) for (_, _, sub) in classes]
+        # split-bf16 launches address the transposed weights by 32-column fragments: every operand that receives a
+        # gradient must start on one
+        offs, co_ = [], 0
+        for s in srcs:
+            offs.append(co_)
+            co_ += _ru(s.t.C, 8)
+        aligned = all(o % 32 == 0 for o, s in zip(offs, srcs) if s.t.needs_grad)
+        ref = next(s for s in srcs if s.t.needs_grad)
+
+        def class_probe(sub, py, px):
+            def fill(d):
+                H, W = ref.t.H, ref.t.W
+                d.N = dz.N
+                d.OH, d.OW = (H, W) if stride == 1 else ((H - py + 1) // 2, (W - px + 1) // 2)
+                d.Cout, d.nsrc = ref.t.C, 1
+                sv = d.src[0]
+                sv.C, sv.ldc, sv.H, sv.W = Kd, dz.ldc, dz.H, dz.W
+                d.ntaps = len(sub)
+                for i, (dy, dx, _) in enumerate(sub):
+                    d.tdy[i], d.tdx[i] = dy, dx
+                d.in_stride, d.gather = 1, gather
+            return fill
+        dg_s3 = [aligned and Kd % 16 == 0 and self.s3_ok(class_probe(sub, py, px)) for (py, px, sub) in classes]
+        packs = [self.add_pack(conv.weight, [t[2] for t in sub], 1, Kd, ldwT, int(k3))
+                 for (_, _, sub), k3 in zip(classes, dg_s3)]
         coloff = 0
         for s in srcs:
             Cs = _ru(s.t.C, 8)
@@ -678,8 +719,8 @@ class Plan:
                             self.fill(self.bwd, tgt.buf, tgt.npix * tgt.ldc)
                         acc = 1
                 relu_x = r.t if r.relu else None
-                for (py, px, sub), wT in zip(classes, packs):
-                    def shape_only(d, s=s, sub=sub, tgt=tgt, py=py, px=px):
+                for (py, px, sub), wT, k3 in zip(classes, packs, dg_s3):
+                    def shape_only(d, s=s, sub=sub, tgt=tgt, py=py, px=px, k3=k3):
                         H, W = tgt.H, tgt.W
                         d.N = dz.N
                         d.OH, d.OW = (H, W) if stride == 1 else ((H - py + 1) // 2, (W - px + 1) // 2)
@@ -692,17 +733,22 @@ class Plan:
                         d.in_stride, d.gather = 1, gather
                         d.out_sy = d.out_sx = stride
                         d.splitk_ws, d.splitk_ws_bytes = 1, SPLITK_BYTES
+                        d.w_s3 = 1 if k3 else None
                     # filled in by the BatchNorm backward of the layer that produced this operand when THIS launch is
                     # the last writer of its output gradient: the launch then also writes the BN-backward partial sums
                     hook = {}
 
                     def f(op, s=s, r=r, sub=sub, wT=wT, tgt=tgt, acc=acc, coloff=coloff, py=py, px=px,
-                          relu_x=relu_x, shape_only=shape_only, hook=hook):
+                          relu_x=relu_x, shape_only=shape_only, hook=hook, k3=k3):
                         d = op.u.conv
                         shape_only(d)
                         H, W = tgt.H, tgt.W
                         d.src[0].x = dz.buf.ptr
-                        d.w, d.ldw = wT.at(coloff), ldwT
+                        d.ldw = ldwT
+                        if k3:      # fragment column coloff / 32 (3 planes x 1 KiB each)
+                            d.w_s3 = wT.ptr + (coloff // 32) * 3 * 1024
+                        else:
+                            d.w = wT.at(coloff)
                         d.act = L.ACT_NONE
                         d.out, d.out_ldc, d.out_H, d.out_W = tgt.buf.ptr, tgt.ldc, H, W
                         d.out_sy = d.out_sx = stride
@@ -1204,13 +1250,13 @@ class Plan:
             mine = [j for j in self.pack_jobs if j[6] == lane]
             jobs = (L.PackJob * len(mine))()
             blocks = 0
-            for j, (w, buf, tap_idx, transpose, K_pad, ldw, _) in enumerate(mine):
+            for j, (w, buf, tap_idx, transpose, K_pad, ldw, _, fmt) in enumerate(mine):
                 Cout, Cin, KHW = w.shape[0], w.shape[1], w.shape[2] * w.shape[3]
                 ct = lib.pmf_pack_tile_ci(Cin, KHW)
                 J = jobs[j]
                 J.w, J.dst = w.data_ptr(), buf.ptr
                 J.Cout, J.Cin, J.KHW, J.ntaps, J.transpose = Cout, Cin, KHW, len(tap_idx), transpose
-                J.K_pad, J.ldw, J.CT = K_pad, ldw, ct
+                J.K_pad, J.ldw, J.CT, J.format = K_pad, ldw, ct, fmt
                 J.tiles_ci = (Cin + ct - 1) // ct
                 J.block_start = blocks
                 for i, ti in enumerate(tap_idx):
@@ -1324,7 +1370,7 @@ class Plan:
                           for i in range(d.nsrc)),
                     d.ntaps, tuple(d.tdy[i] for i in range(d.ntaps)), tuple(d.tdx[i] for i in range(d.ntaps)),
                     d.in_stride, d.gather, d.act, d.out_sy, d.out_sx, d.accumulate, bool(d.bias), bool(d.ep_cmul),
-                    bool(d.ep_relu_x), bool(d.stats), bool(d.ep_pmask), bool(d.ep_stat_mean), d.ep_flags)
+                    bool(d.ep_relu_x), bool(d.stats), bool(d.ep_pmask), bool(d.ep_stat_mean), d.ep_flags, bool(d.w_s3))
 
         for ops, n, kinds, shift, fins in ((self.fwd_ops, self.n_fwd, self.fwd_kinds, self.fwd_shift, self._conv_fin),
                                            (self.bwd_ops, self.n_bwd, self.bwd_kinds, self.bwd_shift, self._conv_fold)):

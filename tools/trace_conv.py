@@ -29,6 +29,10 @@ def main(filt, with_stats):
         wpk = G.pack_fwd(w, ci, ldw); out = torch.empty(N, H, W, co, device="cuda")
         d = G.conv_desc([dict(x=x, C=ci)], wpk, ldw, None, out, N, H, W, co, G.taps_of(k, k, dil, pad), 1, 1)
         d.splitk_ws, d.splitk_ws_bytes = ws.data_ptr(), ws.numel()
+        d.cfg = int(os.environ.get("TRACE_CFG", "0"), 0)
+        if os.environ.get("TRACE_S3"):
+            w3 = G.pack_fwd_s3(w, ci, ldw)
+            d.w, d.w_s3 = None, w3.data_ptr()
         if with_stats:
             rows = L.lib().pmf_conv_fwd_stat_rows(C.byref(d))
             st = torch.zeros(rows * 2 * co, dtype=torch.float64, device="cuda")
