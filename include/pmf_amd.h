@@ -128,8 +128,11 @@ typedef struct {
   float* dbias_out;
   int32_t cfg;            /* 0 = built-in heuristics; else (autotuner) NT | kernel << 8: NT = 32-channel output tiles per
                            * workgroup (1, 2, 4); kernel 1 = pipelined (needs NT 1 and its shape conditions), 2 = unit-dealing */
-  int32_t cfg_pad_;
+  int32_t flags;          /* PMF_WGRAD_S3: run the pipelined kernel's products on the bf16 matrix pipe (operands split three
+                           * ways, six products, fp32 accumulate -- fp32-class error, conv_wgrad.hip); ignored where the
+                           * pipelined kernel's shape conditions do not hold */
 } pmf_wgrad_desc_t;
+#define PMF_WGRAD_S3 1
 
 int pmf_conv_wgrad(const pmf_wgrad_desc_t* d, pmf_stream_t s);
 /* its two stages separately (same descriptor): partial-slab kernel, then the deterministic reduction */

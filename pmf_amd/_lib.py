@@ -13,6 +13,7 @@ MAX_SRC, MAX_TAPS = 5, 49
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
 SRC_RELU, SRC_BCAST = 1, 2
 EP_STAT_X_ONLY = 1
+WGRAD_S3 = 1
 
 (OP_CONV, OP_WGRAD, OP_PACK, OP_BN_FINALIZE, OP_BN_EVAL, OP_BN_BWD_REDUCE, OP_BN_BWD_APPLY, OP_ADD_ACT,
  OP_ADD_ACT_BWD, OP_ACT_BWD, OP_AVGPOOL, OP_AVGPOOL_BWD, OP_MAXPOOL, OP_MAXPOOL_BWD, OP_BILINEAR,
@@ -53,7 +54,7 @@ class WgradDesc(C.Structure):
                 ("partial", C.c_void_p), ("nsplit", C.c_int32), ("dw_oihw", C.c_void_p),
                 ("Cin_real", C.c_int32), ("KHW", C.c_int32), ("accumulate", C.c_int32),
                 ("dbias_rows", C.c_void_p), ("dbias_nrows", C.c_int32), ("dbias_ld", C.c_int32),
-                ("dbias_out", C.c_void_p), ("cfg", C.c_int32), ("cfg_pad_", C.c_int32)]
+                ("dbias_out", C.c_void_p), ("cfg", C.c_int32), ("flags", C.c_int32)]
 
 
 class View(C.Structure):

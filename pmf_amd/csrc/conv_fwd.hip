@@ -433,18 +433,17 @@ __device__ __forceinline__ void s3_half(f32x16 (&acc)[MT][BN / 32], const char* 
         for (int p = 0; p < 3; ++p) b[nxt][u][p] = *(const bf16x8*)(bp0 + (((st + 1) * NT + u) * 3 + p) * 1024);
     }
     fill(st, NTH);
-    // smallest terms first
+    // smallest terms first; product-major so that back-to-back MFMAs hit different accumulators
+    constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PB[6] = {2, 1, 0, 1, 0, 0};
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+    for (int pr = 0; pr < 6; ++pr)
 #pragma unroll
-      for (int u = 0; u < NT; ++u) {
-        acc[m][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][m][0], b[cur][u][2], acc[m][u], 0, 0, 0);
-        acc[m][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][m][1], b[cur][u][1], acc[m][u], 0, 0, 0);
-        acc[m][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][m][2], b[cur][u][0], acc[m][u], 0, 0, 0);
-        acc[m][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][m][0], b[cur][u][1], acc[m][u], 0, 0, 0);
-        acc[m][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][m][1], b[cur][u][0], acc[m][u], 0, 0, 0);
-        acc[m][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][m][0], b[cur][u][0], acc[m][u], 0, 0, 0);
-      }
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int u = 0; u < NT; ++u)
+          acc[m][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][m][PA[pr]], b[cur][u][PB[pr]], acc[m][u], 0, 0, 0);
+    // the next tap's 3 (MT + NT) LDS reads and this step's slice of global loads go into the gaps behind the MFMAs
+    pmf_sgb_seq<0, 6 * MT * NT, 3 * (MT + NT), 2>();
     __builtin_amdgcn_sched_barrier(0);
   }
 }

@@ -446,6 +446,255 @@ __device__ __forceinline__ void conv_wgrad_pipe_body(const pmf_wgrad_desc_t& d, 
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// The same pipelined kernel with the products on the bf16 matrix pipe (operands split three ways, six products per
+// fp32 product: see conv_fwd.hip PIPE 5 for the arithmetic).  K of v_mfma_f32_32x32x16_bf16 = 16 consecutive pixels of
+// one row; both operands are wanted pixel-major per channel while memory is channel-major per pixel:
+//   * input tile: split while it is written to LDS as [pixel][plane][32 ci] bf16 (192 B per pixel: four consecutive
+//     pixels land in four different 64-B bank quarters) and read with ds_read_b64_tr_b16, the hardware transpose read:
+//     a 16-lane group fetches a [4 pixels][16 channels] block and every lane receives the 4 pixels of ITS channel --
+//     two reads per plane make the 8-pixel A fragment of a tap (any tap offset: it only shifts the pixel index);
+//   * dz keeps its LDS-DMA path (raw fp32 [pixel][32 co]); the wave that owns a 16-pixel slab reads its B fragment as
+//     8 ds_read_b32 and splits it in registers -- once per slab, shared by all TB taps (54 MFMAs).
+// Wave w owns slab w of every half tile (4 slabs of 16 pixels), TB accumulators as before.
+typedef __attribute__((ext_vector_type(8))) __bf16 wbf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 wbf16x2;
+typedef __attribute__((ext_vector_type(4))) short ws16x4;
+typedef __attribute__((ext_vector_type(8))) short ws16x8;
+typedef __attribute__((ext_vector_type(2))) float wf32x2;
+typedef __attribute__((ext_vector_type(2))) unsigned wu32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned wu32x4;
+#define WS3_XPB 192
+
+__device__ __forceinline__ unsigned ws3_pk(wf32x2 v) { return __builtin_bit_cast(unsigned, __builtin_convertvector(v, wbf16x2)); }
+__device__ __forceinline__ wf32x2 ws3_unpk(unsigned u) {
+  return wf32x2{__builtin_bit_cast(float, u << 16), __builtin_bit_cast(float, u & 0xffff0000u)};
+}
+__device__ __forceinline__ void ws3_split2(float a, float b, unsigned& p0, unsigned& p1, unsigned& p2) {
+  wf32x2 r = {a, b};
+  p0 = ws3_pk(r);
+  r = r - ws3_unpk(p0);
+  p1 = ws3_pk(r);
+  r = r - ws3_unpk(p1);
+  p2 = ws3_pk(r);
+}
+
+template <int TB, int XSL>
+__device__ __forceinline__ void conv_wgrad_s3_body(const pmf_wgrad_desc_t& d, const WgGeom& g, float* __restrict__ smem) {
+  constexpr int BN = 32;
+  constexpr int HPX = 64;
+  constexpr int ZPW = HPX * BN / 256 / 4;   // 2 DMA instructions per wave per half
+  constexpr int PPI = 256 / BN;
+  char* __restrict__ Xs = (char*)smem;
+  float* __restrict__ Z0 = smem + g.x_floats;
+  float* __restrict__ Z1 = Z0 + HPX * BN;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int split = blockIdx.x, chunk = blockIdx.y;
+  const int co0 = (int)blockIdx.z * BN;
+  const int in_cols = g.in_cols;
+
+  int si = 0, c0 = 0, k0 = 0;
+  {
+    int rem = chunk;
+    for (;;) {
+      const int nch = d.src[si].C / WG_CI;
+      if (rem < nch) { c0 = rem * WG_CI; k0 += c0; break; }
+      rem -= nch; k0 += d.src[si].C; ++si;
+    }
+  }
+  const int sld = d.src[si].ldc, sflags = d.src[si].flags;
+  const int sH = d.OH, sW = d.OW;
+  const bool aff = d.src[si].scale != nullptr;
+  const int q = tid & 7, cch = c0 + q * 4;
+  const int totalX = g.in_rows * in_cols * 8;
+  int rc[XSL];
+#pragma unroll
+  for (int j = 0; j < XSL; ++j) {
+    const int f = tid + 256 * j, pix = f >> 3;
+    const int r = pix / in_cols, c = pix - r * in_cols;
+    rc[j] = f < totalX ? (r << 8 | c) : -1;
+  }
+  int offZ[ZPW];
+#pragma unroll
+  for (int jj = 0; jj < ZPW; ++jj) {
+    const int p = (wave + 4 * jj) * PPI + lane / (BN / 4);
+    offZ[jj] = ((p >> 5) * d.OW + (p & 31)) * d.dz_ldc + (lane % (BN / 4)) * 4;
+  }
+  int toff[TB];
+#pragma unroll
+  for (int j = 0; j < TB; ++j)
+    toff[j] = (((int)d.tdy[j] - g.dy_min) * in_cols + ((int)d.tdx[j] - g.dx_min)) * WS3_XPB;
+  // transpose-read addressing: lane p of a 16-lane group supplies [pixel p/4][channels 4 (p%4) ...]; groups 1 / 3 read
+  // channels 16-31, groups 2 / 3 pixels 8-11 (the k = 8..15 half of the MFMA operand)
+  const int trofs = (((lane >> 5) * 8 + ((lane & 15) >> 2)) * WS3_XPB) + ((((lane >> 4) & 1) * 16 + (lane & 3) * 4) * 2);
+
+  f32x16 acc[TB];
+#pragma unroll
+  for (int j = 0; j < TB; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  const __amdgpu_buffer_rsrc_t xrs_on =
+      __builtin_amdgcn_make_buffer_rsrc((void*)d.src[si].x, 0, d.N * sH * sW * sld * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t xrs_off = __builtin_amdgcn_make_buffer_rsrc((void*)d.src[si].x, 0, 0, 0x00020000);
+  f32x4 rX[XSL];
+  unsigned okX = 0u;
+  int ncur = 0;
+  const int tiles_per_n = g.tiles_x * g.tiles_y;
+  auto fetch = [&](int tile, bool on) {
+    const int n = tile / tiles_per_n, rem = tile - n * tiles_per_n;
+    const int ty = rem / g.tiles_x, tx = rem - ty * g.tiles_x;
+    const int by = ty * WG_ROWS + g.dy_min, bx = tx * 32 + g.dx_min;
+    const __amdgpu_buffer_rsrc_t rs = on ? xrs_on : xrs_off;
+    okX = 0u;
+#pragma unroll
+    for (int j = 0; j < XSL; ++j) {
+      const int iy = by + (rc[j] >> 8), ix = bx + (rc[j] & 255);
+      const bool ok = rc[j] >= 0 && iy >= 0 && iy < sH && ix >= 0 && ix < sW;
+      const int gp = ok ? (n * sH + iy) * sW + ix : -1;
+      okX |= ok ? (1u << j) : 0u;
+      rX[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (gp * sld + cch) * 4, 0, 0));
+    }
+    ncur = n;
+  };
+  auto zsrc = [&](int tile, int half) -> const float* {
+    const int n = tile / tiles_per_n, rem = tile - n * tiles_per_n;
+    const int ty = rem / g.tiles_x, tx = rem - ty * g.tiles_x;
+    return d.dz + ((size_t)(n * d.OH + ty * WG_ROWS + 2 * half) * d.OW + tx * 32) * d.dz_ldc + co0;
+  };
+  auto dma = [&](const float* __restrict__ src, float* __restrict__ dst) {
+#pragma unroll
+    for (int jj = 0; jj < ZPW; ++jj)
+      __builtin_amdgcn_global_load_lds(src + offZ[jj], (lds_ptr_t)(dst + (wave + 4 * jj) * 256), 16, 0, 0);
+  };
+  typedef __attribute__((address_space(3))) ws16x4* lds_tr_t;
+  auto afrag = [&](const char* __restrict__ base, wbf16x8 (&a)[3]) {   // 8-pixel A fragment of one tap, three planes
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      const ws16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_t)(base + p * 64));
+      const ws16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_t)(base + p * 64 + 4 * WS3_XPB));
+      a[p] = __builtin_bit_cast(wbf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    }
+  };
+  // one half tile (2 rows x 32 pixels = 4 slabs of 16 pixels): this wave's slab, TB taps x 6 MFMAs
+  auto half = [&](const float* __restrict__ Zh, int h) {
+    const int rr = wave >> 1, xs = (wave & 1) * 16;
+    // B fragment: dz[pixel 8 lh + e][co li], e = 0..7, split in registers
+    const float* zp = Zh + (rr * 32 + xs + lh * 8) * BN + li;
+    float z[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) z[e] = zp[e * BN];
+    const char* xb = Xs + ((2 * h + rr) * in_cols + xs) * WS3_XPB + trofs;
+    wbf16x8 a[2][3];
+    afrag(xb + toff[0], a[0]);
+    wu32x4 b0, b1, b2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      unsigned p0, p1, p2;
+      ws3_split2(z[2 * e], z[2 * e + 1], p0, p1, p2);
+      b0[e] = p0; b1[e] = p1; b2[e] = p2;
+    }
+    wbf16x8 b[3] = {__builtin_bit_cast(wbf16x8, b0), __builtin_bit_cast(wbf16x8, b1), __builtin_bit_cast(wbf16x8, b2)};
+#pragma unroll
+    for (int j = 0; j < TB; ++j) {
+      const int cur = j & 1, nxt = cur ^ 1;
+      if (j + 1 < TB) afrag(xb + toff[j + 1], a[nxt]);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][0], b[2], acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][1], b[1], acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][2], b[0], acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][0], b[1], acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][1], b[0], acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][0], b[0], acc[j], 0, 0, 0);
+    }
+  };
+
+  int tile = split;
+  if (tile < g.total_tiles) {
+    fetch(tile, true);
+    dma(zsrc(tile, 0), Z0);
+  }
+  while (tile < g.total_tiles) {
+    __syncthreads();                       // X: everyone finished the previous tile
+    f32x4 sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f}, cm4 = {1.f, 1.f, 1.f, 1.f};
+    if (aff) { sc4 = *(const f32x4*)(d.src[si].scale + cch); sh4 = *(const f32x4*)(d.src[si].shift + cch); }
+    if (d.src[si].cmul) cm4 = *(const f32x4*)(d.src[si].cmul + (size_t)ncur * d.src[si].cmul_ld + cch);
+#pragma unroll
+    for (int j = 0; j < XSL; ++j) {
+      if (rc[j] >= 0) {
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+        if ((okX >> j) & 1u) {
+          t = rX[j];
+          if (aff) t = t * sc4 + sh4;
+          if (sflags & PMF_SRC_RELU) {
+            t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f);
+          }
+          t = t * cm4;
+        }
+        unsigned l0, l1, l2, h0, h1, h2;
+        ws3_split2(t.x, t.y, l0, l1, l2);
+        ws3_split2(t.z, t.w, h0, h1, h2);
+        char* o = Xs + ((tid + 256 * j) >> 3) * WS3_XPB + q * 8;
+        *(wu32x2*)(o) = wu32x2{l0, h0};
+        *(wu32x2*)(o + 64) = wu32x2{l1, h1};
+        *(wu32x2*)(o + 128) = wu32x2{l2, h2};
+      }
+    }
+    const int next = tile + d.nsplit;
+    const bool have = next < g.total_tiles;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                       // Y: input tile + half 0 visible
+    dma(zsrc(tile, 1), Z1);
+    fetch(have ? next : tile, have);
+    __builtin_amdgcn_sched_barrier(0);
+    half(Z0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                       // Z: everyone finished half 0
+    if (have) dma(zsrc(next, 0), Z0);
+    __builtin_amdgcn_sched_barrier(0);
+    half(Z1, 1);
+    tile = next;
+  }
+
+  // ---- sum the four pixel groups (fixed order) and write this workgroup's partial slab
+  {
+    float* red = smem;   // [4 waves][16][64]
+#pragma unroll
+    for (int j = 0; j < TB; ++j) {
+      __syncthreads();
+      if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[j][r];
+      }
+      __syncthreads();
+      if (wave == 0) {
+#pragma unroll
+        for (int p = 1; p < 4; ++p)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[j][r] += red[((p) * 16 + r) * 64 + lane];
+      }
+    }
+  }
+  if (wave == 0) {
+    float* part = d.partial + (size_t)split * d.ntaps * g.Ktot * g.Cout32;
+    const int co = co0 + li;
+#pragma unroll
+    for (int j = 0; j < TB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ci = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        part[((size_t)j * g.Ktot + k0 + ci) * g.Cout32 + co] = acc[j][r];
+      }
+  }
+}
+
+template <int TB, int XSL>
+__global__ __launch_bounds__(256) void conv_wgrad_s3_k(const pmf_wgrad_desc_t d, const WgGeom g) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  conv_wgrad_s3_body<TB, XSL>(d, g, smem);
+}
+
 template <int TB, int NT, int XSL>
 __global__ __launch_bounds__(256) void conv_wgrad_pipe_k(const pmf_wgrad_desc_t d, const WgGeom g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1058,7 +1307,20 @@ static int wg_launch(const pmf_wgrad_desc_t* d, hipStream_t s, int phase) {
   dim3 grid(d->nsplit, g.nchunks, g.co_tiles * g.tap_batches);
   bool piped = false;
   if constexpr (NT == 1) {
-    if (wg_simple(d, g, TB, 32) && !getenv("PMF_WGRAD_NOPIPE") && ((d->cfg >> 8) & 0xff) != 2) {
+    if (wg_simple(d, g, TB, 32) && (d->flags & PMF_WGRAD_S3)) {
+      static bool attr3 = false;
+      if (!attr3) {
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_s3_k<TB, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_s3_k<TB, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr3 = true;
+      }
+      g.x_floats = g.in_rows * g.in_cols * (WS3_XPB / 4);
+      int lds3 = (g.x_floats + WG_ROWS * 32 * 32) * 4;
+      if (lds3 < 16 * 1024) lds3 = 16 * 1024;
+      if (g.in_rows * g.in_cols * 8 <= 256 * 7) hipLaunchKernelGGL((conv_wgrad_s3_k<TB, 7>), grid, dim3(256), lds3, s, *d, g);
+      else hipLaunchKernelGGL((conv_wgrad_s3_k<TB, 9>), grid, dim3(256), lds3, s, *d, g);
+      piped = true;
+    } else if (wg_simple(d, g, TB, 32) && !getenv("PMF_WGRAD_NOPIPE") && ((d->cfg >> 8) & 0xff) != 2) {
       const int lds2 = lds < 16 * 1024 ? 16 * 1024 : lds;   // room for the pixel-group reduction
       if (g.in_rows * g.in_cols * 8 <= 256 * 7) hipLaunchKernelGGL((conv_wgrad_pipe_k<TB, 1, 7>), grid, dim3(256), lds2, s, *d, g);
       else hipLaunchKernelGGL((conv_wgrad_pipe_k<TB, 1, 9>), grid, dim3(256), lds2, s, *d, g);

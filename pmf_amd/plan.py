@@ -816,6 +816,7 @@ class Plan:
             d.nsplit = nsplit
             d.dw_oihw = self.pgrad_buf.at(goff)
             d.accumulate = 0
+            d.flags = L.WGRAD_S3 if self.s3 else 0
             if dbias_rows:
                 d.dbias_rows, d.dbias_nrows, d.dbias_ld = dbr.ptr, dbias_rows, dbr_ld
                 d.dbias_out = self.pgrad_buf.at(boff)

@@ -96,6 +96,10 @@ CONVS = [
     ("c1x1_odd_big", 1, 129, 129, [96], 32, 1, 1, 0, 1, True, "lrelu", False),
     ("c1x1_c20_big", 1, 129, 129, [128], 20, 1, 1, 0, 1, True, "none", False),
     ("c1x1_wide_big", 2, 64, 128, [128, 256], 128, 1, 1, 0, 1, True, "act_bn", True),
+    # shapes of the pipelined weight-gradient kernel (rows % 4 == 0, cols % 32 == 0, channels % 32 == 0), 9 / 4 / 1 taps
+    ("c3x3_wpipe", 2, 8, 64, [32, 64], 64, 3, 1, 1, 1, True, "act_bn", True),
+    ("c3x3d2_wpipe", 1, 12, 32, [64], 32, 3, 2, 2, 1, False, "bn_relu", True),
+    ("c2x2d2_wpipe", 2, 8, 64, [64], 64, 2, 2, 1, 1, True, "act_bn", True),
 ]
 
 
