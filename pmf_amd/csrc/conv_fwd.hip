@@ -402,6 +402,22 @@ __device__ __forceinline__ void s3_split2(float a, float b, unsigned& p0, unsign
   p2 = s3_pk(r);
 }
 
+// MFMA i of NM is followed by its share of the NR LDS reads, all of them behind the first NF MFMAs (the tail of the
+// step gives the last reads time to land before the next step's first MFMA wants them), and one global load behind
+// each of the first NV
+template <int I, int NM, int NR, int NF, int NV>
+__device__ __forceinline__ void s3_sgb() {
+  if constexpr (I < NM) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    if constexpr (I < NF) {
+      constexpr int k = (NR * (I + 1)) / NF - (NR * I) / NF;
+      if constexpr (k > 0) __builtin_amdgcn_sched_group_barrier(0x100, k, 0);
+    }
+    if constexpr (I < NV) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    s3_sgb<I + 1, NM, NR, NF, NV>();
+  }
+}
+
 // NTH taps of one half: A fragments (MT x 3 planes) and B fragments (NT x 3 planes) of tap i+1 are read while the
 // 6 MT NT MFMAs of tap i run
 template <int BN, int MT, int NTH, class Fill = NoFill>
@@ -419,6 +435,7 @@ __device__ __forceinline__ void s3_half(f32x16 (&acc)[MT][BN / 32], const char* 
   for (int u = 0; u < NT; ++u)
 #pragma unroll
     for (int p = 0; p < 3; ++p) b[0][u][p] = *(const bf16x8*)(bp0 + (u * 3 + p) * 1024);
+  __builtin_amdgcn_sched_barrier(0);   // (keeps the first tap's reads out of the interleave pattern of its MFMAs)
 #pragma unroll
   for (int st = 0; st < NTH; ++st) {
     const int cur = st & 1, nxt = cur ^ 1;
@@ -443,33 +460,39 @@ __device__ __forceinline__ void s3_half(f32x16 (&acc)[MT][BN / 32], const char* 
         for (int u = 0; u < NT; ++u)
           acc[m][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][m][PA[pr]], b[cur][u][PB[pr]], acc[m][u], 0, 0, 0);
     // the next tap's 3 (MT + NT) LDS reads and this step's slice of global loads go into the gaps behind the MFMAs
-    pmf_sgb_seq<0, 6 * MT * NT, 3 * (MT + NT), 2>();
+    s3_sgb<0, 6 * MT * NT, 3 * (MT + NT), (6 * MT * NT * 2 + 2) / 3, 2>();
     __builtin_amdgcn_sched_barrier(0);
   }
 }
 
-template <int BN, int MT>
+// SL = 16-channel slabs per stage.  Few-tap convolutions (1x1, 2x2, 1x3) carry SL = 4 / 2 slabs per stage as "virtual
+// taps" v = tap * SL + slab (same idea as VT of PIPE 4): a 16-channel stage of a 1x1 layer is 6 MT NT MFMAs between
+// three barriers.  Stages are sized so that virtual taps <= 9 and the staging slots per thread <= 8.
+template <int BN, int MT, int SL>
 __device__ __forceinline__ void conv_kloop_s3(const pmf_conv_desc_t& d, const ConvGeom& g, f32x16 (&acc)[MT][BN / 32],
                                               char* __restrict__ As, char* __restrict__ Bs, const int (&segrow)[MT],
                                               const int (&segcol)[MT], int tid, int li, int lh, int n, int n0, int ks,
                                               int oy0, int ox0, int& tri_) {
   constexpr int NT = BN / 32;
-  constexpr int ASL = MT == 2 ? 7 : 5;            // float4 slots per thread for the input tile
-  constexpr int NF = 5 * NT * 3;                  // fragments of the larger half (<= 5 taps)
+  constexpr int ASL = SL > 1 ? 8 : (MT == 2 ? 7 : 5);   // float4 slots per thread for the input tile
+  constexpr int NF = 5 * NT * 3;                  // fragments of the larger half (<= 5 virtual taps)
   constexpr int NDMA = (NF + 3) / 4;              // DMA instructions per wave per half
   const int in_cols = g.in_cols;
   const int sH = d.src[0].H, sW = d.src[0].W;
   const int q = tid & 3;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  const int totalA = g.in_rows * in_cols * 4;
-  const int nt0 = (d.ntaps + 1) >> 1, nt1 = d.ntaps - nt0;   // taps of half 0 / half 1
+  const int npixA = g.in_rows * in_cols;
+  const int totalA = npixA * 4 * SL;
+  const int a_slab = g.a_floats * 4 / SL;         // bytes of one slab's tile
+  const int nv = d.ntaps * SL;                    // virtual taps
+  const int nt0 = (nv + 1) >> 1, nt1 = nv - nt0;  // ... of half 0 / half 1
   char* __restrict__ Bh1 = Bs + nt0 * NT * 3 * 1024;
   const int KS = g.Ktot >> 4, CT = d.ldw >> 5;
   int gA[ASL];
   unsigned okA = 0u;
 #pragma unroll
   for (int j = 0; j < ASL; ++j) {
-    const int f = tid + 256 * j, pix = f >> 2;
+    const int f = tid + 256 * j, pix = SL > 1 ? (f >> 2) % npixA : (f >> 2);
     const int r = pix / in_cols, c = pix - r * in_cols;
     const int iy = oy0 + g.dy_min + r, ix = ox0 + g.dx_min + c;
     const bool ok = f < totalA && iy >= 0 && iy < sH && ix >= 0 && ix < sW;
@@ -486,8 +509,10 @@ __device__ __forceinline__ void conv_kloop_s3(const pmf_conv_desc_t& d, const Co
                    "s"(ty[8]), "s"(tx[0]), "s"(tx[1]), "s"(tx[2]), "s"(tx[3]), "s"(tx[4]), "s"(tx[5]), "s"(tx[6]),
                    "s"(tx[7]), "s"(tx[8]));
 #pragma unroll
-    for (int t = 0; t < TAPG; ++t)
-      aoff[t] = t < d.ntaps ? ((ty[t] - g.dy_min) * in_cols + (tx[t] - g.dx_min)) * S3_APB : 0;
+    for (int v = 0; v < TAPG; ++v) {
+      const int t = v / SL, sl = v % SL;            // compile-time after unrolling
+      aoff[v] = v < nv ? ((ty[t] - g.dy_min) * in_cols + (tx[t] - g.dx_min)) * S3_APB + sl * a_slab : 0;
+    }
   }
   int abase[MT];
 #pragma unroll
@@ -499,7 +524,7 @@ __device__ __forceinline__ void conv_kloop_s3(const pmf_conv_desc_t& d, const Co
       if (si >= d.nsrc) return false;
       if (c0 >= d.src[si].C) { kb += d.src[si].C; ++si; c0 = 0; continue; }
       if ((cn % g.ksplit) == ks) return true;
-      ++cn; c0 += KC;
+      ++cn; c0 += KC * SL;
     }
   };
   f32x4 rA[ASL], sc4, sh4, cm4;
@@ -507,8 +532,9 @@ __device__ __forceinline__ void conv_kloop_s3(const pmf_conv_desc_t& d, const Co
   bool cur_aff = false;
   __amdgpu_buffer_rsrc_t nrs;
   int nld = 0, ncch = 0;
-  const char* __restrict__ nw = nullptr;   // fragment (tap 0, plane 0) of the stage being fetched, first output tile (uniform)
-  const size_t tap_stride = (size_t)KS * CT * 3 * 1024;
+  const float* cur_sc = nullptr; const float* cur_sh = nullptr; const float* cur_cm = nullptr;   // SL > 1: re-read at store time
+  const char* __restrict__ nw = nullptr;   // fragment (tap 0, slab 0, plane 0) of the stage being fetched, first output tile
+  const size_t tap_stride = (size_t)KS * CT * 3 * 1024, slab_stride = (size_t)CT * 3 * 1024;
   auto head = [&]() {
     const float* sx = d.src[si].x;
     const float* ssc = d.src[si].scale;
@@ -520,22 +546,29 @@ __device__ __forceinline__ void conv_kloop_s3(const pmf_conv_desc_t& d, const Co
     nld = sld; ncch = c0 + q * 4;
     cur_flags = sfl;
     cur_aff = ssc != nullptr;
-    sc4 = f32x4{1.f, 1.f, 1.f, 1.f}; sh4 = f32x4{0.f, 0.f, 0.f, 0.f}; cm4 = f32x4{1.f, 1.f, 1.f, 1.f};
-    if (cur_aff) { sc4 = *(const f32x4*)(ssc + ncch); sh4 = *(const f32x4*)(ssh + ncch); }
-    if (scm) cm4 = *(const f32x4*)(scm + (size_t)n * scl + ncch);
+    if (SL == 1) {
+      sc4 = f32x4{1.f, 1.f, 1.f, 1.f}; sh4 = f32x4{0.f, 0.f, 0.f, 0.f}; cm4 = f32x4{1.f, 1.f, 1.f, 1.f};
+      if (cur_aff) { sc4 = *(const f32x4*)(ssc + ncch); sh4 = *(const f32x4*)(ssh + ncch); }
+      if (scm) cm4 = *(const f32x4*)(scm + (size_t)n * scl + ncch);
+    } else {
+      cur_sc = cur_aff ? ssc + ncch : nullptr; cur_sh = cur_aff ? ssh + ncch : nullptr;
+      cur_cm = scm ? scm + (size_t)n * scl + ncch : nullptr;
+    }
     nw = (const char*)d.w_s3 + ((size_t)((kb + c0) >> 4) * CT + (n0 >> 5)) * 3 * 1024;
   };
   auto loadA = [&](int j) {
-    rA[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(nrs, (gA[j] * nld + ncch) * 4, 0, 0));
+    const int sch = SL > 1 ? ((tid + 256 * j) >> 2) / npixA * KC : 0;
+    rA[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(nrs, (gA[j] * nld + ncch + sch) * 4, 0, 0));
   };
-  // fragments ((t - ta) NT + u) 3 + p of taps [ta, ta + nth) -> dst, one 1-KiB DMA instruction each
-  auto dma_half = [&](const char* __restrict__ wsrc, char* __restrict__ dst, int ta, int nth) {
+  // fragments ((v - va) NT + u) 3 + p of virtual taps [va, va + nth) -> dst, one 1-KiB DMA instruction each
+  auto dma_half = [&](const char* __restrict__ wsrc, char* __restrict__ dst, int va, int nth) {
 #pragma unroll
     for (int jj = 0; jj < NDMA; ++jj) {
       const int f = wave + 4 * jj;                 // wave-uniform
       if (f < nth * NT * 3) {
-        const int tl = f / (NT * 3), up = f - tl * (NT * 3);
-        __builtin_amdgcn_global_load_lds((const float*)(wsrc + (size_t)(ta + tl) * tap_stride + up * 1024 + lane * 16),
+        const int vl = f / (NT * 3), up = f - vl * (NT * 3);
+        const int v = va + vl, t = v / SL, sl = v % SL;
+        __builtin_amdgcn_global_load_lds((const float*)(wsrc + (size_t)t * tap_stride + sl * slab_stride + up * 1024 + lane * 16),
                                          (lds_ptr_t)(dst + f * 1024), 16, 0, 0);
       }
     }
@@ -551,24 +584,31 @@ __device__ __forceinline__ void conv_kloop_s3(const pmf_conv_desc_t& d, const Co
     dma_half(nw, Bs, 0, nt0);
   }
   TR();
+  const float* st_sc = nullptr; const float* st_sh = nullptr; const float* st_cm = nullptr;
   auto storeA = [&](char* __restrict__ dst) {
 #pragma unroll
     for (int j = 0; j < ASL; ++j) {
       const int f = tid + 256 * j;
       if (f < totalA) {
+        const int sl = SL > 1 ? (f >> 2) / npixA : 0, pix = (f >> 2) - sl * npixA;
         f32x4 t = {0.f, 0.f, 0.f, 0.f};
         if ((okA >> j) & 1u) {
           t = rA[j];
-          if (cur_aff) t = t * sc4 + sh4;
+          if (SL == 1) {
+            if (cur_aff) t = t * sc4 + sh4;
+          } else if (st_sc) {
+            t = t * *(const f32x4*)(st_sc + sl * KC) + *(const f32x4*)(st_sh + sl * KC);
+          }
           if (cur_flags & PMF_SRC_RELU) {
             t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f);
           }
-          t = t * cm4;
+          if (SL == 1) t = t * cm4;
+          else if (st_cm) t = t * *(const f32x4*)(st_cm + sl * KC);
         }
         unsigned l0, l1, l2, h0, h1, h2;
         s3_split2(t.x, t.y, l0, l1, l2);
         s3_split2(t.z, t.w, h0, h1, h2);
-        char* o = dst + (f >> 2) * S3_APB + q * 8;
+        char* o = dst + sl * a_slab + pix * S3_APB + q * 8;
         *(u32x2*)(o) = u32x2{l0, h0};
         *(u32x2*)(o + 32) = u32x2{l1, h1};
         *(u32x2*)(o + 64) = u32x2{l2, h2};
@@ -592,10 +632,13 @@ __device__ __forceinline__ void conv_kloop_s3(const pmf_conv_desc_t& d, const Co
     __builtin_amdgcn_sched_barrier(0);
     if (with_fill) {
       if (nth == 5) s3_half<BN, MT, 5>(acc, As, Bt, abase, aoff, t0, lane, fill);
+      else if (nth == 4) s3_half<BN, MT, 4>(acc, As, Bt, abase, aoff, t0, lane, fill);
+      else if (nth == 3) s3_half<BN, MT, 3>(acc, As, Bt, abase, aoff, t0, lane, fill);
       else if (nth == 2) s3_half<BN, MT, 2>(acc, As, Bt, abase, aoff, t0, lane, fill);
       else s3_half<BN, MT, 1>(acc, As, Bt, abase, aoff, t0, lane, fill);
     } else {
       if (nth == 4) s3_half<BN, MT, 4>(acc, As, Bt, abase, aoff, t0, lane);
+      else if (nth == 3) s3_half<BN, MT, 3>(acc, As, Bt, abase, aoff, t0, lane);
       else if (nth == 2) s3_half<BN, MT, 2>(acc, As, Bt, abase, aoff, t0, lane);
       else if (nth == 1) s3_half<BN, MT, 1>(acc, As, Bt, abase, aoff, t0, lane);
     }
@@ -603,12 +646,13 @@ __device__ __forceinline__ void conv_kloop_s3(const pmf_conv_desc_t& d, const Co
   while (have) {
     __syncthreads();                       // X: everyone finished the MFMAs of the previous chunk
     TR();
+    if (SL > 1) { st_sc = cur_sc; st_sh = cur_sh; st_cm = cur_cm; }
     storeA(As);
     wcur = nw;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of B(half 0) has landed in LDS
     __syncthreads();                       // Y: input tile + half 0 visible
     TR();
-    ++cn; c0 += KC;
+    ++cn; c0 += KC * SL;
     have = settle();
     if (have) head();
     else nrs = __builtin_amdgcn_make_buffer_rsrc((void*)d.src[0].x, 0, 0, 0x00020000);
@@ -683,8 +727,8 @@ __global__ __launch_bounds__(256) void conv_fwd_k(const pmf_conv_desc_t d, const
     segcol[m] = s & ((1 << g.segs_x_log2) - 1);
   }
 
-  if constexpr (PIPE == 5) {
-    conv_kloop_s3<BN, MT>(d, g, acc, (char*)smem, (char*)(smem + g.a_floats), segrow, segcol, tid, li, lh, n, n0, ks, oy0, ox0, tri_);
+  if constexpr (PIPE >= 5) {          // 5, 6, 7: 1, 2, 4 slabs per stage
+    conv_kloop_s3<BN, MT, (1 << (PIPE - 5))>(d, g, acc, (char*)smem, (char*)(smem + g.a_floats), segrow, segcol, tid, li, lh, n, n0, ks, oy0, ox0, tri_);
   } else if constexpr (PIPE != 0) {
     conv_kloop_pipe<BN, MT, (PIPE > 1 ? PIPE : 1)>(d, g, acc, As, Bs, segrow, segcol, tid, li, lh, n, n0, ks, oy0, ox0, tri_);
   } else {
@@ -1163,6 +1207,19 @@ static int conv_pipe_mode(const pmf_conv_desc_t* d, const ConvGeom& g, int gathe
   return 1;
 }
 
+// split-bf16 path: 16-channel slabs per stage (1, 2 or 4) -- see conv_kloop_s3
+static int conv_s3_slabs(const pmf_conv_desc_t* d, const ConvGeom& g) {
+  int cap = 4;
+  if (const char* e = getenv("PMF_S3_SL")) cap = atoi(e);
+  for (int c = 4; c >= 2; c >>= 1) {
+    if (c > cap || d->ntaps * c > TAPG || g.in_rows * g.in_cols * 4 * c > 256 * 8) continue;
+    bool ok = true;
+    for (int i = 0; i < d->nsrc; ++i) ok = ok && d->src[i].C % (KC * c) == 0;
+    if (ok) return c;
+  }
+  return 1;
+}
+
 template <int BN, int MT>
 static int launch(const pmf_conv_desc_t* d, hipStream_t s) {
   ConvGeom g;
@@ -1189,15 +1246,20 @@ static int launch(const pmf_conv_desc_t* d, hipStream_t s) {
     if constexpr (MT == 1)
       (void)hipFuncSetAttribute((const void*)conv_fwd_k<BN, 1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)conv_fwd_k<BN, MT, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_fwd_k<BN, MT, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_fwd_k<BN, MT, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   const int co_tiles = cdiv(d->Cout, BN);
   int mode = conv_pipe_mode(d, g, gather, MT);
   if (d->w_s3) {             // split-bf16 weights: the pipelined class only (pmf_conv_s3_eligible)
     if (mode == 0 || (d->ldw & 31)) return PMF_E_UNSUPPORTED;
-    mode = 5;
-    g.a_floats = round_up(g.in_rows * g.in_cols * (S3_APB / 4), 4);
-    lds = g.a_floats * 4 + d->ntaps * (BN / 32) * 3 * 1024;
+    const int sl = conv_s3_slabs(d, g);
+    mode = sl == 4 ? 7 : (sl == 2 ? 6 : 5);
+    g.a_floats = sl * round_up(g.in_rows * g.in_cols * (S3_APB / 4), 4);
+    lds = g.a_floats * 4 + d->ntaps * sl * (BN / 32) * 3 * 1024;
+    nchunks = 0;
+    for (int i = 0; i < d->nsrc; ++i) nchunks += d->src[i].C / (KC * sl);
     if (lds < 2 * 4 * 64 * 2 * 8) lds = 2 * 4 * 64 * 2 * 8;
     if (lds > 160 * 1024) return PMF_E_UNSUPPORTED;
   } else if (!d->w) {
@@ -1214,6 +1276,10 @@ static int launch(const pmf_conv_desc_t* d, hipStream_t s) {
   dim3 grid(g.tiles_x * g.tiles_y, co_tiles * g.ksplit, d->N);
   if (mode == 5) {
     hipLaunchKernelGGL((conv_fwd_k<BN, MT, 5>), grid, dim3(256), lds, s, dd, g);
+  } else if (mode == 6) {
+    hipLaunchKernelGGL((conv_fwd_k<BN, MT, 6>), grid, dim3(256), lds, s, dd, g);
+  } else if (mode == 7) {
+    hipLaunchKernelGGL((conv_fwd_k<BN, MT, 7>), grid, dim3(256), lds, s, dd, g);
   } else if (mode == 4) {
     if constexpr (MT == 1) hipLaunchKernelGGL((conv_fwd_k<BN, 1, 4>), grid, dim3(256), lds, s, dd, g);
   } else if (mode == 1) {
@@ -1248,6 +1314,11 @@ extern "C" int pmf_conv_fwd_stat_rows(const pmf_conv_desc_t* d) {
     nchunks = 0;
     for (int i = 0; i < d->nsrc; ++i) nchunks += d->src[i].C / (KC * 4);
   }
+  if (d->w_s3 && conv_pipe_mode(d, g, gather, MT) != 0) {
+    const int sl = conv_s3_slabs(d, g);
+    nchunks = 0;
+    for (int i = 0; i < d->nsrc; ++i) nchunks += d->src[i].C / (KC * sl);
+  }
   if (choose_ksplit(d, tiles * d->N * cdiv(d->Cout, BN), nchunks, d->ntaps * 8 * MT * (BN / 32)) > 1) return finish_rows(d);
   return tiles * d->N;
 }
@@ -1261,7 +1332,8 @@ extern "C" int pmf_conv_s3_eligible(const pmf_conv_desc_t* d) {
     pmf_conv_geometry(d->OH, d->OW, d->ntaps, d->tdy, d->tdx, d->in_stride, d->gather, 64, MT, cmax < KC ? cmax : KC, &g,
                       &gather);
     if (conv_pipe_mode(d, g, gather, MT) == 0) return 0;
-    if (g.in_rows * g.in_cols * S3_APB + d->ntaps * 2 * 3 * 1024 > 160 * 1024) return 0;
+    const int sl = conv_s3_slabs(d, g);
+    if (sl * (g.in_rows * g.in_cols * S3_APB + 16) + d->ntaps * sl * 2 * 3 * 1024 > 160 * 1024) return 0;
   }
   return 1;
 }
@@ -1286,6 +1358,11 @@ extern "C" int pmf_conv_fwd_kstages(const pmf_conv_desc_t* d) {
   if (!d->w_s3 && conv_pipe_mode(d, g, gather, MT) == 4) {
     nchunks = 0;
     for (int i = 0; i < d->nsrc; ++i) nchunks += d->src[i].C / (KC * 4);
+  }
+  if (d->w_s3 && conv_pipe_mode(d, g, gather, MT) != 0) {
+    const int sl = conv_s3_slabs(d, g);
+    nchunks = 0;
+    for (int i = 0; i < d->nsrc; ++i) nchunks += d->src[i].C / (KC * sl);
   }
   return nchunks;
 }

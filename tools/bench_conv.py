@@ -12,6 +12,10 @@ CASES = [  # name, N, H, W, Cin, Cout, k, dil
     ("full_32_32_3x3d2", 2, 64, 2048, 32, 32, 3, 2),
     ("full_64_64_3x3d2", 2, 64, 2048, 64, 64, 3, 2),
     ("full_32_32_1x1", 2, 64, 2048, 32, 32, 1, 1),
+    ("full_192_64_1x1", 2, 64, 2048, 192, 64, 1, 1),
+    ("full_64_64_1x1", 2, 64, 2048, 64, 64, 1, 1),
+    ("full_64_64_2x2d2", 2, 64, 2048, 64, 64, 2, 2),
+    ("half_128_128_2x2d2", 2, 32, 1024, 128, 128, 2, 2),
     ("half_64_64_3x3", 2, 32, 1024, 64, 64, 3, 1),
     ("half_128_128_3x3d2", 2, 32, 1024, 128, 128, 3, 2),
     ("quar_128_128_3x3", 2, 16, 512, 128, 128, 3, 1),
@@ -33,6 +37,7 @@ def run(which, filt):
     for name, N, H, W, ci, co, k, dil in CASES:
         if filt and filt not in name: continue
         pad = dil * (k - 1) // 2
+        if k == 2: pad = 1
         x = torch.randn(N, H, W, ci, device="cuda"); w = torch.randn(co, ci, k, k) * 0.05
         ldw = (co + 63) // 64 * 64
         wpk = G.pack_fwd(w, ci, ldw); out = torch.empty(N, H, W, co, device="cuda")

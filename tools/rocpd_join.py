@@ -3,7 +3,8 @@
 list `bench.py --profile-out` writes (same process), by walking both in launch order.
 
 usage: rocpd_join.py results.db ops.txt step_index [out.txt]
-  step_index = which pack_k launch (0-based) starts the step to analyse (warmup + steps - 1 = last timed step)."""
+  step_index = which step (0-based count of pack_k launch groups) to analyse (warmup + steps - 1 = last timed step).
+  Run the traced process with PMF_LANES=0: the join walks kernels in start order, which is the op order only on one lane."""
 import sqlite3, sys
 
 
@@ -22,7 +23,7 @@ def main(db, ops_file, step, out=None):
     rows = c.execute("select d.start, d.end, s.kernel_name, d.grid_size_x, d.grid_size_y, d.grid_size_z, d.workgroup_size_x "
                      "from rocpd_kernel_dispatch%s d join rocpd_info_kernel_symbol%s s "
                      "on d.kernel_id = s.id order by d.start" % (suf, suf)).fetchall()
-    packs = [i for i, r in enumerate(rows) if "pack_k" in r[2]]
+    packs = [i for i, r in enumerate(rows) if "pack_k" in r[2] and (i == 0 or "pack_k" not in rows[i - 1][2])]
     lo, hi = packs[step], packs[step + 1]
     ker = rows[lo:hi]
     span = (max(r[1] for r in ker) - ker[0][0]) / 1e3
