@@ -38,6 +38,9 @@ import torch.distributed as dist  # noqa: E402
 
 KITTI_MEAN = [12.12, 10.88, 0.23, -1.04, 0.21]      # tasks/pmf/config_server_kitti.yaml:80-91
 KITTI_STD = [12.32, 11.47, 6.91, 0.86, 0.16]
+ARITH_NOTE = ("fp32 in / fp32 out / fp32 accumulate; conv products of the pipelined layer class run as 6 bf16 MFMA "
+              "products of 3-way split operands (error of one fp32 rounding per product; PMF_CONV_F32=1 = fp32 MFMA only)")
+PEAK_BF16_MFMA = 2500.0     # TFLOP/s dense (MI355X_MICROARCH.md)
 PEAK_FP32_MFMA = 157.3                                # TFLOP/s, MI355X_MICROARCH.md
 
 
@@ -99,6 +102,7 @@ def infer_bench(args, model, dev):
         "value": bs * args.steps / dt, "unit": "frame/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
+        "arithmetic": ARITH_NOTE,
         "config": {"workload": "PMF-ResNet34 inference, both streams %dx%d (BASELINE configs[1]), bs=%d, KNN 5/5/1.0/1.0 "
                                "on %d points per frame" % (args.height, args.width, bs, frames[0][1].numel())},
         "roofline": roof, "roofline_hbm": hbm, "cpu_baseline": cpu}))
@@ -153,6 +157,7 @@ def salsanext_bench(args, dev, multi, rank, world):
             "value": world * args.steps / dt, "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "arithmetic": ARITH_NOTE,
             "config": {"workload": "SalsaNext (LiDAR-only task, SURVEY 8f-2) %dx%d range image from 120k-point sweeps, "
                                    "bs=%d/GPU, AdamW" % (args.height, args.width, args.bs), "final_loss": float(loss)},
             "roofline": None, "cpu_baseline": None}))
@@ -251,10 +256,30 @@ def plan_rooflines(plan, prof, model_tag):
     mfma_fl = sum(fam[k][1] for k in convs)
     n_launch = sum(fam[k][0] for k in convs)
     achieved = mfma_fl / (mfma_ms * 1e-3) / 1e12
-    roof = {"bound": "mfma", "kernel": "conv_fwd_k (forward%s launches, fp32 MFMA 32x32x2)" % (
-                " + input-gradient" if "conv_dgrad" in fam else ""),
+    # which of those launches run their fp32 products as six bf16 MFMA products (three-way operand split, conv_fwd.hip
+    # PIPE 5) and which on v_mfma_f32_32x32x2_f32: algorithmic flops by path, from the op arrays
+    from pmf_amd import _lib as L
+    split_fl = 0.0
+    for ph in ("fwd", "bwd"):
+        ops, kinds = getattr(plan, ph + "_ops", None), getattr(plan, ph + "_kinds", None)
+        shift, meta = getattr(plan, ph + "_shift", 0), getattr(plan, "meta_" + ph, None)
+        if not ops or not kinds or not meta:
+            continue
+        for i, m in meta.items():
+            if m.get("family") in convs and kinds[i + shift] == L.OP_CONV and ops[i + shift].u.conv.w_s3:
+                split_fl += m["flops"]
+    share = split_fl / max(mfma_fl, 1.0)
+    roof = {"bound": "mfma",
+            "kernel": "conv_fwd_k (forward%s launches): fp32 arithmetic, %.0f %% of the flops as 6 bf16 MFMA products per "
+                      "fp32 product (3-way operand split, v_mfma_f32_32x32x16_bf16, fp32 accumulate), the rest on "
+                      "v_mfma_f32_32x32x2_f32" % (" + input-gradient" if "conv_dgrad" in fam else "", 100.0 * share),
             "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_FP32_MFMA, 4), "traffic": None, "traffic_source": None,
+            "frac": round(achieved / PEAK_FP32_MFMA, 4),
+            "peak_note": "peak = dense fp32 MFMA (the arithmetic type); achieved = algorithmic fp32 flops / kernel time",
+            "bf16_pipe": {"executed_tflops": round(achieved * (6.0 * share), 1), "peak": PEAK_BF16_MFMA,
+                          "frac": round(achieved * 6.0 * share / PEAK_BF16_MFMA, 4),
+                          "fp32_equivalent_ceiling_tflops": round(PEAK_BF16_MFMA / 6.0, 1)},
+            "traffic": None, "traffic_source": None,
             "launches_per_iter": n_launch, "avg_launch_us": round(1e3 * mfma_ms / n_launch, 2),
             "algorithmic_gflop_per_iter": round(mfma_fl / 1e9, 1)}
     hbm = []
@@ -305,6 +330,7 @@ def main():
                          "tasks/pmf/trainer.py:289-303): the captured graphs must keep replaying")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-f32-ref", action="store_true", help="skip the fp32-MFMA-only reference measurement")
     ap.add_argument("--profile-out", default=None, help="write the per-launch HIP-event profile (one line per op)")
     args = ap.parse_args()
 
@@ -422,6 +448,29 @@ def main():
                 roof["traffic_source"] = "profiles/%s (%s)" % (os.path.basename(tp), tj["method"])
                 break
 
+    # the same training step with every convolution on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32; PMF_CONV_F32=1): the
+    # split-bf16 products carry fp32-class error (tests), this line shows what they buy
+    f32_only = None
+    if rank == 0 and world == 1 and args.mode == "train" and not args.no_f32_ref:
+        os.environ["PMF_CONV_F32"] = "1"
+        try:
+            torch.manual_seed(1)
+            model2 = net(5, 3, args.nclasses, 32, imagenet_pretrained=False, image_backbone=args.backbone).to(dev)
+            eng2 = Engine(model2, args.nclasses, lr=1e-3, momentum=0.9, weight_decay=1e-5, lambda_=1.0, gamma=0.5, tau=0.7,
+                          feature_mean=KITTI_MEAN, feature_std=KITTI_STD, warmup_steps=10 * 100, max_steps=49 * 100)
+            for _ in range(6):
+                eng2.train_step(feat0.clone(), mask, label)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(15):
+                eng2.train_step(feat0.clone(), mask, label)
+            torch.cuda.synchronize()
+            f32_only = {"value": 15 / (time.perf_counter() - t1), "unit": "iter/s", "steps": 15,
+                        "note": "PMF_CONV_F32=1: all conv / weight-gradient products on v_mfma_f32_32x32x2_f32"}
+            del eng2, model2
+        finally:
+            del os.environ["PMF_CONV_F32"]
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.bs, args.height, args.width, args.model, args.backbone, args.nclasses)
@@ -437,6 +486,7 @@ def main():
             "value": iters / dt, "unit": "iter/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "arithmetic": ARITH_NOTE,
             "config": {"workload": "%s-%s, full train loop, both streams %dx%d (BASELINE configs[%d]%s), bs=%d/GPU, "
                                    "%d classes, dropout on, local-stat BN"
                                    % (tag, bb, args.height, args.width,
@@ -448,7 +498,8 @@ def main():
                        "samples_per_s": world * args.bs * args.steps / dt, "final_loss": loss_val,
                        "fresh_input_addresses": bool(args.fresh_inputs),
                        "graphs_captured": len(next(iter(model._plans.values()))._graphs)},
-            "roofline": roof, "roofline_hbm": hbm, "cpu_baseline": cpu, "kernel_time_breakdown": detail,
+            "roofline": roof, "roofline_hbm": hbm, "cpu_baseline": cpu, "fp32_mfma_only": f32_only,
+            "kernel_time_breakdown": detail,
         }
         try:       # RCCL prints its version banner through C stdio (buffered when piped): push it out first so that the
             import ctypes           # JSON line is the LAST line of stdout
