@@ -392,6 +392,11 @@ __device__ __forceinline__ unsigned s3_pk(f32x2 v) { return __builtin_bit_cast(u
 __device__ __forceinline__ f32x2 s3_unpk(unsigned u) {
   return f32x2{__builtin_bit_cast(float, u << 16), __builtin_bit_cast(float, u & 0xffff0000u)};
 }
+__device__ __forceinline__ float s3_vmax(float a, float b) {   // plain v_max_f32 (fmaxf adds a canonicalising v_max)
+  float r;
+  asm("v_max_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 // two floats -> their three bf16 planes (packed pairs)
 __device__ __forceinline__ void s3_split2(float a, float b, unsigned& p0, unsigned& p1, unsigned& p2) {
   f32x2 r = {a, b};
@@ -585,34 +590,34 @@ __device__ __forceinline__ void conv_kloop_s3(const pmf_conv_desc_t& d, const Co
   }
   TR();
   const float* st_sc = nullptr; const float* st_sh = nullptr; const float* st_cm = nullptr;
+  // Straight-line (no exec masking, no uniform branches): seven of these in a row interleave freely.  Out-of-image
+  // pixels are zeroed AFTER the transform (zero padding of the transformed map); slots past the end of the tile write
+  // to a per-thread scratch word pair instead of being masked off.
+  char* const trash = Bs + nv * NT * 3 * 1024 + tid * 8;
   auto storeA = [&](char* __restrict__ dst) {
+    const float relu_lo = (cur_flags & PMF_SRC_RELU) ? 0.f : -__builtin_inff();
 #pragma unroll
     for (int j = 0; j < ASL; ++j) {
       const int f = tid + 256 * j;
-      if (f < totalA) {
-        const int sl = SL > 1 ? (f >> 2) / npixA : 0, pix = (f >> 2) - sl * npixA;
-        f32x4 t = {0.f, 0.f, 0.f, 0.f};
-        if ((okA >> j) & 1u) {
-          t = rA[j];
-          if (SL == 1) {
-            if (cur_aff) t = t * sc4 + sh4;
-          } else if (st_sc) {
-            t = t * *(const f32x4*)(st_sc + sl * KC) + *(const f32x4*)(st_sh + sl * KC);
-          }
-          if (cur_flags & PMF_SRC_RELU) {
-            t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f);
-          }
-          if (SL == 1) t = t * cm4;
-          else if (st_cm) t = t * *(const f32x4*)(st_cm + sl * KC);
-        }
-        unsigned l0, l1, l2, h0, h1, h2;
-        s3_split2(t.x, t.y, l0, l1, l2);
-        s3_split2(t.z, t.w, h0, h1, h2);
-        char* o = dst + sl * a_slab + pix * S3_APB + q * 8;
-        *(u32x2*)(o) = u32x2{l0, h0};
-        *(u32x2*)(o + 32) = u32x2{l1, h1};
-        *(u32x2*)(o + 64) = u32x2{l2, h2};
+      const int sl = SL > 1 ? (f >> 2) / npixA : 0, pix = (f >> 2) - sl * npixA;
+      f32x4 t = rA[j];
+      if (SL == 1) {
+        t = t * sc4 + sh4;
+      } else if (st_sc) {
+        t = t * *(const f32x4*)(st_sc + sl * KC) + *(const f32x4*)(st_sh + sl * KC);
       }
+      t.x = s3_vmax(t.x, relu_lo); t.y = s3_vmax(t.y, relu_lo); t.z = s3_vmax(t.z, relu_lo); t.w = s3_vmax(t.w, relu_lo);
+      if (SL == 1) t = t * cm4;
+      else if (st_cm) t = t * *(const f32x4*)(st_cm + sl * KC);
+      const bool ok = (okA >> j) & 1u;
+      t.x = ok ? t.x : 0.f; t.y = ok ? t.y : 0.f; t.z = ok ? t.z : 0.f; t.w = ok ? t.w : 0.f;
+      unsigned l0, l1, l2, h0, h1, h2;
+      s3_split2(t.x, t.y, l0, l1, l2);
+      s3_split2(t.z, t.w, h0, h1, h2);
+      char* o = f < totalA ? dst + sl * a_slab + pix * S3_APB + q * 8 : trash;
+      *(u32x2*)(o) = u32x2{l0, h0};
+      *(u32x2*)(o + (f < totalA ? 32 : 0)) = u32x2{l1, h1};
+      *(u32x2*)(o + (f < totalA ? 64 : 0)) = u32x2{l2, h2};
     }
   };
   auto fill = [&](int st, int ns) {
@@ -1257,7 +1262,7 @@ static int launch(const pmf_conv_desc_t* d, hipStream_t s) {
     const int sl = conv_s3_slabs(d, g);
     mode = sl == 4 ? 7 : (sl == 2 ? 6 : 5);
     g.a_floats = sl * round_up(g.in_rows * g.in_cols * (S3_APB / 4), 4);
-    lds = g.a_floats * 4 + d->ntaps * sl * (BN / 32) * 3 * 1024;
+    lds = g.a_floats * 4 + d->ntaps * sl * (BN / 32) * 3 * 1024 + 2048;   // + per-thread scratch of the staging stores
     nchunks = 0;
     for (int i = 0; i < d->nsrc; ++i) nchunks += d->src[i].C / (KC * sl);
     if (lds < 2 * 4 * 64 * 2 * 8) lds = 2 * 4 * 64 * 2 * 8;
@@ -1333,7 +1338,7 @@ extern "C" int pmf_conv_s3_eligible(const pmf_conv_desc_t* d) {
                       &gather);
     if (conv_pipe_mode(d, g, gather, MT) == 0) return 0;
     const int sl = conv_s3_slabs(d, g);
-    if (sl * (g.in_rows * g.in_cols * S3_APB + 16) + d->ntaps * sl * 2 * 3 * 1024 > 160 * 1024) return 0;
+    if (sl * (g.in_rows * g.in_cols * S3_APB + 16) + d->ntaps * sl * 2 * 3 * 1024 + 2048 > 160 * 1024) return 0;
   }
   return 1;
 }

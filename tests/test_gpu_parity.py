@@ -218,6 +218,45 @@ def test_eval_forward_matches_oracle(backbone, ncls, n, h, w, golden):
         assert G.rel_err(lg, g["r50.eval.lidar_logits"]) < 1e-3
 
 
+def test_precision_probe_split_bf16_vs_fp32_mfma():
+    """BASELINE.md's precision probe (eval forward, deterministic init, pre-softmax logits against float64) on both
+    arithmetic paths of the conv kernels: v_mfma_f32_32x32x2_f32 (PMF_CONV_F32=1) and the three-way split on the bf16
+    matrix pipe (default).  Both must sit at fp32 rounding level -- three orders of magnitude below what bf16 inputs
+    leave (1.8e-3 in BASELINE.md) -- and the split path within 3x of the fp32 pipe."""
+    import copy
+    from pmf_amd.models import PMFNet
+    from oracle import pmf_torch as O
+    n, h, w = 1, 64, 512
+    pcd, rgb, _, _ = synthetic_batch(n, h, w, 20, seed=1)
+    ref64 = deterministic_init(O.PMFNet(5, 3, 20, 32, False, "resnet34")).double().eval()
+    with torch.no_grad():
+        ref64(pcd.double(), rgb.double())
+    want = ref64.lidar_stream.last_logits.detach()
+    errs = {}
+    for tag, env in (("split_bf16", None), ("fp32_mfma", "1")):
+        if env is None:
+            os.environ.pop("PMF_CONV_F32", None)
+        else:
+            os.environ["PMF_CONV_F32"] = env
+        try:
+            hip = deterministic_init(PMFNet(5, 3, 20, 32, False, "resnet34")).cuda().eval()
+            with torch.no_grad():
+                hip(pcd.cuda(), rgb.cuda())
+            torch.cuda.synchronize()
+            plan = next(iter(hip._plans.values()))
+            n_split = sum(1 for i in range(plan.n_fwd) if plan.fwd_kinds[i] == L.OP_CONV and plan.fwd_ops[i].u.conv.w_s3)
+            assert (n_split > 90) == (env is None)
+            got = plan.read(plan.tensors["logits"]).cpu().double()
+            errs[tag] = ((got - want).abs().max().item(), want.abs().max().item())
+        finally:
+            os.environ.pop("PMF_CONV_F32", None)
+    _dump("precision_probe.txt", [(k, v[0], v[1]) for k, v in errs.items()])
+    e3, ef = errs["split_bf16"][0], errs["fp32_mfma"][0]
+    scale = errs["split_bf16"][1]
+    assert ef < 2e-5 * max(scale, 1.0) and e3 < 2e-5 * max(scale, 1.0), errs
+    assert e3 <= 3 * ef + 1e-6, errs
+
+
 def _masks(ref, n, seed=3):
     from oracle import pmf_torch as O
     g = torch.Generator().manual_seed(seed)
