@@ -94,11 +94,24 @@ __global__ void bn_bwd_reduce_k(const float* __restrict__ gy, int gy_ldc, const 
   double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};   // float64 accumulation (HBM-bound kernel: free)
   if (active) {
     const f32x4 mu = *(const f32x4*)(save_mean + c);   // centre first: sum g*(a - mean) has no cancellation
-    for (int64_t p = (int64_t)blockIdx.x * rows + row; p < npix; p += (int64_t)gridDim.x * rows) {
-      const f32x4 g = *(const f32x4*)(gy + p * gy_ldc + c);
-      const f32x4 x = *(const f32x4*)(a + p * a_ldc + c) - mu;
+    // four pixels per trip: 8 independent 16-byte loads in flight per thread (one pixel per trip left the kernel at
+    // 1.8 TB/s: 512 workgroups x 2 loads do not cover the HBM latency)
+    const int64_t step = (int64_t)gridDim.x * rows;
+    for (int64_t p = (int64_t)blockIdx.x * rows + row; p < npix; p += 4 * step) {
+      f32x4 g[4], x[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) { s1[k] += (double)g[k]; s2[k] += (double)g[k] * (double)x[k]; }
+      for (int u = 0; u < 4; ++u) {
+        const int64_t pp = p + u * step;
+        if (pp < npix) { g[u] = *(const f32x4*)(gy + pp * gy_ldc + c); x[u] = *(const f32x4*)(a + pp * a_ldc + c); }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (p + u * step < npix) {
+          const f32x4 xc = x[u] - mu;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { s1[k] += (double)g[u][k]; s2[k] += (double)g[u][k] * (double)xc[k]; }
+        }
+      }
     }
   }
 #pragma unroll
@@ -176,15 +189,27 @@ __global__ void bn_bwd_apply_k(const float* __restrict__ gy, int gy_ldc, const f
     const f32x4 A = *(const f32x4*)(coef + c), K = *(const f32x4*)(coef + C + c), MG = *(const f32x4*)(coef + 2 * C + c);
     const f32x4 MU = *(const f32x4*)(save_mean + c);
     const float sl = act == PMF_ACT_LRELU ? 0.01f : (act == PMF_ACT_RELU ? 0.f : 1.f);
-    for (int64_t p = (int64_t)blockIdx.x * rows + row; p < npix; p += (int64_t)gridDim.x * rows) {
-      const f32x4 g = *(const f32x4*)(gy + p * gy_ldc + c);
-      const f32x4 x = *(const f32x4*)(a + p * a_ldc + c);
-      f32x4 d = A * ((g - MG) - (x - MU) * K);
-      if (act != PMF_ACT_NONE) {
-        d.x *= x.x > 0.f ? 1.f : sl; d.y *= x.y > 0.f ? 1.f : sl; d.z *= x.z > 0.f ? 1.f : sl; d.w *= x.w > 0.f ? 1.f : sl;
+    const int64_t step = (int64_t)gridDim.x * rows;
+    for (int64_t p = (int64_t)blockIdx.x * rows + row; p < npix; p += 4 * step) {     // four pixels per trip (see above)
+      f32x4 g[4], x[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t pp = p + u * step;
+        if (pp < npix) { g[u] = *(const f32x4*)(gy + pp * gy_ldc + c); x[u] = *(const f32x4*)(a + pp * a_ldc + c); }
       }
-      *(f32x4*)(dz + p * dz_ldc + c) = d;
-      part += d;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t pp = p + u * step;
+        if (pp < npix) {
+          f32x4 d = A * ((g[u] - MG) - (x[u] - MU) * K);
+          if (act != PMF_ACT_NONE) {
+            d.x *= x[u].x > 0.f ? 1.f : sl; d.y *= x[u].y > 0.f ? 1.f : sl;
+            d.z *= x[u].z > 0.f ? 1.f : sl; d.w *= x[u].w > 0.f ? 1.f : sl;
+          }
+          *(f32x4*)(dz + pp * dz_ldc + c) = d;
+          part += d;
+        }
+      }
     }
   }
   if (dbias_rows) {
