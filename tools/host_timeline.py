@@ -62,9 +62,9 @@ def main(steps):
     print("steps %d: wall %.2f ms/step, host enqueue %.2f ms/step" % (steps, t_all / steps * 1e3, t_enq / steps * 1e3))
     print("%-12s %10s %10s" % ("phase", "gpu ms", "host ms"))
     for i, n in enumerate(names):
-        print("%-12s %10.3f %10.3f" % (n, np.median(gpu[3:, i]), np.median(host[3:, i])))
+        print("%-12s %10.3f %10.3f" % (n, np.median(gpu[3:, i]), 1e3 * np.median(host[3:, i])))
     print("between steps (gpu): %.3f ms" % np.median(step_gap[3:]))
-    print("first 3 steps host ms (GPU idle at start):", host[:3].sum(1).round(2))
+    print("first 3 steps host ms (GPU idle at start):", (1e3 * host[:3].sum(1)).round(2))
 
 
 if __name__ == "__main__":
