@@ -391,7 +391,10 @@ class Plan:
         """register a pack job; returns the Buf of the packed slab [ntaps][K_pad][ldw] (fmt 0, fp32) or of the split-bf16
         fragments [ntaps][K_pad/16][ldw/32][3][64][8] (fmt 1, 6 bytes per weight; pmf_conv_desc_t.w_s3)."""
         buf = self.persist.alloc((6 if fmt else 4) * len(taps_widx) * K_pad * ldw)
-        self.pack_jobs.append((weight, buf, list(taps_widx), transpose, K_pad, ldw, self.lane, fmt))
+        # forward packs: index of the conv op about to be emitted (the first reader); input-gradient packs: none (they are
+        # read by the backward graph only)
+        owner = len(self.fwd) if (not transpose and self.fwd is not None) else None
+        self.pack_jobs.append((weight, buf, list(taps_widx), transpose, K_pad, ldw, self.lane, fmt, owner))
         return buf
 
     def s3_ok(self, shape_fill):
@@ -1246,12 +1249,35 @@ class Plan:
         lib = L.lib()
         # pack job tables (device), one per lane: every lane re-packs the weights of its own layers at the start of the
         # forward pass (they change every step), concurrently with the other lane's ---------------------------------
+        # Only the first PACK_EARLY layers of a lane are packed in front of it; everything else (later layers, all
+        # input-gradient packs) goes to ONE table that lane 2 works through while lanes 0 / 1 already run their first
+        # layers: the first op of a lane that reads a late-packed weight waits for that launch's event.
         self.pack_tables = []
+        PACK_EARLY = int(os.environ.get("PMF_PACK_EARLY", "8"))
+        late, late_event = [], None
+        groups = []
         for lane in sorted({j[6] for j in self.pack_jobs}):
             mine = [j for j in self.pack_jobs if j[6] == lane]
+            fwdj = [j for j in mine if j[8] is not None]
+            early = mine
+            if PACK_EARLY > 0 and self.n_lanes >= 3 and len(fwdj) > PACK_EARLY + 4 and dev.type == "cuda":
+                first_late = fwdj[PACK_EARLY]
+                waiter = self.fwd[first_late[8]]
+                if not ((waiter[2] >> 8) & 0xff) and (waiter[2] & 3) == lane:      # its wait slot is free
+                    if late_event is None:
+                        late_event = self.n_events
+                        self.n_events += 1
+                    waiter[2] |= (late_event + 1) << 8
+                    early = fwdj[:PACK_EARLY]
+                    keep = {id(j) for j in early}
+                    late += [j for j in mine if id(j) not in keep]
+            groups.append((lane, early))
+        if late:
+            groups.append((2, late))
+        for lane, mine in groups:
             jobs = (L.PackJob * len(mine))()
             blocks = 0
-            for j, (w, buf, tap_idx, transpose, K_pad, ldw, _, fmt) in enumerate(mine):
+            for j, (w, buf, tap_idx, transpose, K_pad, ldw, _, fmt, _o) in enumerate(mine):
                 Cout, Cin, KHW = w.shape[0], w.shape[1], w.shape[2] * w.shape[3]
                 ct = lib.pmf_pack_tile_ci(Cin, KHW)
                 J = jobs[j]
@@ -1264,7 +1290,10 @@ class Plan:
                     J.tap_idx[i] = ti
                 blocks += J.tiles_ci * ((Cout + 31) // 32)
             dev_tab = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(dev)
-            self.pack_tables.append((lane, dev_tab, len(mine), blocks))
+            bits = lane
+            if late and mine is late:
+                bits |= (late_event + 1) << 16          # records the event the first late readers wait for
+            self.pack_tables.append((lane, dev_tab, len(mine), blocks, bits))
         self.n_pack_jobs = len(self.pack_jobs)
         self.n_pack_blocks = sum(t[3] for t in self.pack_tables)
 
@@ -1294,7 +1323,8 @@ class Plan:
             return z
 
         # lane 0 first: a side lane forks from the main stream at its first op and must not wait for lane 0's packing
-        pro_f = [(L.OP_PACK, pack_op(tab, n, blocks), lane) for lane, tab, n, blocks in sorted(self.pack_tables, key=lambda t: -t[0])]
+        pro_f = [(L.OP_PACK, pack_op(tab, n, blocks), bits)
+                 for lane, tab, n, blocks, bits in sorted(self.pack_tables, key=lambda t: -t[0])]
         if self.zero_fwd.size:
             pro_f.insert(0, (L.OP_FILL, zero_arena(self.zero_fwd)))
         self.fwd_shift = len(pro_f)
@@ -1314,7 +1344,6 @@ class Plan:
         self.bwd_kinds = [e[0] for e in (pro_b + self.bwd)] if self.training else []
         self.fwd = self.bwd = None
         self.param_ptrs = [p.data_ptr() for p in self.params]
-        import os
         if self.device.type == "cuda" and os.environ.get("PMF_AUTOTUNE", "1") != "0":
             self.autotune()
         return self
