@@ -13,6 +13,7 @@
 #include "common.h"
 #include <stdio.h>
 #include <stdlib.h>
+#include <type_traits>
 
 #define KC 16
 #define APITCH 20
@@ -534,7 +535,7 @@ __device__ __forceinline__ void conv_kloop_s3(const pmf_conv_desc_t& d, const Co
   };
   f32x4 rA[ASL], sc4, sh4, cm4;
   int cur_flags = 0;
-  bool cur_aff = false;
+  bool cur_aff = false, cur_plain = false;
   __amdgpu_buffer_rsrc_t nrs;
   int nld = 0, ncch = 0;
   const float* cur_sc = nullptr; const float* cur_sh = nullptr; const float* cur_cm = nullptr;   // SL > 1: re-read at store time
@@ -551,6 +552,7 @@ __device__ __forceinline__ void conv_kloop_s3(const pmf_conv_desc_t& d, const Co
     nld = sld; ncch = c0 + q * 4;
     cur_flags = sfl;
     cur_aff = ssc != nullptr;
+    cur_plain = !ssc && !scm && !(sfl & PMF_SRC_RELU);
     if (SL == 1) {
       sc4 = f32x4{1.f, 1.f, 1.f, 1.f}; sh4 = f32x4{0.f, 0.f, 0.f, 0.f}; cm4 = f32x4{1.f, 1.f, 1.f, 1.f};
       if (cur_aff) { sc4 = *(const f32x4*)(ssc + ncch); sh4 = *(const f32x4*)(ssh + ncch); }
@@ -594,23 +596,28 @@ __device__ __forceinline__ void conv_kloop_s3(const pmf_conv_desc_t& d, const Co
   // pixels are zeroed AFTER the transform (zero padding of the transformed map); slots past the end of the tile write
   // to a per-thread scratch word pair instead of being masked off.
   char* const trash = Bs + nv * NT * 3 * 1024 + tid * 8;
-  auto storeA = [&](char* __restrict__ dst) {
+  // PLAIN: the operand is a raw tensor (no BatchNorm view, no ReLU, no channel multiplier -- every input-gradient launch
+  // reads dz this way): nothing to transform, and out-of-image slots already hold the 0 the buffer load returned
+  auto storeA_impl = [&](char* __restrict__ dst, auto plain_c) {
+    constexpr bool PLAIN = decltype(plain_c)::value;
     const float relu_lo = (cur_flags & PMF_SRC_RELU) ? 0.f : -__builtin_inff();
 #pragma unroll
     for (int j = 0; j < ASL; ++j) {
       const int f = tid + 256 * j;
       const int sl = SL > 1 ? (f >> 2) / npixA : 0, pix = (f >> 2) - sl * npixA;
       f32x4 t = rA[j];
-      if (SL == 1) {
-        t = t * sc4 + sh4;
-      } else if (st_sc) {
-        t = t * *(const f32x4*)(st_sc + sl * KC) + *(const f32x4*)(st_sh + sl * KC);
+      if (!PLAIN) {
+        if (SL == 1) {
+          t = t * sc4 + sh4;
+        } else if (st_sc) {
+          t = t * *(const f32x4*)(st_sc + sl * KC) + *(const f32x4*)(st_sh + sl * KC);
+        }
+        t.x = s3_vmax(t.x, relu_lo); t.y = s3_vmax(t.y, relu_lo); t.z = s3_vmax(t.z, relu_lo); t.w = s3_vmax(t.w, relu_lo);
+        if (SL == 1) t = t * cm4;
+        else if (st_cm) t = t * *(const f32x4*)(st_cm + sl * KC);
+        const bool ok = (okA >> j) & 1u;
+        t.x = ok ? t.x : 0.f; t.y = ok ? t.y : 0.f; t.z = ok ? t.z : 0.f; t.w = ok ? t.w : 0.f;
       }
-      t.x = s3_vmax(t.x, relu_lo); t.y = s3_vmax(t.y, relu_lo); t.z = s3_vmax(t.z, relu_lo); t.w = s3_vmax(t.w, relu_lo);
-      if (SL == 1) t = t * cm4;
-      else if (st_cm) t = t * *(const f32x4*)(st_cm + sl * KC);
-      const bool ok = (okA >> j) & 1u;
-      t.x = ok ? t.x : 0.f; t.y = ok ? t.y : 0.f; t.z = ok ? t.z : 0.f; t.w = ok ? t.w : 0.f;
       unsigned l0, l1, l2, h0, h1, h2;
       s3_split2(t.x, t.y, l0, l1, l2);
       s3_split2(t.z, t.w, h0, h1, h2);
@@ -619,6 +626,10 @@ __device__ __forceinline__ void conv_kloop_s3(const pmf_conv_desc_t& d, const Co
       *(u32x2*)(o + (f < totalA ? 32 : 0)) = u32x2{l1, h1};
       *(u32x2*)(o + (f < totalA ? 64 : 0)) = u32x2{l2, h2};
     }
+  };
+  auto storeA = [&](char* __restrict__ dst) {
+    if (cur_plain) storeA_impl(dst, std::true_type{});
+    else storeA_impl(dst, std::false_type{});
   };
   auto fill = [&](int st, int ns) {
     constexpr int per = 2;
