@@ -275,7 +275,8 @@ def plan_rooflines(plan, prof, model_tag):
                       "v_mfma_f32_32x32x2_f32" % (" + input-gradient" if "conv_dgrad" in fam else "", 100.0 * share),
             "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_FP32_MFMA, 4),
-            "peak_note": "peak = dense fp32 MFMA (the arithmetic type); achieved = algorithmic fp32 flops / kernel time",
+            "peak_note": "peak = dense fp32 MFMA (the arithmetic type); achieved = algorithmic fp32 flops / launch time; "
+                         "launch time = HIP events around 3 back-to-back launches of every conv op, one lane",
             "bf16_pipe": {"executed_tflops": round(achieved * (6.0 * share), 1), "peak": PEAK_BF16_MFMA,
                           "frac": round(achieved * 6.0 * share / PEAK_BF16_MFMA, 4),
                           "fp32_equivalent_ceiling_tflops": round(PEAK_BF16_MFMA / 6.0, 1)},
