@@ -474,7 +474,9 @@ __device__ __forceinline__ void s3_half(f32x16 (&acc)[MT][BN / 32], const char* 
 // SL = 16-channel slabs per stage.  Few-tap convolutions (1x1, 2x2, 1x3) carry SL = 4 / 2 slabs per stage as "virtual
 // taps" v = tap * SL + slab (same idea as VT of PIPE 4): a 16-channel stage of a 1x1 layer is 6 MT NT MFMAs between
 // three barriers.  Stages are sized so that virtual taps <= 9 and the staging slots per thread <= 8.
-template <int BN, int MT, int SL>
+// NTAPS: 9 = the 3x3 case with its tap count known at compile time (no dispatch on the half sizes inside the stage
+// loop: the branches end scheduling regions and cost accumulator copies at their joins), 0 = read from the descriptor
+template <int BN, int MT, int SL, int NTAPS = 0>
 __device__ __forceinline__ void conv_kloop_s3(const pmf_conv_desc_t& d, const ConvGeom& g, f32x16 (&acc)[MT][BN / 32],
                                               char* __restrict__ As, char* __restrict__ Bs, const int (&segrow)[MT],
                                               const int (&segcol)[MT], int tid, int li, int lh, int n, int n0, int ks,
@@ -490,7 +492,7 @@ __device__ __forceinline__ void conv_kloop_s3(const pmf_conv_desc_t& d, const Co
   const int npixA = g.in_rows * in_cols;
   const int totalA = npixA * 4 * SL;
   const int a_slab = g.a_floats * 4 / SL;         // bytes of one slab's tile
-  const int nv = d.ntaps * SL;                    // virtual taps
+  const int nv = (NTAPS ? NTAPS : d.ntaps) * SL;  // virtual taps
   const int nt0 = (nv + 1) >> 1, nt1 = nv - nt0;  // ... of half 0 / half 1
   char* __restrict__ Bh1 = Bs + nt0 * NT * 3 * 1024;
   const int KS = g.Ktot >> 4, CT = d.ldw >> 5;
@@ -646,6 +648,11 @@ __device__ __forceinline__ void conv_kloop_s3(const pmf_conv_desc_t& d, const Co
 #pragma unroll
     for (int m = 0; m < MT; ++m) asm volatile("" : "+v"(abase[m]));
     __builtin_amdgcn_sched_barrier(0);
+    if (NTAPS == 9) {
+      if (with_fill) s3_half<BN, MT, 5>(acc, As, Bt, abase, aoff, 0, lane, fill);
+      else s3_half<BN, MT, 4>(acc, As, Bt, abase, aoff, 5, lane);
+      return;
+    }
     if (with_fill) {
       if (nth == 5) s3_half<BN, MT, 5>(acc, As, Bt, abase, aoff, t0, lane, fill);
       else if (nth == 4) s3_half<BN, MT, 4>(acc, As, Bt, abase, aoff, t0, lane, fill);
@@ -743,7 +750,9 @@ __global__ __launch_bounds__(256) void conv_fwd_k(const pmf_conv_desc_t d, const
     segcol[m] = s & ((1 << g.segs_x_log2) - 1);
   }
 
-  if constexpr (PIPE >= 5) {          // 5, 6, 7: 1, 2, 4 slabs per stage
+  if constexpr (PIPE == 8) {          // one slab per stage, 9 taps at compile time
+    conv_kloop_s3<BN, MT, 1, 9>(d, g, acc, (char*)smem, (char*)(smem + g.a_floats), segrow, segcol, tid, li, lh, n, n0, ks, oy0, ox0, tri_);
+  } else if constexpr (PIPE >= 5) {          // 5, 6, 7: 1, 2, 4 slabs per stage, tap count from the descriptor
     conv_kloop_s3<BN, MT, (1 << (PIPE - 5))>(d, g, acc, (char*)smem, (char*)(smem + g.a_floats), segrow, segcol, tid, li, lh, n, n0, ks, oy0, ox0, tri_);
   } else if constexpr (PIPE != 0) {
     conv_kloop_pipe<BN, MT, (PIPE > 1 ? PIPE : 1)>(d, g, acc, As, Bs, segrow, segcol, tid, li, lh, n, n0, ks, oy0, ox0, tri_);
@@ -1264,6 +1273,7 @@ static int launch(const pmf_conv_desc_t* d, hipStream_t s) {
     (void)hipFuncSetAttribute((const void*)conv_fwd_k<BN, MT, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)conv_fwd_k<BN, MT, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)conv_fwd_k<BN, MT, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_fwd_k<BN, MT, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   const int co_tiles = cdiv(d->Cout, BN);
@@ -1274,6 +1284,7 @@ static int launch(const pmf_conv_desc_t* d, hipStream_t s) {
     mode = sl == 4 ? 7 : (sl == 2 ? 6 : 5);
     g.a_floats = sl * round_up(g.in_rows * g.in_cols * (S3_APB / 4), 4);
     lds = g.a_floats * 4 + d->ntaps * sl * (BN / 32) * 3 * 1024 + 2048;   // + per-thread scratch of the staging stores
+    if (sl == 1 && d->ntaps == 9 && !getenv("PMF_S3_NO9")) mode = 8;
     nchunks = 0;
     for (int i = 0; i < d->nsrc; ++i) nchunks += d->src[i].C / (KC * sl);
     if (lds < 2 * 4 * 64 * 2 * 8) lds = 2 * 4 * 64 * 2 * 8;
@@ -1296,6 +1307,8 @@ static int launch(const pmf_conv_desc_t* d, hipStream_t s) {
     hipLaunchKernelGGL((conv_fwd_k<BN, MT, 6>), grid, dim3(256), lds, s, dd, g);
   } else if (mode == 7) {
     hipLaunchKernelGGL((conv_fwd_k<BN, MT, 7>), grid, dim3(256), lds, s, dd, g);
+  } else if (mode == 8) {
+    hipLaunchKernelGGL((conv_fwd_k<BN, MT, 8>), grid, dim3(256), lds, s, dd, g);
   } else if (mode == 4) {
     if constexpr (MT == 1) hipLaunchKernelGGL((conv_fwd_k<BN, 1, 4>), grid, dim3(256), lds, s, dd, g);
   } else if (mode == 1) {
