@@ -648,9 +648,10 @@ __device__ __forceinline__ void conv_kloop_s3(const pmf_conv_desc_t& d, const Co
 #pragma unroll
     for (int m = 0; m < MT; ++m) asm volatile("" : "+v"(abase[m]));
     __builtin_amdgcn_sched_barrier(0);
-    if (NTAPS == 9) {
-      if (with_fill) s3_half<BN, MT, 5>(acc, As, Bt, abase, aoff, 0, lane, fill);
-      else s3_half<BN, MT, 4>(acc, As, Bt, abase, aoff, 5, lane);
+    if (NTAPS != 0) {
+      constexpr int NV = (NTAPS ? NTAPS : 1) * SL, N0 = (NV + 1) / 2, N1 = NV - N0;
+      if (with_fill) s3_half<BN, MT, N0>(acc, As, Bt, abase, aoff, 0, lane, fill);
+      else s3_half<BN, MT, (N1 > 0 ? N1 : 1)>(acc, As, Bt, abase, aoff, N0, lane);
       return;
     }
     if (with_fill) {
@@ -752,6 +753,8 @@ __global__ __launch_bounds__(256) void conv_fwd_k(const pmf_conv_desc_t d, const
 
   if constexpr (PIPE == 8) {          // one slab per stage, 9 taps at compile time
     conv_kloop_s3<BN, MT, 1, 9>(d, g, acc, (char*)smem, (char*)(smem + g.a_floats), segrow, segcol, tid, li, lh, n, n0, ks, oy0, ox0, tri_);
+  } else if constexpr (PIPE == 10) {  // two slabs per stage, 4 taps at compile time (the 2x2 dilated layers)
+    conv_kloop_s3<BN, MT, 2, 4>(d, g, acc, (char*)smem, (char*)(smem + g.a_floats), segrow, segcol, tid, li, lh, n, n0, ks, oy0, ox0, tri_);
   } else if constexpr (PIPE >= 5) {          // 5, 6, 7: 1, 2, 4 slabs per stage, tap count from the descriptor
     conv_kloop_s3<BN, MT, (1 << (PIPE - 5))>(d, g, acc, (char*)smem, (char*)(smem + g.a_floats), segrow, segcol, tid, li, lh, n, n0, ks, oy0, ox0, tri_);
   } else if constexpr (PIPE != 0) {
@@ -1274,6 +1277,7 @@ static int launch(const pmf_conv_desc_t* d, hipStream_t s) {
     (void)hipFuncSetAttribute((const void*)conv_fwd_k<BN, MT, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)conv_fwd_k<BN, MT, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)conv_fwd_k<BN, MT, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_fwd_k<BN, MT, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   const int co_tiles = cdiv(d->Cout, BN);
@@ -1285,6 +1289,7 @@ static int launch(const pmf_conv_desc_t* d, hipStream_t s) {
     g.a_floats = sl * round_up(g.in_rows * g.in_cols * (S3_APB / 4), 4);
     lds = g.a_floats * 4 + d->ntaps * sl * (BN / 32) * 3 * 1024 + 2048;   // + per-thread scratch of the staging stores
     if (sl == 1 && d->ntaps == 9 && !getenv("PMF_S3_NO9")) mode = 8;
+    if (sl == 2 && d->ntaps == 4 && !getenv("PMF_S3_NO9")) mode = 10;
     nchunks = 0;
     for (int i = 0; i < d->nsrc; ++i) nchunks += d->src[i].C / (KC * sl);
     if (lds < 2 * 4 * 64 * 2 * 8) lds = 2 * 4 * 64 * 2 * 8;
@@ -1309,6 +1314,8 @@ static int launch(const pmf_conv_desc_t* d, hipStream_t s) {
     hipLaunchKernelGGL((conv_fwd_k<BN, MT, 7>), grid, dim3(256), lds, s, dd, g);
   } else if (mode == 8) {
     hipLaunchKernelGGL((conv_fwd_k<BN, MT, 8>), grid, dim3(256), lds, s, dd, g);
+  } else if (mode == 10) {
+    hipLaunchKernelGGL((conv_fwd_k<BN, MT, 10>), grid, dim3(256), lds, s, dd, g);
   } else if (mode == 4) {
     if constexpr (MT == 1) hipLaunchKernelGGL((conv_fwd_k<BN, 1, 4>), grid, dim3(256), lds, s, dd, g);
   } else if (mode == 1) {
