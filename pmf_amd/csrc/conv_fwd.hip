@@ -521,6 +521,12 @@ __device__ __forceinline__ void conv_kloop_s3(const pmf_conv_desc_t& d, const Co
       const int t = v / SL, sl = v % SL;            // compile-time after unrolling
       aoff[v] = v < nv ? ((ty[t] - g.dy_min) * in_cols + (tx[t] - g.dx_min)) * S3_APB + sl * a_slab : 0;
     }
+    // the tap offsets are wave-uniform: left alone they sit in 9 SGPRs for the whole loop, and the kernel is short of
+    // SGPRs (spills through v_readlane next to the MFMAs); as VGPRs they cost nothing that is scarce here
+    if (NTAPS != 0) {
+#pragma unroll
+      for (int v = 0; v < TAPG; ++v) asm volatile("" : "+v"(aoff[v]));
+    }
   }
   int abase[MT];
 #pragma unroll
