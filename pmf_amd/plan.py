@@ -155,6 +155,10 @@ class Plan:
         self._graphs, self._graph_seen = {}, {}   # hipGraph replay cache (see run)
         # fp32 convolutions on the bf16 matrix pipe (three-way operand split, six products; PMF_CONV_F32=1: fp32 MFMA only)
         self.s3 = os.environ.get("PMF_CONV_F32", "0") != "1"
+        # 1x1 layers stay on the fp32 pipe: they are HBM-bound (24 flop / byte at full resolution), the 2.67x shorter MFMA
+        # phase buys nothing there and the split + store of the input tile costs more than it saves (103 vs 149 us on the
+        # 192 -> 64 concat conv)
+        self.s3_min_taps = int(os.environ.get("PMF_S3_MIN_TAPS", "2"))
         self._conv_fold = {}                # backward conv op index -> index of the BN-backward fold op reading its rows
         self.bn_bwd_fused = os.environ.get("PMF_BN_BWD_FUSED", "1") != "0"
         self._conv_fin = {}                 # forward conv op index -> index of the BN finalize op reading its rows
@@ -403,6 +407,8 @@ class Plan:
             return False
         probe = L.ConvDesc()
         shape_fill(probe)
+        if probe.ntaps < self.s3_min_taps:
+            return False
         return bool(L.lib().pmf_conv_s3_eligible(C.byref(probe)))
 
     def conv(self, srcs, conv, act=L.ACT_NONE, bn=None, order="act_bn", relu_view=False, name="", pmask=None,
