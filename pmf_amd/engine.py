@@ -9,6 +9,8 @@ times exactly what the trainer runs.  The confusion matrices are rank-local unti
 (IOUEval.getIoU / getAcc / getRecall: one cached all-reduce per read; the reference reduces 6x per iteration, SURVEY.md
 5.8) -- the trainer reads at its print frequency and at the end of the epoch, so epoch-end numbers are identical."""
 import numpy as np
+import os
+
 import torch
 import torch.nn as nn
 
@@ -188,6 +190,8 @@ class TrainEngine:
         """called between segments of the backward plan: all-reduce the gradient ranges that are final by now.
         The collective is asynchronous (RCCL stream): it overlaps with the remaining segments."""
         import torch.distributed as dist
+        if os.environ.get("PMF_DP_DEBUG_SKIP") == "1":       # diagnosis only: segments without collectives
+            return
         front = plan.grad_frontier(op_end)
         if self._frontier is None:
             self._frontier = [a for (a, _) in self.flat.ranges]
