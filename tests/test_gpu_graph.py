@@ -35,7 +35,8 @@ def test_graph_replay_with_fresh_input_addresses():
 
     l0, a0, g0, s0 = run(False)
     l1, a1, g1, s1 = run(True)
-    assert a1 >= 3 and a0 <= 2                      # the fresh run really saw different input addresses
+    assert a1 >= 3                                  # the fresh run really saw different input addresses (what the
+    # reference run sees is up to the caching allocator: usually two, more in a long-lived process)
     assert g0 == g1 == 2                            # one forward graph + one backward graph, captured once
     assert l0 == l1
     for k in s0:
