@@ -499,7 +499,7 @@ __device__ __forceinline__ void conv_wgrad_s3_body(const pmf_wgrad_desc_t& d, co
   {
     int rem = chunk;
     for (;;) {
-      const int nch = d.src[si].C / WG_CI;
+      const int nch = (d.src[si].C + WG_CI - 1) / WG_CI;     // (a 16-channel operand is one half-empty chunk)
       if (rem < nch) { c0 = rem * WG_CI; k0 += c0; break; }
       rem -= nch; k0 += d.src[si].C; ++si;
     }
@@ -508,6 +508,8 @@ __device__ __forceinline__ void conv_wgrad_s3_body(const pmf_wgrad_desc_t& d, co
   const int sH = d.OH, sW = d.OW;
   const bool aff = d.src[si].scale != nullptr;
   const int q = tid & 7, cch = c0 + q * 4;
+  const int kc = min(WG_CI, d.src[si].C - c0);      // channels of this chunk that exist
+  const bool qok = q * 4 < kc;                      // this thread's four channels exist (else: zeros)
   const int totalX = g.in_rows * in_cols * 8;
   int rc[XSL];
 #pragma unroll
@@ -552,7 +554,7 @@ __device__ __forceinline__ void conv_wgrad_s3_body(const pmf_wgrad_desc_t& d, co
 #pragma unroll
     for (int j = 0; j < XSL; ++j) {
       const int iy = by + (rc[j] >> 8), ix = bx + (rc[j] & 255);
-      const bool ok = rc[j] >= 0 && iy >= 0 && iy < sH && ix >= 0 && ix < sW;
+      const bool ok = qok && rc[j] >= 0 && iy >= 0 && iy < sH && ix >= 0 && ix < sW;
       const int gp = ok ? (n * sH + iy) * sW + ix : -1;
       okX |= ok ? (1u << j) : 0u;
       rX[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (gp * sld + cch) * 4, 0, 0));
@@ -618,8 +620,8 @@ __device__ __forceinline__ void conv_wgrad_s3_body(const pmf_wgrad_desc_t& d, co
   while (tile < g.total_tiles) {
     __syncthreads();                       // X: everyone finished the previous tile
     f32x4 sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f}, cm4 = {1.f, 1.f, 1.f, 1.f};
-    if (aff) { sc4 = *(const f32x4*)(d.src[si].scale + cch); sh4 = *(const f32x4*)(d.src[si].shift + cch); }
-    if (d.src[si].cmul) cm4 = *(const f32x4*)(d.src[si].cmul + (size_t)ncur * d.src[si].cmul_ld + cch);
+    if (aff && qok) { sc4 = *(const f32x4*)(d.src[si].scale + cch); sh4 = *(const f32x4*)(d.src[si].shift + cch); }
+    if (d.src[si].cmul && qok) cm4 = *(const f32x4*)(d.src[si].cmul + (size_t)ncur * d.src[si].cmul_ld + cch);
 #pragma unroll
     for (int j = 0; j < XSL; ++j) {
       if (rc[j] >= 0) {
@@ -684,7 +686,7 @@ __device__ __forceinline__ void conv_wgrad_s3_body(const pmf_wgrad_desc_t& d, co
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int ci = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        part[((size_t)j * g.Ktot + k0 + ci) * g.Cout32 + co] = acc[j][r];
+        if (ci < kc) part[((size_t)j * g.Ktot + k0 + ci) * g.Cout32 + co] = acc[j][r];
       }
   }
 }
@@ -1175,12 +1177,15 @@ static int wg_geometry(const pmf_wgrad_desc_t* d, int TB, int BN, WgGeom* g, int
 }
 
 // conditions of the software-pipelined kernel
-static bool wg_simple(const pmf_wgrad_desc_t* d, const WgGeom& g, int TB, int BN) {
+// cmod: operand channel counts must be multiples of it (32; the split-bf16 kernel also takes half-empty chunks: 16)
+static bool wg_simple(const pmf_wgrad_desc_t* d, const WgGeom& g, int TB, int BN, int cmod = WG_CI) {
+  static const bool no_half = getenv("PMF_WGRAD_S3_C32") != nullptr;   // A/B switch: no half-empty chunks
+  if (no_half) cmod = WG_CI;
   if (d->gather || d->in_stride != 1 || d->ntaps != TB) return false;
   if (d->OH % WG_ROWS || d->OW % 32 || d->Cout % BN) return false;
   if (g.in_rows * g.in_cols * 8 > 256 * 9 || g.in_cols > 255) return false;
   for (int i = 0; i < d->nsrc; ++i) {
-    if (d->src[i].C % WG_CI || (d->src[i].flags & PMF_SRC_BCAST)) return false;
+    if (d->src[i].C % cmod || (d->src[i].flags & PMF_SRC_BCAST)) return false;
     if (d->src[i].H != d->OH || d->src[i].W != d->OW) return false;
     if ((int64_t)d->N * d->OH * d->OW * d->src[i].ldc * 4 >= (1ll << 31)) return false;
   }
@@ -1201,17 +1206,18 @@ static void wg_config(const pmf_wgrad_desc_t* d, int* TB, int* NT) {
   // 1x1 convolutions with wide outputs are plain GEMMs: one MFMA per operand pair either way, so the wider tile of
   // the unit-dealing kernel (fewer re-reads of the input tile) wins there (measured 123 vs 164 us on 384 -> 128)
   const bool wide_1x1 = d->ntaps == 1 && d->Cout > 64;
+  const int cmod = (d->flags & PMF_WGRAD_S3) ? 16 : WG_CI;
   if (d->cfg) {                        // caller-tuned
     int nt = d->cfg & 0xff;
     const int kern = (d->cfg >> 8) & 0xff;
     if (nt != 1 && nt != 2 && nt != 4) nt = 1;
     if (nt == 4 && *TB != 1) nt = 2;                        // 128-wide tiles are only built for per-tap staging
     while (nt > 1 && (nt - 1) * 32 >= d->Cout) nt >>= 1;
-    if (kern == 1 && wg_simple(d, g, *TB, 32)) nt = 1;
+    if (kern == 1 && wg_simple(d, g, *TB, 32, cmod)) nt = 1;
     *NT = nt;
     return;
   }
-  if (!wide_1x1 && wg_simple(d, g, *TB, 32) && !getenv("PMF_WGRAD_NOPIPE")) { *NT = 1; return; }
+  if (!wide_1x1 && wg_simple(d, g, *TB, 32, cmod) && !getenv("PMF_WGRAD_NOPIPE")) { *NT = 1; return; }
   *NT = wide_1x1 ? 4 : (d->Cout > 32 ? 2 : 1);
 }
 
@@ -1307,7 +1313,7 @@ static int wg_launch(const pmf_wgrad_desc_t* d, hipStream_t s, int phase) {
   dim3 grid(d->nsplit, g.nchunks, g.co_tiles * g.tap_batches);
   bool piped = false;
   if constexpr (NT == 1) {
-    if (wg_simple(d, g, TB, 32) && (d->flags & PMF_WGRAD_S3)) {
+    if ((d->flags & PMF_WGRAD_S3) && wg_simple(d, g, TB, 32, 16)) {
       static bool attr3 = false;
       if (!attr3) {
         (void)hipFuncSetAttribute((const void*)conv_wgrad_s3_k<TB, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
