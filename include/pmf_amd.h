@@ -97,7 +97,10 @@ typedef struct {
 } pmf_conv_desc_t;
 #define PMF_EP_STAT_X_ONLY 1
 /* 1 when every tile configuration of this descriptor runs the software-pipelined K loop (stride 1, one halo tile,
- * every operand a multiple of 16 channels, same H x W, no broadcast): the class pmf_conv_fwd accepts w_s3 for */
+ * every operand a multiple of 16 channels, same H x W, no broadcast): the class pmf_conv_fwd accepts w_s3 for.
+ * 2 for one-tap descriptors (1x1 layers, any stride) that qualify for the direct variant (conv_fwd.hip PIPE 11:
+ * activations straight from global memory, all weight fragments of an output-channel tile resident in LDS; operands
+ * multiples of 16 channels, same H x W, no broadcast, Ktot * 32 * 6 bytes + tables within 160 KiB); 0 otherwise */
 int pmf_conv_s3_eligible(const pmf_conv_desc_t* d);
 
 int pmf_conv_fwd(const pmf_conv_desc_t* d, pmf_stream_t s);

@@ -697,6 +697,165 @@ __device__ __forceinline__ void conv_kloop_s3(const pmf_conv_desc_t& d, const Co
   }
 }
 
+// PIPE 11 -- 1x1 convolutions on the split-bf16 path, activations straight from global memory.
+// A 1x1 layer has no halo and no reuse of an input pixel across taps: staging its input tile through LDS buys nothing and
+// costs three barriers per 16-channel stage around 6 MT NT MFMAs.  Here every weight fragment of the output-channel tile
+// ([K/16][NT][3 planes] x 1 KiB, e.g. 72 KiB for 192 -> 64) is DMA'd into LDS ONCE, and then each wave runs free of
+// barriers: lane (pixel li, half lh) loads channels 16 k + 8 lh .. + 7 of its pixel (two 16-byte buffer loads: exactly
+// the A-operand layout of v_mfma_f32_32x32x16_bf16), applies the operand transform from an LDS table
+// [K] x {scale, shift, relu floor, channel multiplier}, splits into three bf16 planes in registers and multiplies.
+// PF k-steps of loads are in flight per wave; the split of step k + 1 is issued next to the MFMAs of step k.
+// Host conditions: conv_direct_lds().
+template <int BN, int MT>
+__device__ __forceinline__ void conv_kloop_direct(const pmf_conv_desc_t& d, const ConvGeom& g, f32x16 (&acc)[MT][BN / 32],
+                                                  char* __restrict__ Bs, const int (&segrow)[MT], const int (&segcol)[MT],
+                                                  int tid, int li, int lh, int n, int n0, int oy0, int ox0) {
+  constexpr int NT = BN / 32;
+  constexpr int PF = 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int Ktot = g.Ktot, nks = Ktot >> 4, CT = d.ldw >> 5;
+  const int is = d.in_stride, sH = d.src[0].H, sW = d.src[0].W;
+  const int nfrag = nks * NT * 3;
+  {  // ---- every weight fragment of this output-channel tile -> LDS, one 1-KiB DMA instruction each
+    const char* wsrc = (const char*)d.w_s3 + (size_t)(n0 >> 5) * 3 * 1024 + lane * 16;
+    for (int f = wave; f < nfrag; f += 4) {
+      const int k16 = f / (NT * 3), up = f - k16 * (NT * 3);
+      __builtin_amdgcn_global_load_lds((const float*)(wsrc + ((size_t)k16 * CT * 3 + up) * 1024), (lds_ptr_t)(Bs + f * 1024), 16, 0, 0);
+    }
+  }
+  bool plain = true;
+  for (int i = 0; i < d.nsrc; ++i)
+    plain = plain && !d.src[i].scale && !d.src[i].cmul && !(d.src[i].flags & PMF_SRC_RELU);
+  float* __restrict__ tab = (float*)(Bs + nfrag * 1024);   // [4][Ktot]
+  if (!plain) {
+    for (int k = tid; k < Ktot; k += 256) {
+      int si = 0, c = k;
+      while (c >= d.src[si].C) { c -= d.src[si].C; ++si; }
+      const float* ssc = d.src[si].scale;
+      const float* scm = d.src[si].cmul;
+      tab[k] = ssc ? ssc[c] : 1.f;
+      tab[Ktot + k] = ssc ? d.src[si].shift[c] : 0.f;
+      tab[2 * Ktot + k] = (d.src[si].flags & PMF_SRC_RELU) ? 0.f : -__builtin_inff();
+      tab[3 * Ktot + k] = scm ? scm[(size_t)n * d.src[si].cmul_ld + c] : 1.f;
+    }
+  }
+  // ---- load stream: (source, channel) of the next k-step to fetch
+  int pix[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int oy = oy0 + segrow[m], ox = ox0 + segcol[m] * 32 + li;
+    const int iy = oy * is + (int)d.tdy[0], ix = ox * is + (int)d.tdx[0];
+    const bool ok = oy < d.OH && ox < d.OW && iy >= 0 && iy < sH && ix >= 0 && ix < sW;
+    pix[m] = ok ? (n * sH + iy) * sW + ix : -1;
+  }
+  int lsi = 0, lc0 = 0, lC = 0;
+  unsigned lbase[MT];
+  __amdgpu_buffer_rsrc_t lrs;
+  auto lhead = [&]() {
+    if (lsi < d.nsrc) {
+      const float* sx = d.src[lsi].x;
+      const int sld = d.src[lsi].ldc, sC = d.src[lsi].C;
+      PMF_SGPR_BATCH("s"(sx), "s"(sld), "s"(sC));
+      lrs = __builtin_amdgcn_make_buffer_rsrc((void*)sx, 0, d.N * sH * sW * sld * 4, 0x00020000);
+      lC = sC;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) lbase[m] = pix[m] >= 0 ? (unsigned)(pix[m] * sld * 4 + lh * 32) : 0x80000000u;
+    } else {          // past the last k-step: the range check returns zeros without touching memory
+      lrs = __builtin_amdgcn_make_buffer_rsrc((void*)d.src[0].x, 0, 0, 0x00020000);
+      lC = 1 << 30;
+    }
+  };
+  f32x4 raw[PF][MT][2];
+  auto issue = [&](auto slot_c) {
+    constexpr int j = decltype(slot_c)::value;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      raw[j][m][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(lrs, lbase[m] + lc0 * 4, 0, 0));
+      raw[j][m][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(lrs, lbase[m] + lc0 * 4 + 16, 0, 0));
+    }
+    lc0 += 16;
+    if (lc0 >= lC) { ++lsi; lc0 = 0; lhead(); }
+  };
+  lhead();
+  issue(std::integral_constant<int, 0>{});
+  issue(std::integral_constant<int, 1>{});
+  issue(std::integral_constant<int, 2>{});
+  issue(std::integral_constant<int, 3>{});
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PF * MT * 2) : "memory");   // the weight DMA (older than the 4 prefetches) landed
+  __syncthreads();
+  const char* bp = Bs + lane * 16;
+  // transform + split of the 8 channels this lane holds of k-step kk
+  auto prep = [&](auto slot_c, int kk, bf16x8 (&a)[MT][3]) {
+    constexpr int j = decltype(slot_c)::value;
+    f32x4 sc[2], sh[2], lo[2], cm[2];
+    if (!plain) {
+      const float* t0 = tab + kk * 16 + lh * 8;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        sc[h] = *(const f32x4*)(t0 + h * 4); sh[h] = *(const f32x4*)(t0 + Ktot + h * 4);
+        lo[h] = *(const f32x4*)(t0 + 2 * Ktot + h * 4); cm[h] = *(const f32x4*)(t0 + 3 * Ktot + h * 4);
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      u32x2 p0[2], p1[2], p2[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        f32x4 t = raw[j][m][h];
+        if (!plain) {
+          t = t * sc[h] + sh[h];
+          t.x = s3_vmax(t.x, lo[h].x); t.y = s3_vmax(t.y, lo[h].y); t.z = s3_vmax(t.z, lo[h].z); t.w = s3_vmax(t.w, lo[h].w);
+          t = t * cm[h];
+        }
+        unsigned a0, a1, a2, b0, b1, b2;
+        s3_split2(t.x, t.y, a0, a1, a2);
+        s3_split2(t.z, t.w, b0, b1, b2);
+        p0[h] = u32x2{a0, b0}; p1[h] = u32x2{a1, b1}; p2[h] = u32x2{a2, b2};
+      }
+      typedef __attribute__((ext_vector_type(4))) unsigned u32x4_;
+      a[m][0] = __builtin_bit_cast(bf16x8, u32x4_{p0[0].x, p0[0].y, p0[1].x, p0[1].y});
+      a[m][1] = __builtin_bit_cast(bf16x8, u32x4_{p1[0].x, p1[0].y, p1[1].x, p1[1].y});
+      a[m][2] = __builtin_bit_cast(bf16x8, u32x4_{p2[0].x, p2[0].y, p2[1].x, p2[1].y});
+    }
+  };
+  auto mma = [&](int kk, const bf16x8 (&a)[MT][3]) {
+    bf16x8 b[NT][3];
+#pragma unroll
+    for (int u = 0; u < NT; ++u)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) b[u][p] = *(const bf16x8*)(bp + ((kk * NT + u) * 3 + p) * 1024);
+    constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PB[6] = {2, 1, 0, 1, 0, 0};
+#pragma unroll
+    for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int u = 0; u < NT; ++u)
+          acc[m][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][PA[pr]], b[u][PB[pr]], acc[m][u], 0, 0, 0);
+  };
+  bf16x8 a0[MT][3], a1[MT][3];
+  prep(std::integral_constant<int, 0>{}, 0, a0);
+  // step kk (slot kk % 4): refill its slot for step kk + 4, split step kk + 1, multiply step kk
+  auto quad = [&](int kk, auto guard_c) {
+    constexpr bool G = decltype(guard_c)::value;
+    issue(std::integral_constant<int, 0>{});
+    prep(std::integral_constant<int, 1>{}, kk + 1, a1);
+    if (!G || kk < nks) mma(kk, a0);
+    issue(std::integral_constant<int, 1>{});
+    prep(std::integral_constant<int, 2>{}, kk + 2, a0);
+    if (!G || kk + 1 < nks) mma(kk + 1, a1);
+    issue(std::integral_constant<int, 2>{});
+    prep(std::integral_constant<int, 3>{}, kk + 3, a1);
+    if (!G || kk + 2 < nks) mma(kk + 2, a0);
+    issue(std::integral_constant<int, 3>{});
+    prep(std::integral_constant<int, 0>{}, kk + 4, a0);
+    if (!G || kk + 3 < nks) mma(kk + 3, a1);
+  };
+  int kk = 0;
+  for (; kk + PF <= nks; kk += PF) quad(kk, std::false_type{});
+  if (kk < nks) quad(kk, std::true_type{});
+}
+
 // PIPE: 0 generic K loop, 1 pipelined, 4 pipelined with 64-channel stages (1x1 convs).
 // Measured and rejected on this loop (kept out of the code): a second input tile in LDS (two barriers per chunk instead
 // of three: 49.2 vs 47.8 us on 64->64 3x3 at 32x1024, 23.60 vs 23.23 ms per training step); a start delay for the
@@ -728,9 +887,18 @@ __global__ __launch_bounds__(256) void conv_fwd_k(const pmf_conv_desc_t d, const
     const unsigned total = gridDim.x * gridDim.y * gridDim.z;
     if ((total & 7u) == 0u) lin = (lin & 7u) * (total >> 3) + (lin >> 3);
   }
-  const int tile = lin % gridDim.x;
-  const unsigned lin_r = lin / gridDim.x;
-  const int bz = lin_r % gridDim.z, by = lin_r / gridDim.z;
+  int tile, bz, by;
+  if constexpr (PIPE == 11) {
+    // no input tile in LDS to share: the output-channel tiles of one pixel tile run back to back on one XCD, so the
+    // activations come from HBM once and from that XCD's L2 for the other tiles
+    by = lin % gridDim.y;
+    const unsigned lin_r = lin / gridDim.y;
+    tile = lin_r % gridDim.x; bz = lin_r / gridDim.x;
+  } else {
+    tile = lin % gridDim.x;
+    const unsigned lin_r = lin / gridDim.x;
+    bz = lin_r % gridDim.z; by = lin_r / gridDim.z;
+  }
   const int tx = tile % g.tiles_x, ty = tile / g.tiles_x;
   const int n = bz, n0 = (by / g.ksplit) * BN, ks = by % g.ksplit;
   const int oy0 = ty * g.th, ox0 = tx * g.tw;
@@ -757,7 +925,9 @@ __global__ __launch_bounds__(256) void conv_fwd_k(const pmf_conv_desc_t d, const
     segcol[m] = s & ((1 << g.segs_x_log2) - 1);
   }
 
-  if constexpr (PIPE == 8) {          // one slab per stage, 9 taps at compile time
+  if constexpr (PIPE == 11) {         // 1x1, split-bf16, activations straight from global memory
+    conv_kloop_direct<BN, MT>(d, g, acc, (char*)smem, segrow, segcol, tid, li, lh, n, n0, oy0, ox0);
+  } else if constexpr (PIPE == 8) {   // one slab per stage, 9 taps at compile time
     conv_kloop_s3<BN, MT, 1, 9>(d, g, acc, (char*)smem, (char*)(smem + g.a_floats), segrow, segcol, tid, li, lh, n, n0, ks, oy0, ox0, tri_);
   } else if constexpr (PIPE == 10) {  // two slabs per stage, 4 taps at compile time (the 2x2 dilated layers)
     conv_kloop_s3<BN, MT, 2, 4>(d, g, acc, (char*)smem, (char*)(smem + g.a_floats), segrow, segcol, tid, li, lh, n, n0, ks, oy0, ox0, tri_);
@@ -1169,7 +1339,15 @@ static int finish_rows(const pmf_conv_desc_t* d) {
   return (int)(gx > 1024 ? 1024 : (gx < 1 ? 1 : gx));
 }
 
+static int conv_direct_lds(const pmf_conv_desc_t* d, int BN);
+static void conv_config_(const pmf_conv_desc_t* d, int* BN, int* MT);
 static void conv_config(const pmf_conv_desc_t* d, int* BN, int* MT) {
+  conv_config_(d, BN, MT);
+  // 1x1 on split-bf16 weights: the direct variant was promised for the 32-wide tile (pmf_conv_s3_eligible); a 64-wide
+  // tile whose weight fragments do not fit LDS falls back to it
+  if (d->w_s3 && d->ntaps == 1 && *BN == 64 && !conv_direct_lds(d, 64) && conv_direct_lds(d, 32)) *BN = 32;
+}
+static void conv_config_(const pmf_conv_desc_t* d, int* BN, int* MT) {
   if (d->cfg) {                       // caller-tuned tile configuration
     const int bn = d->cfg & 0xff, mt = (d->cfg >> 8) & 0xff;
     *BN = (bn == 64 && d->Cout > 32) ? 64 : 32;
@@ -1241,6 +1419,24 @@ static int conv_pipe_mode(const pmf_conv_desc_t* d, const ConvGeom& g, int gathe
   return 1;
 }
 
+// PIPE 11 (conv_kloop_direct): LDS bytes of the launch, or 0 when the layer does not qualify -- one tap, split-bf16
+// weights, operands multiples of 16 channels with the same H x W, all weight fragments of one output-channel tile
+// resident in LDS.  PMF_NO_DIRECT=1 switches the variant off.
+static int conv_direct_lds(const pmf_conv_desc_t* d, int BN) {
+  static const bool off = getenv("PMF_NO_DIRECT") != nullptr;
+  if (off || !d->w_s3 || d->ntaps != 1 || d->gather || (d->ldw & 31)) return 0;
+  int Ktot = 0;
+  for (int i = 0; i < d->nsrc; ++i) {
+    if (d->src[i].C % 16 || (d->src[i].flags & PMF_SRC_BCAST)) return 0;
+    if (d->src[i].H != d->src[0].H || d->src[i].W != d->src[0].W) return 0;
+    if ((int64_t)d->N * d->src[i].H * d->src[i].W * d->src[i].ldc * 4 >= (1ll << 31)) return 0;
+    Ktot += d->src[i].C;
+  }
+  int lds = (Ktot / 16) * (BN / 32) * 3 * 1024 + 16 * Ktot + 256;
+  if (lds < 2 * 4 * 64 * 2 * 8) lds = 2 * 4 * 64 * 2 * 8;
+  return lds <= 160 * 1024 ? lds : 0;
+}
+
 // split-bf16 path: 16-channel slabs per stage (1, 2 or 4) -- see conv_kloop_s3
 static int conv_s3_slabs(const pmf_conv_desc_t* d, const ConvGeom& g) {
   int cap = 4;
@@ -1284,11 +1480,16 @@ static int launch(const pmf_conv_desc_t* d, hipStream_t s) {
     (void)hipFuncSetAttribute((const void*)conv_fwd_k<BN, MT, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)conv_fwd_k<BN, MT, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)conv_fwd_k<BN, MT, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_fwd_k<BN, MT, 11>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   const int co_tiles = cdiv(d->Cout, BN);
   int mode = conv_pipe_mode(d, g, gather, MT);
-  if (d->w_s3) {             // split-bf16 weights: the pipelined class only (pmf_conv_s3_eligible)
+  if (const int dl = conv_direct_lds(d, BN)) {   // 1x1 on split-bf16 weights: no input tile in LDS, no K split
+    mode = 11;
+    lds = dl;
+    nchunks = 1;
+  } else if (d->w_s3) {      // split-bf16 weights: the pipelined class only (pmf_conv_s3_eligible)
     if (mode == 0 || (d->ldw & 31)) return PMF_E_UNSUPPORTED;
     const int sl = conv_s3_slabs(d, g);
     mode = sl == 4 ? 7 : (sl == 2 ? 6 : 5);
@@ -1312,7 +1513,9 @@ static int launch(const pmf_conv_desc_t* d, hipStream_t s) {
   g.ws = d->splitk_ws;
   g.ws_ld = round_up(d->Cout, 4);
   dim3 grid(g.tiles_x * g.tiles_y, co_tiles * g.ksplit, d->N);
-  if (mode == 5) {
+  if (mode == 11) {
+    hipLaunchKernelGGL((conv_fwd_k<BN, MT, 11>), grid, dim3(256), lds, s, dd, g);
+  } else if (mode == 5) {
     hipLaunchKernelGGL((conv_fwd_k<BN, MT, 5>), grid, dim3(256), lds, s, dd, g);
   } else if (mode == 6) {
     hipLaunchKernelGGL((conv_fwd_k<BN, MT, 6>), grid, dim3(256), lds, s, dd, g);
@@ -1361,11 +1564,18 @@ extern "C" int pmf_conv_fwd_stat_rows(const pmf_conv_desc_t* d) {
     nchunks = 0;
     for (int i = 0; i < d->nsrc; ++i) nchunks += d->src[i].C / (KC * sl);
   }
+  if (conv_direct_lds(d, BN)) nchunks = 1;
   if (choose_ksplit(d, tiles * d->N * cdiv(d->Cout, BN), nchunks, d->ntaps * 8 * MT * (BN / 32)) > 1) return finish_rows(d);
   return tiles * d->N;
 }
 
 extern "C" int pmf_conv_s3_eligible(const pmf_conv_desc_t* d) {
+  if (d->ntaps == 1) {       // 1x1: only the direct variant (2), judged on the narrow tile; the caller sets w_s3 afterwards
+    pmf_conv_desc_t t = *d;
+    t.w_s3 = (const void*)1;
+    if (!t.ldw) t.ldw = 64;
+    return conv_direct_lds(&t, 32) ? 2 : 0;
+  }
   int cmax = 0;
   for (int i = 0; i < d->nsrc; ++i) cmax = d->src[i].C > cmax ? d->src[i].C : cmax;
   for (int MT = 1; MT <= 2; ++MT) {
@@ -1406,6 +1616,7 @@ extern "C" int pmf_conv_fwd_kstages(const pmf_conv_desc_t* d) {
     nchunks = 0;
     for (int i = 0; i < d->nsrc; ++i) nchunks += d->src[i].C / (KC * sl);
   }
+  if (conv_direct_lds(d, BN)) nchunks = 1;
   return nchunks;
 }
 

@@ -155,10 +155,11 @@ class Plan:
         self._graphs, self._graph_seen = {}, {}   # hipGraph replay cache (see run)
         # fp32 convolutions on the bf16 matrix pipe (three-way operand split, six products; PMF_CONV_F32=1: fp32 MFMA only)
         self.s3 = os.environ.get("PMF_CONV_F32", "0") != "1"
-        # 1x1 layers stay on the fp32 pipe: they are HBM-bound (24 flop / byte at full resolution), the 2.67x shorter MFMA
-        # phase buys nothing there and the split + store of the input tile costs more than it saves (103 vs 149 us on the
-        # 192 -> 64 concat conv)
+        # 1x1 layers never use the LDS-staged split kernel (the split + store of the input tile costs more than the 2.67x
+        # shorter MFMA phase saves: 103 vs 149 us on the 192 -> 64 concat conv); they have their own variant that reads
+        # the activations straight from global memory (s3_direct_min_pix, 67 us on that layer)
         self.s3_min_taps = int(os.environ.get("PMF_S3_MIN_TAPS", "2"))
+        self.s3_direct_min_pix = int(os.environ.get("PMF_S3_DIRECT_MIN_PIX", "1"))   # 0: 1x1 layers stay on fp32 MFMA
         self._conv_fold = {}                # backward conv op index -> index of the BN-backward fold op reading its rows
         self.bn_bwd_fused = os.environ.get("PMF_BN_BWD_FUSED", "1") != "0"
         self._conv_fin = {}                 # forward conv op index -> index of the BN finalize op reading its rows
@@ -407,6 +408,11 @@ class Plan:
             return False
         probe = L.ConvDesc()
         shape_fill(probe)
+        if probe.ntaps == 1:
+            # 1x1 layers: only the direct variant (activations straight from global memory, conv_fwd.hip PIPE 11), and only
+            # where the map is large enough to fill the chip without a K split
+            return (self.s3_direct_min_pix > 0 and probe.N * probe.OH * probe.OW >= self.s3_direct_min_pix
+                    and L.lib().pmf_conv_s3_eligible(C.byref(probe)) == 2)
         if probe.ntaps < self.s3_min_taps:
             return False
         return bool(L.lib().pmf_conv_s3_eligible(C.byref(probe)))

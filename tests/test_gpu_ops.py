@@ -122,6 +122,20 @@ def test_conv_unit_fwd_bwd(case):
     _conv_case(case, 0)
 
 
+DIRECT_1X1 = [c for c in CONVS if c[0] in ("c1x1cat3", "c1x1_plain_lrelu", "c1x1s2", "c1x1cat3_big", "c1x1_odd_big",
+                                            "c1x1_c20_big", "c1x1_wide_big")]
+
+
+@pytest.mark.parametrize("case", DIRECT_1X1, ids=[c[0] for c in DIRECT_1X1])
+def test_conv_unit_direct_1x1(case, monkeypatch):
+    """the 1x1 layers again with the direct split-bf16 variant (conv_fwd.hip PIPE 11) admitted at every size (the plan
+    only uses it from 32768 pixels up): forward, input gradients (its transposed launches), BatchNorm statistics"""
+    monkeypatch.setenv("PMF_S3_DIRECT_MIN_PIX", "1")
+    Hn = _conv_case(case, 0)
+    assert sum(1 for j in Hn.P.pack_jobs if j[7] == 1) >= 1      # split-bf16 weight fragments were requested
+    _conv_case(case, 64 | (2 << 8) | (1 << 16))
+
+
 def _conv_case(case, cfg):
     name, N, H, W, cins, Cout, k, dil, pad, stride, bias, mode, use_bn = case
     conv = nn.Conv2d(sum(cins), Cout, k, stride, pad, dil, bias=bias)
@@ -193,6 +207,7 @@ def _conv_case(case, cfg):
     if bn is not None:
         _check(name + ".running_mean", bn.running_mean, bn64.running_mean, 1e-5)
         _check(name + ".running_var", bn.running_var, bn64.running_var, 1e-5)
+    return Hn
 
 
 def test_bcast_operand_conv():

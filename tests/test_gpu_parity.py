@@ -39,6 +39,10 @@ CONV_CASES = [
     ("3x3d18_64_64", 1, 8, 40, [64], 64, 3, 18, 18, 1, 0, False),
     ("3x3_16_20", 1, 16, 32, [16], 20, 3, 1, 1, 1, 0, False),
     ("3x3_256_256_small", 2, 4, 16, [256], 256, 3, 1, 1, 1, 1, False),
+    # 1x1 shapes of the direct split-bf16 variant (PIPE 11): 5 k-steps (guarded tail of the 4-step loop), ragged output
+    # tile and image edge, operand transforms; a plain one with 20 output channels
+    ("1x1_cat2_80_48_xf", 2, 17, 45, [16, 64], 48, 1, 1, 0, 1, 1, True),
+    ("1x1_32_20", 1, 16, 64, [32], 20, 1, 1, 0, 1, 0, False),
 ]
 
 
@@ -85,7 +89,8 @@ def test_conv_fwd_vs_torch_cpu(case):
 
 
 S3_CASES = [c for c in CONV_CASES if c[0] in ("3x3_32_32", "3x3d2_64_64_xf", "2x2d2_32", "1x1_cat3", "3x3_cat2_80_32",
-                                               "3x3_16_20", "3x3_256_256_small")]
+                                               "3x3_16_20", "3x3_256_256_small", "1x1_cat2_80_48_xf", "1x1_32_20",
+                                               "1x1s2_64_128")]
 
 
 @pytest.mark.parametrize("cfg", [0, 32 | (1 << 8) | (1 << 16), 64 | (1 << 8) | (1 << 16), 32 | (2 << 8) | (1 << 16),
@@ -129,7 +134,7 @@ def test_conv_fwd_split_bf16_vs_float64(case, cfg):
         d.cfg = cfg
         if kind == "s3":
             d.w, d.w_s3 = None, wpk.data_ptr()
-            assert lib.pmf_conv_s3_eligible(C.byref(d)) == 1
+            assert lib.pmf_conv_s3_eligible(C.byref(d)) == (2 if k == 1 else 1)      # 2: the direct 1x1 variant
         rows = lib.pmf_conv_fwd_stat_rows(C.byref(d))
         stats = torch.full((rows, 2, Cout), float("nan"), device="cuda", dtype=torch.float64)
         d.stats = stats.data_ptr()
