@@ -1240,7 +1240,11 @@ extern "C" int pmf_conv_wgrad_nsplit(const pmf_wgrad_desc_t* d) {
   wg_config(d, &TB, &NT);
   wg_geometry(d, TB, NT * 32, &g, &lds);
   int other = g.nchunks * g.co_tiles * g.tap_batches;
-  int ns = 512 / (other > 0 ? other : 1);
+  // workgroups per launch: one per CU.  Two per CU make the launch itself ~10 % faster in isolation (4.8 vs 5.4 ms over the
+  // 110 layers), but the weight gradients run on a side lane next to the input-gradient launches of the main lane, and
+  // half the partial slabs is half the stage-2 traffic: 18.64 vs 18.74 ms per training step (PMF_WGRAD_WGS=512: old rule)
+  static const int target = getenv("PMF_WGRAD_WGS") ? atoi(getenv("PMF_WGRAD_WGS")) : 256;
+  int ns = target / (other > 0 ? other : 1);
   if (ns < 1) ns = 1;
   if (ns > g.total_tiles) ns = g.total_tiles;
   return ns;
