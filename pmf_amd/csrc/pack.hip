@@ -29,6 +29,45 @@ __global__ __launch_bounds__(256) void pack_k(const pmf_pack_job_t* __restrict__
     // element k%8 (the B-operand layout of v_mfma_f32_32x32x16_bf16); planes are 512 bf16 apart
     unsigned short* __restrict__ dst = (unsigned short*)J.dst;
     const int KS = J.K_pad >> 4, CTL = J.ldw >> 5;
+    // whole k-octets inside this tile: one thread builds the 16 bytes a lane of the fragment holds (8 consecutive k of one
+    // n), three 16-byte stores per thread, consecutive threads -> consecutive lanes of the fragment (coalesced)
+    const int kdim = J.transpose ? nco : ct, ndim = J.transpose ? ct : nco;
+    const int kbase = J.transpose ? co0 : ci0, nbase = J.transpose ? ci0 : co0;
+    if ((kdim & 7) == 0 && (kbase & 7) == 0) {
+      typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+      const int noct = kdim >> 3, totalv = J.ntaps * noct * ndim;
+      for (int i = threadIdx.x; i < totalv; i += 256) {
+        const int nl = i % ndim, r = i / ndim, oc = r % noct, t = r / noct;
+        const int tap = J.tap_idx[t];
+        unsigned p0[4], p1[4], p2[4];
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+          float x[2];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int kl = oc * 8 + e + h;
+            x[h] = J.transpose ? T[kl][nl * J.KHW + tap] : T[nl][kl * J.KHW + tap];
+          }
+          unsigned u[2][3];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const unsigned u0 = __builtin_bit_cast(unsigned short, (__bf16)x[h]);
+            const float r1 = x[h] - __builtin_bit_cast(float, u0 << 16);
+            const unsigned u1 = __builtin_bit_cast(unsigned short, (__bf16)r1);
+            const float r2 = r1 - __builtin_bit_cast(float, u1 << 16);
+            const unsigned u2 = __builtin_bit_cast(unsigned short, (__bf16)r2);
+            u[h][0] = u0; u[h][1] = u1; u[h][2] = u2;
+          }
+          p0[e >> 1] = u[0][0] | (u[1][0] << 16); p1[e >> 1] = u[0][1] | (u[1][1] << 16); p2[e >> 1] = u[0][2] | (u[1][2] << 16);
+        }
+        const int k = kbase + oc * 8, nn = nbase + nl;
+        const size_t e0 = ((((size_t)t * KS + (k >> 4)) * CTL + (nn >> 5)) * 3) * 512 + ((nn & 31) + 32 * ((k & 15) >> 3)) * 8;
+        *(u32x4*)(dst + e0) = u32x4{p0[0], p0[1], p0[2], p0[3]};
+        *(u32x4*)(dst + e0 + 512) = u32x4{p1[0], p1[1], p1[2], p1[3]};
+        *(u32x4*)(dst + e0 + 1024) = u32x4{p2[0], p2[1], p2[2], p2[3]};
+      }
+      return;
+    }
     const int total = J.ntaps * nco * ct;
     for (int i = threadIdx.x; i < total; i += 256) {
       int col, cil, t;
@@ -68,6 +107,7 @@ extern "C" int pmf_pack_tile_ci(int32_t Cin, int32_t KHW) {
   int ct = PACK_L / KHW;
   if (ct < 1) ct = 1;
   if (ct > Cin) ct = Cin;
+  if (ct >= 8) ct &= ~7;      // whole k-octets per tile (the vectorised split-bf16 writer)
   return ct;
 }
 
