@@ -163,6 +163,8 @@ typedef struct {
   int32_t Cout, Cin, KHW, ntaps, transpose, K_pad, ldw, CT, tiles_ci, block_start;
   int8_t tap_idx[PMF_MAX_TAPS + 3];
   int32_t format;            /* 0: fp32 slabs [tap][K_pad][ldw]; 1: split-bf16 fragments (pmf_conv_desc_t.w_s3) */
+  int32_t w_ld;              /* input channels per output-channel row of w when the job packs a channel sub-range
+                              * (w then points at its first channel, Cin = channels of the range); 0: Cin */
 } pmf_pack_job_t;
 int pmf_pack_tile_ci(int32_t Cin, int32_t KHW);
 int pmf_pack_weights_batched(const pmf_pack_job_t* jobs_dev, int32_t njobs, int32_t total_blocks, pmf_stream_t s);

@@ -79,7 +79,7 @@ class PackJob(C.Structure):
     _fields_ = [("w", C.c_void_p), ("dst", C.c_void_p), ("Cout", C.c_int32), ("Cin", C.c_int32), ("KHW", C.c_int32),
                 ("ntaps", C.c_int32), ("transpose", C.c_int32), ("K_pad", C.c_int32), ("ldw", C.c_int32),
                 ("CT", C.c_int32), ("tiles_ci", C.c_int32), ("block_start", C.c_int32),
-                ("tap_idx", C.c_int8 * (MAX_TAPS + 3)), ("format", C.c_int32)]
+                ("tap_idx", C.c_int8 * (MAX_TAPS + 3)), ("format", C.c_int32), ("w_ld", C.c_int32)]
 
 
 _lib = None

@@ -18,10 +18,10 @@ __global__ __launch_bounds__(256) void pack_k(const pmf_pack_job_t* __restrict__
   const int tci = b % J.tiles_ci, tco = b / J.tiles_ci;
   const int co0 = tco * 32, ci0 = tci * J.CT;
   const int nco = min(32, J.Cout - co0), ct = min(J.CT, J.Cin - ci0);
-  const int L = ct * J.KHW;
+  const int L = ct * J.KHW, wld = J.w_ld ? J.w_ld : J.Cin;
   for (int i = threadIdx.x; i < nco * L; i += 256) {
     const int col = i / L, j = i - col * L;
-    T[col][j] = J.w[((size_t)(co0 + col) * J.Cin + ci0) * J.KHW + j];
+    T[col][j] = J.w[((size_t)(co0 + col) * wld + ci0) * J.KHW + j];
   }
   __syncthreads();
   if (J.format == 1) {

@@ -392,14 +392,15 @@ class Plan:
                 out.append((ky * dil - pad, kx * dil - pad, ky * kw + kx))
         return out
 
-    def add_pack(self, weight, taps_widx, transpose, K_pad, ldw, fmt=0):
+    def add_pack(self, weight, taps_widx, transpose, K_pad, ldw, fmt=0, cin=None):
         """register a pack job; returns the Buf of the packed slab [ntaps][K_pad][ldw] (fmt 0, fp32) or of the split-bf16
         fragments [ntaps][K_pad/16][ldw/32][3][64][8] (fmt 1, 6 bytes per weight; pmf_conv_desc_t.w_s3)."""
         buf = self.persist.alloc((6 if fmt else 4) * len(taps_widx) * K_pad * ldw)
         # forward packs: index of the conv op about to be emitted (the first reader); input-gradient packs: none (they are
         # read by the backward graph only)
         owner = len(self.fwd) if (not transpose and self.fwd is not None) else None
-        self.pack_jobs.append((weight, buf, list(taps_widx), transpose, K_pad, ldw, self.lane, fmt, owner))
+        # cin = (first input channel, count): pack that channel range only (its own column origin)
+        self.pack_jobs.append((weight, buf, list(taps_widx), transpose, K_pad, ldw, self.lane, fmt, owner, cin))
         return buf
 
     def s3_ok(self, shape_fill):
@@ -709,13 +710,22 @@ class Plan:
                     d.tdy[i], d.tdx[i] = dy, dx
                 d.in_stride, d.gather = 1, gather
             return fill
-        dg_s3 = [aligned and Kd % 16 == 0 and self.s3_ok(class_probe(sub, py, px)) for (py, px, sub) in classes]
-        packs = [self.add_pack(conv.weight, [t[2] for t in sub], 1, Kd, ldwT, int(k3))
-                 for (_, _, sub), k3 in zip(classes, dg_s3)]
+        dg_s3 = [Kd % 16 == 0 and self.s3_ok(class_probe(sub, py, px)) for (py, px, sub) in classes]
+        # operands that do not start on a 32-column fragment (16 + 64 channels): every operand gets its own transposed
+        # pack of its channel range, starting at column 0
+        own_packs = not aligned and all(dg_s3) and all(_ru(s.t.C, 8) == s.t.C for s in srcs)
+        if not aligned and not own_packs:
+            dg_s3 = [False] * len(classes)
+        packs = None if own_packs else [self.add_pack(conv.weight, [t[2] for t in sub], 1, Kd, ldwT, int(k3))
+                                        for (_, _, sub), k3 in zip(classes, dg_s3)]
         coloff = 0
         for s in srcs:
             Cs = _ru(s.t.C, 8)
             if s.t.needs_grad:
+                if own_packs:
+                    ldwT = _ru(Cs, 64) + 64
+                    packs = [self.add_pack(conv.weight, [t[2] for t in sub], 1, Kd, ldwT, 1, cin=(coloff, Cs))
+                             for (_, _, sub) in classes]
                 r = s.root()
                 tmp = None
                 if s.bcast:
@@ -753,8 +763,8 @@ class Plan:
                     # the last writer of its output gradient: the launch then also writes the BN-backward partial sums
                     hook = {}
 
-                    def f(op, s=s, r=r, sub=sub, wT=wT, tgt=tgt, acc=acc, coloff=coloff, py=py, px=px,
-                          relu_x=relu_x, shape_only=shape_only, hook=hook, k3=k3):
+                    def f(op, s=s, r=r, sub=sub, wT=wT, tgt=tgt, acc=acc, coloff=(0 if own_packs else coloff), py=py, px=px,
+                          relu_x=relu_x, shape_only=shape_only, hook=hook, k3=k3, ldwT=ldwT):
                         d = op.u.conv
                         shape_only(d)
                         H, W = tgt.H, tgt.W
@@ -1289,11 +1299,13 @@ class Plan:
         for lane, mine in groups:
             jobs = (L.PackJob * len(mine))()
             blocks = 0
-            for j, (w, buf, tap_idx, transpose, K_pad, ldw, _, fmt, _o) in enumerate(mine):
+            for j, (w, buf, tap_idx, transpose, K_pad, ldw, _, fmt, _o, cin) in enumerate(mine):
                 Cout, Cin, KHW = w.shape[0], w.shape[1], w.shape[2] * w.shape[3]
-                ct = lib.pmf_pack_tile_ci(Cin, KHW)
                 J = jobs[j]
                 J.w, J.dst = w.data_ptr(), buf.ptr
+                if cin is not None:
+                    J.w, J.w_ld, Cin = w.data_ptr() + 4 * cin[0] * KHW, Cin, cin[1]
+                ct = lib.pmf_pack_tile_ci(Cin, KHW)
                 J.Cout, J.Cin, J.KHW, J.ntaps, J.transpose = Cout, Cin, KHW, len(tap_idx), transpose
                 J.K_pad, J.ldw, J.CT, J.format = K_pad, ldw, ct, fmt
                 J.tiles_ci = (Cin + ct - 1) // ct
