@@ -470,6 +470,11 @@ __device__ __forceinline__ unsigned ws3_pk(wf32x2 v) { return __builtin_bit_cast
 __device__ __forceinline__ wf32x2 ws3_unpk(unsigned u) {
   return wf32x2{__builtin_bit_cast(float, u << 16), __builtin_bit_cast(float, u & 0xffff0000u)};
 }
+__device__ __forceinline__ float ws3_vmax(float a, float b) {   // plain v_max_f32 (fmaxf adds a canonicalising v_max)
+  float r;
+  asm("v_max_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 __device__ __forceinline__ void ws3_split2(float a, float b, unsigned& p0, unsigned& p1, unsigned& p2) {
   wf32x2 r = {a, b};
   p0 = ws3_pk(r);
@@ -991,8 +996,161 @@ __global__ __launch_bounds__(256, 2) void wgrad_1x1_k(const pmf_wgrad_desc_t d, 
     }
 }
 
+// The same on the bf16 matrix pipe with split operands (PMF_WGRAD_S3): v_mfma_f32_32x32x16_bf16 wants 8 consecutive k
+// (= pixels here) per lane, so a step is a group of 16 pixels: lane (m, g) loads two channels (2m, 2m+1 of the block's
+// 64) of X and two of dz for the 8 pixels 8g .. 8g+7 of the group -- sixteen 8-byte loads, 256 contiguous bytes per
+// pixel and half wave -- and component j of X against component j' of dz feeds accumulator tile (j, j') whose row m
+// stands for channel 2m + j, column n for output channel 2n + j'.  Every pair of pixels is split into its three bf16
+// planes in registers (no LDS staging); 24 MFMAs per 16 pixels and wave on a 64 x 64 block.
+__global__ __launch_bounds__(256, 2) void wgrad_1x1_s3_k(const pmf_wgrad_desc_t d, int Ktot, int Cout32) {
+  extern __shared__ __attribute__((aligned(16))) float fold[];       // [4 tiles][16][64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = lane & 31, lh = lane >> 5;
+  const int split = blockIdx.x, kb = blockIdx.y, ob = blockIdx.z;
+  const int kch = kb * 64 + q * 2;
+  int si = 0, cin = kch;
+  const bool kok = kch < Ktot;
+  if (kok) while (cin >= d.src[si].C) { cin -= d.src[si].C; ++si; }
+  const float* __restrict__ sx = kok ? d.src[si].x + cin : d.src[0].x;
+  const int sld = kok ? d.src[si].ldc : 0;
+  const bool has_sc = kok && d.src[si].scale != nullptr, relu = kok && (d.src[si].flags & PMF_SRC_RELU);
+  const float* __restrict__ scm = kok ? d.src[si].cmul : nullptr;
+  const int cm_ld = kok ? d.src[si].cmul_ld : 0;
+  float2 sc2 = {1.f, 1.f}, sh2 = {0.f, 0.f};
+  if (has_sc) { sc2 = *(const float2*)(d.src[si].scale + cin); sh2 = *(const float2*)(d.src[si].shift + cin); }
+  const float relu_lo = relu ? 0.f : -__builtin_inff();
+  const int co = ob * 64 + q * 2;
+  const bool cok = co < d.Cout;                                          // Cout even (host-checked)
+  const float* __restrict__ zp = cok ? d.dz + co : d.dz;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][jj][r] = 0.f;
+
+  const int64_t hw = (int64_t)d.OH * d.OW, npix = hw * d.N, ngrp = (npix + 15) >> 4;
+  const int64_t per = (ngrp + d.nsplit - 1) / d.nsplit, g_begin = (int64_t)split * per,
+                g_end = g_begin + per < ngrp ? g_begin + per : ngrp;
+  // loads of group s+1 are requested before group s is split and multiplied; branch-free (an out-of-range pixel reads
+  // pixel 0 and its dz is zeroed afterwards: 0 * finite = 0)
+  auto issue = [&](int64_t grp, float2 (&xv)[8], float2 (&zv)[8], float2 (&cv)[8]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int64_t px = grp * 16 + lh * 8 + e;
+      const int64_t pxs = (grp < g_end && px < npix) ? px : 0;
+      xv[e] = *(const float2*)(sx + pxs * sld);
+      if (scm) cv[e] = *(const float2*)(scm + (pxs / hw) * cm_ld + cin);
+      zv[e] = *(const float2*)(zp + pxs * d.dz_ldc);
+    }
+  };
+  auto planes = [&](int64_t grp, const float2 (&xv)[8], const float2 (&zv)[8], const float2 (&cv)[8],
+                    wbf16x8 (&a)[2][3], wbf16x8 (&b)[2][3]) {
+    wu32x4 ap[2][3], bp[2][3];
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+      float x[2][2], z[2][2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int64_t px = grp * 16 + lh * 8 + e + h;
+        const bool ok = grp < g_end && px < npix;
+        float2 t = xv[e + h];
+        if (has_sc) { t.x = t.x * sc2.x + sh2.x; t.y = t.y * sc2.y + sh2.y; }
+        t.x = ws3_vmax(t.x, relu_lo); t.y = ws3_vmax(t.y, relu_lo);
+        if (scm) { t.x *= cv[e + h].x; t.y *= cv[e + h].y; }
+        x[0][h] = kok ? t.x : 0.f; x[1][h] = kok ? t.y : 0.f;
+        z[0][h] = (ok && cok) ? zv[e + h].x : 0.f; z[1][h] = (ok && cok) ? zv[e + h].y : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        unsigned p0, p1, p2;
+        ws3_split2(x[j][0], x[j][1], p0, p1, p2);
+        ap[j][0][e >> 1] = p0; ap[j][1][e >> 1] = p1; ap[j][2][e >> 1] = p2;
+        ws3_split2(z[j][0], z[j][1], p0, p1, p2);
+        bp[j][0][e >> 1] = p0; bp[j][1][e >> 1] = p1; bp[j][2][e >> 1] = p2;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) { a[j][p] = __builtin_bit_cast(wbf16x8, ap[j][p]); b[j][p] = __builtin_bit_cast(wbf16x8, bp[j][p]); }
+  };
+  float2 xa[8], za[8], ca[8], xb[8], zb[8], cb[8];
+  int64_t grp = g_begin + wave;
+  issue(grp, xa, za, ca);
+  for (; grp < g_end; grp += 4) {
+    issue(grp + 4, xb, zb, cb);
+    wbf16x8 a[2][3], b[2][3];
+    planes(grp, xa, za, ca, a, b);
+    constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PB[6] = {2, 1, 0, 1, 0, 0};
+#pragma unroll
+    for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+          acc[j][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[j][PA[pr]], b[jj][PB[pr]], acc[j][jj], 0, 0, 0);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { xa[e] = xb[e]; za[e] = zb[e]; ca[e] = cb[e]; }
+  }
+  // fold waves 1..3 into wave 0 (fixed order)
+  for (int w = 1; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) fold[((j * 2 + jj) * 16 + r) * 64 + lane] = acc[j][jj][r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[j][jj][r] += fold[((j * 2 + jj) * 16 + r) * 64 + lane];
+    }
+    __syncthreads();
+  }
+  if (wave) return;
+  float* part = d.partial + (size_t)split * Ktot * Cout32;
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int k = kb * 64 + 2 * m + j;
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int c = ob * 64 + q * 2 + jj;
+        if (k < Ktot && c < Cout32) part[(size_t)k * Cout32 + c] = acc[j][jj][r];
+      }
+    }
+}
+
+// conditions of the split-bf16 direct 1x1 kernel (64 x 64 output blocks)
+static bool wg_direct_s3(const pmf_wgrad_desc_t* d) {
+  static const bool off = getenv("PMF_WGRAD_NODIRECT_S3") != nullptr;
+  static const int min_pix = getenv("PMF_WGRAD_DIRECT_S3_MIN_PIX") ? atoi(getenv("PMF_WGRAD_DIRECT_S3_MIN_PIX")) : 16384;
+  if (off || !(d->flags & PMF_WGRAD_S3) || ((d->cfg >> 8) & 0xff) == 2) return false;
+  if (d->ntaps != 1 || d->gather || d->in_stride != 1 || d->tdy[0] || d->tdx[0] || (d->Cout & 1) || (d->dz_ldc & 1)) return false;
+  const int64_t npix = (int64_t)d->N * d->OH * d->OW;
+  if (d->Cout < 64) return false;   // full 64 x 64 blocks only (measured: narrower layers are faster on the other kernels)
+  for (int i = 0; i < d->nsrc; ++i) {
+    const pmf_src_t& s = d->src[i];
+    if ((s.flags & PMF_SRC_BCAST) || s.H != d->OH || s.W != d->OW || (s.C & 63) || (s.ldc & 1)) return false;
+    if (s.flags & ~(PMF_SRC_RELU)) return false;
+  }
+  return npix >= min_pix;
+}
+
 // conditions of the direct 1x1 kernel + its grid
 static bool wg_direct_1x1(const pmf_wgrad_desc_t* d) {
+  if (wg_direct_s3(d)) return true;
   if (getenv("PMF_WGRAD_NODIRECT") || ((d->cfg >> 8) & 0xff) == 2) return false;
   if (d->ntaps != 1 || d->gather || d->in_stride != 1 || d->tdy[0] || d->tdx[0] || (d->Cout & 1) || (d->dz_ldc & 1)) return false;
   for (int i = 0; i < d->nsrc; ++i) {
@@ -1011,6 +1169,10 @@ static bool wg_direct_1x1(const pmf_wgrad_desc_t* d) {
 static void wg_direct_grid(const pmf_wgrad_desc_t* d, int* kblocks, int* oblocks, int* nco) {
   int Ktot = 0;
   for (int i = 0; i < d->nsrc; ++i) Ktot += d->src[i].C;
+  if (wg_direct_s3(d)) {               // 64 x 64 blocks
+    *nco = 2; *kblocks = cdiv(Ktot, 64); *oblocks = cdiv(round_up(d->Cout, 32), 64);
+    return;
+  }
   *nco = d->Cout > 32 ? 2 : 1;
   *kblocks = cdiv(Ktot, 128);
   *oblocks = cdiv(round_up(d->Cout, 32), 32 * *nco);
@@ -1230,7 +1392,8 @@ extern "C" int pmf_conv_wgrad_nsplit(const pmf_wgrad_desc_t* d) {
   if (wg_direct_1x1(d)) {  // two resident workgroups per CU in total; every workgroup gets >= 64 pixel pairs
     int kb, ob, nco;
     wg_direct_grid(d, &kb, &ob, &nco);
-    int ns = 512 / (kb * ob);
+    static const int dtarget = getenv("PMF_WGRAD_DIRECT_WGS") ? atoi(getenv("PMF_WGRAD_DIRECT_WGS")) : 512;
+    int ns = dtarget / (kb * ob);
     const int64_t pairs = ((int64_t)d->N * d->OH * d->OW + 1) / 2;
     if (ns > pairs / 64) ns = (int)(pairs / 64);
     return ns < 1 ? 1 : ns;
@@ -1420,7 +1583,8 @@ static int wgrad_phases(const pmf_wgrad_desc_t* d, pmf_stream_t st, int phase) {
         attr_set = true;
       }
       const dim3 grid(d->nsplit, kb, ob);
-      if (nco == 2) hipLaunchKernelGGL(wgrad_1x1_k<2>, grid, dim3(256), 8 * 16 * 64 * 4, s, *d, g.Ktot, g.Cout32);
+      if (wg_direct_s3(d)) hipLaunchKernelGGL(wgrad_1x1_s3_k, grid, dim3(256), 4 * 16 * 64 * 4, s, *d, g.Ktot, g.Cout32);
+      else if (nco == 2) hipLaunchKernelGGL(wgrad_1x1_k<2>, grid, dim3(256), 8 * 16 * 64 * 4, s, *d, g.Ktot, g.Cout32);
       else hipLaunchKernelGGL(wgrad_1x1_k<1>, grid, dim3(256), 4 * 16 * 64 * 4, s, *d, g.Ktot, g.Cout32);
       PMF_LAUNCH_CHECK();
     }

@@ -96,6 +96,8 @@ CONVS = [
     ("c1x1_odd_big", 1, 129, 129, [96], 32, 1, 1, 0, 1, True, "lrelu", False),
     ("c1x1_c20_big", 1, 129, 129, [128], 20, 1, 1, 0, 1, True, "none", False),
     ("c1x1_wide_big", 2, 64, 128, [128, 256], 128, 1, 1, 0, 1, True, "act_bn", True),
+    # split-bf16 direct 1x1 weight gradient (64 x 64 blocks, 16-pixel groups): ragged last group, 80 output channels
+    ("c1x1_odd_wide", 1, 129, 129, [64, 128], 80, 1, 1, 0, 1, False, "bn_relu", True),
     # shapes of the pipelined weight-gradient kernel (rows % 4 == 0, cols % 32 == 0, channels % 32 == 0), 9 / 4 / 1 taps
     ("c3x3_wpipe", 2, 8, 64, [32, 64], 64, 3, 1, 1, 1, True, "act_bn", True),
     ("c3x3d2_wpipe", 1, 12, 32, [64], 32, 3, 2, 2, 1, False, "bn_relu", True),
@@ -123,7 +125,7 @@ def test_conv_unit_fwd_bwd(case):
 
 
 DIRECT_1X1 = [c for c in CONVS if c[0] in ("c1x1cat3", "c1x1_plain_lrelu", "c1x1s2", "c1x1cat3_big", "c1x1_odd_big",
-                                            "c1x1_c20_big", "c1x1_wide_big")]
+                                            "c1x1_c20_big", "c1x1_wide_big", "c1x1_odd_wide")]
 
 
 @pytest.mark.parametrize("case", DIRECT_1X1, ids=[c[0] for c in DIRECT_1X1])
