@@ -1340,12 +1340,15 @@ static int finish_rows(const pmf_conv_desc_t* d) {
 }
 
 static int conv_direct_lds(const pmf_conv_desc_t* d, int BN);
+static bool conv_s3_fits(const pmf_conv_desc_t* d, int MT);
 static void conv_config_(const pmf_conv_desc_t* d, int* BN, int* MT);
 static void conv_config(const pmf_conv_desc_t* d, int* BN, int* MT) {
   conv_config_(d, BN, MT);
   // 1x1 on split-bf16 weights: the direct variant was promised for the 32-wide tile (pmf_conv_s3_eligible); a 64-wide
   // tile whose weight fragments do not fit LDS falls back to it
   if (d->w_s3 && d->ntaps == 1 && *BN == 64 && !conv_direct_lds(d, 64) && conv_direct_lds(d, 32)) *BN = 32;
+  // LDS-staged split loop: the 256-pixel tile may not qualify where the 128-pixel one does (dilated 3x3 on a 4-row map)
+  if (d->w_s3 && d->ntaps > 1 && *MT == 2 && !conv_s3_fits(d, 2)) *MT = 1;
 }
 static void conv_config_(const pmf_conv_desc_t* d, int* BN, int* MT) {
   if (d->cfg) {                       // caller-tuned tile configuration
@@ -1576,18 +1579,20 @@ extern "C" int pmf_conv_s3_eligible(const pmf_conv_desc_t* d) {
     if (!t.ldw) t.ldw = 64;
     return conv_direct_lds(&t, 32) ? 2 : 0;
   }
+  return conv_s3_fits(d, 1) ? 1 : 0;      // (a 256-pixel tile that does not qualify falls back to 128 pixels: conv_config)
+}
+
+// the LDS-staged split loop with MT x 128-pixel tiles: pipelined class + LDS budget (judged on the 64-wide tile)
+static bool conv_s3_fits(const pmf_conv_desc_t* d, int MT) {
   int cmax = 0;
   for (int i = 0; i < d->nsrc; ++i) cmax = d->src[i].C > cmax ? d->src[i].C : cmax;
-  for (int MT = 1; MT <= 2; ++MT) {
-    ConvGeom g;
-    int gather;
-    pmf_conv_geometry(d->OH, d->OW, d->ntaps, d->tdy, d->tdx, d->in_stride, d->gather, 64, MT, cmax < KC ? cmax : KC, &g,
-                      &gather);
-    if (conv_pipe_mode(d, g, gather, MT) == 0) return 0;
-    const int sl = conv_s3_slabs(d, g);
-    if (sl * (g.in_rows * g.in_cols * S3_APB + 16) + d->ntaps * sl * 2 * 3 * 1024 + 2048 > 160 * 1024) return 0;
-  }
-  return 1;
+  ConvGeom g;
+  int gather;
+  pmf_conv_geometry(d->OH, d->OW, d->ntaps, d->tdy, d->tdx, d->in_stride, d->gather, 64, MT, cmax < KC ? cmax : KC, &g,
+                    &gather);
+  if (conv_pipe_mode(d, g, gather, MT) == 0) return false;
+  const int sl = conv_s3_slabs(d, g);
+  return sl * (g.in_rows * g.in_cols * S3_APB + 16) + d->ntaps * sl * 2 * 3 * 1024 + 2048 <= 160 * 1024;
 }
 
 extern "C" int pmf_conv_fwd_stat_rows_max(const pmf_conv_desc_t* d) {

@@ -710,6 +710,13 @@ class Plan:
                     d.tdy[i], d.tdx[i] = dy, dx
                 d.in_stride, d.gather = 1, gather
             return fill
+        if Kd % 16 and self.s3:
+            # 20 output channels (the logits heads): K = 24 keeps the launch off the split kernels.  Rounded up to 32 the last
+            # eight "channels" of a pixel are the first eight of the next pixel (finite values; past the end of the tensor the
+            # buffer range check returns 0) against weight rows that are zero -- they add exactly 0
+            Kd8, Kd = Kd, _ru(Cout, 16)
+            if not all(self.s3_ok(class_probe(sub, py, px)) for (py, px, sub) in classes):
+                Kd = Kd8
         dg_s3 = [Kd % 16 == 0 and self.s3_ok(class_probe(sub, py, px)) for (py, px, sub) in classes]
         # operands that do not start on a 32-column fragment (16 + 64 channels): every operand gets its own transposed
         # pack of its channel range, starting at column 0
