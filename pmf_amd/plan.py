@@ -442,8 +442,11 @@ class Plan:
         Ktot = sum(_ru(s.t.C, 8) for s in srcs)
         ldw = _ru(Cout, 64)
         # very large dilations: per-tap staging (the halo tile would not fit LDS)
-        span = max(max(t[0] for t in taps) - min(t[0] for t in taps), max(t[1] for t in taps) - min(t[1] for t in taps))
-        gather = 1 if (8 * stride + span) * (32 * stride + span) * 80 > 110 * 1024 else 0
+        # (rows and columns separately: the dilation-12 / 18 ASPP branches keep one ROW of three taps on the 4-row map -- a
+        # 4 x 56-pixel halo tile, not a 32 x 56 one)
+        span_y = max(t[0] for t in taps) - min(t[0] for t in taps)
+        span_x = max(t[1] for t in taps) - min(t[1] for t in taps)
+        gather = 1 if (8 * stride + span_y) * (32 * stride + span_x) * 80 > 110 * 1024 else 0
         # a BatchNorm module in eval mode inside a training plan (frozen statistics, torch semantics): running statistics in
         # the forward pass, no statistics update, backward through the fixed affine map (dgamma / dbeta still flow)
         train_bn = bn is not None and self.training and bn.training
