@@ -457,6 +457,26 @@ __device__ __forceinline__ void conv_wgrad_pipe_body(const pmf_wgrad_desc_t& d, 
 //   * dz keeps its LDS-DMA path (raw fp32 [pixel][32 co]); the wave that owns a 16-pixel slab reads its B fragment as
 //     8 ds_read_b32 and splits it in registers -- once per slab, shared by all TB taps (54 MFMAs).
 // Wave w owns slab w of every half tile (4 slabs of 16 pixels), TB accumulators as before.
+// Phase tracing of conv_wgrad_s3_k (tools/trace_wgrad.py builds a private copy with -DPMF_WG_TRACE): thread 0 of every
+// workgroup stamps s_memtime at phase boundaries.  Compiled out of libpmf_amd.so.
+#ifdef PMF_WG_TRACE
+__device__ unsigned long long* pmf_wg_trace_buf = nullptr;
+extern "C" int pmf_wg_trace_set(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(pmf_wg_trace_buf), &p, sizeof(p)); }
+#define WTR()                                                                                              \
+  do {                                                                                                     \
+    if (threadIdx.x == 0 && pmf_wg_trace_buf && wtri_ < 62)                                                \
+      pmf_wg_trace_buf[(size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 64 + wtri_++] = \
+          __builtin_amdgcn_s_memtime();                                                                    \
+  } while (0)
+#define WTR_END()                                                                                          \
+  do {                                                                                                     \
+    if (threadIdx.x == 0 && pmf_wg_trace_buf)                                                              \
+      pmf_wg_trace_buf[(size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 64 + 63] = wtri_; \
+  } while (0)
+#else
+#define WTR() do { } while (0)
+#define WTR_END() do { } while (0)
+#endif
 typedef __attribute__((ext_vector_type(8))) __bf16 wbf16x8;
 typedef __attribute__((ext_vector_type(2))) __bf16 wbf16x2;
 typedef __attribute__((ext_vector_type(4))) short ws16x4;
@@ -500,6 +520,9 @@ __device__ __forceinline__ void conv_wgrad_s3_body(const pmf_wgrad_desc_t& d, co
   const int co0 = (int)blockIdx.z * BN;
   const int in_cols = g.in_cols;
 
+  int wtri_ = 0;
+  (void)wtri_;
+  WTR();
   int si = 0, c0 = 0, k0 = 0;
   {
     int rem = chunk;
@@ -594,8 +617,13 @@ __device__ __forceinline__ void conv_wgrad_s3_body(const pmf_wgrad_desc_t& d, co
 #pragma unroll
     for (int e = 0; e < 8; ++e) z[e] = zp[e * BN];
     const char* xb = Xs + ((2 * h + rr) * in_cols + xs) * WS3_XPB + trofs;
-    wbf16x8 a[2][3];
-    afrag(xb + toff[0], a[0]);
+    // Taps go in groups of G with their MFMAs interleaved product-major: six MFMAs in a row into ONE accumulator are a
+    // dependent chain (measured 345 cycles per tap against 6 x 32: tools/trace_wgrad.py); G accumulators in rotation keep
+    // the matrix pipe issuing back to back.  The next group's A fragments are read while this group multiplies.
+    constexpr int G = TB % 3 == 0 ? 3 : (TB % 2 == 0 ? 2 : 1), NG = TB / G;
+    wbf16x8 a[2][G][3];
+#pragma unroll
+    for (int t = 0; t < G; ++t) afrag(xb + toff[t], a[0][t]);
     wu32x4 b0, b1, b2;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -604,16 +632,19 @@ __device__ __forceinline__ void conv_wgrad_s3_body(const pmf_wgrad_desc_t& d, co
       b0[e] = p0; b1[e] = p1; b2[e] = p2;
     }
     wbf16x8 b[3] = {__builtin_bit_cast(wbf16x8, b0), __builtin_bit_cast(wbf16x8, b1), __builtin_bit_cast(wbf16x8, b2)};
+    constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PB[6] = {2, 1, 0, 1, 0, 0};   // smallest terms first
 #pragma unroll
-    for (int j = 0; j < TB; ++j) {
-      const int cur = j & 1, nxt = cur ^ 1;
-      if (j + 1 < TB) afrag(xb + toff[j + 1], a[nxt]);
-      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][0], b[2], acc[j], 0, 0, 0);
-      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][1], b[1], acc[j], 0, 0, 0);
-      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][2], b[0], acc[j], 0, 0, 0);
-      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][0], b[1], acc[j], 0, 0, 0);
-      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][1], b[0], acc[j], 0, 0, 0);
-      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][0], b[0], acc[j], 0, 0, 0);
+    for (int gq = 0; gq < NG; ++gq) {
+      const int cur = gq & 1, nxt = cur ^ 1;
+      if (gq + 1 < NG) {
+#pragma unroll
+        for (int t = 0; t < G; ++t) afrag(xb + toff[(gq + 1) * G + t], a[nxt][t]);
+      }
+#pragma unroll
+      for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+        for (int t = 0; t < G; ++t)
+          acc[gq * G + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][t][PA[pr]], b[PB[pr]], acc[gq * G + t], 0, 0, 0);
     }
   };
 
@@ -622,8 +653,10 @@ __device__ __forceinline__ void conv_wgrad_s3_body(const pmf_wgrad_desc_t& d, co
     fetch(tile, true);
     dma(zsrc(tile, 0), Z0);
   }
+  WTR();
   while (tile < g.total_tiles) {
     __syncthreads();                       // X: everyone finished the previous tile
+    WTR();
     f32x4 sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f}, cm4 = {1.f, 1.f, 1.f, 1.f};
     if (aff && qok) { sc4 = *(const f32x4*)(d.src[si].scale + cch); sh4 = *(const f32x4*)(d.src[si].shift + cch); }
     if (d.src[si].cmul && qok) cm4 = *(const f32x4*)(d.src[si].cmul + (size_t)ncur * d.src[si].cmul_ld + cch);
@@ -650,19 +683,25 @@ __device__ __forceinline__ void conv_wgrad_s3_body(const pmf_wgrad_desc_t& d, co
     }
     const int next = tile + d.nsplit;
     const bool have = next < g.total_tiles;
+    WTR();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                       // Y: input tile + half 0 visible
+    WTR();
     dma(zsrc(tile, 1), Z1);
     fetch(have ? next : tile, have);
     __builtin_amdgcn_sched_barrier(0);
     half(Z0, 0);
+    WTR();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                       // Z: everyone finished half 0
+    WTR();
     if (have) dma(zsrc(next, 0), Z0);
     __builtin_amdgcn_sched_barrier(0);
     half(Z1, 1);
+    WTR();
     tile = next;
   }
+  WTR();
 
   // ---- sum the four pixel groups (fixed order) and write this workgroup's partial slab
   {
@@ -694,6 +733,8 @@ __device__ __forceinline__ void conv_wgrad_s3_body(const pmf_wgrad_desc_t& d, co
         if (ci < kc) part[((size_t)j * g.Ktot + k0 + ci) * g.Cout32 + co] = acc[j][r];
       }
   }
+  WTR();
+  WTR_END();
 }
 
 template <int TB, int XSL>
