@@ -549,7 +549,7 @@ __device__ __forceinline__ void conv_wgrad_s3_body(const pmf_wgrad_desc_t& d, co
   int offZ[ZPW];
 #pragma unroll
   for (int jj = 0; jj < ZPW; ++jj) {
-    const int p = (wave + 4 * jj) * PPI + lane / (BN / 4);
+    const int p = (ZPW * wave + jj) * PPI + lane / (BN / 4);       // wave w DMAs the 16 pixels of ITS slab (it alone reads them)
     offZ[jj] = ((p >> 5) * d.OW + (p & 31)) * d.dz_ldc + (lane % (BN / 4)) * 4;
   }
   int toff[TB];
@@ -597,10 +597,15 @@ __device__ __forceinline__ void conv_wgrad_s3_body(const pmf_wgrad_desc_t& d, co
   auto dma = [&](const float* __restrict__ src, float* __restrict__ dst) {
 #pragma unroll
     for (int jj = 0; jj < ZPW; ++jj)
-      __builtin_amdgcn_global_load_lds(src + offZ[jj], (lds_ptr_t)(dst + (wave + 4 * jj) * 256), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(src + offZ[jj], (lds_ptr_t)(dst + (ZPW * wave + jj) * 256), 16, 0, 0);
   };
   typedef __attribute__((address_space(3))) ws16x4* lds_tr_t;
   auto afrag = [&](const char* __restrict__ base, wbf16x8 (&a)[3]) {   // 8-pixel A fragment of one tap, three planes
+#ifdef PMF_WG_NOTR       /* ablation build: no transposing LDS reads */
+#pragma unroll
+    for (int p = 0; p < 3; ++p) { wu32x4 t = {(unsigned)(size_t)base, (unsigned)p, 1u, 2u}; asm volatile("" : "+v"(t)); a[p] = __builtin_bit_cast(wbf16x8, t); }
+    return;
+#endif
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
       const ws16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_t)(base + p * 64));
@@ -608,22 +613,14 @@ __device__ __forceinline__ void conv_wgrad_s3_body(const pmf_wgrad_desc_t& d, co
       a[p] = __builtin_bit_cast(wbf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
     }
   };
-  // one half tile (2 rows x 32 pixels = 4 slabs of 16 pixels): this wave's slab, TB taps x 6 MFMAs
-  auto half = [&](const float* __restrict__ Zh, int h) {
-    const int rr = wave >> 1, xs = (wave & 1) * 16;
-    // B fragment: dz[pixel 8 lh + e][co li], e = 0..7, split in registers
+  // one half tile = 2 rows x 32 pixels = 4 slabs of 16 pixels; wave w owns slab w of both halves.
+  // prep: B fragment dz[pixel 8 lh + e][co li], e = 0..7, of the wave's slab, split in registers
+  const int rr = wave >> 1, xs = (wave & 1) * 16;
+  auto prep = [&](const float* __restrict__ Zh, wbf16x8 (&bf)[3]) {
     const float* zp = Zh + (rr * 32 + xs + lh * 8) * BN + li;
     float z[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) z[e] = zp[e * BN];
-    const char* xb = Xs + ((2 * h + rr) * in_cols + xs) * WS3_XPB + trofs;
-    // Taps go in groups of G with their MFMAs interleaved product-major: six MFMAs in a row into ONE accumulator are a
-    // dependent chain (measured 345 cycles per tap against 6 x 32: tools/trace_wgrad.py); G accumulators in rotation keep
-    // the matrix pipe issuing back to back.  The next group's A fragments are read while this group multiplies.
-    constexpr int G = TB % 3 == 0 ? 3 : (TB % 2 == 0 ? 2 : 1), NG = TB / G;
-    wbf16x8 a[2][G][3];
-#pragma unroll
-    for (int t = 0; t < G; ++t) afrag(xb + toff[t], a[0][t]);
     wu32x4 b0, b1, b2;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -631,7 +628,16 @@ __device__ __forceinline__ void conv_wgrad_s3_body(const pmf_wgrad_desc_t& d, co
       ws3_split2(z[2 * e], z[2 * e + 1], p0, p1, p2);
       b0[e] = p0; b1[e] = p1; b2[e] = p2;
     }
-    wbf16x8 b[3] = {__builtin_bit_cast(wbf16x8, b0), __builtin_bit_cast(wbf16x8, b1), __builtin_bit_cast(wbf16x8, b2)};
+    bf[0] = __builtin_bit_cast(wbf16x8, b0); bf[1] = __builtin_bit_cast(wbf16x8, b1); bf[2] = __builtin_bit_cast(wbf16x8, b2);
+  };
+  // mma: TB taps x 6 MFMAs of half h.  Taps go in groups of G with their MFMAs interleaved product-major (six MFMAs in a
+  // row into ONE accumulator are a dependent chain); the next group's A fragments are read while this group multiplies.
+  auto mma = [&](int h, const wbf16x8 (&bf)[3]) {
+    const char* xb = Xs + ((2 * h + rr) * in_cols + xs) * WS3_XPB + trofs;
+    constexpr int G = TB % 3 == 0 ? 3 : (TB % 2 == 0 ? 2 : 1), NG = TB / G;
+    wbf16x8 a[2][G][3];
+#pragma unroll
+    for (int t = 0; t < G; ++t) afrag(xb + toff[t], a[0][t]);
     constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PB[6] = {2, 1, 0, 1, 0, 0};   // smallest terms first
 #pragma unroll
     for (int gq = 0; gq < NG; ++gq) {
@@ -644,18 +650,28 @@ __device__ __forceinline__ void conv_wgrad_s3_body(const pmf_wgrad_desc_t& d, co
       for (int pr = 0; pr < 6; ++pr)
 #pragma unroll
         for (int t = 0; t < G; ++t)
-          acc[gq * G + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][t][PA[pr]], b[PB[pr]], acc[gq * G + t], 0, 0, 0);
+#ifdef PMF_WG_NOMFMA     /* ablation build of tools/trace_wgrad.py: keep the LDS reads alive, no matrix work */
+          acc[gq * G + t][pr] += __builtin_bit_cast(float, __builtin_bit_cast(wu32x4, a[cur][t][PA[pr]])[pr & 3] ^ __builtin_bit_cast(wu32x4, bf[PB[pr]])[pr & 3]);
+#else
+          acc[gq * G + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][t][PA[pr]], bf[PB[pr]], acc[gq * G + t], 0, 0, 0);
+#endif
     }
   };
 
+  // Vector-memory queue of a wave (operations complete in order) while it computes tile t:  [dz half 0 (t)] [dz half 1 (t)]
+  // [input tile (t+1)].  Every wave DMAs and reads only its own dz slab, so the dz buffers need no barrier: a wave waits for
+  // ITS DMA (vmcnt), copies the slab into registers (prep) and re-issues the DMA of the next tile into the same slab at once.
+  // Both B fragments are prepared up front and the 2 x 54 MFMAs run as one stream.  Two barriers per tile (input tile
+  // write-after-read / read-after-write).
   int tile = split;
   if (tile < g.total_tiles) {
     fetch(tile, true);
     dma(zsrc(tile, 0), Z0);
+    dma(zsrc(tile, 1), Z1);
   }
   WTR();
   while (tile < g.total_tiles) {
-    __syncthreads();                       // X: everyone finished the previous tile
+    __syncthreads();                       // X: everyone finished reading the previous input tile
     WTR();
     f32x4 sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f}, cm4 = {1.f, 1.f, 1.f, 1.f};
     if (aff && qok) { sc4 = *(const f32x4*)(d.src[si].scale + cch); sh4 = *(const f32x4*)(d.src[si].shift + cch); }
@@ -683,24 +699,27 @@ __device__ __forceinline__ void conv_wgrad_s3_body(const pmf_wgrad_desc_t& d, co
     }
     const int next = tile + d.nsplit;
     const bool have = next < g.total_tiles;
+    const int nt = have ? next : tile;     // past the end: re-request the current tile (keeps the queue shape; never used)
     WTR();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                       // Y: input tile + half 0 visible
+    __syncthreads();                       // Y: input tile visible
     WTR();
-    dma(zsrc(tile, 1), Z1);
-    fetch(have ? next : tile, have);
-    __builtin_amdgcn_sched_barrier(0);
-    half(Z0, 0);
+    fetch(nt, have);
+    wbf16x8 bf0[3], bf1[3];
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XSL + ZPW) : "memory");    // my dz slab of half 0 landed
+    prep(Z0, bf0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // slab read: the DMA below may overwrite it
+    dma(zsrc(nt, 0), Z0);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XSL + ZPW) : "memory");    // ... of half 1
+    prep(Z1, bf1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    dma(zsrc(nt, 1), Z1);
     WTR();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                       // Z: everyone finished half 0
-    WTR();
-    if (have) dma(zsrc(next, 0), Z0);
-    __builtin_amdgcn_sched_barrier(0);
-    half(Z1, 1);
+    mma(0, bf0);
+    mma(1, bf1);
     WTR();
     tile = next;
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   WTR();
 
   // ---- sum the four pixel groups (fixed order) and write this workgroup's partial slab

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Phase trace of one conv_wgrad_s3_k launch: builds a private copy of conv_wgrad.hip with -DPMF_WG_TRACE (thread 0 of
 every workgroup stamps s_memtime at phase boundaries: start, loop entry, then per tile X-barrier / input tile stored /
-Y-barrier / half 0 done / Z-barrier / half 1 done, loop exit, end) and prints the median cycle count of every phase.
+Y-barrier / B fragments ready / MFMAs done, loop exit, end) and prints the median cycle count of every phase.
 usage: python tools/trace_wgrad.py [case-substring] [nsplit]     (cases of tools/bench_conv.py)"""
 import ctypes as C, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,7 +15,8 @@ def build():
     so = "/tmp/libpmf_wg_trace.so"
     src = os.path.join(ROOT, "pmf_amd/csrc/conv_wgrad.hip")
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-                           "-munsafe-fp-atomics", "-mllvm", "-amdgpu-mfma-vgpr-form", "-DPMF_WG_TRACE", src, "-o", so])
+                           "-munsafe-fp-atomics", "-DPMF_WG_TRACE"] +        # (as the Makefile: no -amdgpu-mfma-vgpr-form for this file)
+                          os.environ.get("TRACE_DEFS", "").split() + [src, "-o", so])     # e.g. TRACE_DEFS="-DPMF_WG_NOMFMA"
     return C.CDLL(so)
 
 def main(filt, ns):
@@ -56,15 +57,15 @@ def main(filt, ns):
         print("== %s nsplit %d: %d workgroups, %d stamps, launch span %d ticks; per-workgroup total median %d" % (
             name, wd.nsplit, len(t), cnt, span, int(np.median(t[:, cnt - 1] - t[:, 0]))))
         names = ["prologue"]
-        per = ["X barrier", "split+store X", "wait+Y barrier", "dma+fetch+half0", "wait+Z barrier", "dma+half1"]
-        ntile = (cnt - 1 - 1 - 2) // 6
+        per = ["X barrier", "split+store X", "Y barrier", "fetch + dz wait + B prep", "108 MFMAs"]
+        ntile = (cnt - 1 - 1 - 2) // len(per)
         for i in range(ntile): names += ["t%d %s" % (i, p) for p in per]
         names += ["loop exit", "reduce+write"]
         med = np.median(d, axis=0)
         for n_, m in zip(names, med): print("   %-26s %8d" % (n_, m))
         agg = {p: 0 for p in per}
         for i in range(1, ntile):
-            for j, p in enumerate(per): agg[p] += med[1 + 6 * i + j]
+            for j, p in enumerate(per): agg[p] += med[1 + len(per) * i + j]
         print("   per tile (tiles 1..%d):" % (ntile - 1), {p: int(v / max(ntile - 1, 1)) for p, v in agg.items()})
 
 if __name__ == "__main__":
