@@ -836,6 +836,7 @@ class Plan:
             d.Cin_real, d.KHW = conv.in_channels, kh * kw
         probe = L.WgradDesc()
         shape_fill(probe)
+        probe.flags = L.WGRAD_S3 if self.s3 else 0       # (the kernel choice, hence the grid, depends on it)
         probe.nsplit = 1
         nsplit = L.lib().pmf_conv_wgrad_nsplit(C.byref(probe))
         probe.nsplit = nsplit

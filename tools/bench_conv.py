@@ -74,6 +74,7 @@ def run(which, filt):
             for i, (dy, dx) in enumerate(taps): wd.tdy[i], wd.tdx[i], wd.tap_widx[i] = dy, dx, i
             wd.in_stride = 1; wd.dz, wd.dz_ldc = dz.data_ptr(), co
             wd.flags = L.WGRAD_S3 if os.environ.get("WG_S3", "1") != "0" else 0     # split-bf16 kernels (the plan's default)
+            wd.Cin_real, wd.KHW = ci, k * k          # (before the split count: the few-channel stem kernel keys on it)
             wd.nsplit = 1; wd.nsplit = lib.pmf_conv_wgrad_nsplit(C.byref(wd))
             part = torch.empty(lib.pmf_conv_wgrad_workspace(C.byref(wd)), dtype=torch.uint8, device="cuda")
             gw = torch.empty(co, ci, k, k, device="cuda")

@@ -36,6 +36,7 @@ def main(filt, ns):
         for i, (dy, dx) in enumerate(taps): wd.tdy[i], wd.tdx[i], wd.tap_widx[i] = dy, dx, i
         wd.in_stride = 1; wd.dz, wd.dz_ldc = dz.data_ptr(), co
         wd.flags = L.WGRAD_S3
+        wd.Cin_real, wd.KHW = ci, k * k
         wd.nsplit = 1; wd.nsplit = ns if ns else lib.pmf_conv_wgrad_nsplit(C.byref(wd))
         part = torch.empty(lib.pmf_conv_wgrad_workspace(C.byref(wd)), dtype=torch.uint8, device="cuda")
         gw = torch.empty(co, ci, k, k, device="cuda")
