@@ -11,9 +11,18 @@ __global__ void bn_finalize_k(const double* __restrict__ stats, int nrows, float
   __shared__ double sh[2][256];
   const int c = blockIdx.x;
   double s1 = 0.0, s2 = 0.0;
-  for (int r = threadIdx.x; r < nrows; r += 256) {
-    s1 += stats[(size_t)r * 2 * C + c];
-    s2 += stats[(size_t)r * 2 * C + C + c];
+  // four rows per trip: eight independent loads in flight per thread (a load -> add loop is one memory round trip per
+  // row, and this kernel is nothing but latency)
+  for (int r = threadIdx.x; r < nrows; r += 1024) {
+    double a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int rr = r + 256 * u;
+      a[u] = rr < nrows ? stats[(size_t)rr * 2 * C + c] : 0.0;
+      b[u] = rr < nrows ? stats[(size_t)rr * 2 * C + C + c] : 0.0;
+    }
+    s1 += (a[0] + a[1]) + (a[2] + a[3]);
+    s2 += (b[0] + b[1]) + (b[2] + b[3]);
   }
   sh[0][threadIdx.x] = s1; sh[1][threadIdx.x] = s2;
   __syncthreads();
@@ -130,13 +139,23 @@ __global__ void bn_bwd_reduce_k(const float* __restrict__ gy, int gy_ldc, const 
 __global__ void bn_bwd_fold_k(const double* __restrict__ part, int nrows, int C, float invM, int train,
                               const float* __restrict__ gamma, const float* __restrict__ save_invstd, float* coef,
                               float* dgamma, float* dbeta) {
-  __shared__ double sh[2][64];
+  __shared__ double sh[2][256];
   const int c = blockIdx.x;
   double s1 = 0.0, s2 = 0.0;
-  for (int r = threadIdx.x; r < nrows; r += 64) { s1 += part[(size_t)r * 2 * C + c]; s2 += part[(size_t)r * 2 * C + C + c]; }
+  for (int r = threadIdx.x; r < nrows; r += 1024) {       // 256 threads, four rows per trip (see bn_finalize_k)
+    double a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int rr = r + 256 * u;
+      a[u] = rr < nrows ? part[(size_t)rr * 2 * C + c] : 0.0;
+      b[u] = rr < nrows ? part[(size_t)rr * 2 * C + C + c] : 0.0;
+    }
+    s1 += (a[0] + a[1]) + (a[2] + a[3]);
+    s2 += (b[0] + b[1]) + (b[2] + b[3]);
+  }
   sh[0][threadIdx.x] = s1; sh[1][threadIdx.x] = s2;
   __syncthreads();
-  for (int o = 32; o > 0; o >>= 1) {
+  for (int o = 128; o > 0; o >>= 1) {
     if (threadIdx.x < o) { sh[0][threadIdx.x] += sh[0][threadIdx.x + o]; sh[1][threadIdx.x] += sh[1][threadIdx.x + o]; }
     __syncthreads();
   }
@@ -158,7 +177,7 @@ extern "C" int pmf_bn_bwd_reduce(const float* gy, int32_t gy_ldc, const float* a
   ColL L = col_l(npix, C / 4);
   hipLaunchKernelGGL(bn_bwd_reduce_k, L.grid, L.block, 0, (hipStream_t)s, gy, gy_ldc, a, a_ldc, npix, C / 4, C, save_mean,
                      part);
-  hipLaunchKernelGGL(bn_bwd_fold_k, dim3(C), dim3(64), 0, (hipStream_t)s, (const double*)part, (int)L.grid.x, C,
+  hipLaunchKernelGGL(bn_bwd_fold_k, dim3(C), dim3(256), 0, (hipStream_t)s, (const double*)part, (int)L.grid.x, C,
                      1.f / (float)npix, train, gamma, save_invstd, coef, dgamma, dbeta);
   PMF_LAUNCH_CHECK();
   return 0;
@@ -168,7 +187,7 @@ extern "C" int pmf_bn_bwd_fold(const double* part, int32_t nrows, int32_t C, int
                                const float* gamma, const float* save_invstd, float* coef, float* dgamma, float* dbeta,
                                pmf_stream_t s) {
   if (nrows < 1) return PMF_E_ARG;
-  hipLaunchKernelGGL(bn_bwd_fold_k, dim3(C), dim3(64), 0, (hipStream_t)s, part, (int)nrows, C, 1.f / (float)npix, train,
+  hipLaunchKernelGGL(bn_bwd_fold_k, dim3(C), dim3(256), 0, (hipStream_t)s, part, (int)nrows, C, 1.f / (float)npix, train,
                      gamma, save_invstd, coef, dgamma, dbeta);
   PMF_LAUNCH_CHECK();
   return 0;
