@@ -96,7 +96,7 @@ typedef struct {
                               * conv_fwd.hip PIPE 5); only for descriptors with pmf_conv_s3_eligible() != 0 */
 } pmf_conv_desc_t;
 #define PMF_EP_STAT_X_ONLY 1
-/* 1 when every tile configuration of this descriptor runs the software-pipelined K loop (stride 1, one halo tile,
+/* 1 when the descriptor runs the software-pipelined K loop (stride 1 -- or a stride-2 3x3 with all nine taps --, one halo tile,
  * every operand a multiple of 16 channels, same H x W, no broadcast): the class pmf_conv_fwd accepts w_s3 for.
  * 2 for one-tap descriptors (1x1 layers, any stride) that qualify for the direct variant (conv_fwd.hip PIPE 11:
  * activations straight from global memory, all weight fragments of an output-channel tile resident in LDS; operands

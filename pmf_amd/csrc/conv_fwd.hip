@@ -476,13 +476,13 @@ __device__ __forceinline__ void s3_half(f32x16 (&acc)[MT][BN / 32], const char* 
 // three barriers.  Stages are sized so that virtual taps <= 9 and the staging slots per thread <= 8.
 // NTAPS: 9 = the 3x3 case with its tap count known at compile time (no dispatch on the half sizes inside the stage
 // loop: the branches end scheduling regions and cost accumulator copies at their joins), 0 = read from the descriptor
-template <int BN, int MT, int SL, int NTAPS = 0>
+template <int BN, int MT, int SL, int NTAPS = 0, int IS = 1>      // IS: input stride (2: the stride-2 3x3 layers, MT = 1 only)
 __device__ __forceinline__ void conv_kloop_s3(const pmf_conv_desc_t& d, const ConvGeom& g, f32x16 (&acc)[MT][BN / 32],
                                               char* __restrict__ As, char* __restrict__ Bs, const int (&segrow)[MT],
                                               const int (&segcol)[MT], int tid, int li, int lh, int n, int n0, int ks,
                                               int oy0, int ox0, int& tri_) {
   constexpr int NT = BN / 32;
-  constexpr int ASL = SL > 1 ? 8 : (MT == 2 ? 7 : 5);   // float4 slots per thread for the input tile
+  constexpr int ASL = IS == 2 ? 10 : (SL > 1 ? 8 : (MT == 2 ? 7 : 5));   // float4 slots per thread for the input tile
   constexpr int NF = 5 * NT * 3;                  // fragments of the larger half (<= 5 virtual taps)
   constexpr int NDMA = (NF + 3) / 4;              // DMA instructions per wave per half
   const int in_cols = g.in_cols;
@@ -502,7 +502,7 @@ __device__ __forceinline__ void conv_kloop_s3(const pmf_conv_desc_t& d, const Co
   for (int j = 0; j < ASL; ++j) {
     const int f = tid + 256 * j, pix = SL > 1 ? (f >> 2) % npixA : (f >> 2);
     const int r = pix / in_cols, c = pix - r * in_cols;
-    const int iy = oy0 + g.dy_min + r, ix = ox0 + g.dx_min + c;
+    const int iy = oy0 * IS + g.dy_min + r, ix = ox0 * IS + g.dx_min + c;
     const bool ok = f < totalA && iy >= 0 && iy < sH && ix >= 0 && ix < sW;
     gA[j] = ok ? (n * sH + iy) * sW + ix : -1;
     okA |= ok ? (1u << j) : 0u;
@@ -530,7 +530,7 @@ __device__ __forceinline__ void conv_kloop_s3(const pmf_conv_desc_t& d, const Co
   }
   int abase[MT];
 #pragma unroll
-  for (int m = 0; m < MT; ++m) abase[m] = (segrow[m] * in_cols + segcol[m] * 32 + li) * S3_APB + lh * 16;
+  for (int m = 0; m < MT; ++m) abase[m] = (segrow[m] * IS * in_cols + (segcol[m] * 32 + li) * IS) * S3_APB + lh * 16;
 
   int si = 0, c0 = 0, kb = 0, cn = 0;
   auto settle = [&]() {
@@ -925,7 +925,10 @@ __global__ __launch_bounds__(256) void conv_fwd_k(const pmf_conv_desc_t d, const
     segcol[m] = s & ((1 << g.segs_x_log2) - 1);
   }
 
-  if constexpr (PIPE == 11) {         // 1x1, split-bf16, activations straight from global memory
+  if constexpr (PIPE == 12) {         // stride-2 3x3 (one slab per stage, 9 taps at compile time, 128-pixel tiles only)
+    if constexpr (MT == 1)
+      conv_kloop_s3<BN, 1, 1, 9, 2>(d, g, acc, (char*)smem, (char*)(smem + g.a_floats), segrow, segcol, tid, li, lh, n, n0, ks, oy0, ox0, tri_);
+  } else if constexpr (PIPE == 11) {  // 1x1, split-bf16, activations straight from global memory
     conv_kloop_direct<BN, MT>(d, g, acc, (char*)smem, segrow, segcol, tid, li, lh, n, n0, oy0, ox0);
   } else if constexpr (PIPE == 8) {   // one slab per stage, 9 taps at compile time
     conv_kloop_s3<BN, MT, 1, 9>(d, g, acc, (char*)smem, (char*)(smem + g.a_floats), segrow, segcol, tid, li, lh, n, n0, ks, oy0, ox0, tri_);
@@ -1341,6 +1344,7 @@ static int finish_rows(const pmf_conv_desc_t* d) {
 
 static int conv_direct_lds(const pmf_conv_desc_t* d, int BN);
 static bool conv_s3_fits(const pmf_conv_desc_t* d, int MT);
+static bool conv_s3_stride2(const pmf_conv_desc_t* d);
 static void conv_config_(const pmf_conv_desc_t* d, int* BN, int* MT);
 static void conv_config(const pmf_conv_desc_t* d, int* BN, int* MT) {
   conv_config_(d, BN, MT);
@@ -1349,6 +1353,7 @@ static void conv_config(const pmf_conv_desc_t* d, int* BN, int* MT) {
   if (d->w_s3 && d->ntaps == 1 && *BN == 64 && !conv_direct_lds(d, 64) && conv_direct_lds(d, 32)) *BN = 32;
   // LDS-staged split loop: the 256-pixel tile may not qualify where the 128-pixel one does (dilated 3x3 on a 4-row map)
   if (d->w_s3 && d->ntaps > 1 && *MT == 2 && !conv_s3_fits(d, 2)) *MT = 1;
+  if (d->w_s3 && d->in_stride == 2 && d->ntaps > 1) *MT = 1;      // the stride-2 split loop: 128-pixel tiles
 }
 static void conv_config_(const pmf_conv_desc_t* d, int* BN, int* MT) {
   if (d->cfg) {                       // caller-tuned tile configuration
@@ -1484,6 +1489,8 @@ static int launch(const pmf_conv_desc_t* d, hipStream_t s) {
     (void)hipFuncSetAttribute((const void*)conv_fwd_k<BN, MT, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)conv_fwd_k<BN, MT, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)conv_fwd_k<BN, MT, 11>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if constexpr (MT == 1)
+      (void)hipFuncSetAttribute((const void*)conv_fwd_k<BN, 1, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   const int co_tiles = cdiv(d->Cout, BN);
@@ -1492,6 +1499,15 @@ static int launch(const pmf_conv_desc_t* d, hipStream_t s) {
     mode = 11;
     lds = dl;
     nchunks = 1;
+  } else if (d->w_s3 && d->in_stride == 2) {     // stride-2 3x3
+    if constexpr (MT != 1) return PMF_E_UNSUPPORTED;
+    if (!conv_s3_stride2(d) || (d->ldw & 31)) return PMF_E_UNSUPPORTED;
+    mode = 12;
+    g.a_floats = round_up(g.in_rows * g.in_cols * (S3_APB / 4), 4);
+    lds = g.a_floats * 4 + 9 * (BN / 32) * 3 * 1024 + 2048;
+    nchunks = 0;
+    for (int i = 0; i < d->nsrc; ++i) nchunks += d->src[i].C / KC;
+    if (lds > 160 * 1024) return PMF_E_UNSUPPORTED;
   } else if (d->w_s3) {      // split-bf16 weights: the pipelined class only (pmf_conv_s3_eligible)
     if (mode == 0 || (d->ldw & 31)) return PMF_E_UNSUPPORTED;
     const int sl = conv_s3_slabs(d, g);
@@ -1516,7 +1532,9 @@ static int launch(const pmf_conv_desc_t* d, hipStream_t s) {
   g.ws = d->splitk_ws;
   g.ws_ld = round_up(d->Cout, 4);
   dim3 grid(g.tiles_x * g.tiles_y, co_tiles * g.ksplit, d->N);
-  if (mode == 11) {
+  if (mode == 12) {
+    if constexpr (MT == 1) hipLaunchKernelGGL((conv_fwd_k<BN, 1, 12>), grid, dim3(256), lds, s, dd, g);
+  } else if (mode == 11) {
     hipLaunchKernelGGL((conv_fwd_k<BN, MT, 11>), grid, dim3(256), lds, s, dd, g);
   } else if (mode == 5) {
     hipLaunchKernelGGL((conv_fwd_k<BN, MT, 5>), grid, dim3(256), lds, s, dd, g);
@@ -1582,8 +1600,28 @@ extern "C" int pmf_conv_s3_eligible(const pmf_conv_desc_t* d) {
   return conv_s3_fits(d, 1) ? 1 : 0;      // (a 256-pixel tile that does not qualify falls back to 128 pixels: conv_config)
 }
 
+// stride-2 3x3 layers on the split loop (PIPE 12): all nine taps live, halo tile of the 4 x 32-pixel output tile
+// (9 x 65 input pixels) within ten staging slots per thread and the LDS budget of the 64-wide tile
+static bool conv_s3_stride2(const pmf_conv_desc_t* d) {
+  static const bool off = getenv("PMF_S3_NO_STRIDE2") != nullptr;
+  if (off || d->in_stride != 2 || d->ntaps != 9 || d->gather) return false;
+  for (int i = 0; i < d->nsrc; ++i) {
+    if (d->src[i].C % 16 || (d->src[i].flags & PMF_SRC_BCAST)) return false;
+    if (d->src[i].H != d->src[0].H || d->src[i].W != d->src[0].W) return false;
+    if ((int64_t)d->N * d->src[i].H * d->src[i].W * d->src[i].ldc * 4 >= (1ll << 31)) return false;
+  }
+  int cmax = 0;
+  for (int i = 0; i < d->nsrc; ++i) cmax = d->src[i].C > cmax ? d->src[i].C : cmax;
+  ConvGeom g;
+  int gather;
+  pmf_conv_geometry(d->OH, d->OW, d->ntaps, d->tdy, d->tdx, 2, 0, 64, 1, cmax < KC ? cmax : KC, &g, &gather);
+  if (gather || g.in_rows * g.in_cols * 4 > 256 * 10) return false;
+  return g.in_rows * g.in_cols * S3_APB + 16 + 9 * 2 * 3 * 1024 + 2048 <= 160 * 1024;
+}
+
 // the LDS-staged split loop with MT x 128-pixel tiles: pipelined class + LDS budget (judged on the 64-wide tile)
 static bool conv_s3_fits(const pmf_conv_desc_t* d, int MT) {
+  if (d->in_stride == 2) return MT == 1 && conv_s3_stride2(d);
   int cmax = 0;
   for (int i = 0; i < d->nsrc; ++i) cmax = d->src[i].C > cmax ? d->src[i].C : cmax;
   ConvGeom g;

@@ -90,7 +90,7 @@ def test_conv_fwd_vs_torch_cpu(case):
 
 S3_CASES = [c for c in CONV_CASES if c[0] in ("3x3_32_32", "3x3d2_64_64_xf", "2x2d2_32", "1x1_cat3", "3x3_cat2_80_32",
                                                "3x3_16_20", "3x3_256_256_small", "1x1_cat2_80_48_xf", "1x1_32_20",
-                                               "1x1s2_64_128")]
+                                               "1x1s2_64_128", "3x3s2_64_128")]
 
 
 @pytest.mark.parametrize("cfg", [0, 32 | (1 << 8) | (1 << 16), 64 | (1 << 8) | (1 << 16), 32 | (2 << 8) | (1 << 16),
