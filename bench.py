@@ -5,11 +5,17 @@ One "step" = one full optimisation iteration of tasks/pmf/trainer.py on a synthe
 bs=2 per GPU at 64x2048 (both streams, SURVEY.md fact 4 / 8d S_A): normalise -> PMFNet forward (HIP plan) ->
 focal + Lovasz (x2 heads) + perception-aware loss -> backward (HIP plan) -> AdamW(lidar) + SGD-Nesterov(camera)
 -> 2 LR-scheduler steps -> confusion-matrix updates.  Dropout2d active (p=0.2), train-mode BatchNorm with local
-statistics, fp32 arithmetic (fp32 MFMA).  Nothing is skipped inside the timed region.
+statistics, fp32 arithmetic (fp32 in / out / accumulate; the conv products run as six bf16 MFMA products of three-way split
+fp32 operands, fp32-class error -- DESIGN.md section 4; PMF_CONV_F32=1 = v_mfma_f32_32x32x2_f32 only).  Nothing is skipped
+inside the timed region.
 
     python bench.py --gpus N --steps K --warmup W
-N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (one rank per GPU,
-RCCL); weak scaling (bs=2 per GPU); value = N*K iterations / max-over-ranks wall time.
+N > 1: either launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (one rank per GPU,
+RCCL), or -- when no launcher environment (WORLD_SIZE) is present -- bench.py re-executes itself under
+torch.distributed.run with N ranks on 127.0.0.1 (the reference takes its world from the launcher environment too:
+pc_processor/utils/utils.py:21-44, tasks/pmf/trainer.py:33-39).  It fails loudly when fewer than N devices exist or when
+the launcher's WORLD_SIZE disagrees with --gpus.  Weak scaling (bs=2 per GPU); value = N*K iterations / max-over-ranks
+wall time.
 
 Extra objects on the JSON line (every mode: --mode infer, --backbone resnet50 ..., --model epmf carry them too):
   roofline     -- the dominant kernel, the conv MFMA kernel (conv_fwd_k: forward + input-gradient launches): algorithmic
@@ -308,6 +314,41 @@ def timed_ms(fn, reps=5):
     return e0.elapsed_time(e1) / reps
 
 
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def spawn_ranks(n, argv):
+    """--gpus N without a launcher environment: re-execute this script under torch.distributed.run, one rank per GPU.
+    The children see WORLD_SIZE / RANK / LOCAL_RANK exactly as under the driver's own launch line; their stdout is ours
+    (rank 0 prints the JSON line last).  Returns the launcher's exit code."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+def dist_probe(world, rank):
+    """PMF_BENCH_DIST_PROBE=1 (tests/test_ddp_gloo.py): bring up the process group the way the bench does -- with gloo
+    standing in for RCCL so that it runs without a GPU -- all-reduce one value and print what rank 0 saw.  Exercises the
+    --gpus N self-spawn path on a CPU-only host; measures nothing."""
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29517")
+    dist.init_process_group("gloo", init_method="env://", world_size=world, rank=rank)
+    t = torch.tensor([float(rank + 1)])
+    dist.all_reduce(t)
+    if rank == 0:
+        print(json.dumps({"probe": "dist", "n_gpus": dist.get_world_size(), "backend": "gloo", "sum": t.item()}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -335,12 +376,28 @@ def main():
     ap.add_argument("--profile-out", default=None, help="write the per-launch HIP-event profile (one line per op)")
     args = ap.parse_args()
 
+    probe = os.environ.get("PMF_BENCH_DIST_PROBE") == "1"
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher around us: become the launcher (one rank per GPU)
+        if not probe:
+            have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+            if have < args.gpus:
+                raise SystemExit("bench.py: --gpus %d asked for, %d device(s) visible" % (args.gpus, have))
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher environment has WORLD_SIZE=%d" % (args.gpus, world))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if probe:
+        return dist_probe(world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an AMD GPU: the HIP hot path has no CPU fallback")
+    if torch.cuda.device_count() <= local:
+        raise SystemExit("bench.py: rank %d has no device %d (%d visible)" % (rank, local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     multi = world > 1 or args.force_dist

@@ -137,3 +137,30 @@ def test_range_allreduce_covers_every_gradient_once():
     for off, n in calls:
         covered += list(range(off, off + n))
     assert covered == list(range(1024)), "ranges overlap or leave gaps: %s" % (calls,)
+
+
+def test_bench_gpus_flag_spawns_ranks():
+    """`python bench.py --gpus 2` with no launcher environment must start TWO ranks itself (the reference
+    takes its world from the launcher env, pc_processor/utils/utils.py:21-44).  PMF_BENCH_DIST_PROBE=1 swaps RCCL for
+    gloo and stops after the first collective, so the spawn + rendezvous path runs on a CPU-only host."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["PMF_BENCH_DIST_PROBE"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["sum"] == 3.0          # ranks 0 and 1 each added rank + 1
+    # a launcher world that disagrees with --gpus is an error, not a silent single-rank run
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env2, capture_output=True,
+                        text=True, timeout=120)
+    assert r2.returncode != 0 and "WORLD_SIZE" in (r2.stderr + r2.stdout)
+    # and without devices the real (non-probe) path refuses instead of running one rank
+    env3 = {k: v for k, v in env.items() if k != "PMF_BENCH_DIST_PROBE"}
+    r3 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env3, capture_output=True,
+                        text=True, timeout=120)
+    assert r3.returncode != 0 and "device" in (r3.stderr + r3.stdout)
