@@ -10,7 +10,7 @@
 // conflict-free), B[k][j=lane&31] = ds_read_b32 from the [k][BN] slab (32 consecutive banks).
 // Epilogue: + bias, activation, optional (n,c) multiplier / ReLU mask (input-gradient form), optional
 // per-channel sum / sum-of-squares for the BatchNorm that follows, coalesced 128-B row stores.
-#include "common.h"
+#include "conv_epi.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <type_traits>
@@ -19,40 +19,10 @@
 #define APITCH 20
 #define TAPG 9
 
-// Phase tracing (tools/trace_conv.py builds a private copy of this file with -DPMF_CONV_TRACE): thread 0 of every
-// workgroup stamps s_memtime at phase boundaries.  Compiled out of libpmf_amd.so.
 #ifdef PMF_CONV_TRACE
-__device__ unsigned long long* pmf_trace_buf = nullptr;
 extern "C" int pmf_conv_trace_set(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(pmf_trace_buf), &p, sizeof(p)); }
-#define TR()                                                                                            \
-  do {                                                                                                  \
-    if (threadIdx.x == 0 && pmf_trace_buf && tri_ < 60)                                                 \
-      pmf_trace_buf[(size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 64 + tri_++] = \
-          __builtin_amdgcn_s_memtime();                                                                 \
-  } while (0)
-#define TR_END()                                                                                        \
-  do {                                                                                                  \
-    if (threadIdx.x == 0 && pmf_trace_buf) {                                                            \
-      unsigned long long* t_ = pmf_trace_buf + (size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 64; \
-      t_[59] = tr_w0_;                                                                                  \
-      t_[60] = wall_clock64();                                                                          \
-      t_[61] = __builtin_amdgcn_s_getreg(63508);                                                        \
-      t_[62] = __builtin_amdgcn_s_getreg(63492);                                                        \
-      t_[63] = tri_;                                                                                    \
-    }                                                                                                   \
-  } while (0)
-#define TR_START() const unsigned long long tr_w0_ = wall_clock64()
-#else
-#define TR_START() do { } while (0)
-#define TR() do { } while (0)
-#define TR_END() do { } while (0)
 #endif
 
-// Kernel-argument fields travel through the scalar cache.  Left alone, hipcc sinks every s_load to its first use and
-// waits for it there: 9 tap offsets + 6 operand fields were 15 dependent scalar-cache round trips (~5.5k cycles, 2.6 us)
-// at the start of EVERY workgroup, before its first global load was issued.  Naming the values in one empty asm
-// statement makes the compiler fetch them as one batch with a single wait.
-#define PMF_SGPR_BATCH(...) asm volatile("" ::__VA_ARGS__)
 
 // NTAPS taps x 16 channels of one staged chunk, fully unrolled and branch-free.  The LDS operands of step i+1 (one
 // ds_read_b128 per M tile + 4 ds_read_b32 per N tile) are issued BEFORE the 4*MT*NT MFMAs of step i (explicit double
@@ -427,7 +397,7 @@ __device__ __forceinline__ void s3_sgb() {
 // NTH taps of one half: A fragments (MT x 3 planes) and B fragments (NT x 3 planes) of tap i+1 are read while the
 // 6 MT NT MFMAs of tap i run
 template <int BN, int MT, int NTH, class Fill = NoFill>
-__device__ __forceinline__ void s3_half(f32x16 (&acc)[MT][BN / 32], const char* __restrict__ As,
+__device__ __forceinline__ void s3_half(f32x16 (&acc)[MT][BN / 32], f32x16& alt, const char* __restrict__ As,
                                         const char* __restrict__ Bh, const int (&abase)[MT], const int (&aoff)[TAPG],
                                         int t0, int lane, Fill fill = Fill()) {
   constexpr int NT = BN / 32;
@@ -458,6 +428,16 @@ __device__ __forceinline__ void s3_half(f32x16 (&acc)[MT][BN / 32], const char* 
     fill(st, NTH);
     // smallest terms first; product-major so that back-to-back MFMAs hit different accumulators
     constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PB[6] = {2, 1, 0, 1, 0, 0};
+    if constexpr (MT * NT == 1) {
+      // one output tile per wave: six MFMAs in a row into ONE accumulator are a dependent chain (a v_mfma_f32_32x32x16_bf16
+      // that reads the accumulator of its predecessor issues after ~64 cycles, not 32: measured 63-73 cycles per MFMA in
+      // these stages).  Alternate between two accumulators; the kernel adds them once after the K loop.
+#pragma unroll
+      for (int pr = 0; pr < 6; ++pr) {
+        if (pr & 1) alt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][0][PA[pr]], b[cur][0][PB[pr]], alt, 0, 0, 0);
+        else acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][0][PA[pr]], b[cur][0][PB[pr]], acc[0][0], 0, 0, 0);
+      }
+    } else {
 #pragma unroll
     for (int pr = 0; pr < 6; ++pr)
 #pragma unroll
@@ -465,6 +445,7 @@ __device__ __forceinline__ void s3_half(f32x16 (&acc)[MT][BN / 32], const char* 
 #pragma unroll
         for (int u = 0; u < NT; ++u)
           acc[m][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][m][PA[pr]], b[cur][u][PB[pr]], acc[m][u], 0, 0, 0);
+    }
     // the next tap's 3 (MT + NT) LDS reads and this step's slice of global loads go into the gaps behind the MFMAs
     s3_sgb<0, 6 * MT * NT, 3 * (MT + NT), (6 * MT * NT * 2 + 2) / 3, 2>();
     __builtin_amdgcn_sched_barrier(0);
@@ -482,6 +463,9 @@ __device__ __forceinline__ void conv_kloop_s3(const pmf_conv_desc_t& d, const Co
                                               const int (&segcol)[MT], int tid, int li, int lh, int n, int n0, int ks,
                                               int oy0, int ox0, int& tri_) {
   constexpr int NT = BN / 32;
+  f32x16 alt;                                    // second accumulator of the one-tile wave (s3_half)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) alt[r] = 0.f;
   constexpr int ASL = IS == 2 ? 10 : (SL > 1 ? 8 : (MT == 2 ? 7 : 5));   // float4 slots per thread for the input tile
   constexpr int NF = 5 * NT * 3;                  // fragments of the larger half (<= 5 virtual taps)
   constexpr int NDMA = (NF + 3) / 4;              // DMA instructions per wave per half
@@ -656,21 +640,21 @@ __device__ __forceinline__ void conv_kloop_s3(const pmf_conv_desc_t& d, const Co
     __builtin_amdgcn_sched_barrier(0);
     if (NTAPS != 0) {
       constexpr int NV = (NTAPS ? NTAPS : 1) * SL, N0 = (NV + 1) / 2, N1 = NV - N0;
-      if (with_fill) s3_half<BN, MT, N0>(acc, As, Bt, abase, aoff, 0, lane, fill);
-      else s3_half<BN, MT, (N1 > 0 ? N1 : 1)>(acc, As, Bt, abase, aoff, N0, lane);
+      if (with_fill) s3_half<BN, MT, N0>(acc, alt, As, Bt, abase, aoff, 0, lane, fill);
+      else s3_half<BN, MT, (N1 > 0 ? N1 : 1)>(acc, alt, As, Bt, abase, aoff, N0, lane);
       return;
     }
     if (with_fill) {
-      if (nth == 5) s3_half<BN, MT, 5>(acc, As, Bt, abase, aoff, t0, lane, fill);
-      else if (nth == 4) s3_half<BN, MT, 4>(acc, As, Bt, abase, aoff, t0, lane, fill);
-      else if (nth == 3) s3_half<BN, MT, 3>(acc, As, Bt, abase, aoff, t0, lane, fill);
-      else if (nth == 2) s3_half<BN, MT, 2>(acc, As, Bt, abase, aoff, t0, lane, fill);
-      else s3_half<BN, MT, 1>(acc, As, Bt, abase, aoff, t0, lane, fill);
+      if (nth == 5) s3_half<BN, MT, 5>(acc, alt, As, Bt, abase, aoff, t0, lane, fill);
+      else if (nth == 4) s3_half<BN, MT, 4>(acc, alt, As, Bt, abase, aoff, t0, lane, fill);
+      else if (nth == 3) s3_half<BN, MT, 3>(acc, alt, As, Bt, abase, aoff, t0, lane, fill);
+      else if (nth == 2) s3_half<BN, MT, 2>(acc, alt, As, Bt, abase, aoff, t0, lane, fill);
+      else s3_half<BN, MT, 1>(acc, alt, As, Bt, abase, aoff, t0, lane, fill);
     } else {
-      if (nth == 4) s3_half<BN, MT, 4>(acc, As, Bt, abase, aoff, t0, lane);
-      else if (nth == 3) s3_half<BN, MT, 3>(acc, As, Bt, abase, aoff, t0, lane);
-      else if (nth == 2) s3_half<BN, MT, 2>(acc, As, Bt, abase, aoff, t0, lane);
-      else if (nth == 1) s3_half<BN, MT, 1>(acc, As, Bt, abase, aoff, t0, lane);
+      if (nth == 4) s3_half<BN, MT, 4>(acc, alt, As, Bt, abase, aoff, t0, lane);
+      else if (nth == 3) s3_half<BN, MT, 3>(acc, alt, As, Bt, abase, aoff, t0, lane);
+      else if (nth == 2) s3_half<BN, MT, 2>(acc, alt, As, Bt, abase, aoff, t0, lane);
+      else if (nth == 1) s3_half<BN, MT, 1>(acc, alt, As, Bt, abase, aoff, t0, lane);
     }
   };
   while (have) {
@@ -695,6 +679,7 @@ __device__ __forceinline__ void conv_kloop_s3(const pmf_conv_desc_t& d, const Co
     if (nt1) mfma_half(Bh1, nt0, nt1, false);
     TR();
   }
+  if constexpr (MT * NT == 1) acc[0][0] += alt;
 }
 
 // PIPE 11 -- 1x1 convolutions on the split-bf16 path, activations straight from global memory.
@@ -711,6 +696,9 @@ __device__ __forceinline__ void conv_kloop_direct(const pmf_conv_desc_t& d, cons
                                                   char* __restrict__ Bs, const int (&segrow)[MT], const int (&segcol)[MT],
                                                   int tid, int li, int lh, int n, int n0, int oy0, int ox0) {
   constexpr int NT = BN / 32;
+  f32x16 alt;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) alt[r] = 0.f;
   constexpr int PF = 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int Ktot = g.Ktot, nks = Ktot >> 4, CT = d.ldw >> 5;
@@ -825,6 +813,13 @@ __device__ __forceinline__ void conv_kloop_direct(const pmf_conv_desc_t& d, cons
 #pragma unroll
       for (int p = 0; p < 3; ++p) b[u][p] = *(const bf16x8*)(bp + ((kk * NT + u) * 3 + p) * 1024);
     constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PB[6] = {2, 1, 0, 1, 0, 0};
+    if constexpr (MT * NT == 1) {       // two accumulators: see s3_half
+#pragma unroll
+      for (int pr = 0; pr < 6; ++pr) {
+        if (pr & 1) alt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][PA[pr]], b[0][PB[pr]], alt, 0, 0, 0);
+        else acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][PA[pr]], b[0][PB[pr]], acc[0][0], 0, 0, 0);
+      }
+    } else {
 #pragma unroll
     for (int pr = 0; pr < 6; ++pr)
 #pragma unroll
@@ -832,6 +827,7 @@ __device__ __forceinline__ void conv_kloop_direct(const pmf_conv_desc_t& d, cons
 #pragma unroll
         for (int u = 0; u < NT; ++u)
           acc[m][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][PA[pr]], b[u][PB[pr]], acc[m][u], 0, 0, 0);
+    }
   };
   bf16x8 a0[MT][3], a1[MT][3];
   prep(std::integral_constant<int, 0>{}, 0, a0);
@@ -854,6 +850,7 @@ __device__ __forceinline__ void conv_kloop_direct(const pmf_conv_desc_t& d, cons
   int kk = 0;
   for (; kk + PF <= nks; kk += PF) quad(kk, std::false_type{});
   if (kk < nks) quad(kk, std::true_type{});
+  if constexpr (MT * NT == 1) acc[0][0] += alt;
 }
 
 // PIPE: 0 generic K loop, 1 pipelined, 4 pipelined with 64-channel stages (1x1 convs).
@@ -1085,148 +1082,12 @@ __global__ __launch_bounds__(256) void conv_fwd_k(const pmf_conv_desc_t d, const
   }
   }  // !PIPE
 
-  // ---- epilogue: branch-free.  Every element is one buffer store (buffer loads for the ReLU mask / accumulate) at
-  // a 32-bit byte offset; masked-off elements get offset 0xffffffff, which the hardware range check drops (host
-  // guarantees all tensors < 2 GiB).  The loads of a 16-row group are issued together, not load -> wait -> store.
-  TR();
-  if (g.ksplit > 1) {   // raw partial sums -> slab ks; bias / activation / statistics happen in conv_finish_k
-    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)g.ws, 0, 0x7fffffff, 0x00020000);
-#pragma unroll
-    for (int u = 0; u < NT; ++u) {
-      const int co = n0 + u * 32 + li;
-#pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        const int oy = oy0 + segrow[m], oxb = ox0 + segcol[m] * 32 + 4 * lh;
-        const bool rok = co < g.ws_ld && oy < d.OH;
-        const int base = ((((ks * d.N + n) * d.OH + oy) * d.OW + oxb) * g.ws_ld + co) * 4, estep = g.ws_ld * 4;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int dx = (r & 3) + 8 * (r >> 2);
-          const unsigned off = (rok && oxb + dx < d.OW) ? (unsigned)(base + dx * estep) : 0xffffffffu;
-          float v = acc[m][u][r];
-          asm volatile("" : "+v"(v));   // hipcc (ROCm 7.2) otherwise stores element 0 of each accumulator quad 4x
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), wr, off, 0, 0);
-        }
-      }
-    }
-    TR();
-    TR_END();
-    return;
-  }
-  // BatchNorm statistics in float64: float*float is exact in double, so var = E[x^2] - mean^2 keeps full
-  // float32 accuracy even for nearly-constant channels (the classic cancellation), at ~2 DP ops per output
-  double ssum[NT], ssq[NT];
-#pragma unroll
-  for (int u = 0; u < NT; ++u) ssum[u] = ssq[u] = 0.0;
-  PMF_SGPR_BATCH("s"(d.out), "s"(d.bias), "s"(d.act), "s"(d.Cout), "s"(d.out_ldc), "s"(d.out_H), "s"(d.out_W), "s"(d.out_sy),
-                 "s"(d.out_sx), "s"(d.out_oy), "s"(d.out_ox), "s"(d.accumulate), "s"(d.ep_cmul), "s"(d.ep_cmul_ld),
-                 "s"(d.ep_relu_x), "s"(d.ep_relu_scale), "s"(d.ep_relu_shift), "s"(d.ep_relu_ldc), "s"(d.stats),
-                 "s"(d.ep_pmask), "s"(d.ep_flags), "s"(d.ep_stat_mean));
-  {
-    const __amdgpu_buffer_rsrc_t orr = __builtin_amdgcn_make_buffer_rsrc((void*)d.out, 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t xrr =
-        __builtin_amdgcn_make_buffer_rsrc((void*)d.ep_relu_x, 0, d.ep_relu_x ? 0x7fffffff : 0, 0x00020000);
-    const float slope = d.act == PMF_ACT_LRELU ? 0.01f : (d.act == PMF_ACT_RELU ? 0.f : 1.f);
-    const bool sig = d.act == PMF_ACT_SIGMOID, has_rx = d.ep_relu_x != nullptr, accum = d.accumulate != 0;
-    const bool want_stats = d.stats != nullptr;
-    // BatchNorm-backward reduction riding on the last input-gradient launch into a gradient map: second column
-    // sum v*(x - mean) instead of sum v^2 (x = the BN input, the same tensor the ReLU mask reads when there is one)
-    const bool stat_bwd = d.ep_stat_mean != nullptr, x_only = (d.ep_flags & PMF_EP_STAT_X_ONLY) != 0;
-#pragma unroll
-    for (int u = 0; u < NT; ++u) {
-      const int co = n0 + u * 32 + li;
-      const bool cok = co < d.Cout;
-      const float bias = (cok && d.bias) ? d.bias[co] : 0.f;
-      const float ecm = (cok && d.ep_cmul) ? d.ep_cmul[(size_t)n * d.ep_cmul_ld + co] : 1.f;
-      const float smu = (cok && stat_bwd) ? d.ep_stat_mean[co] : 0.f;
-      float rs = 1.f, rt = 0.f;
-      if (cok && has_rx && d.ep_relu_scale) { rs = d.ep_relu_scale[co]; rt = d.ep_relu_shift[co]; }
-#pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        const int oy = oy0 + segrow[m], oxb = ox0 + segcol[m] * 32 + 4 * lh;
-        const bool rok = cok && oy < d.OH;
-        const int pix0 = (n * d.out_H + oy * d.out_sy + d.out_oy) * d.out_W + oxb * d.out_sx + d.out_ox;
-        const int obase = (pix0 * d.out_ldc + co) * 4, ostep = d.out_sx * d.out_ldc * 4;
-        const int xbase = (pix0 * d.ep_relu_ldc + co) * 4, xstep = d.out_sx * d.ep_relu_ldc * 4;
-        unsigned off[16];
-        float xr[16], old[16], pm[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int dx = (r & 3) + 8 * (r >> 2);
-          const bool ok = rok && oxb + dx < d.OW;
-          off[r] = ok ? (unsigned)(obase + dx * ostep) : 0xffffffffu;
-          xr[r] = 1.f; old[r] = 0.f; pm[r] = 1.f;
-        }
-        if (d.ep_pmask) {   // per-pixel multiplier (EPMF dilated validity mask): one value per output pixel
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int dx = (r & 3) + 8 * (r >> 2);
-            if (off[r] != 0xffffffffu) pm[r] = d.ep_pmask[pix0 + dx * d.out_sx];
-          }
-        }
-        if (has_rx) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int dx = (r & 3) + 8 * (r >> 2);
-            const unsigned xo = off[r] == 0xffffffffu ? 0xffffffffu : (unsigned)(xbase + dx * xstep);
-            xr[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrr, xo, 0, 0));
-          }
-        }
-        if (accum) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            old[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(orr, off[r], 0, 0));
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float v = acc[m][u][r] + bias;
-          if (sig) v = 1.f / (1.f + __expf(-v));
-          else v = v > 0.f ? v : v * slope;
-          v *= ecm * pm[r];
-          if (!(xr[r] * rs + rt > 0.f) && !x_only) v = 0.f;
-          v += old[r];
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), orr, off[r], 0, 0);
-          if (want_stats && off[r] != 0xffffffffu) {
-            ssum[u] += (double)v;
-            ssq[u] += (double)v * (double)(stat_bwd ? xr[r] - smu : v);
-          }
-        }
-      }
-    }
-  }
-  TR();
-  if (d.stats) {
-    __syncthreads();
-    double* red = (double*)smem;  // [4 waves][NT][32][2]
-#pragma unroll
-    for (int u = 0; u < NT; ++u) {
-      double a = ssum[u] + __shfl_xor(ssum[u], 32);
-      double b = ssq[u] + __shfl_xor(ssq[u], 32);
-      if (lh == 0) {
-        red[((wave * NT + u) * 32 + li) * 2 + 0] = a;
-        red[((wave * NT + u) * 32 + li) * 2 + 1] = b;
-      }
-    }
-    __syncthreads();
-    if (tid < BN) {
-      const int u = tid >> 5, l = tid & 31, co = n0 + tid;
-      if (co < d.Cout) {
-        double a = 0.0, b = 0.0;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-          a += red[((w * NT + u) * 32 + l) * 2 + 0];
-          b += red[((w * NT + u) * 32 + l) * 2 + 1];
-        }
-        // one partial row per (tile, sample): no atomics (contended f64 atomics cost ~80 us per launch); the
-        // BatchNorm finalize kernel folds the rows in a fixed order (deterministic)
-        double* row = d.stats + ((size_t)tile + (size_t)gridDim.x * n) * 2 * d.Cout;
-        row[co] = a;
-        row[d.Cout + co] = b;
-      }
-    }
-  }
-  TR();
-  TR_END();
+  // ---- epilogue (conv_epi.h)
+#ifdef PMF_CONV_TRACE
+  conv_epilogue<BN, MT>(d, g, acc, segrow, segcol, n, n0, ks, oy0, ox0, tile, smem, tri_, tr_w0_);
+#else
+  conv_epilogue<BN, MT>(d, g, acc, segrow, segcol, n, n0, ks, oy0, ox0, tile, smem, tri_);
+#endif
 }
 
 // Deterministic split-K tail: out = ep( act( sum_ks ws[ks] + bias ) ), optional BatchNorm statistics.
@@ -1342,6 +1203,16 @@ static int finish_rows(const pmf_conv_desc_t* d) {
   return (int)(gx > 1024 ? 1024 : (gx < 1 ? 1 : gx));
 }
 
+// deterministic split-K tail of a launch whose workgroups wrote g.ksplit partial slabs (shared with conv_ps.hip)
+int pmf_conv_finish_launch(const pmf_conv_desc_t* d, const ConvGeom& g, hipStream_t s) {
+  const int Q = g.ws_ld / 4, Qg = Q < 256 ? Q : 256, rows = 256 / Qg;
+  const int gx = finish_rows(d);
+  hipLaunchKernelGGL(conv_finish_k, dim3((unsigned)gx, (unsigned)cdiv(Q, 256), 1), dim3(rows * Qg), 0, s, *d, g.ksplit,
+                     (const float*)g.ws, g.ws_ld, Q);
+  PMF_LAUNCH_CHECK();
+  return 0;
+}
+
 static int conv_direct_lds(const pmf_conv_desc_t* d, int BN);
 static bool conv_s3_fits(const pmf_conv_desc_t* d, int MT);
 static bool conv_s3_stride2(const pmf_conv_desc_t* d);
@@ -1354,6 +1225,17 @@ static void conv_config(const pmf_conv_desc_t* d, int* BN, int* MT) {
   // LDS-staged split loop: the 256-pixel tile may not qualify where the 128-pixel one does (dilated 3x3 on a 4-row map)
   if (d->w_s3 && d->ntaps > 1 && *MT == 2 && !conv_s3_fits(d, 2)) *MT = 1;
   if (d->w_s3 && d->in_stride == 2 && d->ntaps > 1) *MT = 1;      // the stride-2 split loop: 128-pixel tiles
+}
+void pmf_conv_config_raw(const pmf_conv_desc_t* d, int* BN, int* MT) { conv_config_(d, BN, MT); }
+// pre-split operands (conv_ps.hip): every operand carries its bf16 planes and the layer is in that kernel's class
+int pmf_conv_ps_config(const pmf_conv_desc_t* d, int* BN, int* MT);
+int pmf_conv_ps_launch(const pmf_conv_desc_t* d, int BN, int MT, hipStream_t s);
+int pmf_conv_ps_shape(const pmf_conv_desc_t* d, int BN, int MT, int* tiles, int* nchunks, int* ksplit);
+static bool conv_is_ps(const pmf_conv_desc_t* d, int* BN, int* MT) {
+  if (!d->w_s3) return false;
+  for (int i = 0; i < d->nsrc; ++i)
+    if (!d->src[i].xs) return false;
+  return pmf_conv_ps_config(d, BN, MT) != 0;
 }
 static void conv_config_(const pmf_conv_desc_t* d, int* BN, int* MT) {
   if (d->cfg) {                       // caller-tuned tile configuration
@@ -1379,6 +1261,10 @@ static void conv_config_(const pmf_conv_desc_t* d, int* BN, int* MT) {
 }
 
 // split-K factor: only when the M x N grid cannot fill the 256 CUs (low-resolution, many-channel layers)
+static int choose_ksplit(const pmf_conv_desc_t* d, int blocks_mn, int nchunks, int mfma_per_chunk);
+int pmf_conv_choose_ksplit(const pmf_conv_desc_t* d, int blocks_mn, int nchunks, int mfma_per_chunk) {
+  return choose_ksplit(d, blocks_mn, nchunks, mfma_per_chunk);
+}
 static int choose_ksplit(const pmf_conv_desc_t* d, int blocks_mn, int nchunks, int mfma_per_chunk) {
   if (const char* e = getenv("PMF_CONV_FORCE")) {   // sweeps only
     int bn = 0, mt = 0, ks = 0;
@@ -1555,19 +1441,18 @@ static int launch(const pmf_conv_desc_t* d, hipStream_t s) {
     hipLaunchKernelGGL((conv_fwd_k<BN, MT, 0>), grid, dim3(256), lds, s, dd, g);
   }
   PMF_LAUNCH_CHECK();
-  if (g.ksplit > 1) {
-    const int Q = g.ws_ld / 4, Qg = Q < 256 ? Q : 256, rows = 256 / Qg;
-    const int gx = finish_rows(d);
-    hipLaunchKernelGGL(conv_finish_k, dim3((unsigned)gx, (unsigned)cdiv(Q, 256), 1), dim3(rows * Qg), 0, s, dd, g.ksplit,
-                       (const float*)g.ws, g.ws_ld, Q);
-    PMF_LAUNCH_CHECK();
-  }
+  if (g.ksplit > 1) return pmf_conv_finish_launch(&dd, g, s);
   return 0;
 }
 
 // number of partial-statistics rows pmf_conv_fwd writes for this descriptor (stats must hold rows*2*Cout doubles)
 extern "C" int pmf_conv_fwd_stat_rows(const pmf_conv_desc_t* d) {
   int BN, MT, gather, Ktot = 0, cmax = 0, nchunks = 0;
+  if (conv_is_ps(d, &BN, &MT)) {
+    int tiles, ksplit;
+    pmf_conv_ps_shape(d, BN, MT, &tiles, &nchunks, &ksplit);
+    return ksplit > 1 ? finish_rows(d) : tiles * d->N;
+  }
   conv_config(d, &BN, &MT);
   for (int i = 0; i < d->nsrc; ++i) {
     Ktot += d->src[i].C; cmax = d->src[i].C > cmax ? d->src[i].C : cmax; nchunks += cdiv(d->src[i].C, KC);
@@ -1645,6 +1530,11 @@ extern "C" int pmf_conv_fwd_stat_rows_max(const pmf_conv_desc_t* d) {
 
 extern "C" int pmf_conv_fwd_kstages(const pmf_conv_desc_t* d) {
   int BN, MT, gather, cmax = 0, nchunks = 0;
+  if (conv_is_ps(d, &BN, &MT)) {
+    int tiles, ksplit;
+    pmf_conv_ps_shape(d, BN, MT, &tiles, &nchunks, &ksplit);
+    return nchunks;
+  }
   conv_config(d, &BN, &MT);
   for (int i = 0; i < d->nsrc; ++i) { cmax = d->src[i].C > cmax ? d->src[i].C : cmax; nchunks += cdiv(d->src[i].C, KC); }
   ConvGeom g;
@@ -1670,6 +1560,7 @@ extern "C" int pmf_conv_fwd(const pmf_conv_desc_t* d, pmf_stream_t st) {
   for (int i = 0; i < d->nsrc; ++i)
     if (d->src[i].C % 8 || d->src[i].ldc % 4) return PMF_E_ARG;
   int BN, MT;
+  if (conv_is_ps(d, &BN, &MT)) return pmf_conv_ps_launch(d, BN, MT, s);
   conv_config(d, &BN, &MT);
   if (BN == 64) return MT == 2 ? launch<64, 2>(d, s) : launch<64, 1>(d, s);
   return MT == 2 ? launch<32, 2>(d, s) : launch<32, 1>(d, s);
