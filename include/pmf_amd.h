@@ -45,10 +45,6 @@ typedef struct {
   int32_t H, W;
   int32_t flags;
   int32_t cmul_ld;
-  const void* xs;   /* optional: the VIEWED operand (scale/shift/ReLU/cmul already applied) pre-split into three bf16
-                     * planes by pmf_presplit, layout [plane 3][C/8][N*H*W][8 bf16]; when every operand of a stride-1
-                     * convolution on split-bf16 weights carries one, the kernel feeds the matrix pipe by LDS-DMA alone
-                     * (conv_ps.hip) and x / scale / shift / cmul are not read */
 } pmf_src_t;
 
 /* Generic convolution as an implicit GEMM on fp32 MFMA (v_mfma_f32_32x32x2_f32).
@@ -464,18 +460,6 @@ int pmf_plan_lanes(int on);
 int pmf_graph_destroy(void* graph_exec);
 /* pixel splits pmf_conv_wgrad will use for this descriptor (sizes `partial`) */
 int pmf_conv_wgrad_nsplit(const pmf_wgrad_desc_t* d);
-/* ---- pre-split operands (conv_ps.hip, presplit.hip) -------------------------------------------------------
- * fp32 -> three bf16 planes h1 = bf16(v), h2 = bf16(v - h1), h3 = bf16(v - h1 - h2) (round to nearest even; v = the
- * view's value: x*scale+shift, optional ReLU, optional (n,c) multiplier), written channel-group-major:
- *   dst[plane][c/8][pixel][c%8]   (bf16; pixel = (n*H + y)*W + x; C a multiple of 8; bytes = pmf_presplit_bytes)
- * so that 64 consecutive pixels of one 8-channel group are 1 KiB contiguous = one LDS-DMA wave instruction.
- * Replaces nothing in the reference (its convolutions are cuDNN calls on fp32 tensors, pmf_net.py / salsanext.py);
- * it is the operand format of the split-bf16 matrix-pipe path. */
-int64_t pmf_presplit_bytes(int64_t npix, int32_t C);
-int pmf_presplit(const pmf_view_t* v, int32_t N, int32_t HW, int32_t C, void* dst, pmf_stream_t s);
-/* 1 when pmf_conv_fwd would take the pre-split path for this descriptor if every src[i].xs were set */
-int pmf_conv_ps_eligible(const pmf_conv_desc_t* d);
-
 /* sizeof() of the structs above, for bindings to self-check: 0 src, 1 conv, 2 wgrad, 3 view, 4 small, 5 op, 6 pack job */
 int pmf_sizeof(int which);
 

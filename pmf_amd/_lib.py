@@ -27,7 +27,7 @@ OP_NAMES = {v: k for k, v in list(globals().items()) if k.startswith("OP_")}
 class Src(C.Structure):
     _fields_ = [("x", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p), ("cmul", C.c_void_p),
                 ("C", C.c_int32), ("ldc", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
-                ("flags", C.c_int32), ("cmul_ld", C.c_int32), ("xs", C.c_void_p)]
+                ("flags", C.c_int32), ("cmul_ld", C.c_int32)]
 
 
 class ConvDesc(C.Structure):
@@ -114,12 +114,6 @@ def lib():
     L.pmf_conv_fwd.argtypes = [C.POINTER(ConvDesc), C.c_void_p]
     L.pmf_conv_wgrad.restype = C.c_int
     L.pmf_conv_wgrad.argtypes = [C.POINTER(WgradDesc), C.c_void_p]
-    L.pmf_presplit_bytes.restype = C.c_int64
-    L.pmf_presplit_bytes.argtypes = [C.c_int64, C.c_int32]
-    L.pmf_presplit.restype = C.c_int
-    L.pmf_presplit.argtypes = [C.POINTER(View), C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
-    L.pmf_conv_ps_eligible.restype = C.c_int
-    L.pmf_conv_ps_eligible.argtypes = [C.POINTER(ConvDesc)]
     L.pmf_conv_wgrad_nsplit.restype = C.c_int
     L.pmf_conv_wgrad_nsplit.argtypes = [C.POINTER(WgradDesc)]
     L.pmf_conv_wgrad_workspace.restype = C.c_int64
@@ -213,7 +207,7 @@ EXPORTS = [
     "pmf_maxpool3s2_bwd", "pmf_bilinear2x", "pmf_bilinear2x_bwd", "pmf_pixel_shuffle2", "pmf_pixel_shuffle2_bwd",
     "pmf_fusion_gate", "pmf_fusion_gate_bwd", "pmf_global_mean", "pmf_global_mean_bwd", "pmf_colsum",
     "pmf_pmask_from", "pmf_pmask_pool", "pmf_pmask_mul", "pmf_pmask_mul_bwd", "pmf_vec_add", "pmf_softmax_nhwc_to_nchw", "pmf_softmax_bwd_nchw_to_nhwc", "pmf_nchw_to_nhwc", "pmf_fill", "pmf_knn_vote", "pmf_merge_pred", "pmf_merge_pred_fallback",
-    "pmf_project_scatter", "pmf_project_v2_index", "pmf_project_v2_index_scaled", "pmf_project_v2_scatter", "pmf_points_transform", "pmf_range_project_index", "pmf_range_project_gather", "pmf_crop_pad", "pmf_flip_rotate_crop", "pmf_color_jitter", "pmf_lovasz_grad", "pmf_loss_rows", "pmf_loss_chunks", "pmf_loss_pixel", "pmf_loss_lovasz", "pmf_loss_pixel_w", "pmf_loss_lovasz_w", "pmf_plan_run", "pmf_plan_run_range", "pmf_plan_capture", "pmf_graph_launch", "pmf_graph_destroy", "pmf_plan_lanes", "pmf_sizeof", "pmf_version", "pmf_presplit", "pmf_presplit_bytes", "pmf_conv_ps_eligible",
+    "pmf_project_scatter", "pmf_project_v2_index", "pmf_project_v2_index_scaled", "pmf_project_v2_scatter", "pmf_points_transform", "pmf_range_project_index", "pmf_range_project_gather", "pmf_crop_pad", "pmf_flip_rotate_crop", "pmf_color_jitter", "pmf_lovasz_grad", "pmf_loss_rows", "pmf_loss_chunks", "pmf_loss_pixel", "pmf_loss_lovasz", "pmf_loss_pixel_w", "pmf_loss_lovasz_w", "pmf_plan_run", "pmf_plan_run_range", "pmf_plan_capture", "pmf_graph_launch", "pmf_graph_destroy", "pmf_plan_lanes", "pmf_sizeof", "pmf_version",
 ]
 
 

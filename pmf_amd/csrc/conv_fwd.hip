@@ -1,14 +1,18 @@
-// Implicit-GEMM convolution on fp32 MFMA (v_mfma_f32_32x32x2_f32), NHWC, LDS halo staging.  gfx950 only.
+// Implicit-GEMM convolution, NHWC, LDS halo staging, fp32 in / out / accumulate.  gfx950 only.
 //
+// Arithmetic: the pipelined layer classes (PIPE 5-12: ~99 % of the forward / input-gradient flops) compute every fp32
+// product as SIX v_mfma_f32_32x32x16_bf16 products of three-way bf16-split operands with fp32 accumulation (fp32-class
+// error, see "PIPE 5" below); the generic loops (PIPE 0/1/4: the 7x7 stem, ragged channel counts, PMF_CONV_F32=1) use
+// v_mfma_f32_32x32x2_f32.
 // GEMM view:  M = output pixels (32-pixel row segments), N = Cout, K = taps x concatenated input channels.
 // A 256-thread workgroup (4 waves) owns a TH x TW output tile = 4*MT segments of 32 pixels and BN output
 // channels; wave w owns segments [w*MT, w*MT+MT) x all BN channels  ->  MT x BN/32 accumulators of 32x32.
 // K loop: for every 16-channel chunk of every operand, the input tile INCLUDING ITS HALO is staged once in
 // LDS (with BatchNorm-apply / ReLU / Dropout2d multiplier folded into the load and zero padding applied
-// after it) and reused by all taps; the matching [taps][16][BN] slab of packed weights is staged next to it.
-// MFMA operands: A[i=lane&31][k=lane>>5] = one ds_read_b128 per 8 channels (pixel pitch 20 floats ->
+// after it) and reused by all taps; the matching weight slab / weight fragments are staged next to it (LDS-DMA).
+// fp32-MFMA operands: A[i=lane&31][k=lane>>5] = one ds_read_b128 per 8 channels (pixel pitch 20 floats ->
 // conflict-free), B[k][j=lane&31] = ds_read_b32 from the [k][BN] slab (32 consecutive banks).
-// Epilogue: + bias, activation, optional (n,c) multiplier / ReLU mask (input-gradient form), optional
+// Epilogue (conv_epi.h): + bias, activation, optional (n,c) multiplier / ReLU mask (input-gradient form), optional
 // per-channel sum / sum-of-squares for the BatchNorm that follows, coalesced 128-B row stores.
 #include "conv_epi.h"
 #include <stdio.h>
@@ -397,7 +401,7 @@ __device__ __forceinline__ void s3_sgb() {
 // NTH taps of one half: A fragments (MT x 3 planes) and B fragments (NT x 3 planes) of tap i+1 are read while the
 // 6 MT NT MFMAs of tap i run
 template <int BN, int MT, int NTH, class Fill = NoFill>
-__device__ __forceinline__ void s3_half(f32x16 (&acc)[MT][BN / 32], f32x16& alt, const char* __restrict__ As,
+__device__ __forceinline__ void s3_half(f32x16 (&acc)[MT][BN / 32], const char* __restrict__ As,
                                         const char* __restrict__ Bh, const int (&abase)[MT], const int (&aoff)[TAPG],
                                         int t0, int lane, Fill fill = Fill()) {
   constexpr int NT = BN / 32;
@@ -428,16 +432,6 @@ __device__ __forceinline__ void s3_half(f32x16 (&acc)[MT][BN / 32], f32x16& alt,
     fill(st, NTH);
     // smallest terms first; product-major so that back-to-back MFMAs hit different accumulators
     constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PB[6] = {2, 1, 0, 1, 0, 0};
-    if constexpr (MT * NT == 1) {
-      // one output tile per wave: six MFMAs in a row into ONE accumulator are a dependent chain (a v_mfma_f32_32x32x16_bf16
-      // that reads the accumulator of its predecessor issues after ~64 cycles, not 32: measured 63-73 cycles per MFMA in
-      // these stages).  Alternate between two accumulators; the kernel adds them once after the K loop.
-#pragma unroll
-      for (int pr = 0; pr < 6; ++pr) {
-        if (pr & 1) alt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][0][PA[pr]], b[cur][0][PB[pr]], alt, 0, 0, 0);
-        else acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][0][PA[pr]], b[cur][0][PB[pr]], acc[0][0], 0, 0, 0);
-      }
-    } else {
 #pragma unroll
     for (int pr = 0; pr < 6; ++pr)
 #pragma unroll
@@ -445,7 +439,6 @@ __device__ __forceinline__ void s3_half(f32x16 (&acc)[MT][BN / 32], f32x16& alt,
 #pragma unroll
         for (int u = 0; u < NT; ++u)
           acc[m][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][m][PA[pr]], b[cur][u][PB[pr]], acc[m][u], 0, 0, 0);
-    }
     // the next tap's 3 (MT + NT) LDS reads and this step's slice of global loads go into the gaps behind the MFMAs
     s3_sgb<0, 6 * MT * NT, 3 * (MT + NT), (6 * MT * NT * 2 + 2) / 3, 2>();
     __builtin_amdgcn_sched_barrier(0);
@@ -463,9 +456,6 @@ __device__ __forceinline__ void conv_kloop_s3(const pmf_conv_desc_t& d, const Co
                                               const int (&segcol)[MT], int tid, int li, int lh, int n, int n0, int ks,
                                               int oy0, int ox0, int& tri_) {
   constexpr int NT = BN / 32;
-  f32x16 alt;                                    // second accumulator of the one-tile wave (s3_half)
-#pragma unroll
-  for (int r = 0; r < 16; ++r) alt[r] = 0.f;
   constexpr int ASL = IS == 2 ? 10 : (SL > 1 ? 8 : (MT == 2 ? 7 : 5));   // float4 slots per thread for the input tile
   constexpr int NF = 5 * NT * 3;                  // fragments of the larger half (<= 5 virtual taps)
   constexpr int NDMA = (NF + 3) / 4;              // DMA instructions per wave per half
@@ -640,21 +630,21 @@ __device__ __forceinline__ void conv_kloop_s3(const pmf_conv_desc_t& d, const Co
     __builtin_amdgcn_sched_barrier(0);
     if (NTAPS != 0) {
       constexpr int NV = (NTAPS ? NTAPS : 1) * SL, N0 = (NV + 1) / 2, N1 = NV - N0;
-      if (with_fill) s3_half<BN, MT, N0>(acc, alt, As, Bt, abase, aoff, 0, lane, fill);
-      else s3_half<BN, MT, (N1 > 0 ? N1 : 1)>(acc, alt, As, Bt, abase, aoff, N0, lane);
+      if (with_fill) s3_half<BN, MT, N0>(acc, As, Bt, abase, aoff, 0, lane, fill);
+      else s3_half<BN, MT, (N1 > 0 ? N1 : 1)>(acc, As, Bt, abase, aoff, N0, lane);
       return;
     }
     if (with_fill) {
-      if (nth == 5) s3_half<BN, MT, 5>(acc, alt, As, Bt, abase, aoff, t0, lane, fill);
-      else if (nth == 4) s3_half<BN, MT, 4>(acc, alt, As, Bt, abase, aoff, t0, lane, fill);
-      else if (nth == 3) s3_half<BN, MT, 3>(acc, alt, As, Bt, abase, aoff, t0, lane, fill);
-      else if (nth == 2) s3_half<BN, MT, 2>(acc, alt, As, Bt, abase, aoff, t0, lane, fill);
-      else s3_half<BN, MT, 1>(acc, alt, As, Bt, abase, aoff, t0, lane, fill);
+      if (nth == 5) s3_half<BN, MT, 5>(acc, As, Bt, abase, aoff, t0, lane, fill);
+      else if (nth == 4) s3_half<BN, MT, 4>(acc, As, Bt, abase, aoff, t0, lane, fill);
+      else if (nth == 3) s3_half<BN, MT, 3>(acc, As, Bt, abase, aoff, t0, lane, fill);
+      else if (nth == 2) s3_half<BN, MT, 2>(acc, As, Bt, abase, aoff, t0, lane, fill);
+      else s3_half<BN, MT, 1>(acc, As, Bt, abase, aoff, t0, lane, fill);
     } else {
-      if (nth == 4) s3_half<BN, MT, 4>(acc, alt, As, Bt, abase, aoff, t0, lane);
-      else if (nth == 3) s3_half<BN, MT, 3>(acc, alt, As, Bt, abase, aoff, t0, lane);
-      else if (nth == 2) s3_half<BN, MT, 2>(acc, alt, As, Bt, abase, aoff, t0, lane);
-      else if (nth == 1) s3_half<BN, MT, 1>(acc, alt, As, Bt, abase, aoff, t0, lane);
+      if (nth == 4) s3_half<BN, MT, 4>(acc, As, Bt, abase, aoff, t0, lane);
+      else if (nth == 3) s3_half<BN, MT, 3>(acc, As, Bt, abase, aoff, t0, lane);
+      else if (nth == 2) s3_half<BN, MT, 2>(acc, As, Bt, abase, aoff, t0, lane);
+      else if (nth == 1) s3_half<BN, MT, 1>(acc, As, Bt, abase, aoff, t0, lane);
     }
   };
   while (have) {
@@ -679,7 +669,6 @@ __device__ __forceinline__ void conv_kloop_s3(const pmf_conv_desc_t& d, const Co
     if (nt1) mfma_half(Bh1, nt0, nt1, false);
     TR();
   }
-  if constexpr (MT * NT == 1) acc[0][0] += alt;
 }
 
 // PIPE 11 -- 1x1 convolutions on the split-bf16 path, activations straight from global memory.
@@ -696,9 +685,6 @@ __device__ __forceinline__ void conv_kloop_direct(const pmf_conv_desc_t& d, cons
                                                   char* __restrict__ Bs, const int (&segrow)[MT], const int (&segcol)[MT],
                                                   int tid, int li, int lh, int n, int n0, int oy0, int ox0) {
   constexpr int NT = BN / 32;
-  f32x16 alt;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) alt[r] = 0.f;
   constexpr int PF = 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int Ktot = g.Ktot, nks = Ktot >> 4, CT = d.ldw >> 5;
@@ -813,13 +799,6 @@ __device__ __forceinline__ void conv_kloop_direct(const pmf_conv_desc_t& d, cons
 #pragma unroll
       for (int p = 0; p < 3; ++p) b[u][p] = *(const bf16x8*)(bp + ((kk * NT + u) * 3 + p) * 1024);
     constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PB[6] = {2, 1, 0, 1, 0, 0};
-    if constexpr (MT * NT == 1) {       // two accumulators: see s3_half
-#pragma unroll
-      for (int pr = 0; pr < 6; ++pr) {
-        if (pr & 1) alt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][PA[pr]], b[0][PB[pr]], alt, 0, 0, 0);
-        else acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][PA[pr]], b[0][PB[pr]], acc[0][0], 0, 0, 0);
-      }
-    } else {
 #pragma unroll
     for (int pr = 0; pr < 6; ++pr)
 #pragma unroll
@@ -827,7 +806,6 @@ __device__ __forceinline__ void conv_kloop_direct(const pmf_conv_desc_t& d, cons
 #pragma unroll
         for (int u = 0; u < NT; ++u)
           acc[m][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][PA[pr]], b[u][PB[pr]], acc[m][u], 0, 0, 0);
-    }
   };
   bf16x8 a0[MT][3], a1[MT][3];
   prep(std::integral_constant<int, 0>{}, 0, a0);
@@ -850,7 +828,6 @@ __device__ __forceinline__ void conv_kloop_direct(const pmf_conv_desc_t& d, cons
   int kk = 0;
   for (; kk + PF <= nks; kk += PF) quad(kk, std::false_type{});
   if (kk < nks) quad(kk, std::true_type{});
-  if constexpr (MT * NT == 1) acc[0][0] += alt;
 }
 
 // PIPE: 0 generic K loop, 1 pipelined, 4 pipelined with 64-channel stages (1x1 convs).
@@ -1203,8 +1180,8 @@ static int finish_rows(const pmf_conv_desc_t* d) {
   return (int)(gx > 1024 ? 1024 : (gx < 1 ? 1 : gx));
 }
 
-// deterministic split-K tail of a launch whose workgroups wrote g.ksplit partial slabs (shared with conv_ps.hip)
-int pmf_conv_finish_launch(const pmf_conv_desc_t* d, const ConvGeom& g, hipStream_t s) {
+// deterministic split-K tail of a launch whose workgroups wrote g.ksplit partial slabs
+static int pmf_conv_finish_launch(const pmf_conv_desc_t* d, const ConvGeom& g, hipStream_t s) {
   const int Q = g.ws_ld / 4, Qg = Q < 256 ? Q : 256, rows = 256 / Qg;
   const int gx = finish_rows(d);
   hipLaunchKernelGGL(conv_finish_k, dim3((unsigned)gx, (unsigned)cdiv(Q, 256), 1), dim3(rows * Qg), 0, s, *d, g.ksplit,
@@ -1225,17 +1202,6 @@ static void conv_config(const pmf_conv_desc_t* d, int* BN, int* MT) {
   // LDS-staged split loop: the 256-pixel tile may not qualify where the 128-pixel one does (dilated 3x3 on a 4-row map)
   if (d->w_s3 && d->ntaps > 1 && *MT == 2 && !conv_s3_fits(d, 2)) *MT = 1;
   if (d->w_s3 && d->in_stride == 2 && d->ntaps > 1) *MT = 1;      // the stride-2 split loop: 128-pixel tiles
-}
-void pmf_conv_config_raw(const pmf_conv_desc_t* d, int* BN, int* MT) { conv_config_(d, BN, MT); }
-// pre-split operands (conv_ps.hip): every operand carries its bf16 planes and the layer is in that kernel's class
-int pmf_conv_ps_config(const pmf_conv_desc_t* d, int* BN, int* MT);
-int pmf_conv_ps_launch(const pmf_conv_desc_t* d, int BN, int MT, hipStream_t s);
-int pmf_conv_ps_shape(const pmf_conv_desc_t* d, int BN, int MT, int* tiles, int* nchunks, int* ksplit);
-static bool conv_is_ps(const pmf_conv_desc_t* d, int* BN, int* MT) {
-  if (!d->w_s3) return false;
-  for (int i = 0; i < d->nsrc; ++i)
-    if (!d->src[i].xs) return false;
-  return pmf_conv_ps_config(d, BN, MT) != 0;
 }
 static void conv_config_(const pmf_conv_desc_t* d, int* BN, int* MT) {
   if (d->cfg) {                       // caller-tuned tile configuration
@@ -1261,10 +1227,6 @@ static void conv_config_(const pmf_conv_desc_t* d, int* BN, int* MT) {
 }
 
 // split-K factor: only when the M x N grid cannot fill the 256 CUs (low-resolution, many-channel layers)
-static int choose_ksplit(const pmf_conv_desc_t* d, int blocks_mn, int nchunks, int mfma_per_chunk);
-int pmf_conv_choose_ksplit(const pmf_conv_desc_t* d, int blocks_mn, int nchunks, int mfma_per_chunk) {
-  return choose_ksplit(d, blocks_mn, nchunks, mfma_per_chunk);
-}
 static int choose_ksplit(const pmf_conv_desc_t* d, int blocks_mn, int nchunks, int mfma_per_chunk) {
   if (const char* e = getenv("PMF_CONV_FORCE")) {   // sweeps only
     int bn = 0, mt = 0, ks = 0;
@@ -1448,11 +1410,6 @@ static int launch(const pmf_conv_desc_t* d, hipStream_t s) {
 // number of partial-statistics rows pmf_conv_fwd writes for this descriptor (stats must hold rows*2*Cout doubles)
 extern "C" int pmf_conv_fwd_stat_rows(const pmf_conv_desc_t* d) {
   int BN, MT, gather, Ktot = 0, cmax = 0, nchunks = 0;
-  if (conv_is_ps(d, &BN, &MT)) {
-    int tiles, ksplit;
-    pmf_conv_ps_shape(d, BN, MT, &tiles, &nchunks, &ksplit);
-    return ksplit > 1 ? finish_rows(d) : tiles * d->N;
-  }
   conv_config(d, &BN, &MT);
   for (int i = 0; i < d->nsrc; ++i) {
     Ktot += d->src[i].C; cmax = d->src[i].C > cmax ? d->src[i].C : cmax; nchunks += cdiv(d->src[i].C, KC);
@@ -1530,11 +1487,6 @@ extern "C" int pmf_conv_fwd_stat_rows_max(const pmf_conv_desc_t* d) {
 
 extern "C" int pmf_conv_fwd_kstages(const pmf_conv_desc_t* d) {
   int BN, MT, gather, cmax = 0, nchunks = 0;
-  if (conv_is_ps(d, &BN, &MT)) {
-    int tiles, ksplit;
-    pmf_conv_ps_shape(d, BN, MT, &tiles, &nchunks, &ksplit);
-    return nchunks;
-  }
   conv_config(d, &BN, &MT);
   for (int i = 0; i < d->nsrc; ++i) { cmax = d->src[i].C > cmax ? d->src[i].C : cmax; nchunks += cdiv(d->src[i].C, KC); }
   ConvGeom g;
@@ -1560,7 +1512,6 @@ extern "C" int pmf_conv_fwd(const pmf_conv_desc_t* d, pmf_stream_t st) {
   for (int i = 0; i < d->nsrc; ++i)
     if (d->src[i].C % 8 || d->src[i].ldc % 4) return PMF_E_ARG;
   int BN, MT;
-  if (conv_is_ps(d, &BN, &MT)) return pmf_conv_ps_launch(d, BN, MT, s);
   conv_config(d, &BN, &MT);
   if (BN == 64) return MT == 2 ? launch<64, 2>(d, s) : launch<64, 1>(d, s);
   return MT == 2 ? launch<32, 2>(d, s) : launch<32, 1>(d, s);

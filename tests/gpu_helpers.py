@@ -55,24 +55,6 @@ def stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def presplit(x, C_, scale=None, shift=None, cmul=None, relu=False):
-    """pmf_presplit of the NHWC view (x[..., :C_] * scale + shift, ReLU, (n,c) multiplier) -> uint8 device buffer
-    [plane 3][C/8][N*H*W][8 bf16] (pmf_src_t.xs)."""
-    N, H, W, ldc = x.shape
-    v = L.View()
-    v.x, v.ldc = x.data_ptr(), ldc
-    v.scale = scale.data_ptr() if scale is not None else None
-    v.shift = shift.data_ptr() if shift is not None else None
-    if cmul is not None:
-        v.cmul, v.cmul_ld = cmul.data_ptr(), cmul.shape[1]
-    v.flags = L.SRC_RELU if relu else 0
-    lib = L.lib()
-    out = torch.empty(lib.pmf_presplit_bytes(N * H * W, C_), dtype=torch.uint8, device=x.device)
-    rc = lib.pmf_presplit(C.byref(v), N, H * W, C_, C.c_void_p(out.data_ptr()), stream())
-    assert rc == 0, rc
-    return out
-
-
 def conv_desc(srcs, wpk, ldw, bias, out, N, OH, OW, Cout, taps, stride=1, act=0, gather=0, stats=None):
     """srcs: list of dict(x=tensor NHWC, C=int, scale=, shift=, cmul=, relu=bool, bcast=bool)."""
     d = L.ConvDesc()

@@ -65,35 +65,6 @@ def run(which, filt):
                     res.append(timeit(lambda: lib.pmf_conv_fwd(C.byref(d), st)))
                 print("%-22s cfg %#8x  f32 %7.1f us %6.1f TF/s | s3 %7.1f us %6.1f TF/s" % (
                     name, cfg, res[0], gf / res[0] * 1e3, res[1], gf / res[1] * 1e3), flush=True)
-        if which == "ps":      # pre-split operands (conv_ps.hip) next to the staged split kernel, every tile configuration
-            w3 = G.pack_fwd_s3(w, ci, ldw)
-            xs = G.presplit(x, ci)
-            tp = timeit(lambda: G.presplit(x, ci), 50)
-            print("%-22s presplit %7.1f us (%.2f TB/s)" % (name, tp, 10.0 * x.numel() / tp / 1e6), flush=True)
-            cfgs = (32 | (1 << 8) | (1 << 16), 64 | (1 << 8) | (1 << 16), 32 | (2 << 8) | (1 << 16), 64 | (2 << 8) | (1 << 16))
-            if os.environ.get("PS_CFG"): cfgs = (int(os.environ["PS_CFG"], 0),)
-            for cfg in cfgs:
-                if (cfg & 0xff) == 64 and co <= 32: continue
-                res, outs = [], []
-                for kind in ("s3", "ps"):
-                    o = torch.zeros(N, H, W, co, device="cuda")
-                    d = G.conv_desc([dict(x=x, C=ci)], wpk, ldw, None, o, N, H, W, co, taps, 1, 1)
-                    d.splitk_ws, d.splitk_ws_bytes = ws.data_ptr(), ws.numel()
-                    d.cfg = cfg
-                    d.w, d.w_s3 = None, w3.data_ptr()
-                    if kind == "ps": d.src[0].xs = xs.data_ptr()
-                    st = G.stream()
-                    rc = lib.pmf_conv_fwd(C.byref(d), st)
-                    torch.cuda.synchronize()
-                    if rc != 0:
-                        res.append(float("nan")); outs.append(None); continue
-                    outs.append(o.clone())
-                    res.append(timeit(lambda: lib.pmf_conv_fwd(C.byref(d), st)))
-                err = float("nan")
-                if outs[0] is not None and outs[1] is not None:
-                    err = ((outs[1] - outs[0]).abs().max() / outs[0].abs().max()).item()
-                print("%-22s cfg %#8x  s3 %7.1f us %6.1f TF/s | ps %7.1f us %6.1f TF/s  (max diff %.2e of max)" % (
-                    name, cfg, res[0], gf / res[0] * 1e3, res[1], gf / res[1] * 1e3, err), flush=True)
         if which in ("wgrad", "all"):
             dz = torch.randn(N, H, W, co, device="cuda")
             wd = L.WgradDesc()
