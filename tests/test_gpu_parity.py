@@ -419,20 +419,18 @@ def test_wholenet_backward_well_conditioned():
             assert e_h < 1e-4, (k, e_h)
 
 
-def test_full_size_train_mode_step_vs_oracle():
-    """the headline size (2 x 64 x 2048) in TRAIN mode against the fp32 CPU oracle: batch-statistics BatchNorm, Dropout2d
+def _full_size_train_mode(hip, ref, n, h, w, ncls):
+    """one TRAIN-mode forward at a BASELINE size against the fp32 CPU oracle: batch-statistics BatchNorm, Dropout2d
     multipliers, logits of both heads, the 5-term objective and the updated running statistics"""
     from oracle import pmf_torch as O
     from oracle import losses_ref
-    hip, ref = _models()
     hip.train()
     ref.train()
-    n, h, w = 2, 64, 2048
     m = _masks(ref, n)
     O.set_dropout_masks(ref, m)
     hip.set_dropout_masks({k: v.cuda() for k, v in m.items()})
-    pcd, rgb, label, _ = synthetic_batch(n, h, w, 20, seed=21)
-    alpha = torch.linspace(0.2, 1.0, 20)
+    pcd, rgb, label, _ = synthetic_batch(n, h, w, ncls, seed=21)
+    alpha = torch.linspace(0.2, 1.0, ncls)
     alpha[0] = 0
     torch.set_num_threads(min(32, torch.get_num_threads() * 4))
     with torch.no_grad():
@@ -449,6 +447,32 @@ def test_full_size_train_mode_step_vs_oracle():
     for k, v in hip.state_dict().items():
         if "running_" in k:
             assert G.scale_err(v.cpu().numpy(), rsd[k].numpy()) < 1e-4, k
+
+
+@pytest.mark.gpu
+def test_full_size_train_mode_step_vs_oracle():
+    """the headline size (BASELINE configs[2]: PMF-ResNet34, 2 x 64 x 2048) in TRAIN mode"""
+    hip, ref = _models()
+    _full_size_train_mode(hip, ref, 2, 64, 2048, 20)
+
+
+@pytest.mark.gpu
+def test_full_size_train_mode_r50_nuscenes_vs_oracle():
+    """BASELINE configs[3] at its real size: PMF-ResNet50, 17 classes, 2 x 32 x 1024 -- the Bottleneck layers with 1024 /
+    2048 input channels select other kernel paths than the small-shape tests reach (direct 1x1 only while the weight
+    fragments fit 160 KiB of LDS)"""
+    hip, ref = _models("resnet50", 17)
+    _full_size_train_mode(hip, ref, 2, 32, 1024, 17)
+
+
+@pytest.mark.gpu
+def test_full_size_train_mode_epmf_vs_oracle():
+    """BASELINE configs[4] at its real size: EPMF-ResNet34, 2 x 64 x 2048 (validity masks: 30 % of the pixels filled)"""
+    from pmf_amd.models import EPMFNet
+    from oracle import epmf_torch as E
+    hip = deterministic_init(EPMFNet(5, 3, 20, 32, False, "resnet34")).cuda()
+    ref = deterministic_init(E.EPMFNet(5, 3, 20, 32, False, "resnet34"))
+    _full_size_train_mode(hip, ref, 2, 64, 2048, 20)
 
 
 
