@@ -114,6 +114,175 @@ def infer_bench(args, model, dev):
         "roofline": roof, "roofline_hbm": hbm, "cpu_baseline": cpu}))
 
 
+def loader_bench(args, dev):
+    """the perspective-projection loader, reported separately from the training step.
+    Part A -- one KITTI-sized frame (120 k raw LiDAR points, a 376 x 1241 camera image): microseconds per frame of every
+    loader kernel (HIP events, launches back to back), algorithmic bytes of SURVEY 8d (projection 16 P + 43 h w) against
+    8 TB/s, the numpy oracle (oracle/loader_ref.py, one core) beside it.
+    Part B -- loader in the loop: a synthetic on-disk SemanticKITTI tree (oracle/cases.kitti_tree: .bin / .label / .png /
+    calib.txt) read by the SemanticKitti parser, projected / augmented by PerspectiveViewLoader exactly as
+    tasks/pmf/trainer.py builds it (is_train, img_aug, use_padding; batches of 2 through DataLoader + the prefetch
+    thread) feeding TrainEngine.train_step at the KITTI training crop 256 x 1024 (the largest crop a 376 x 1241 frame
+    yields; 64 x 2048 cannot be cut from it), next to the same step on a resident batch of the same shape."""
+    import shutil
+    import tempfile
+    import yaml
+    from oracle import loader_ref
+    from oracle.cases import lidar_sweep, kitti_tree
+    from pmf_amd.dataset import perspective_view_loader as PV
+    from pmf_amd.dataset.semantic_kitti import SemanticKitti
+    from pmf_amd.engine import TrainEngine
+    from pmf_amd.models import PMFNet
+    from pmf_amd.utils.detinit import deterministic_init
+    from tasks.pmf.trainer import Prefetcher
+    from torch.utils.data import DataLoader
+    H, W, P = 376, 1241, 120000
+    pts, sem, lut = lidar_sweep(5, P)
+    rng = np.random.default_rng(7)
+    img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    P2 = np.array([[0.58 * W, 0, W / 2.0, 4.5e1], [0, 0.58 * W, H / 2.0, -0.3], [0, 0, 1.0, 2.7e-3]])
+    Tr = np.array([[4.2e-4, -9.9996e-1, -8.4e-3, -1.2e-2], [-7.2e-3, 8.4e-3, -9.9993e-1, -5.4e-2],
+                   [9.9997e-1, 4.8e-4, -7.2e-3, -2.9e-1], [0, 0, 0, 1.0]])
+    mat = P2 @ Tr
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "tasks", "pmf", "config_server_kitti.yaml")))
+    sensor = cfg["sensor"]
+    d_pts = torch.from_numpy(pts).to(dev)
+    d_img = torch.from_numpy(img).to(dev)
+
+    def ev_ms(fn, reps=50):
+        for _ in range(10):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / reps
+    proj, xd, yd, depth, keep = PV.project_frame_gpu(d_pts, sem, d_img, mat, lut, dev)
+    kept = int(xd.numel())
+    rows = []
+
+    def add(name, ms, nbytes, note=""):
+        rows.append({"kernel": name, "us_per_frame": round(1e3 * ms, 2), "algorithmic_mb": round(nbytes / 1e6, 3),
+                     "achieved": round(nbytes / ms / 1e6, 1), "peak": PEAK_HBM, "unit": "GB/s",
+                     "frac": round(nbytes / ms / 1e6 / PEAK_HBM, 5), "note": note})
+    # the Python wrapper allocates its outputs and uploads sem / matrix / LUT each call: time it as the loader runs it
+    add("pmf_project_scatter (count + scan + project + scatter + gather, via project_frame_gpu)",
+        ev_ms(lambda: PV.project_frame_gpu(d_pts, sem, d_img, mat, lut, dev, need_uproj=False)),
+        16.0 * P + 43.0 * H * W, "P = %d raw points, %d inside the image; includes the wrapper's allocations and the "
+        "host -> device copies of labels / matrix / LUT" % (P, kept))
+    add("pmf_crop_pad (validation: CenterCrop + Pad, 10 channels)",
+        ev_ms(lambda: PV.center_crop_pad_gpu(proj, sensor["proj_h"], sensor["proj_w"], sensor["h_pad"], sensor["w_pad"])),
+        4.0 * 10 * (min(H, sensor["proj_h"]) * min(W, sensor["proj_w"]) + sensor["proj_h"] * sensor["proj_w"]))
+    frc = PV.FlipRotateCrop(sensor["proj_ht"] - 2 * sensor["h_pad"], sensor["proj_wt"] - 2 * sensor["w_pad"],
+                            sensor["h_pad"], sensor["w_pad"])
+    add("pmf_flip_rotate_crop (training: flip + rotation 15 deg + RandomCrop + Pad as one gather, 10 channels)",
+        ev_ms(lambda: frc.apply(proj, True, 9.0, 40, 100)), 4.0 * 10 * 2 * sensor["proj_ht"] * sensor["proj_wt"])
+    cj = PV.ColorJitter(*cfg["augmentation"]["img_jitter"])
+    scratch = d_img.clone()
+    add("pmf_color_jitter (training: brightness, contrast, saturation on the uint8 frame)",
+        ev_ms(lambda: cj.apply(scratch, [0, 1, 2, 3], [1.2, 0.8, 1.1, None])), 3.0 * H * W * 2 * 3,
+        "three active operations (hue range is zero in config_server_kitti.yaml), each one read + one write of the frame")
+    # numpy oracle, one core, same frame
+    t0 = time.time()
+    rp, rx, ry, rd = loader_ref.project_frame(pts, sem, img, mat, lut)
+    loader_ref.center_crop_pad(rp, sensor["proj_h"], sensor["proj_w"], sensor["h_pad"], sensor["w_pad"])
+    t_np = time.time() - t0
+    same = bool(np.array_equal(proj.cpu().numpy(), rp))
+    gpu_eval_us = rows[0]["us_per_frame"] + rows[1]["us_per_frame"]
+
+    # ---- part B: loader in the loop
+    root = tempfile.mkdtemp(prefix="pmf_kitti_")
+    loop = None
+    try:
+        nfr = 12
+        cfg_path, _ = kitti_tree(root, seed=1, seqs=(0, 8), frames=nfr, npts=P, h=H, w=W)
+        ds = SemanticKitti(root=root, sequences=[0], config_path=cfg_path)
+        ncls = len(ds.mapped_cls_name) if hasattr(ds, "mapped_cls_name") else 20
+        cfg["augmentation"]["img_jitter"] = cfg["augmentation"]["img_jitter"]
+        pv = PV.PerspectiveViewLoader(dataset=ds, config=cfg, is_train=True, pcd_aug=False, img_aug=True, use_padding=True,
+                                      device=dev)
+        # host part alone (file read + PNG decode), per frame
+        t0 = time.time()
+        for i in range(len(ds)):
+            ds.loadDataByIndex(i)
+            np.array(ds.loadImage(i))
+        host_ms = 1e3 * (time.time() - t0) / len(ds)
+        t0 = time.time()
+        for i in range(len(ds)):
+            pv[i]
+        torch.cuda.synchronize()
+        item_ms = 1e3 * (time.time() - t0) / len(ds)
+        torch.manual_seed(1)
+        model = deterministic_init(PMFNet(5, 3, 20, 32, imagenet_pretrained=False, image_backbone="resnet34")).to(dev)
+        eng = TrainEngine(model, 20, lr=1e-3, feature_mean=KITTI_MEAN, feature_std=KITTI_STD, warmup_steps=1000, max_steps=4900)
+        hh, ww = sensor["proj_ht"], sensor["proj_wt"]
+        feat0, mask0, label0 = make_batch(2, hh, ww, 1, dev, 20)
+
+        def run_resident(k):
+            for _ in range(k):
+                eng.train_step(feat0.clone(), mask0, label0)
+        run_resident(6)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_resident(args.steps)
+        torch.cuda.synchronize()
+        res_ips = args.steps / (time.perf_counter() - t0)
+
+        def batches(workers):
+            while True:
+                dl = DataLoader(pv, batch_size=2, num_workers=0, shuffle=True, drop_last=True)
+                for b in (Prefetcher(dl, workers=workers) if workers else dl):
+                    yield b
+
+        def timed_loop(workers, train):
+            it = batches(workers)
+            for _ in range(4):
+                f, m, l = next(it)
+                if train:
+                    eng.train_step(f, m, (l % 20))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                f, m, l = next(it)
+                if train:
+                    eng.train_step(f, m, (l % 20))
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            it.close()
+            return args.steps / dt
+        out = {"in_line": timed_loop(0, True), "prefetch_1": timed_loop(1, True), "prefetch_2": timed_loop(2, True),
+               "pipeline_alone_1": 2 * timed_loop(1, False), "pipeline_alone_2": 2 * timed_loop(2, False),
+               "pipeline_alone_4": 2 * timed_loop(4, False)}
+        loop = {"workload": "PMF-ResNet34 train step at the KITTI training crop %dx%d, bs=2, batches from a synthetic "
+                            "on-disk SemanticKITTI tree (%d frames of %d points + %dx%d PNG)" % (hh, ww, len(ds), P, H, W),
+                "resident_batch_iter_per_s": res_ips,
+                "loader_in_loop_iter_per_s": {"no prefetch (loader calls on the training stream)": out["in_line"],
+                                              "1 prefetch thread": out["prefetch_1"], "2 prefetch threads": out["prefetch_2"]},
+                "loader_pipeline_alone_frames_per_s": {"1 thread": out["pipeline_alone_1"], "2 threads": out["pipeline_alone_2"],
+                                                       "4 threads": out["pipeline_alone_4"]},
+                "host_read_decode_ms_per_frame": host_ms, "loader_item_ms_per_frame": item_ms,
+                "frames_per_s_consumed": {"this crop, resident batch": 2 * res_ips,
+                                          "headline step (64x2048, ~55 it/s)": 110.0},
+                "steps": args.steps}
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+    print(json.dumps({
+        "metric": "perspective loader: frames/sec of the eval path (project + crop/pad) on one KITTI-sized frame",
+        "value": 1e6 / gpu_eval_us, "unit": "frame/s", "n_gpus": 1, "steps": 50, "warmup": 10,
+        "ms_per_step": gpu_eval_us / 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64 projection / int32 indices / f32 features", "data": "synthetic",
+        "config": {"workload": "PerspectiveViewLoader kernels on a %dx%d frame with %d raw points (%d in the image); "
+                               "sensor block of tasks/pmf/config_server_kitti.yaml" % (H, W, P, kept),
+                   "bit_exact_vs_numpy_oracle": same},
+        "roofline": rows[0] | {"bound": "hbm"}, "roofline_hbm": rows,
+        "cpu_baseline": {"value": 1.0 / t_np, "unit": "frame/s", "cores": 1, "kind": "port",
+                         "sample": "one frame, project_frame + center_crop_pad of oracle/loader_ref.py (numpy): %.1f ms" % (1e3 * t_np)},
+        "loader_in_loop": loop}))
+
+
 def salsanext_bench(args, dev, multi, rank, world):
     """the LiDAR-only task (tasks/salsanext) -- range-image loader kernels feeding one
     SalsaNextEngine iteration per step; the sweep (one per sample, 120 k points) is resident, projected inside the
@@ -418,7 +587,7 @@ def main():
     ap.add_argument("--bs", type=int, default=2)
     ap.add_argument("--force-dist", action="store_true",
                     help="testing: take the data-parallel code path (process group, range all-reduce) even with one rank")
-    ap.add_argument("--mode", default="train", choices=["train", "infer"],
+    ap.add_argument("--mode", default="train", choices=["train", "infer", "loader"],
                     help="train = the headline metric; infer = BASELINE configs[1]: eval-mode forward at bs=4 + KNN "
                          "post-processing per frame, reported as frames/s under its own metric name")
     ap.add_argument("--backbone", default="resnet34", help="camera backbone (resnet50: BASELINE configs[3] family)")
@@ -467,6 +636,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", init_method="env://", world_size=world, rank=rank)
+    if args.mode == "loader":
+        return loader_bench(args, dev)
     if args.model == "salsanext":
         return salsanext_bench(args, dev, multi, rank, world)
     from pmf_amd.engine import TrainEngine, EPMFEngine

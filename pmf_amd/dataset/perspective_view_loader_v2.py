@@ -27,9 +27,11 @@ def project_frame_v2_gpu(points, sem_label, image_u8, proj_matrix, label_lut, fo
     projected (row, col) coordinates (the caller passes the image already rescaled by it)."""
     lib = L.lib()
     dev = torch.device(device)
-    pts = torch.as_tensor(np.ascontiguousarray(points, np.float32)).to(dev)
-    sem = torch.as_tensor(np.ascontiguousarray(sem_label, np.int32)).to(dev)
     from .perspective_view_loader import image_to_device
+    pts = points.to(dev, torch.float32).contiguous() if isinstance(points, torch.Tensor) else \
+        torch.as_tensor(np.ascontiguousarray(points, np.float32)).to(dev)
+    sem = sem_label.to(dev, torch.int32).contiguous() if isinstance(sem_label, torch.Tensor) else \
+        torch.as_tensor(np.ascontiguousarray(sem_label, np.int32)).to(dev)
     img = image_to_device(image_u8, dev)
     mat = torch.as_tensor(np.ascontiguousarray(proj_matrix, np.float64).reshape(12)).to(dev)
     lut = torch.as_tensor(np.ascontiguousarray(label_lut, np.int32)).to(dev)
@@ -99,6 +101,11 @@ class PerspectiveViewLoaderV2(Dataset):
         seq_id, _ = self.dataset.parsePathInfoByIndex(index)
         fl = getattr(self.dataset, "fov_left", -45 / 180.0 * math.pi)
         fr = getattr(self.dataset, "fov_right", 45 / 180.0 * math.pi)
+        if not self.return_uproj and not isinstance(image, torch.Tensor) and not isinstance(pointcloud, torch.Tensor):
+            from .perspective_view_loader import upload_packed     # one host -> device copy per frame
+            pointcloud, sem_label, image = upload_packed(
+                [np.asarray(pointcloud, np.float32), np.asarray(sem_label, np.int32), np.ascontiguousarray(image, np.uint8)],
+                self.device)
         proj, xy, depth, keep = project_frame_v2_gpu(pointcloud, sem_label, image, self.dataset.proj_matrix[seq_id],
                                                      self.dataset.class_map_lut, fl, fr, self.device, img_scale)
         if self.return_uproj:

@@ -42,9 +42,13 @@ class FlatOptimizerView(object):
 
     _PER_PARAM = ("exp_avg", "exp_avg_sq", "max_exp_avg_sq", "momentum_buffer")
 
-    def __init__(self, optimizer, flat, ref_groups):
+    def __init__(self, optimizer, flat, ref_groups, extra_groups=()):
+        """extra_groups: parameter lists that live OUTSIDE the flat buffer as ordinary tensors, one per further
+        param_group of the fused optimiser, in order (EPMF: the MultiTaskLoss sigmas, the reference's second AdamW group,
+        tasks/epmf/trainer.py:105-109); they follow the flat parameters in the checkpoint, as in the reference."""
         self.optimizer, self.flat = optimizer, flat
         self.ref_groups = [list(g) for g in ref_groups]
+        self.extra_groups = [list(g) for g in extra_groups]
         self.flat_param = optimizer.param_groups[0]["params"][0]
 
     # ---- what the training loop and the schedulers use
@@ -85,13 +89,37 @@ class FlatOptimizerView(object):
                 ids.append(idx)
                 idx += 1
             groups.append(dict(hyper, params=ids))
+        for gi, g in enumerate(self.extra_groups):
+            hyper_g = {k: v for k, v in self.optimizer.param_groups[1 + gi].items() if k != "params"}
+            ids = []
+            for p in g:
+                ent = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in self.optimizer.state.get(p, {}).items()}
+                if ent:
+                    state[idx] = ent
+                ids.append(idx)
+                idx += 1
+            groups.append(dict(hyper_g, params=ids))
         return {"state": state, "param_groups": groups}
 
     def load_state_dict(self, sd):
         n = sum(len(g) for g in self.ref_groups)
+        extra = [p for g in self.extra_groups for p in g]
         ids = [i for g in sd["param_groups"] for i in g["params"]]
-        if len(ids) != n:
-            raise ValueError("optimizer checkpoint holds %d parameters, this model has %d" % (len(ids), n))
+        if len(ids) != n + len(extra):
+            raise ValueError("optimizer checkpoint holds %d parameters, this model has %d" % (len(ids), n + len(extra)))
+        for i, p in zip(ids[n:], extra):            # ordinary tensors: their state entries as saved
+            ent = sd["state"].get(i, sd["state"].get(str(i)))
+            if ent:
+                fused = bool(self.optimizer.param_groups[0].get("fused"))
+                self.optimizer.state[p] = {
+                    k: (v.to(p.device, torch.float32 if k == "step" else v.dtype) if torch.is_tensor(v) and (k != "step" or fused)
+                        else (v.clone() if torch.is_tensor(v) else v)) for k, v in ent.items()}
+        for gi in range(len(self.extra_groups)):
+            src_g = sd["param_groups"][len(self.ref_groups) + gi]
+            for k, v in src_g.items():
+                if k != "params" and k in self.optimizer.param_groups[1 + gi] and k not in ("fused", "foreach", "capturable"):
+                    self.optimizer.param_groups[1 + gi][k] = v
+        ids = ids[:n]
         params = [p for g in self.ref_groups for p in g]
         fp = self.flat_param
         st = self.optimizer.state[fp]
@@ -310,8 +338,19 @@ class EPMFEngine(TrainEngine):
         if self.distributed:
             import torch.distributed as dist
             dist.broadcast(self.mt_loss.sigma.data, 0)
-        if self.flat is not None:                       # checkpoint view: lidar parameters, then the sigmas (group 2)
-            self.optimizer_view = self.optimizer
+            if self.flat is None:
+                # per-tensor path (DistributedDataParallel over the model): the sigmas are not inside that wrapper --
+                # average their gradient as the reference's own DistributedDataParallel(mt_loss) does (:44-49)
+                world = dist.get_world_size()
+
+                def _avg(p):
+                    dist.all_reduce(p.grad)
+                    p.grad.div_(world)
+                self.mt_loss.sigma.register_post_accumulate_grad_hook(_avg)
+        if self.flat is not None:
+            # checkpoint view in the reference's layout: the lidar parameters one by one, then the sigmas as group 2
+            self.optimizer_view = FlatOptimizerView(self.optimizer, self.flat, [list(model.lidar_stream.parameters())],
+                                                    extra_groups=[list(self.mt_loss.parameters())])
 
     def forward_loss(self, pcd, rgb, label):
         if self.flat is not None:
@@ -371,6 +410,9 @@ class SalsaNextEngine:
         elif distributed:
             raise RuntimeError("SalsaNextEngine: data parallelism needs the flat training state on a GPU")
         self.optimizer = torch.optim.AdamW(params, lr=lr, **fused)                      # trainer.py:57-61
+        # what the task script saves / restores (tasks/salsanext/main.py:64-70,105-110): per-parameter layout
+        self.optimizer_view = self.optimizer if self.flat is None else \
+            FlatOptimizerView(self.optimizer, self.flat, [list(model.parameters())])
         if alpha is None:
             alpha = np.ones(nclasses, np.float32)
             alpha[0] = 0

@@ -43,37 +43,109 @@ class SyntheticPV(Dataset):
         return torch.cat((pcd[0], rgb[0]), 0), mask[0], label[0].float()
 
 
-class Prefetcher(object):
-    """iterates a DataLoader from a background thread, ``depth`` batches ahead (HIP calls are thread-safe; the thread
-    uses the loader's device and its own stream is not needed: the loader kernels are tiny next to a training step)."""
+def _record_stream(x, stream):
+    if torch.is_tensor(x):
+        if x.is_cuda:
+            x.record_stream(stream)
+    elif isinstance(x, (list, tuple)):
+        for y in x:
+            _record_stream(y, stream)
+    elif isinstance(x, dict):
+        for y in x.values():
+            _record_stream(y, stream)
 
-    def __init__(self, loader, depth=2):
+
+class Prefetcher(object):
+    """iterates a DataLoader from background threads, ``depth`` batches ahead per thread, each on a HIP stream of its own.
+    The device-side loaders upload a frame with a pageable host -> device copy; on the training stream it would wait for
+    everything queued there (a whole step), which serialises the thread behind the GPU (measured: no gain at all).  On a
+    side stream the uploads and the loader kernels run under the step; every batch carries an event the consumer's stream
+    waits on, and its tensors are marked as used by that stream (caching-allocator safety).
+    ``workers`` > 1 (a plain DataLoader with num_workers=0 only): worker j builds batches j, j + workers, ... of the
+    loader's batch sampler itself (dataset items + collate), so PNG decoding and the uploads of several batches overlap;
+    batches are delivered in sampler order, but the workers draw their augmentation parameters from the global RNGs
+    concurrently -- like the reference's multi-process DataLoader the draws are then not reproducible run to run.
+    The producers stop when the consumer stops: leaving the loop early (debug break, exception, generator collected) sets
+    a flag they check between items, so no thread -- and none of the device batches it holds -- outlives an epoch."""
+
+    def __init__(self, loader, depth=2, workers=1):
         self.loader, self.depth = loader, depth
+        self.workers = workers if (workers > 1 and isinstance(loader, DataLoader) and loader.num_workers == 0
+                                   and loader.batch_sampler is not None) else 1
 
     def __len__(self):
         return len(self.loader)
 
     def __iter__(self):
-        q = queue.Queue(maxsize=self.depth)
-        dev = torch.cuda.current_device() if torch.cuda.is_available() else None
+        W = self.workers
+        qs = [queue.Queue(maxsize=self.depth) for _ in range(W)]
+        stop = threading.Event()
+        gpu = torch.cuda.is_available()
+        dev = torch.cuda.current_device() if gpu else None
+        batches = list(self.loader.batch_sampler) if W > 1 else None      # the index lists, drawn once, in order
 
-        def work():
+        def put(q, x):                            # False: the consumer is gone
+            while not stop.is_set():
+                try:
+                    q.put(x, timeout=0.05)
+                    return True
+                except queue.Full:
+                    pass
+            return False
+
+        def source(j):
+            if W == 1:
+                return iter(self.loader)
+            ds, collate = self.loader.dataset, self.loader.collate_fn
+            return (collate([ds[i] for i in idx]) for idx in batches[j::W])
+
+        def work(j):
+            q = qs[j]
             try:
-                if dev is not None:
+                if gpu:
                     torch.cuda.set_device(dev)
-                for item in self.loader:
-                    q.put(("item", item))
-                q.put(("end", None))
+                    side = torch.cuda.Stream(device=dev)
+                    with torch.cuda.stream(side):
+                        for item in source(j):
+                            ev = torch.cuda.Event()
+                            ev.record(side)
+                            if not put(q, ("item", (item, ev))):
+                                return
+                else:
+                    for item in source(j):
+                        if not put(q, ("item", (item, None))):
+                            return
+                put(q, ("end", None))
             except BaseException as e:            # surfaces in the consumer
-                q.put(("error", e))
-        threading.Thread(target=work, daemon=True).start()
-        while True:
-            kind, item = q.get()
-            if kind == "end":
-                return
-            if kind == "error":
-                raise item
-            yield item
+                put(q, ("error", e))
+        ths = [threading.Thread(target=work, args=(j,), daemon=True) for j in range(W)]
+        for th in ths:
+            th.start()
+        try:
+            j = 0
+            while True:
+                kind, payload = qs[j].get()
+                if kind == "end":                 # worker j is the first to run out (sampler order): all are done
+                    return
+                if kind == "error":
+                    raise payload
+                item, ev = payload
+                if ev is not None:
+                    cur = torch.cuda.current_stream(dev)
+                    cur.wait_event(ev)
+                    _record_stream(item, cur)
+                yield item
+                j = (j + 1) % W
+        finally:
+            stop.set()
+            for q in qs:                          # release what the producers queued, then let them finish
+                while True:
+                    try:
+                        q.get_nowait()
+                    except queue.Empty:
+                        break
+            for th in ths:
+                th.join(timeout=10.0)
 
 
 class Trainer(object):
@@ -82,21 +154,32 @@ class Trainer(object):
         self.model = model.cuda()
         self.remain_time = pc_processor.utils.RemainTime(settings.n_epochs)
         self.train_loader, self.val_loader, self.train_sampler, self.val_sampler = self._initDataloader()
-        sensor = settings.config["sensor"]
-        total = len(self.train_loader)
-        self.engine = TrainEngine(
-            self.model, settings.nclasses, lr=settings.lr, momentum=settings.momentum,
-            weight_decay=settings.weight_decay, lambda_=settings.lambda_, gamma=settings.gamma, tau=settings.tau,
-            alpha=self.alpha, ignore_class=self.ignore_class, warmup_steps=settings.warmup_epochs * total,
-            max_steps=total * (settings.n_epochs - settings.warmup_epochs),
-            feature_mean=sensor["img_mean"], feature_std=sensor["img_stds"],
-            distributed=settings.distributed and settings.world_size > 1,
-            device_ids=[settings.gpu] if settings.distributed else None)
+        self.engine = self._initEngine(len(self.train_loader))
         # main.py reads / restores these two (:72-83,104-127): reference checkpoint layout on top of the flat state
         self.optimizer, self.aux_optimizer = self.engine.optimizer_view, self.engine.aux_optimizer_view
         self.metrics, self.metrics_img = self.engine.metrics, self.engine.metrics_img
         self.scheduler, self.aux_scheduler = self.engine.scheduler, self.engine.aux_scheduler
         self.last_summary = {}
+
+    TERMS = TERMS                       # loss terms the engine reports, in logging order
+    TERM_TAGS = ("LossFocal", "LossLovasz", "LossImageFocal", "LossImageLovasz", "LossPerception")
+
+    def _initEngine(self, total):
+        """the per-iteration work (trainer.py:289-341); tasks/epmf overrides this with the six-term engine"""
+        s = self.settings
+        sensor = s.config["sensor"]
+        return TrainEngine(
+            self.model, s.nclasses, lr=s.lr, momentum=s.momentum, weight_decay=s.weight_decay, lambda_=s.lambda_,
+            gamma=s.gamma, tau=s.tau, alpha=self.alpha, ignore_class=self.ignore_class,
+            warmup_steps=s.warmup_epochs * total, max_steps=total * (s.n_epochs - s.warmup_epochs),
+            feature_mean=sensor["img_mean"], feature_std=sensor["img_stds"],
+            distributed=s.distributed and s.world_size > 1, device_ids=[s.gpu] if s.distributed else None)
+
+    @staticmethod
+    def _unpack(batch):
+        """one DataLoader batch -> (feature [N,8,H,W], mask [N,H,W], label [N,H,W]) (trainer.py:289-297)"""
+        feat, mask, label = batch
+        return feat.cuda(non_blocking=True), mask.cuda(non_blocking=True), label.cuda(non_blocking=True)
 
     # ------------------------------------------------------------------ data
     def _initDataloader(self):
@@ -151,8 +234,8 @@ class Trainer(object):
                         drop_last=True)
         vl = DataLoader(val_pv, batch_size=s.batch_size[1], num_workers=workers, shuffle=False, sampler=vsamp,
                         drop_last=False)
-        if device_side and s.n_threads > 0:
-            tl, vl = Prefetcher(tl), Prefetcher(vl)
+        if device_side and s.n_threads > 0:      # n_threads: the reference's DataLoader workers = prefetch threads here
+            tl, vl = Prefetcher(tl, workers=s.n_threads), Prefetcher(vl, workers=s.n_threads)
         return tl, vl, tsamp, vsamp
 
     # ------------------------------------------------------------------ one epoch
@@ -168,14 +251,15 @@ class Trainer(object):
             raise ValueError("invalid mode: {}".format(mode))
         self.metrics.reset()
         self.metrics_img.reset()
+        TERMS = self.TERMS
         sums = torch.zeros(1 + len(TERMS), dtype=torch.float64, device="cuda")     # sum of (loss x batch) per term
         count = 0
         total_iter = len(loader)
         t_start = time.time()
         lr = self.optimizer.param_groups[0]["lr"]
-        for i, (feat, mask, label) in enumerate(loader):
+        for i, batch in enumerate(loader):
             t0 = time.time()
-            feat, mask, label = feat.cuda(non_blocking=True), mask.cuda(non_blocking=True), label.cuda(non_blocking=True)
+            feat, mask, label = self._unpack(batch)
             step = eng.train_step if mode == "Train" else eng.eval_step
             total, terms = step(feat, mask, label)
             sums += torch.stack([total.detach()] + [terms[k].detach() for k in TERMS]).double() * feat.size(0)
@@ -205,7 +289,7 @@ class Trainer(object):
         miou_i, _ = self.metrics_img.getIoU()
         if self.recorder is not None:
             tb = self.recorder.tensorboard
-            for k, v in zip(("Loss", "LossFocal", "LossLovasz", "LossImageFocal", "LossImageLovasz", "LossPerception"), avg):
+            for k, v in zip(("Loss",) + tuple(self.TERM_TAGS), avg):
                 tb.add_scalar("{}_{}".format(mode, k), v, epoch)
             tb.add_scalar("{}_lr".format(mode), lr, epoch)
             for k, v in (("meanAcc", macc), ("meanIOU", miou), ("meanRecall", mrec), ("Image_meanIOU", miou_i)):

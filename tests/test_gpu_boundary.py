@@ -339,6 +339,82 @@ def test_checkpoint_roundtrip_in_reference_layout():
         eD.optimizer_view.load_state_dict(bad)
 
 
+def test_epmf_checkpoint_in_reference_layout():
+    """the EPMF AdamW owns the LiDAR stream AND the MultiTaskLoss sigmas (tasks/epmf/trainer.py:95-109: two
+    param groups).  On the flat state the checkpoint must still list the LiDAR parameters one by one followed by the
+    sigmas as group 2, load into per-parameter torch optimisers (the reference's layout) and back, with a bit-identical
+    next step."""
+    import io
+    from pmf_amd.engine import EPMFEngine
+    from pmf_amd.models import EPMFNet
+    from pmf_amd.utils.detinit import deterministic_init, synthetic_batch
+    pcd, rgb, label, mask = synthetic_batch(2, 64, 64, 20, seed=9, fill=0.5)
+    feat = torch.cat((pcd, rgb), 1).cuda()
+    mask, label = mask.cuda(), label.cuda()
+
+    def engine(flat, seed_init=True):
+        m = EPMFNet(5, 3, 20, 32, imagenet_pretrained=False, image_backbone="resnet34")
+        if seed_init:
+            deterministic_init(m)
+        m = m.cuda()
+        m.set_dropout_masks(_ones_masks(m, 2))
+        return m, EPMFEngine(m, 20, lr=1e-3, warmup_steps=2, max_steps=50, flat_state=flat)
+
+    def save(m, e):
+        buf = io.BytesIO()
+        torch.save({"model": m.state_dict(), "optimizer": e.optimizer_view.state_dict(),
+                    "aux_optimizer": e.aux_optimizer_view.state_dict(), "sigma": e.mt_loss.sigma.detach().clone()}, buf)
+        buf.seek(0)
+        return torch.load(buf, map_location="cpu")
+
+    def restore(m, e, ck, it):
+        m.load_state_dict(ck["model"])
+        with torch.no_grad():
+            e.mt_loss.sigma.copy_(ck["sigma"])
+        e.optimizer_view.load_state_dict(ck["optimizer"])
+        e.aux_optimizer_view.load_state_dict(ck["aux_optimizer"])
+        for sch in (e.scheduler, e.aux_scheduler):
+            for _ in range(it):
+                sch.step()
+
+    def step(e):
+        return e.train_step(feat.clone(), mask, label)[0].item()
+
+    mA, eA = engine(True)
+    for _ in range(2):
+        step(eA)
+    ck = save(mA, eA)
+    lossA = step(eA)
+    wantA = {k: v.clone() for k, v in mA.state_dict().items()}
+    sigA = eA.mt_loss.sigma.detach().clone()
+    lidar = list(mA.lidar_stream.parameters())
+    groups = ck["optimizer"]["param_groups"]
+    assert len(groups) == 2 and groups[0]["params"] == list(range(len(lidar))) and groups[1]["params"] == [len(lidar)]
+    assert tuple(ck["optimizer"]["state"][len(lidar)]["exp_avg"].shape) == (6,)
+    assert all(tuple(ck["optimizer"]["state"][i]["exp_avg"].shape) == tuple(p.shape) for i, p in enumerate(lidar))
+
+    def same(m, e, loss):
+        # not bitwise as in the PMF test: the bias gradients of EPMF's masked convolutions are column sums accumulated
+        # with float atomics (elementwise.hip colsum), whose order differs run to run in the last bit (measured 1e-9)
+        assert abs(loss - lossA) <= 1e-6 * abs(lossA), (loss, lossA)
+        assert (e.mt_loss.sigma.detach() - sigA).abs().max().item() <= 1e-6
+        bad = [(k, (v.float() - wantA[k].float()).abs().max().item()) for k, v in m.state_dict().items()
+               if (v.float() - wantA[k].float()).abs().max().item() > 1e-6 * max(1.0, wantA[k].float().abs().max().item())]
+        assert not bad, bad[:8]
+
+    mB, eB = engine(True, seed_init=False)                 # flat <- checkpoint
+    restore(mB, eB, ck, 2)
+    same(mB, eB, step(eB))
+    mC, eC = engine(False, seed_init=False)                # per-parameter torch optimisers (reference layout) <- checkpoint
+    restore(mC, eC, ck, 2)
+    ckC = save(mC, eC)
+    assert [g["params"] for g in ckC["optimizer"]["param_groups"]] == [g["params"] for g in groups]
+    same(mC, eC, step(eC))
+    mD, eD = engine(True, seed_init=False)                 # flat <- a checkpoint written by per-parameter optimisers
+    restore(mD, eD, ckC, 2)
+    same(mD, eD, step(eD))
+
+
 def test_tasks_pmf_train_resume_and_infer(tmp_path):
     """the task scripts end to end on a synthetic on-disk SemanticKITTI tree: tasks/pmf/main.py (SemanticKitti branch of the
     trainer: parser -> PerspectiveViewLoader(is_train, img_aug, use_padding) -> engine, validation schedule, best_* and
@@ -460,3 +536,92 @@ def test_epmf_engine_matches_reference_trace(golden):
                 name = k[len("etrace.param1."):]
                 err = np.abs(_checksum(sd[name]) - g[k]).max() / max(abs(g[k][1]), 1e-3)
                 assert err < 1e-4, (name, err)
+
+
+def _run_task(script, conf, timeout=900):
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, PMF_AUTOTUNE="0")
+    env.pop("RANK", None), env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.basename(script), conf], cwd=os.path.dirname(script), env=env,
+                       capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    return r.stdout
+
+
+def test_tasks_epmf_train_and_resume(tmp_path):
+    """tasks/epmf/main.py end to end (tasks/epmf/{main,trainer}.py of the reference): the file-free synthetic set first
+    (EPMFNet + six-term MultiTaskLoss engine, validation, best_* and checkpoint.pth with the sigmas as the AdamW's second
+    param group), a resumed run, then the SemanticKitti branch on an on-disk tree through PerspectiveViewLoaderV2."""
+    import os
+    import yaml
+    from oracle.cases import kitti_tree
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    main = os.path.join(repo, "tasks", "epmf", "main.py")
+    with open(os.path.join(repo, "tasks", "epmf", "config_synthetic.yaml")) as f:
+        cfg = yaml.safe_load(f)
+    cfg.update(save_path=str(tmp_path / "exp"), n_epochs=2, synthetic_frames=[4, 2], print_frequency=1)
+    cfg["PVconfig"].update(proj_h=64, proj_w=128, proj_ht=64, proj_wt=128)
+    conf = str(tmp_path / "epmf.yaml")
+    with open(conf, "w") as f:
+        yaml.safe_dump(cfg, f)
+    out = _run_task(main, conf)
+    assert "===init env success===" in out and ">>> Validation" in out
+    exp = os.listdir(cfg["save_path"])
+    assert len(exp) == 1
+    ckdir = os.path.join(cfg["save_path"], exp[0], "checkpoint")
+    assert {"checkpoint.pth", "best_IOU_model.pth"} <= set(os.listdir(ckdir))
+    ck = torch.load(os.path.join(ckdir, "checkpoint.pth"), map_location="cpu")
+    groups = ck["optimizer"]["param_groups"]
+    assert ck["epoch"] == 1 and len(groups) == 2 and len(groups[1]["params"]) == 1      # LiDAR stream, then the sigmas
+    assert tuple(ck["mt_loss"]["sigma"].shape) == (6,) and len(ck["aux_optimizer"]["param_groups"]) == 2
+    cfg.update(checkpoint=os.path.join(ckdir, "checkpoint.pth"), n_epochs=3, experiment_id="resume")
+    with open(conf, "w") as f:
+        yaml.safe_dump(cfg, f)
+    out = _run_task(main, conf)
+    assert "E[003|003]" in out and "E[003|001]" not in out
+    # SemanticKitti branch: parser -> PerspectiveViewLoaderV2(is_train, img_aug) -> [N,10,H,W] batches
+    root = str(tmp_path / "sequences")
+    cfg_path, _ = kitti_tree(root, seqs=(0, 8), frames=4, npts=3000, h=96, w=320)
+    with open(cfg_path) as f:
+        lab = yaml.safe_load(f)
+    lab["learning_ignore"] = {k: k == 0 for k in lab["learning_map_inv"]}
+    with open(cfg_path, "w") as f:
+        yaml.safe_dump(lab, f)
+    cfg.update(dataset="SemanticKitti", data_root=root, data_config_path=cfg_path, sequences={"train": [0], "valid": [8]},
+               nclasses=6, cls_freq=[0.0, 5.0, 4.0, 3.0, 2.0, 1.0], checkpoint=None, n_epochs=1, experiment_id="kitti",
+               n_threads=1)
+    cfg["PVconfig"].update(proj_h=64, proj_w=256, proj_ht=64, proj_wt=256)
+    with open(conf, "w") as f:
+        yaml.safe_dump(cfg, f)
+    out = _run_task(main, conf)
+    assert ">>> Train" in out and ">>> Validation" in out
+
+
+def test_tasks_salsanext_train_and_resume(tmp_path):
+    """tasks/salsanext/main.py end to end (tasks/salsanext/{main,trainer}.py of the reference) on synthetic LiDAR sweeps:
+    SalsaNextLoader (range projection + augmentation kernels) -> SalsaNextEngine, validation, checkpoint, resume."""
+    import os
+    import yaml
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    main = os.path.join(repo, "tasks", "salsanext", "main.py")
+    with open(os.path.join(repo, "tasks", "salsanext", "config_synthetic.yaml")) as f:
+        cfg = yaml.safe_load(f)
+    cfg.update(save_path=str(tmp_path / "exp"), n_epochs=2, synthetic_frames=[4, 2], print_frequency="1", n_threads=1)
+    cfg["sensor"].update(proj_h=64, proj_w=256)
+    conf = str(tmp_path / "salsa.yaml")
+    with open(conf, "w") as f:
+        yaml.safe_dump(cfg, f)
+    out = _run_task(main, conf)
+    assert "===init env success===" in out and ">>> Validation" in out
+    exp = os.listdir(cfg["save_path"])
+    ckdir = os.path.join(cfg["save_path"], exp[0], "checkpoint")
+    assert {"checkpoint.pth", "best_IOU_model.pth", "best_Acc_model.pth", "best_Recall_model.pth"} <= set(os.listdir(ckdir))
+    ck = torch.load(os.path.join(ckdir, "checkpoint.pth"), map_location="cpu")
+    assert ck["epoch"] == 1 and set(ck) == {"model", "optimizer", "epoch"}
+    cfg.update(checkpoint=os.path.join(ckdir, "checkpoint.pth"), n_epochs=3, experiment_id="resume")
+    with open(conf, "w") as f:
+        yaml.safe_dump(cfg, f)
+    out = _run_task(main, conf)
+    assert "E[003|003]" in out and "E[003|001]" not in out

@@ -240,3 +240,65 @@ def test_tensor_augmentation_restatement_and_draw_order():
     with pytest.raises(RuntimeError):
         op(torch.zeros(10, 40, 64))                                      # CPU tensor: no fallback
     assert L.lib().pmf_flip_rotate_crop(None, 10, 4, 4, 0, None, 0, 0, 4, 4, 0, 0, None, 4, 4, None) == -1
+
+
+def test_prefetcher_stops_with_its_consumer():
+    """leaving the loop early must end the producer thread (it used to block in q.put forever, holding
+    `depth` batches and drawing from the global RNG next to the following epoch's producer)."""
+    import threading
+    import time
+    from tasks.pmf.trainer import Prefetcher
+    produced = []
+
+    class Src(object):
+        def __len__(self):
+            return 1000
+
+        def __iter__(self):
+            for i in range(1000):
+                produced.append(i)
+                yield i
+    before = threading.active_count()
+    pf = Prefetcher(Src(), depth=2)
+    got = []
+    for x in pf:
+        got.append(x)
+        if x == 3:
+            break
+    t0 = time.time()
+    while threading.active_count() > before and time.time() - t0 < 5.0:
+        time.sleep(0.01)
+    assert got == [0, 1, 2, 3]
+    assert threading.active_count() == before, "producer thread still alive after the consumer left"
+    assert len(produced) < 20                 # it did not run on through the source
+    assert list(Prefetcher(Src(), depth=2)) == list(range(1000))      # and a full pass still delivers everything in order
+
+    class Boom(object):
+        def __iter__(self):
+            yield 1
+            raise ValueError("boom")
+    with pytest.raises(ValueError):
+        list(Prefetcher(Boom()))
+
+
+def test_prefetcher_workers_keep_sampler_order():
+    """several prefetch threads build alternate batches of a DataLoader's batch sampler; delivery stays in sampler order and
+    every item arrives exactly once (also when the batch count is not a multiple of the worker count)"""
+    import torch
+    from torch.utils.data import DataLoader, Dataset
+    from tasks.pmf.trainer import Prefetcher
+
+    class DS(Dataset):
+        def __len__(self):
+            return 23
+
+        def __getitem__(self, i):
+            return torch.tensor([i, 2 * i])
+    dl = DataLoader(DS(), batch_size=3, shuffle=False, drop_last=False)
+    want = [b.tolist() for b in dl]
+    for w in (2, 3):
+        got = [b.tolist() for b in Prefetcher(dl, depth=2, workers=w)]
+        assert got == want, (w, got)
+    it = iter(Prefetcher(dl, workers=3))
+    assert next(it).tolist() == want[0]
+    del it                                     # early exit with several workers: threads end (no hang at interpreter exit)
