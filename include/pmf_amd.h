@@ -414,6 +414,19 @@ int pmf_loss_pixel_w(const float* lidar_prob, const float* camera_prob, const in
 int pmf_loss_lovasz_w(const int64_t* perm, const float* key_sorted, const int64_t* label, int32_t N, int32_t C, int64_t HW,
                       const unsigned long long* cnt, const float* w6, float* bsum, double* dots, const double* rows,
                       float* grad_lidar, float* grad_camera, float* out8, pmf_stream_t s);
+/* The Lovasz stage WITH its sort (lovasz_softmax.py:71-145: torch.sort of the per-class errors, descending): takes the
+ * unsorted key matrix pmf_loss_pixel wrote and sorts every used row -- classes that occur in the batch, pixels with a label
+ * (the count P - cnt[0] is read on the device) -- by four stable 8-bit counting passes over the 30 significant bits of the
+ * errors; equal errors keep ascending pixel order.  workspace: pmf_loss_sort_workspace(C, P) bytes.  Same outputs as
+ * pmf_loss_lovasz (the Lovasz value does not depend on the order of equal errors). */
+int64_t pmf_loss_sort_workspace(int32_t C, int64_t P);
+int pmf_loss_lovasz_sort(const float* key, const int64_t* label, int32_t N, int32_t C, int64_t HW,
+                         const unsigned long long* cnt, float lambda, float gamma_per, void* workspace, float* bsum,
+                         double* dots, const double* rows, float* grad_lidar, float* grad_camera, float* out8,
+                         pmf_stream_t s);
+int pmf_loss_lovasz_sort_w(const float* key, const int64_t* label, int32_t N, int32_t C, int64_t HW,
+                           const unsigned long long* cnt, const float* w6, void* workspace, float* bsum, double* dots,
+                           const double* rows, float* grad_lidar, float* grad_camera, float* out8, pmf_stream_t s);
 
 /* ---- plan executor: a whole forward (or backward) pass = one call --------------------------------------- */
 enum {

@@ -252,17 +252,27 @@ __global__ __launch_bounds__(LP_BLOCK) void loss_pixel_k(const LossPixelArgs a) 
 
 // Lovasz stage (rows r = head * C + class, sorted descending by error; perm[r][k] = pixel of rank k):
 // per-chunk sums of the foreground indicator along the permutation ...
-__global__ __launch_bounds__(LV_BLOCK) void lovasz2_sums_k(const int64_t* __restrict__ perm, const int64_t* __restrict__ label,
-                                                           int64_t P, int C, int nb, float* __restrict__ bsum) {
+// IT: index type of the permutation (int64: torch.sort's; unsigned: the in-library sort's).  cnt != nullptr (in-library
+// sort): only the first P - cnt[0] ranks of a row exist and rows of absent classes / class 0 were never sorted.
+template <typename IT>
+__global__ __launch_bounds__(LV_BLOCK) void lovasz2_sums_k(const IT* __restrict__ perm, const int64_t* __restrict__ label,
+                                                           int64_t P, int C, int nb, float* __restrict__ bsum,
+                                                           const unsigned long long* __restrict__ cnt) {
   __shared__ float sh[LV_BLOCK];
   const int r = blockIdx.y, b = blockIdx.x, cls = r % C;
+  const int64_t lim = cnt ? P - (int64_t)cnt[0] : P;
+  if (cnt && (cls == 0 || cnt[cls] == 0)) return;
+  if ((int64_t)b * LV_CHUNK >= lim) {              // nothing ranked here
+    if (threadIdx.x == 0) bsum[r * nb + b] = 0.f;
+    return;
+  }
   // consecutive threads read consecutive ranks (a thread walking its own 16 ranks touched 64 cache lines per load
   // instruction: 171 us per call); the sum of 0/1 values is exact in any order
   const int64_t base = (int64_t)b * LV_CHUNK + threadIdx.x;
-  const int64_t* row = perm + (int64_t)r * P;
+  const IT* row = perm + (int64_t)r * P;
   int64_t pix[LV_PER_THREAD];
 #pragma unroll
-  for (int k = 0; k < LV_PER_THREAD; ++k) pix[k] = base + k * LV_BLOCK < P ? row[base + k * LV_BLOCK] : -1;
+  for (int k = 0; k < LV_PER_THREAD; ++k) pix[k] = base + k * LV_BLOCK < lim ? (int64_t)row[base + k * LV_BLOCK] : -1;
   float s = 0.f;
 #pragma unroll
   for (int k = 0; k < LV_PER_THREAD; ++k)
@@ -279,7 +289,8 @@ __global__ __launch_bounds__(LV_BLOCK) void lovasz2_sums_k(const int64_t* __rest
 // ... then the Jaccard first differences, the dot product with the sorted errors (value) and the gradient
 // lambda * [class present] / n_present * grad * d|fg - p|/dp, scattered back through the permutation (every (class, pixel)
 // pair occurs exactly once per row: plain read-modify-write, no atomics).
-__global__ __launch_bounds__(LV_BLOCK) void lovasz2_grad_k(const int64_t* __restrict__ perm, const float* __restrict__ key_sorted,
+template <typename IT, bool LIMIT>
+__global__ __launch_bounds__(LV_BLOCK) void lovasz2_grad_k(const IT* __restrict__ perm, const float* __restrict__ key_sorted,
                                                            const int64_t* __restrict__ label, int64_t P, int64_t HW, int C,
                                                            int nb, const float* __restrict__ bsum,
                                                            const unsigned long long* __restrict__ cnt, float lambda,
@@ -290,6 +301,12 @@ __global__ __launch_bounds__(LV_BLOCK) void lovasz2_grad_k(const int64_t* __rest
   __shared__ float carry_s, total_s;
   const int r = blockIdx.y, b = blockIdx.x, cls = r % C, head = r / C;
   const int64_t nvalid = P - (int64_t)cnt[0];
+  const int64_t lim = LIMIT ? nvalid : P;
+  if (LIMIT && (cls == 0 || cnt[cls] == 0)) return;          // (loss_fold_k skips these rows' dots as well)
+  if (LIMIT && (int64_t)b * LV_CHUNK >= lim) {
+    if (threadIdx.x == 0) dots[r * nb + b] = 0.0;
+    return;
+  }
   if (threadIdx.x == 0) {
     float pre = 0.f, tot = 0.f;
     for (int j = 0; j < nb; ++j) { const float v = bsum[r * nb + j]; if (j < b) pre += v; tot += v; }
@@ -300,7 +317,7 @@ __global__ __launch_bounds__(LV_BLOCK) void lovasz2_grad_k(const int64_t* __rest
   const float lam = w6 ? w6[head == 0 ? 1 : 3] : lambda;
   const float wcls = (cls != 0 && cnt[cls] > 0) ? lam / (float)(npresent > 0 ? npresent : 1) : 0.f;
   const int64_t base = (int64_t)b * LV_CHUNK + (int64_t)threadIdx.x * LV_PER_THREAD;
-  const int64_t* row = perm + (int64_t)r * P;
+  const IT* row = perm + (int64_t)r * P;
   const float* krow = key_sorted + (int64_t)r * P;
   // the chunk is read with consecutive threads on consecutive ranks (coalesced) and handed to its owner -- thread t scans
   // ranks 16 t .. 16 t + 15 -- through LDS: rank j sits at word j + j / 16 (17-word pitch per owner: conflict-free);
@@ -314,8 +331,8 @@ __global__ __launch_bounds__(LV_BLOCK) void lovasz2_grad_k(const int64_t* __rest
 #pragma unroll
     for (int k = 0; k < LV_PER_THREAD; ++k) {
       const int64_t i = cb + k * LV_BLOCK + threadIdx.x;
-      pl[k] = i < P ? row[i] : -1;
-      el[k] = i < P ? krow[i] : 0.f;
+      pl[k] = i < lim ? (int64_t)row[i] : -1;
+      el[k] = i < lim ? krow[i] : 0.f;
     }
 #pragma unroll
     for (int k = 0; k < LV_PER_THREAD; ++k) {
@@ -467,9 +484,10 @@ static int loss_lovasz_impl(const int64_t* perm, const float* key_sorted, const 
   const int64_t P = (int64_t)N * HW;
   const int nb = (int)cdiv64(P, LV_CHUNK);
   hipStream_t st = (hipStream_t)s;
-  hipLaunchKernelGGL(lovasz2_sums_k, dim3(nb, 2 * C), dim3(LV_BLOCK), 0, st, perm, label, P, C, nb, bsum);
-  hipLaunchKernelGGL(lovasz2_grad_k, dim3(nb, 2 * C), dim3(LV_BLOCK), 0, st, perm, key_sorted, label, P, HW, C, nb,
-                     (const float*)bsum, cnt, lambda, w6, grad_lidar, grad_camera, dots);
+  hipLaunchKernelGGL(lovasz2_sums_k<int64_t>, dim3(nb, 2 * C), dim3(LV_BLOCK), 0, st, perm, label, P, C, nb, bsum,
+                     (const unsigned long long*)nullptr);
+  hipLaunchKernelGGL((lovasz2_grad_k<int64_t, false>), dim3(nb, 2 * C), dim3(LV_BLOCK), 0, st, perm, key_sorted, label, P, HW, C,
+                     nb, (const float*)bsum, cnt, lambda, w6, grad_lidar, grad_camera, dots);
   hipLaunchKernelGGL(loss_fold_k, dim3(1), dim3(256), 0, st, rows, (int)cdiv64(P, LP_BLOCK), (const double*)dots, C, nb, cnt,
                      lambda, gamma_per, w6, out6);
   PMF_LAUNCH_CHECK();
@@ -488,4 +506,215 @@ extern "C" int pmf_loss_lovasz_w(const int64_t* perm, const float* key_sorted, c
   if (!w6) return PMF_E_ARG;
   return loss_lovasz_impl(perm, key_sorted, label, N, C, HW, cnt, 0.f, 0.f, w6, bsum, dots, rows, grad_lidar, grad_camera,
                           out8, s);
+}
+
+
+// ---- in-library Lovasz sort -----------------------------------------------------------------------------------------
+// torch.sort on the [2C, P] key matrix runs one device radix sort per row (40 rows of 262 144 keys: ~13 us each, 0.53 ms per
+// step) and sorts every pixel, although only pixels with a label (label != 0: the image-plane fill of a LiDAR sweep is
+// 5-15 %) take part in the Lovasz extension and rows of class 0 / absent classes are never read.  Here all rows are sorted
+// together by four stable 8-bit counting passes over the 30 significant bits of the error (errors lie in [0, 1], so their
+// float bit patterns order like integers; key' = 0x3FFFFFFF - bits gives descending errors from an ascending sort); the
+// first pass reads the raw key matrix and drops ignored pixels (key -1) -- it is the compaction -- and every later pass
+// touches only the P - cnt[0] labelled pixels of the rows that are used; the element count is read on the device, no host
+// round trip.  Equal errors keep ascending pixel order (deterministic).  Per pass: per-chunk digit histograms, one scan
+// workgroup per row, stable scatter (wave-level digit matching with ballots).
+#define RS_TILE 256
+#define RS_SUB 16
+#define RS_CHUNK (RS_TILE * RS_SUB)
+
+__device__ __forceinline__ unsigned rs_key_of(float e) { return 0x3FFFFFFFu - __float_as_uint(e); }
+
+template <bool FIRST>
+__global__ __launch_bounds__(RS_TILE) void rs_hist_k(const float* __restrict__ key, const unsigned* __restrict__ kin, int64_t P,
+                                                     int C, int nb, int shift, const unsigned long long* __restrict__ cnt,
+                                                     unsigned* __restrict__ hist) {
+  __shared__ unsigned h[256];
+  const int r = blockIdx.y, b = blockIdx.x, cls = r % C;
+  if (cls == 0 || cnt[cls] == 0) return;
+  const int64_t n = FIRST ? P : P - (int64_t)cnt[0];
+  const int64_t base = (int64_t)b * RS_CHUNK;
+  h[threadIdx.x] = 0u;
+  __syncthreads();
+  if (base < n) {
+#pragma unroll 4
+    for (int s = 0; s < RS_SUB; ++s) {
+      const int64_t i = base + s * RS_TILE + threadIdx.x;
+      if (i < n) {
+        unsigned k;
+        bool ok = true;
+        if (FIRST) { const float e = key[(int64_t)r * P + i]; ok = e >= 0.f; k = rs_key_of(e); }
+        else k = kin[(int64_t)r * P + i];
+        if (ok) atomicAdd(&h[(k >> shift) & 255u], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  hist[((int64_t)r * nb + b) * 256 + threadIdx.x] = h[threadIdx.x];      // [row][chunk][digit]: coalesced here and in the scan
+}
+
+// one workgroup per row: hist[r][chunk][digit] -> exclusive offsets in (digit, chunk) order, in place
+__global__ __launch_bounds__(256) void rs_scan_k(unsigned* __restrict__ hist, int C, int nb, const unsigned long long* __restrict__ cnt) {
+  __shared__ unsigned tot[256];
+  const int r = blockIdx.x, cls = r % C, d = threadIdx.x;
+  if (cls == 0 || cnt[cls] == 0) return;
+  unsigned* hp = hist + (int64_t)r * nb * 256 + d;
+  unsigned s = 0;
+  for (int b = 0; b < nb; ++b) s += hp[b * 256];
+  tot[d] = s;
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) {
+    const unsigned t = d >= o ? tot[d - o] : 0u;
+    __syncthreads();
+    tot[d] += t;
+    __syncthreads();
+  }
+  unsigned run = tot[d] - s;
+  for (int b0 = 0; b0 < nb; b0 += 8) {          // eight independent loads per trip
+    unsigned c[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) c[u] = b0 + u < nb ? hp[(b0 + u) * 256] : 0u;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (b0 + u < nb) { hp[(b0 + u) * 256] = run; run += c[u]; }
+  }
+}
+
+template <bool FIRST>
+__global__ __launch_bounds__(RS_TILE) void rs_scatter_k(const float* __restrict__ key, const unsigned* __restrict__ kin,
+                                                        const unsigned* __restrict__ vin, int64_t P, int C, int nb, int shift,
+                                                        const unsigned long long* __restrict__ cnt,
+                                                        const unsigned* __restrict__ offs, unsigned* __restrict__ kout,
+                                                        unsigned* __restrict__ vout) {
+  __shared__ unsigned run[256];
+  __shared__ unsigned wc[RS_TILE / 64][256];
+  const int r = blockIdx.y, b = blockIdx.x, cls = r % C;
+  if (cls == 0 || cnt[cls] == 0) return;
+  const int64_t n = FIRST ? P : P - (int64_t)cnt[0];
+  const int64_t base = (int64_t)b * RS_CHUNK;
+  if (base >= n) return;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  run[t] = offs[((int64_t)r * nb + b) * 256 + t];
+#pragma unroll
+  for (int w = 0; w < RS_TILE / 64; ++w) wc[w][t] = 0u;
+  __syncthreads();
+  const int64_t ro = (int64_t)r * P;
+  // the whole chunk first (16 independent loads per thread in flight), then the sixteen ranking rounds
+  unsigned ks[RS_SUB], vs[RS_SUB];
+  unsigned okm = 0u;
+#pragma unroll
+  for (int s = 0; s < RS_SUB; ++s) {
+    const int64_t i = base + s * RS_TILE + t;
+    bool ok = i < n;
+    ks[s] = 0u; vs[s] = 0u;
+    if (ok) {
+      if (FIRST) { const float e = key[ro + i]; ok = e >= 0.f; ks[s] = rs_key_of(e); vs[s] = (unsigned)i; }
+      else { ks[s] = kin[ro + i]; vs[s] = vin[ro + i]; }
+    }
+    okm |= ok ? (1u << s) : 0u;
+  }
+#pragma unroll
+  for (int s = 0; s < RS_SUB; ++s) {
+    const unsigned k = ks[s], v = vs[s];
+    const bool ok = (okm >> s) & 1u;
+    const unsigned d = (k >> shift) & 255u;
+    unsigned long long m = __ballot(ok);
+#pragma unroll
+    for (int bit = 0; bit < 8; ++bit) {
+      const bool one = (d >> bit) & 1u;
+      const unsigned long long bal = __ballot(one);
+      m &= one ? bal : ~bal;
+    }
+    const unsigned long long peers = ok ? m : 0ull;
+    const unsigned rank = (unsigned)__popcll(peers & ((1ull << lane) - 1ull));
+    if (ok && rank == 0u) wc[wave][d] = (unsigned)__popcll(peers);       // the lowest lane of every digit group
+    __syncthreads();
+    if (ok) {
+      unsigned pre = run[d];
+      for (int w = 0; w < wave; ++w) pre += wc[w][d];
+      const int64_t dst = ro + pre + rank;
+      kout[dst] = k;
+      vout[dst] = v;
+    }
+    __syncthreads();
+    {
+      unsigned a = 0u;
+#pragma unroll
+      for (int w = 0; w < RS_TILE / 64; ++w) { a += wc[w][t]; wc[w][t] = 0u; }
+      run[t] += a;
+    }
+    __syncthreads();
+  }
+}
+
+// sorted key' -> sorted errors (float), for the rows that were sorted
+__global__ __launch_bounds__(256) void rs_unkey_k(const unsigned* __restrict__ kin, float* __restrict__ e, int64_t P, int C,
+                                                  const unsigned long long* __restrict__ cnt) {
+  const int r = blockIdx.y, cls = r % C;
+  if (cls == 0 || cnt[cls] == 0) return;
+  const int64_t n = P - (int64_t)cnt[0];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    e[(int64_t)r * P + i] = __uint_as_float(0x3FFFFFFFu - kin[(int64_t)r * P + i]);
+}
+
+extern "C" int64_t pmf_loss_sort_workspace(int32_t C, int64_t P) {
+  const int64_t nb = cdiv64(P, RS_CHUNK);
+  return 4 * (int64_t)2 * C * P * 4 + (int64_t)2 * C * 256 * nb * 4;       // 2 key + 2 value buffers, histograms
+}
+
+static int loss_lovasz_sort_impl(const float* key, const int64_t* label, int32_t N, int32_t C, int64_t HW,
+                                 const unsigned long long* cnt, float lambda, float gamma_per, const float* w6, void* ws,
+                                 float* bsum, double* dots, const double* rows, float* grad_lidar, float* grad_camera,
+                                 float* out8, pmf_stream_t s) {
+  if (C < 2 || C > LP_MAXC || N < 1 || HW < 1 || !ws) return PMF_E_ARG;
+  const int64_t P = (int64_t)N * HW;
+  if (P >= (1ll << 31)) return PMF_E_UNSUPPORTED;
+  const int nb = (int)cdiv64(P, RS_CHUNK), R = 2 * C;
+  hipStream_t st = (hipStream_t)s;
+  unsigned* kA = (unsigned*)ws;
+  unsigned* kB = kA + (int64_t)R * P;
+  unsigned* vA = kB + (int64_t)R * P;
+  unsigned* vB = vA + (int64_t)R * P;
+  unsigned* hist = vB + (int64_t)R * P;
+  const dim3 grid(nb, R), blk(RS_TILE);
+  // pass 0 (bits 0-7): raw keys -> A (compaction); 1: A -> B; 2: B -> A; 3: A -> B
+  hipLaunchKernelGGL(rs_hist_k<true>, grid, blk, 0, st, key, (const unsigned*)nullptr, P, C, nb, 0, cnt, hist);
+  hipLaunchKernelGGL(rs_scan_k, dim3(R), dim3(256), 0, st, hist, C, nb, cnt);
+  hipLaunchKernelGGL(rs_scatter_k<true>, grid, blk, 0, st, key, (const unsigned*)nullptr, (const unsigned*)nullptr, P, C, nb, 0,
+                     cnt, (const unsigned*)hist, kA, vA);
+  unsigned* ki = kA; unsigned* vi = vA; unsigned* ko = kB; unsigned* vo = vB;
+  for (int pass = 1; pass < 4; ++pass) {
+    hipLaunchKernelGGL(rs_hist_k<false>, grid, blk, 0, st, (const float*)nullptr, (const unsigned*)ki, P, C, nb, 8 * pass, cnt, hist);
+    hipLaunchKernelGGL(rs_scan_k, dim3(R), dim3(256), 0, st, hist, C, nb, cnt);
+    hipLaunchKernelGGL(rs_scatter_k<false>, grid, blk, 0, st, (const float*)nullptr, (const unsigned*)ki, (const unsigned*)vi, P, C,
+                       nb, 8 * pass, cnt, (const unsigned*)hist, ko, vo);
+    unsigned* t = ki; ki = ko; ko = t;
+    t = vi; vi = vo; vo = t;
+  }
+  // sorted: keys in ki, pixel indices in vi; the errors as floats go to the spare key buffer
+  float* es = (float*)ko;
+  hipLaunchKernelGGL(rs_unkey_k, dim3(nb, R), dim3(256), 0, st, (const unsigned*)ki, es, P, C, cnt);
+  const int nbl = (int)cdiv64(P, LV_CHUNK);
+  hipLaunchKernelGGL(lovasz2_sums_k<unsigned>, dim3(nbl, R), dim3(LV_BLOCK), 0, st, (const unsigned*)vi, label, P, C, nbl, bsum, cnt);
+  hipLaunchKernelGGL((lovasz2_grad_k<unsigned, true>), dim3(nbl, R), dim3(LV_BLOCK), 0, st, (const unsigned*)vi, (const float*)es,
+                     label, P, HW, C, nbl, (const float*)bsum, cnt, lambda, w6, grad_lidar, grad_camera, dots);
+  hipLaunchKernelGGL(loss_fold_k, dim3(1), dim3(256), 0, st, rows, (int)cdiv64(P, LP_BLOCK), (const double*)dots, C, nbl, cnt,
+                     lambda, gamma_per, w6, out8);
+  PMF_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pmf_loss_lovasz_sort(const float* key, const int64_t* label, int32_t N, int32_t C, int64_t HW,
+                                    const unsigned long long* cnt, float lambda, float gamma_per, void* workspace, float* bsum,
+                                    double* dots, const double* rows, float* grad_lidar, float* grad_camera, float* out8,
+                                    pmf_stream_t s) {
+  return loss_lovasz_sort_impl(key, label, N, C, HW, cnt, lambda, gamma_per, nullptr, workspace, bsum, dots, rows, grad_lidar,
+                               grad_camera, out8, s);
+}
+extern "C" int pmf_loss_lovasz_sort_w(const float* key, const int64_t* label, int32_t N, int32_t C, int64_t HW,
+                                      const unsigned long long* cnt, const float* w6, void* workspace, float* bsum, double* dots,
+                                      const double* rows, float* grad_lidar, float* grad_camera, float* out8, pmf_stream_t s) {
+  if (!w6) return PMF_E_ARG;
+  return loss_lovasz_sort_impl(key, label, N, C, HW, cnt, 0.f, 0.f, w6, workspace, bsum, dots, rows, grad_lidar, grad_camera,
+                               out8, s);
 }

@@ -14,6 +14,23 @@ import torch
 from .. import _lib as L
 
 
+_SORT_WS = {}
+
+
+def _sort_workspace(lib, c, p, dev):
+    """scratch of the in-library Lovasz sort (key / pixel ping-pong buffers + histograms), kept per shape and device"""
+    k = (c, p, str(dev))
+    ws = _SORT_WS.get(k)
+    if ws is None:
+        ws = _SORT_WS[k] = torch.empty(lib.pmf_loss_sort_workspace(c, p), dtype=torch.uint8, device=dev)
+    return ws
+
+
+def _use_torch_sort():
+    import os
+    return os.environ.get("PMF_LOVASZ_TORCH_SORT") == "1"      # A/B switch: torch.sort + pmf_loss_lovasz
+
+
 class _FusedPMFLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, lidar_prob, camera_prob, label, alpha, lambda_, gamma_per, tau, focal_gamma, conf_l, conf_c):
@@ -40,10 +57,17 @@ class _FusedPMFLoss(torch.autograd.Function):
                                    gc.data_ptr(), key.data_ptr(), rows.data_ptr(),
                                    conf_l.data_ptr() if conf_l is not None else None,
                                    conf_c.data_ptr() if conf_c is not None else None, st), "pmf_loss_pixel")
-        vals, perm = torch.sort(key, dim=1, descending=True)
-        L.check(lib.pmf_loss_lovasz(perm.data_ptr(), vals.data_ptr(), lab.data_ptr(), n, c, hw, cnt.data_ptr(),
-                                    float(lambda_), float(gamma_per), bsum.data_ptr(), dots.data_ptr(), rows.data_ptr(),
-                                    gl.data_ptr(), gc.data_ptr(), out6.data_ptr(), st), "pmf_loss_lovasz")
+        if _use_torch_sort():
+            vals, perm = torch.sort(key, dim=1, descending=True)
+            L.check(lib.pmf_loss_lovasz(perm.data_ptr(), vals.data_ptr(), lab.data_ptr(), n, c, hw, cnt.data_ptr(),
+                                        float(lambda_), float(gamma_per), bsum.data_ptr(), dots.data_ptr(), rows.data_ptr(),
+                                        gl.data_ptr(), gc.data_ptr(), out6.data_ptr(), st), "pmf_loss_lovasz")
+        else:       # labelled pixels of the classes present only, sorted in the library (no torch.sort, no int64 indices)
+            ws = _sort_workspace(lib, c, p, dev)
+            L.check(lib.pmf_loss_lovasz_sort(key.data_ptr(), lab.data_ptr(), n, c, hw, cnt.data_ptr(), float(lambda_),
+                                             float(gamma_per), ws.data_ptr(), bsum.data_ptr(), dots.data_ptr(),
+                                             rows.data_ptr(), gl.data_ptr(), gc.data_ptr(), out6.data_ptr(), st),
+                    "pmf_loss_lovasz_sort")
         ctx.save_for_backward(gl, gc)
         ctx.mark_non_differentiable(out6)
         return out6[0].clone(), out6
@@ -84,10 +108,16 @@ class _FusedWeightedLoss(torch.autograd.Function):
                                      gc.data_ptr(), key.data_ptr(), rows.data_ptr(),
                                      conf_l.data_ptr() if conf_l is not None else None,
                                      conf_c.data_ptr() if conf_c is not None else None, st), "pmf_loss_pixel_w")
-        vals, perm = torch.sort(key, dim=1, descending=True)
-        L.check(lib.pmf_loss_lovasz_w(perm.data_ptr(), vals.data_ptr(), lab.data_ptr(), n, c, hw, cnt.data_ptr(),
-                                      w.data_ptr(), bsum.data_ptr(), dots.data_ptr(), rows.data_ptr(), gl.data_ptr(),
-                                      gc.data_ptr(), out8.data_ptr(), st), "pmf_loss_lovasz_w")
+        if _use_torch_sort():
+            vals, perm = torch.sort(key, dim=1, descending=True)
+            L.check(lib.pmf_loss_lovasz_w(perm.data_ptr(), vals.data_ptr(), lab.data_ptr(), n, c, hw, cnt.data_ptr(),
+                                          w.data_ptr(), bsum.data_ptr(), dots.data_ptr(), rows.data_ptr(), gl.data_ptr(),
+                                          gc.data_ptr(), out8.data_ptr(), st), "pmf_loss_lovasz_w")
+        else:
+            ws = _sort_workspace(lib, c, p, dev)
+            L.check(lib.pmf_loss_lovasz_sort_w(key.data_ptr(), lab.data_ptr(), n, c, hw, cnt.data_ptr(), w.data_ptr(),
+                                               ws.data_ptr(), bsum.data_ptr(), dots.data_ptr(), rows.data_ptr(),
+                                               gl.data_ptr(), gc.data_ptr(), out8.data_ptr(), st), "pmf_loss_lovasz_sort_w")
         terms = torch.stack([out8[1], out8[2], out8[3], out8[4], out8[6], out8[7]])
         ctx.save_for_backward(gl, gc, terms)
         ctx.mark_non_differentiable(out8)
