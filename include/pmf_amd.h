@@ -56,6 +56,23 @@ typedef struct {
  * (ep_relu_x*scale+shift > 0 at the output position), both used by the input-gradient form.
  * stats (optional): per-channel sum and sum of squares of the activated output, accumulated with atomics
  * into the FLOAT64 array stats[0..Cout) / stats[Cout..2Cout) (train-mode BatchNorm after the activation). */
+/* One destination of a multi-destination launch (pmf_conv_desc_t.ndst > 0): output channels [sum of the C of the
+ * destinations before it, + C) go to this tensor with this epilogue.  Used for the input gradient of a convolution over
+ * concatenated operands (torch.cat + Conv2d, salsanext.py:83-88,150-160; pmf_net.py:31-36): ONE pass over dz with all
+ * transposed weight columns, instead of one launch per operand each re-reading dz. */
+typedef struct {
+  float* out;
+  int32_t out_ldc, C;     /* C: channels of this destination; a multiple of 32 (64 for the 64-wide output tile) */
+  int32_t accumulate, ep_cmul_ld;
+  const float* ep_cmul;
+  const float* ep_relu_x;
+  const float* ep_relu_scale;
+  const float* ep_relu_shift;
+  int32_t ep_relu_ldc, ep_flags;
+  double* stats;          /* [rows][2][C] of THIS destination (rows = pmf_conv_fwd_stat_rows of the launch) */
+  const float* ep_stat_mean;
+} pmf_conv_dst_t;
+
 typedef struct {
   int32_t N, OH, OW;      /* GEMM M-space: output positions computed */
   int32_t Cout;
@@ -94,7 +111,13 @@ typedef struct {
                               * [ntaps][Ktot/16][ldw/32][3][64 lanes][8 bf16] (pmf_pack_job_t.format 1).  The launch then
                               * runs fp32 arithmetic on the bf16 matrix pipe (six split products, fp32 accumulate: see
                               * conv_fwd.hip PIPE 5); only for descriptors with pmf_conv_s3_eligible() != 0 */
+  int32_t ndst;              /* 0: one destination (out / ep_* above).  > 0: dst[0..ndst) replace out, out_ldc, accumulate,
+                              * ep_cmul, ep_relu_*, stats, ep_stat_mean and ep_flags per output-channel range; Cout = the sum
+                              * of their C, no bias, no K split (pmf_conv_multi_ok) */
+  pmf_conv_dst_t dst[PMF_MAX_SRC];
 } pmf_conv_desc_t;
+/* 1 when a descriptor with ndst > 0 can run as one launch (channel ranges on tile boundaries, no split-K workspace needed) */
+int pmf_conv_multi_ok(const pmf_conv_desc_t* d);
 #define PMF_EP_STAT_X_ONLY 1
 /* 1 when the descriptor runs the software-pipelined K loop (stride 1 -- or a stride-2 3x3 with all nine taps --, one halo tile,
  * every operand a multiple of 16 channels, same H x W, no broadcast): the class pmf_conv_fwd accepts w_s3 for.

@@ -30,6 +30,13 @@ class Src(C.Structure):
                 ("flags", C.c_int32), ("cmul_ld", C.c_int32)]
 
 
+class ConvDst(C.Structure):
+    _fields_ = [("out", C.c_void_p), ("out_ldc", C.c_int32), ("C", C.c_int32), ("accumulate", C.c_int32),
+                ("ep_cmul_ld", C.c_int32), ("ep_cmul", C.c_void_p), ("ep_relu_x", C.c_void_p),
+                ("ep_relu_scale", C.c_void_p), ("ep_relu_shift", C.c_void_p), ("ep_relu_ldc", C.c_int32),
+                ("ep_flags", C.c_int32), ("stats", C.c_void_p), ("ep_stat_mean", C.c_void_p)]
+
+
 class ConvDesc(C.Structure):
     _fields_ = [("N", C.c_int32), ("OH", C.c_int32), ("OW", C.c_int32), ("Cout", C.c_int32), ("nsrc", C.c_int32),
                 ("src", Src * MAX_SRC), ("ntaps", C.c_int32),
@@ -42,7 +49,7 @@ class ConvDesc(C.Structure):
                 ("ep_relu_scale", C.c_void_p), ("ep_relu_shift", C.c_void_p), ("ep_relu_ldc", C.c_int32),
                 ("stats", C.c_void_p), ("ep_pmask", C.c_void_p), ("splitk_ws", C.c_void_p),
                 ("splitk_ws_bytes", C.c_int64), ("cfg", C.c_int32), ("ep_flags", C.c_int32),
-                ("ep_stat_mean", C.c_void_p), ("w_s3", C.c_void_p)]
+                ("ep_stat_mean", C.c_void_p), ("w_s3", C.c_void_p), ("ndst", C.c_int32), ("dst", ConvDst * MAX_SRC)]
 
 
 class WgradDesc(C.Structure):
@@ -118,6 +125,8 @@ def lib():
     L.pmf_conv_wgrad_nsplit.argtypes = [C.POINTER(WgradDesc)]
     L.pmf_conv_wgrad_workspace.restype = C.c_int64
     L.pmf_conv_wgrad_workspace.argtypes = [C.POINTER(WgradDesc)]
+    L.pmf_conv_multi_ok.restype = C.c_int
+    L.pmf_conv_multi_ok.argtypes = [C.POINTER(ConvDesc)]
     L.pmf_conv_fwd_stat_rows.restype = C.c_int
     L.pmf_conv_fwd_stat_rows.argtypes = [C.POINTER(ConvDesc)]
     L.pmf_col_rows.restype = C.c_int
@@ -215,7 +224,7 @@ EXPORTS = [
     "pmf_maxpool3s2_bwd", "pmf_bilinear2x", "pmf_bilinear2x_bwd", "pmf_pixel_shuffle2", "pmf_pixel_shuffle2_bwd",
     "pmf_fusion_gate", "pmf_fusion_gate_bwd", "pmf_global_mean", "pmf_global_mean_bwd", "pmf_colsum",
     "pmf_pmask_from", "pmf_pmask_pool", "pmf_pmask_mul", "pmf_pmask_mul_bwd", "pmf_vec_add", "pmf_softmax_nhwc_to_nchw", "pmf_softmax_bwd_nchw_to_nhwc", "pmf_nchw_to_nhwc", "pmf_fill", "pmf_knn_vote", "pmf_merge_pred", "pmf_merge_pred_fallback",
-    "pmf_project_scatter", "pmf_project_v2_index", "pmf_project_v2_index_scaled", "pmf_project_v2_scatter", "pmf_points_transform", "pmf_range_project_index", "pmf_range_project_gather", "pmf_crop_pad", "pmf_flip_rotate_crop", "pmf_color_jitter", "pmf_lovasz_grad", "pmf_loss_rows", "pmf_loss_chunks", "pmf_loss_pixel", "pmf_loss_lovasz", "pmf_loss_pixel_w", "pmf_loss_lovasz_w", "pmf_loss_sort_workspace", "pmf_loss_lovasz_sort", "pmf_loss_lovasz_sort_w", "pmf_plan_run", "pmf_plan_run_range", "pmf_plan_capture", "pmf_graph_launch", "pmf_graph_destroy", "pmf_plan_lanes", "pmf_sizeof", "pmf_version",
+    "pmf_project_scatter", "pmf_project_v2_index", "pmf_project_v2_index_scaled", "pmf_project_v2_scatter", "pmf_points_transform", "pmf_range_project_index", "pmf_range_project_gather", "pmf_crop_pad", "pmf_flip_rotate_crop", "pmf_color_jitter", "pmf_lovasz_grad", "pmf_loss_rows", "pmf_loss_chunks", "pmf_loss_pixel", "pmf_loss_lovasz", "pmf_loss_pixel_w", "pmf_loss_lovasz_w", "pmf_loss_sort_workspace", "pmf_loss_lovasz_sort", "pmf_loss_lovasz_sort_w", "pmf_plan_run", "pmf_plan_run_range", "pmf_plan_capture", "pmf_graph_launch", "pmf_graph_destroy", "pmf_plan_lanes", "pmf_sizeof", "pmf_version", "pmf_conv_multi_ok",
 ]
 
 

@@ -88,33 +88,53 @@ __device__ __forceinline__ void conv_epilogue(const pmf_conv_desc_t& d, const Co
   PMF_SGPR_BATCH("s"(d.out), "s"(d.bias), "s"(d.act), "s"(d.Cout), "s"(d.out_ldc), "s"(d.out_H), "s"(d.out_W), "s"(d.out_sy),
                  "s"(d.out_sx), "s"(d.out_oy), "s"(d.out_ox), "s"(d.accumulate), "s"(d.ep_cmul), "s"(d.ep_cmul_ld),
                  "s"(d.ep_relu_x), "s"(d.ep_relu_scale), "s"(d.ep_relu_shift), "s"(d.ep_relu_ldc), "s"(d.stats),
-                 "s"(d.ep_pmask), "s"(d.ep_flags), "s"(d.ep_stat_mean));
+                 "s"(d.ep_pmask), "s"(d.ep_flags), "s"(d.ep_stat_mean), "s"(d.ndst));
+  // the destination of this workgroup's output channels: the descriptor's own fields, or (ndst > 0) the entry of dst[]
+  // whose channel range holds n0; channel indices below are relative to the destination (n0e), the bias index is not
+  float* e_out = d.out;
+  const float* e_cmul = d.ep_cmul;
+  const float* e_rx = d.ep_relu_x;
+  const float* e_rsc = d.ep_relu_scale;
+  const float* e_rsh = d.ep_relu_shift;
+  double* e_stats = d.stats;
+  const float* e_smean = d.ep_stat_mean;
+  int e_Cout = d.Cout, e_ldc = d.out_ldc, e_acc = d.accumulate, e_cmul_ld = d.ep_cmul_ld, e_rldc = d.ep_relu_ldc,
+      e_flags = d.ep_flags, n0e = n0;
+  if (d.ndst > 0) {
+    int k = 0, c0 = 0;
+    while (k + 1 < d.ndst && n0 >= c0 + d.dst[k].C) { c0 += d.dst[k].C; ++k; }
+    const pmf_conv_dst_t& t = d.dst[k];
+    e_out = t.out; e_cmul = t.ep_cmul; e_rx = t.ep_relu_x; e_rsc = t.ep_relu_scale; e_rsh = t.ep_relu_shift;
+    e_stats = t.stats; e_smean = t.ep_stat_mean;
+    e_Cout = t.C; e_ldc = t.out_ldc; e_acc = t.accumulate; e_cmul_ld = t.ep_cmul_ld; e_rldc = t.ep_relu_ldc;
+    e_flags = t.ep_flags; n0e = n0 - c0;
+  }
   {
-    const __amdgpu_buffer_rsrc_t orr = __builtin_amdgcn_make_buffer_rsrc((void*)d.out, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t orr = __builtin_amdgcn_make_buffer_rsrc((void*)e_out, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t xrr =
-        __builtin_amdgcn_make_buffer_rsrc((void*)d.ep_relu_x, 0, d.ep_relu_x ? 0x7fffffff : 0, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc((void*)e_rx, 0, e_rx ? 0x7fffffff : 0, 0x00020000);
     const float slope = d.act == PMF_ACT_LRELU ? 0.01f : (d.act == PMF_ACT_RELU ? 0.f : 1.f);
-    const bool sig = d.act == PMF_ACT_SIGMOID, has_rx = d.ep_relu_x != nullptr, accum = d.accumulate != 0;
-    const bool want_stats = d.stats != nullptr;
+    const bool sig = d.act == PMF_ACT_SIGMOID, has_rx = e_rx != nullptr, accum = e_acc != 0;
+    const bool want_stats = e_stats != nullptr;
     // BatchNorm-backward reduction riding on the last input-gradient launch into a gradient map: second column
     // sum v*(x - mean) instead of sum v^2 (x = the BN input, the same tensor the ReLU mask reads when there is one)
-    const bool stat_bwd = d.ep_stat_mean != nullptr, x_only = (d.ep_flags & PMF_EP_STAT_X_ONLY) != 0;
+    const bool stat_bwd = e_smean != nullptr, x_only = (e_flags & PMF_EP_STAT_X_ONLY) != 0;
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
-      const int co = n0 + u * 32 + li;
-      const bool cok = co < d.Cout;
-      const float bias = (cok && d.bias) ? d.bias[co] : 0.f;
-      const float ecm = (cok && d.ep_cmul) ? d.ep_cmul[(size_t)n * d.ep_cmul_ld + co] : 1.f;
-      const float smu = (cok && stat_bwd) ? d.ep_stat_mean[co] : 0.f;
+      const int co = n0e + u * 32 + li;
+      const bool cok = co < e_Cout;
+      const float bias = (cok && d.bias) ? d.bias[n0 + u * 32 + li] : 0.f;
+      const float ecm = (cok && e_cmul) ? e_cmul[(size_t)n * e_cmul_ld + co] : 1.f;
+      const float smu = (cok && stat_bwd) ? e_smean[co] : 0.f;
       float rs = 1.f, rt = 0.f;
-      if (cok && has_rx && d.ep_relu_scale) { rs = d.ep_relu_scale[co]; rt = d.ep_relu_shift[co]; }
+      if (cok && has_rx && e_rsc) { rs = e_rsc[co]; rt = e_rsh[co]; }
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
         const int oy = oy0 + segrow[m], oxb = ox0 + segcol[m] * 32 + 4 * lh;
         const bool rok = cok && oy < d.OH;
         const int pix0 = (n * d.out_H + oy * d.out_sy + d.out_oy) * d.out_W + oxb * d.out_sx + d.out_ox;
-        const int obase = (pix0 * d.out_ldc + co) * 4, ostep = d.out_sx * d.out_ldc * 4;
-        const int xbase = (pix0 * d.ep_relu_ldc + co) * 4, xstep = d.out_sx * d.ep_relu_ldc * 4;
+        const int obase = (pix0 * e_ldc + co) * 4, ostep = d.out_sx * e_ldc * 4;
+        const int xbase = (pix0 * e_rldc + co) * 4, xstep = d.out_sx * e_rldc * 4;
         unsigned off[16];
         float xr[16], old[16], pm[16];
 #pragma unroll
@@ -162,7 +182,7 @@ __device__ __forceinline__ void conv_epilogue(const pmf_conv_desc_t& d, const Co
     }
   }
   TR();
-  if (d.stats) {
+  if (e_stats) {
     __syncthreads();
     double* red = (double*)smem;  // [4 waves][NT][32][2]
 #pragma unroll
@@ -176,8 +196,8 @@ __device__ __forceinline__ void conv_epilogue(const pmf_conv_desc_t& d, const Co
     }
     __syncthreads();
     if (tid < BN) {
-      const int u = tid >> 5, l = tid & 31, co = n0 + tid;
-      if (co < d.Cout) {
+      const int u = tid >> 5, l = tid & 31, co = n0e + tid;
+      if (co < e_Cout) {
         double a = 0.0, b = 0.0;
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
@@ -186,9 +206,9 @@ __device__ __forceinline__ void conv_epilogue(const pmf_conv_desc_t& d, const Co
         }
         // one partial row per (tile, sample): no atomics (contended f64 atomics cost ~80 us per launch); the
         // BatchNorm finalize kernel folds the rows in a fixed order (deterministic)
-        double* row = d.stats + ((size_t)tile + (size_t)gridDim.x * n) * 2 * d.Cout;
+        double* row = e_stats + ((size_t)tile + (size_t)gridDim.x * n) * 2 * e_Cout;
         row[co] = a;
-        row[d.Cout + co] = b;
+        row[e_Cout + co] = b;
       }
     }
   }

@@ -1190,6 +1190,20 @@ static int pmf_conv_finish_launch(const pmf_conv_desc_t* d, const ConvGeom& g, h
   return 0;
 }
 
+// multi-destination launches (pmf_conv_desc_t.ndst): every channel range starts on an output-channel tile
+static int multi_tile(const pmf_conv_desc_t* d) {        // 64 / 32: the widest tile all ranges allow; 0: none
+  int t = 64, sum = 0;
+  for (int i = 0; i < d->ndst; ++i) {
+    if (d->dst[i].C <= 0 || d->dst[i].C % 32) return 0;
+    if (d->dst[i].C % 64) t = 32;
+    sum += d->dst[i].C;
+  }
+  return sum == d->Cout ? t : 0;
+}
+extern "C" int pmf_conv_multi_ok(const pmf_conv_desc_t* d) {
+  return d && d->ndst > 0 && d->ndst <= PMF_MAX_SRC && !d->bias && multi_tile(d) != 0;
+}
+
 static int conv_direct_lds(const pmf_conv_desc_t* d, int BN);
 static bool conv_s3_fits(const pmf_conv_desc_t* d, int MT);
 static bool conv_s3_stride2(const pmf_conv_desc_t* d);
@@ -1202,6 +1216,7 @@ static void conv_config(const pmf_conv_desc_t* d, int* BN, int* MT) {
   // LDS-staged split loop: the 256-pixel tile may not qualify where the 128-pixel one does (dilated 3x3 on a 4-row map)
   if (d->w_s3 && d->ntaps > 1 && *MT == 2 && !conv_s3_fits(d, 2)) *MT = 1;
   if (d->w_s3 && d->in_stride == 2 && d->ntaps > 1) *MT = 1;      // the stride-2 split loop: 128-pixel tiles
+  if (d->ndst > 0 && *BN == 64 && multi_tile(d) == 32) *BN = 32;   // a 32-channel destination: no tile may straddle two
 }
 static void conv_config_(const pmf_conv_desc_t* d, int* BN, int* MT) {
   if (d->cfg) {                       // caller-tuned tile configuration
@@ -1376,7 +1391,8 @@ static int launch(const pmf_conv_desc_t* d, hipStream_t s) {
     for (int i = 0; i < d->nsrc; ++i) nchunks += d->src[i].C / (KC * 4);
     lds = (g.a_floats * 4 + 4 * KC * BN) * 4;
   }
-  g.ksplit = choose_ksplit(d, g.tiles_x * g.tiles_y * d->N * co_tiles, nchunks, d->ntaps * 8 * MT * (BN / 32));
+  if (d->ndst > 0 && !pmf_conv_multi_ok(d)) return PMF_E_ARG;
+  g.ksplit = d->ndst > 0 ? 1 : choose_ksplit(d, g.tiles_x * g.tiles_y * d->N * co_tiles, nchunks, d->ntaps * 8 * MT * (BN / 32));
   g.ws = d->splitk_ws;
   g.ws_ld = round_up(d->Cout, 4);
   dim3 grid(g.tiles_x * g.tiles_y, co_tiles * g.ksplit, d->N);
@@ -1428,6 +1444,7 @@ extern "C" int pmf_conv_fwd_stat_rows(const pmf_conv_desc_t* d) {
     for (int i = 0; i < d->nsrc; ++i) nchunks += d->src[i].C / (KC * sl);
   }
   if (conv_direct_lds(d, BN)) nchunks = 1;
+  if (d->ndst > 0) return tiles * d->N;
   if (choose_ksplit(d, tiles * d->N * cdiv(d->Cout, BN), nchunks, d->ntaps * 8 * MT * (BN / 32)) > 1) return finish_rows(d);
   return tiles * d->N;
 }

@@ -597,7 +597,8 @@ class Plan:
                         a.i[0], a.i[1], a.i[2] = Cout, nrows, bn_train_flag
                         a.l[0] = out.npix
                     self.emit(self.bwd, L.OP_BN_BWD_FOLD, r1)
-                    self._conv_fold[lw["index"]] = len(self.bwd) - 1
+                    self._conv_fold.setdefault(lw["index"], []).append(len(self.bwd) - 1)     # (a multi-destination
+                    #                                                      launch feeds one fold per destination)
                 else:
                     def r1(op):
                         a = op.u.sm
@@ -728,6 +729,68 @@ class Plan:
             dg_s3 = [False] * len(classes)
         packs = None if own_packs else [self.add_pack(conv.weight, [t[2] for t in sub], 1, Kd, ldwT, int(k3))
                                         for (_, _, sub), k3 in zip(classes, dg_s3)]
+        # ---- one launch for all operands of a concatenated input (stride 1, split-bf16 path, every operand a whole number
+        # of 32-channel fragments): dz is read ONCE and the output-channel ranges go to the operands' gradient tensors, each
+        # with its own epilogue (accumulate / Dropout2d multiplier / ReLU mask / BatchNorm-backward partial sums)
+        merged = (stride == 1 and len(srcs) >= 2 and not own_packs and aligned and all(dg_s3) and len(srcs) <= L.MAX_SRC
+                  and all(s.t.needs_grad and not s.bcast and s.t.C % 32 == 0 for s in srcs)
+                  and dz.N * dz.H * dz.W >= int(os.environ.get("PMF_DGRAD_MERGE_MINPIX", "1024")) and os.environ.get("PMF_DGRAD_MERGE", "1") != "0")
+        if merged:
+            (_, _, sub), wT = classes[0], packs[0]
+            parts = []
+            for s in srcs:
+                r = s.root()
+                tgt, acc = self.grad_of(s)
+                parts.append(dict(s=s, r=r, tgt=tgt, acc=acc, relu_x=(r.t if r.relu else None), hook={}))
+            Ctot = sum(pt["s"].t.C for pt in parts)
+
+            def shape_only(d, sub=sub, parts=parts, Ctot=Ctot):
+                d.N, d.OH, d.OW = dz.N, ref.t.H, ref.t.W
+                d.Cout, d.nsrc = Ctot, 1
+                sv = d.src[0]
+                sv.C, sv.ldc, sv.H, sv.W = Kd, dz.ldc, dz.H, dz.W
+                d.ntaps = len(sub)
+                for i, (dy, dx, _) in enumerate(sub):
+                    d.tdy[i], d.tdx[i] = dy, dx
+                d.in_stride, d.gather = 1, gather
+                d.out_sy = d.out_sx = 1
+                d.w_s3 = 1
+                d.ndst = len(parts)
+                for k, pt in enumerate(parts):
+                    d.dst[k].C = pt["s"].t.C
+
+            def f(op, parts=parts, wT=wT, shape_only=shape_only, ldwT=ldwT):
+                d = op.u.conv
+                shape_only(d)
+                d.src[0].x = dz.buf.ptr
+                d.ldw = ldwT
+                d.w_s3 = wT.ptr
+                d.act = L.ACT_NONE
+                d.out_H, d.out_W = ref.t.H, ref.t.W
+                d.out, d.out_ldc = parts[0]["tgt"].buf.ptr, parts[0]["tgt"].ldc
+                for k, pt in enumerate(parts):
+                    e, s, r, tgt = d.dst[k], pt["s"], pt["r"], pt["tgt"]
+                    e.out, e.out_ldc, e.accumulate = tgt.buf.ptr, tgt.ldc, pt["acc"]
+                    if s.cmul is not None:
+                        e.ep_cmul, e.ep_cmul_ld = self.masks_ptr + 4 * s.cmul, s.cmul_ld
+                    if pt["relu_x"] is not None:
+                        e.ep_relu_x, e.ep_relu_ldc = pt["relu_x"].buf.ptr, pt["relu_x"].ldc
+                        e.ep_relu_scale = r.scale.ptr if r.scale is not None else None
+                        e.ep_relu_shift = r.shift.ptr if r.shift is not None else None
+                    if pt["hook"]:
+                        e.stats, e.ep_stat_mean = pt["hook"]["rows"].ptr, pt["hook"]["mean"].ptr
+                        if pt["relu_x"] is None:
+                            e.ep_relu_x, e.ep_relu_ldc, e.ep_flags = r.t.buf.ptr, r.t.ldc, L.EP_STAT_X_ONLY
+            self.emit(self.bwd, L.OP_CONV, f)
+            for pt in parts:
+                r = pt["r"]
+                if r.bn is not None and pt["tgt"] is r.gy and self.bn_bwd_fused:
+                    r._gy_last = dict(hook=pt["hook"], index=len(self.bwd) - 1, shape=shape_only, lane=lane)
+            self.meta_bwd[len(self.bwd) - 1] = dict(
+                family="conv_dgrad", flops=2.0 * dz.N * ref.t.H * ref.t.W * Ctot * Cout * len(sub), name=name,
+                shape="%dx%dx%d %d->%s t%d s1" % (dz.N, ref.t.H, ref.t.W, Cout, "+".join(str(pt["s"].t.C) for pt in parts),
+                                                  len(sub)))
+            return
         coloff = 0
         for s in srcs:
             Cs = _ru(s.t.C, 8)
@@ -1396,8 +1459,8 @@ class Plan:
                 d = ops[k].u.conv
                 d.cfg = cfg
                 fin = fins.get(k - shift)
-                if fin is not None:
-                    ops[fin + shift].u.sm.i[1] = lib.pmf_conv_fwd_stat_rows(C.byref(d))
+                for fi in (fin if isinstance(fin, list) else ([] if fin is None else [fin])):
+                    ops[fi + shift].u.sm.i[1] = lib.pmf_conv_fwd_stat_rows(C.byref(d))
         self._graphs.clear()
 
     def autotune(self):
@@ -1435,7 +1498,9 @@ class Plan:
                           for i in range(d.nsrc)),
                     d.ntaps, tuple(d.tdy[i] for i in range(d.ntaps)), tuple(d.tdx[i] for i in range(d.ntaps)),
                     d.in_stride, d.gather, d.act, d.out_sy, d.out_sx, d.accumulate, bool(d.bias), bool(d.ep_cmul),
-                    bool(d.ep_relu_x), bool(d.stats), bool(d.ep_pmask), bool(d.ep_stat_mean), d.ep_flags, bool(d.w_s3))
+                    bool(d.ep_relu_x), bool(d.stats), bool(d.ep_pmask), bool(d.ep_stat_mean), d.ep_flags, bool(d.w_s3),
+                    tuple((d.dst[i].C, d.dst[i].accumulate, bool(d.dst[i].ep_relu_x), bool(d.dst[i].stats))
+                          for i in range(d.ndst)))
 
         for ops, n, kinds, shift, fins in ((self.fwd_ops, self.n_fwd, self.fwd_kinds, self.fwd_shift, self._conv_fin),
                                            (self.bwd_ops, self.n_bwd, self.bwd_kinds, self.bwd_shift, self._conv_fold)):
@@ -1462,8 +1527,8 @@ class Plan:
                     _TUNED[key] = best
                 d.cfg = _TUNED[key]
                 fin = fins.get(k - shift)
-                if fin is not None:
-                    ops[fin + shift].u.sm.i[1] = lib.pmf_conv_fwd_stat_rows(C.byref(d))
+                for fi in (fin if isinstance(fin, list) else ([] if fin is None else [fin])):
+                    ops[fi + shift].u.sm.i[1] = lib.pmf_conv_fwd_stat_rows(C.byref(d))
         # (a tuner over the weight-gradient kernel variant / pixel-split count was measured at 25.44 vs 25.45 ms per
         # step -- no gain over the built-in rules -- and removed.)
         torch.cuda.synchronize(self.device)
