@@ -102,6 +102,13 @@ CONVS = [
     ("c3x3_wpipe", 2, 8, 64, [32, 64], 64, 3, 1, 1, 1, True, "act_bn", True),
     ("c3x3d2_wpipe", 1, 12, 32, [64], 32, 3, 2, 2, 1, False, "bn_relu", True),
     ("c2x2d2_wpipe", 2, 8, 64, [64], 64, 2, 2, 1, 1, True, "act_bn", True),
+    # ResNet-50 bottleneck 1x1 layers at their real channel counts: 1024 / 2048 input channels (the weight fragments of one
+    # output-channel tile do not fit LDS: these run on the generic loop), 256 -> 1024, the stride-2 projection
+    ("c1x1_k1024", 2, 8, 32, [1024], 256, 1, 1, 0, 1, False, "bn_relu", True),
+    ("c1x1_k2048", 1, 4, 64, [2048], 512, 1, 1, 0, 1, False, "bn_relu", True),
+    ("c1x1_to1024", 2, 8, 32, [256], 1024, 1, 1, 0, 1, False, "bn_norelu", True),
+    ("c1x1_k1040_cat", 1, 8, 32, [1024, 16], 64, 1, 1, 0, 1, True, "act_bn", True),
+    ("c1x1s2_k1024", 2, 8, 32, [1024], 2048, 1, 1, 0, 2, False, "bn_norelu", True),
 ]
 
 
@@ -125,7 +132,7 @@ def test_conv_unit_fwd_bwd(case):
 
 
 DIRECT_1X1 = [c for c in CONVS if c[0] in ("c1x1cat3", "c1x1_plain_lrelu", "c1x1s2", "c1x1cat3_big", "c1x1_odd_big",
-                                            "c1x1_c20_big", "c1x1_wide_big", "c1x1_odd_wide")]
+                                            "c1x1_c20_big", "c1x1_wide_big", "c1x1_odd_wide", "c1x1_to1024")]
 
 
 @pytest.mark.parametrize("case", DIRECT_1X1, ids=[c[0] for c in DIRECT_1X1])

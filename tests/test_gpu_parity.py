@@ -417,6 +417,13 @@ def test_wholenet_backward_well_conditioned():
     for k, e_h, _ in rows:
         if k.startswith(("lidar_stream.logits", "lidar_stream.upBlock4.conv4", "camera_stream_decoder.conv")):
             assert e_h < 1e-4, (k, e_h)
+    # the per-parameter bar above admits anything up to the CPU oracle's worst error: rule out a SYSTEMATIC excess over the
+    # fp32 CPU path as well -- over all parameters the HIP errors must be distributed like the CPU oracle's own (measured:
+    # geometric mean of the ratio 1.13, 90th percentile 1.67; a path twice as far from float64 everywhere would show 2.0)
+    ratio = np.array([r[1] / max(r[2], 1e-12) for r in rows if r[2] > 1e-6])
+    gmean, p90 = float(np.exp(np.log(np.maximum(ratio, 1e-6)).mean())), float(np.percentile(ratio, 90))
+    assert gmean < 1.5 and p90 < 2.5, "HIP gradients systematically further from float64 than the fp32 CPU oracle: " \
+        "geometric-mean ratio %.2f, 90th percentile %.2f" % (gmean, p90)
 
 
 def _full_size_train_mode(hip, ref, n, h, w, ncls):
