@@ -15,6 +15,17 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define PMF_COL_ROWS 512   // max partial rows written by the column-reduction kernels (one per workgroup)
 
+// true the first time it is called with `mask` on the current device: per-device one-time work (the dynamic-LDS function
+// attribute is a property of the (function, device) pair)
+static inline bool pmf_first_on_device(unsigned long long* mask) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev >= 64) return true;
+  const bool first = !((*mask >> dev) & 1ull);
+  *mask |= 1ull << dev;
+  return first;
+}
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return cdiv(a, b) * b; }

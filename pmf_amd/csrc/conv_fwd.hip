@@ -1340,8 +1340,9 @@ static int launch(const pmf_conv_desc_t* d, hipStream_t s) {
   g.Ktot = Ktot;
   pmf_conv_desc_t dd = *d;
   dd.gather = gather;
-  static bool attr_set = false;
-  if (!attr_set) {
+  // the 160 KiB dynamic-LDS attribute is per device: set it again when the current device changes (one bit per device)
+  static unsigned long long attr_devs = 0ull;
+  if (pmf_first_on_device(&attr_devs)) {
     (void)hipFuncSetAttribute((const void*)conv_fwd_k<BN, MT, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)conv_fwd_k<BN, MT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if constexpr (MT == 1)
@@ -1354,7 +1355,6 @@ static int launch(const pmf_conv_desc_t* d, hipStream_t s) {
     (void)hipFuncSetAttribute((const void*)conv_fwd_k<BN, MT, 11>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if constexpr (MT == 1)
       (void)hipFuncSetAttribute((const void*)conv_fwd_k<BN, 1, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
   }
   const int co_tiles = cdiv(d->Cout, BN);
   int mode = conv_pipe_mode(d, g, gather, MT);

@@ -1528,24 +1528,22 @@ static int wg_launch(const pmf_wgrad_desc_t* d, hipStream_t s, int phase) {
   wg_geometry(d, TB, NT * 32, &g, &lds);
   if (lds > 160 * 1024) return PMF_E_UNSUPPORTED;
   if (!(phase & 1)) return wg_reduce(d, g, s);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_set = 0ull;
+  if (pmf_first_on_device(&attr_set)) {
     (void)hipFuncSetAttribute((const void*)conv_wgrad_k<TB, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if constexpr (NT == 1) {
       (void)hipFuncSetAttribute((const void*)conv_wgrad_pipe_k<TB, 1, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       (void)hipFuncSetAttribute((const void*)conv_wgrad_pipe_k<TB, 1, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
-    attr_set = true;
   }
   dim3 grid(d->nsplit, g.nchunks, g.co_tiles * g.tap_batches);
   bool piped = false;
   if constexpr (NT == 1) {
     if ((d->flags & PMF_WGRAD_S3) && wg_simple(d, g, TB, 32, 16)) {
-      static bool attr3 = false;
-      if (!attr3) {
+      static unsigned long long attr3 = 0ull;
+      if (pmf_first_on_device(&attr3)) {
         (void)hipFuncSetAttribute((const void*)conv_wgrad_s3_k<TB, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)conv_wgrad_s3_k<TB, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr3 = true;
       }
       g.x_floats = g.in_rows * g.in_cols * (WS3_XPB / 4);
       int lds3 = (g.x_floats + WG_ROWS * 32 * 32) * 4;
@@ -1597,13 +1595,12 @@ static int wg_launch_fewc(const pmf_wgrad_desc_t* d, hipStream_t s, int phase) {
   wg_geometry_fewc(d, &g, &lds);
   if (!(phase & 1)) return wg_reduce(d, g, s);
   const int KGn = cdiv(d->ntaps * d->Cin_real, 32);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_set = 0ull;
+  if (pmf_first_on_device(&attr_set)) {
     (void)hipFuncSetAttribute((const void*)wgrad_fewc_k<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)wgrad_fewc_k<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)wgrad_fewc_k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)wgrad_fewc_k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
   }
   dim3 grid(d->nsplit, 1, g.co_tiles);
   if (KGn <= 1) hipLaunchKernelGGL((wgrad_fewc_k<1>), grid, dim3(256), lds, s, *d, g);
@@ -1636,11 +1633,10 @@ static int wgrad_phases(const pmf_wgrad_desc_t* d, pmf_stream_t st, int phase) {
     if (phase & 1) {
       if (((uintptr_t)d->dz & 7) != 0) return PMF_E_ARG;       // float2 loads of dz
       wg_direct_grid(d, &kb, &ob, &nco);
-      static bool attr_set = false;
-      if (!attr_set) {
+      static unsigned long long attr_set = 0ull;
+      if (pmf_first_on_device(&attr_set)) {
         (void)hipFuncSetAttribute((const void*)wgrad_1x1_k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
         (void)hipFuncSetAttribute((const void*)wgrad_1x1_k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-        attr_set = true;
       }
       const dim3 grid(d->nsplit, kb, ob);
       if (wg_direct_s3(d)) hipLaunchKernelGGL(wgrad_1x1_s3_k, grid, dim3(256), 4 * 16 * 64 * 4, s, *d, g.Ktot, g.Cout32);

@@ -113,7 +113,20 @@ static hipStream_t g_lane[PMF_MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
 static hipEvent_t g_fork = nullptr, g_join[PMF_MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
 static hipEvent_t g_ev[PMF_MAX_EVENTS];
 static int g_nev = 0;
+// The lane streams and events above belong to ONE device (one process per GPU): they are created on the
+// device that is current at the first lane use, and a plan run with another device current is refused instead of being
+// enqueued on foreign streams.  (The lazily created objects are not guarded against concurrent first use either: plans
+// are run from one thread per process.)
+static int g_lane_dev = -1;
+static int lane_device_ok() {
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return (int)e;
+  if (g_lane_dev < 0) g_lane_dev = dev;
+  return dev == g_lane_dev ? 0 : PMF_E_UNSUPPORTED;
+}
 static int lane_stream(int lane, hipStream_t* out) {
+  if (int rc = lane_device_ok()) return rc;
   if (!g_lane[lane]) {
     hipError_t e = hipStreamCreateWithFlags(&g_lane[lane], hipStreamNonBlocking);
     if (e != hipSuccess) return (int)e;
@@ -128,6 +141,7 @@ static int lane_stream(int lane, hipStream_t* out) {
   return 0;
 }
 static int plan_event(int e, hipEvent_t* out) {
+  if (int rc = lane_device_ok()) return rc;
   while (g_nev <= e) {
     hipError_t r = hipEventCreateWithFlags(&g_ev[g_nev], hipEventDisableTiming);
     if (r != hipSuccess) return (int)r;

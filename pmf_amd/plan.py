@@ -249,8 +249,17 @@ class Plan:
             return
         key = (id(lst), self.lane)
         cur = self._pending_wait.get(key)
+        if cur is not None and self._event_lane(lst, cur) != self._event_lane(lst, ev):
+            # list position implies happens-before only along ONE lane: two pending waits on different source lanes
+            # cannot be folded into one slot (an op carries a single wait)
+            raise RuntimeError("plan: an op would have to wait for events of two different lanes (%r, %r)" % (cur, ev))
         if cur is None or ev[1] > cur[1]:
             self._pending_wait[key] = ev
+
+    @staticmethod
+    def _event_lane(lst, ev):
+        """lane of the op behind which plan event ``ev`` = (id, list position) is recorded"""
+        return lst[ev[1]][2] & 3
 
     def on_backward(self, fn):
         """register the backward of the op(s) just emitted; it is emitted on the lane of its forward."""
@@ -274,10 +283,15 @@ class Plan:
             own = [e for e in lst[a:b] if (e[2] & 3) == lane]      # (weight gradients sit on their own lane)
             if not own:
                 continue
-            first, last, wait = own[0], own[-1], None
+            first, last, wait, wait_lane = own[0], own[-1], None, None
             for g in touched:
                 lw = getattr(g, "_last_touch", None)
                 if lw is not None and lw[0] != lane:
+                    if wait_lane is not None and lw[0] != wait_lane:
+                        # the latest position subsumes earlier ones only along one lane (see wait_event)
+                        raise RuntimeError("plan: backward entry on lane %d depends on gradients last written on lanes %d "
+                                           "and %d; an op carries one wait" % (lane, wait_lane, lw[0]))
+                    wait_lane = lw[0]
                     ev = self._event_after(lw[1])
                     if wait is None or ev[1] > wait[1]:
                         wait = ev
