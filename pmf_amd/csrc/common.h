@@ -68,6 +68,16 @@ __device__ __forceinline__ void pmf_sgb_seq() {
   }
 }
 
+// a / b for 0 <= a < 2^22, b > 0 through the float reciprocal rb = 1.f / b with one correction step (exact): the slot tables
+// of the conv prologues divide a dozen times per thread, and an integer division is ~40 instructions on this machine
+__device__ __forceinline__ int pmf_fdiv(int a, int b, float rb) {
+  int q = (int)((float)a * rb);
+  const int r = a - q * b;
+  q += r >= b ? 1 : 0;
+  q -= r < 0 ? 1 : 0;
+  return q;
+}
+
 // geometry shared by conv forward / weight-gradient host code
 struct ConvGeom {
   int segs_x_log2;  // 32-pixel segments across the tile (log2)

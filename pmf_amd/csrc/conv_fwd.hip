@@ -168,8 +168,8 @@ __device__ __forceinline__ void conv_kloop_pipe(const pmf_conv_desc_t& d, const 
   unsigned okA = 0u;
 #pragma unroll
   for (int j = 0; j < ASL; ++j) {
-    const int f = tid + 256 * j, pix = VT > 1 ? (f >> 2) % npixA : (f >> 2);
-    const int r = pix / in_cols, c = pix - r * in_cols;
+    const int f = tid + 256 * j, pix = VT > 1 ? (f >> 2) - pmf_fdiv(f >> 2, npixA, 1.f / (float)npixA) * npixA : (f >> 2);
+    const int r = pmf_fdiv(pix, in_cols, 1.f / (float)in_cols), c = pix - r * in_cols;
     const int iy = oy0 + g.dy_min + r, ix = ox0 + g.dx_min + c;
     const bool ok = f < totalA && iy >= 0 && iy < sH && ix >= 0 && ix < sW;
     gA[j] = ok ? (n * sH + iy) * sW + ix : -1;   // -1: negative byte offset = out of range = the buffer load returns 0
@@ -474,8 +474,8 @@ __device__ __forceinline__ void conv_kloop_s3(const pmf_conv_desc_t& d, const Co
   unsigned okA = 0u;
 #pragma unroll
   for (int j = 0; j < ASL; ++j) {
-    const int f = tid + 256 * j, pix = SL > 1 ? (f >> 2) % npixA : (f >> 2);
-    const int r = pix / in_cols, c = pix - r * in_cols;
+    const int f = tid + 256 * j, pix = SL > 1 ? (f >> 2) - pmf_fdiv(f >> 2, npixA, 1.f / (float)npixA) * npixA : (f >> 2);
+    const int r = pmf_fdiv(pix, in_cols, 1.f / (float)in_cols), c = pix - r * in_cols;
     const int iy = oy0 * IS + g.dy_min + r, ix = ox0 * IS + g.dx_min + c;
     const bool ok = f < totalA && iy >= 0 && iy < sH && ix >= 0 && ix < sW;
     gA[j] = ok ? (n * sH + iy) * sW + ix : -1;
