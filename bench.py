@@ -754,7 +754,7 @@ def main():
         # read from inside the process); tools/pmc_traffic.py wrote the summary that is committed under profiles/
         headline = args.model == "pmf" and args.backbone == "resnet34" and args.nclasses == 20 and \
             (args.height, args.width, args.bs) == (64, 2048, 2)
-        for tp in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for tp in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             tp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", tp)
             if headline and os.path.exists(tp):
                 with open(tp) as f:

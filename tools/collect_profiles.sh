@@ -1,25 +1,25 @@
 #!/bin/bash
-# Run ON the GPU box (gpurun -- 'bash tools/collect_profiles.sh r02'): collects the round's rocprofv3 evidence into
+# Run ON the GPU box (gpurun -- 'bash tools/collect_profiles.sh r03'): collects the round's rocprofv3 evidence into
 # gpurun_out/<tag>/ ; copy the summaries from there into profiles/ (tracked).
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
 export PMF_TUNE_CACHE=/tmp/pmf_tune.txt        # same tile configurations in every pass
-python $ROOT/bench.py --steps 5 --warmup 3 --no-cpu-baseline --no-roofline --no-f32-ref > $OUT/bench_plain.json 2> /dev/null
+python $ROOT/bench.py --steps 5 --warmup 3 --no-cpu-baseline --no-roofline --no-f32-ref --no-parity > $OUT/bench_plain.json 2> /dev/null
 # 1. per-kernel statistics of the default bench command
 rm -rf /tmp/p1; rocprofv3 --kernel-trace --stats -d /tmp/p1 -o r -- python $ROOT/bench.py --no-cpu-baseline --no-f32-ref > $OUT/bench_under_rocprof.json 2> /dev/null
 python $ROOT/tools/rocpd_stats.py /tmp/p1/r_results.db $OUT/${TAG}_bench_kernel_stats.csv 0.5 > /dev/null
 # 2. per-layer kernel durations (one lane: launch order = op order)
-rm -rf /tmp/p2; PMF_LANES=0 rocprofv3 --kernel-trace -d /tmp/p2 -o j -- python $ROOT/bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-f32-ref --profile-out $OUT/ops.txt > /dev/null 2>&1
+rm -rf /tmp/p2; PMF_LANES=0 rocprofv3 --kernel-trace -d /tmp/p2 -o j -- python $ROOT/bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-f32-ref --no-parity --profile-out $OUT/ops.txt > /dev/null 2>&1
 python $ROOT/tools/rocpd_join.py /tmp/p2/j_results.db $OUT/ops.txt 14 $OUT/${TAG}_per_layer_kernel_times.txt
 # 3. HBM-side traffic of the conv launches: FETCH_SIZE and WRITE_SIZE in separate passes
 for c in FETCH_SIZE WRITE_SIZE; do
-  rm -rf /tmp/p_$c; rocprofv3 --kernel-trace --pmc $c -d /tmp/p_$c -o t -- python $ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-f32-ref > /dev/null 2>&1
+  rm -rf /tmp/p_$c; rocprofv3 --kernel-trace --pmc $c -d /tmp/p_$c -o t -- python $ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-f32-ref --no-parity > /dev/null 2>&1
 done
 python $ROOT/tools/pmc_traffic.py /tmp/p_FETCH_SIZE/t_results.db /tmp/p_WRITE_SIZE/t_results.db $OUT/${TAG}_pmc_traffic.json > /dev/null
 # 4. matrix-pipe utilisation of the conv kernels
-rm -rf /tmp/p4; rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_BF16 SQ_INSTS_VALU_MFMA_F32 -d /tmp/p4 -o m -- python $ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-f32-ref > /dev/null 2>&1
+rm -rf /tmp/p4; rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_BF16 SQ_INSTS_VALU_MFMA_F32 -d /tmp/p4 -o m -- python $ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-f32-ref --no-parity > /dev/null 2>&1
 python $ROOT/tools/pmc_summary.py /tmp/p4/m_results.db conv > $OUT/${TAG}_pmc_mfma.txt 2>&1
 ls -la $OUT
