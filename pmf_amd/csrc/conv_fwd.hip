@@ -689,14 +689,23 @@ __device__ __forceinline__ void conv_kloop_direct(const pmf_conv_desc_t& d, cons
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int Ktot = g.Ktot, nks = Ktot >> 4, CT = d.ldw >> 5;
   const int is = d.in_stride, sH = d.src[0].H, sW = d.src[0].W;
-  const int nfrag = nks * NT * 3;
-  {  // ---- every weight fragment of this output-channel tile -> LDS, one 1-KiB DMA instruction each
+  // weights: every fragment of this output-channel tile resident in LDS (kchunk 0), or streamed in chunks of kchunk
+  // 16-channel steps through two buffers: chunk c + 1 is DMA'd while chunk c is multiplied, one wait + barrier per chunk
+  // (layers whose fragments would leave room for only one workgroup per CU)
+  const int kch = g.kchunk;
+  const int nres = kch ? kch : nks;                    // steps per buffer
+  const int bufbytes = nres * NT * 3 * 1024;
+  auto dma_chunk = [&](int c, char* __restrict__ dst) {
+    const int k0 = c * nres;
+    const int nf = min(nks - k0, nres) * NT * 3;
     const char* wsrc = (const char*)d.w_s3 + (size_t)(n0 >> 5) * 3 * 1024 + lane * 16;
-    for (int f = wave; f < nfrag; f += 4) {
+    for (int f = wave; f < nf; f += 4) {
       const int k16 = f / (NT * 3), up = f - k16 * (NT * 3);
-      __builtin_amdgcn_global_load_lds((const float*)(wsrc + ((size_t)k16 * CT * 3 + up) * 1024), (lds_ptr_t)(Bs + f * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const float*)(wsrc + ((size_t)(k0 + k16) * CT * 3 + up) * 1024), (lds_ptr_t)(dst + f * 1024), 16, 0, 0);
     }
-  }
+  };
+  dma_chunk(0, Bs);
+  const int nfrag = (kch ? 2 : 1) * nres * NT * 3;     // (fragment slots ahead of the operand table)
   bool plain = true;
   for (int i = 0; i < d.nsrc; ++i)
     plain = plain && !d.src[i].scale && !d.src[i].cmul && !(d.src[i].flags & PMF_SRC_RELU);
@@ -826,8 +835,20 @@ __device__ __forceinline__ void conv_kloop_direct(const pmf_conv_desc_t& d, cons
     if (!G || kk + 3 < nks) mma(kk + 3, a1);
   };
   int kk = 0;
-  for (; kk + PF <= nks; kk += PF) quad(kk, std::false_type{});
-  if (kk < nks) quad(kk, std::true_type{});
+  for (int c = 0; c * nres < nks; ++c) {
+    const int kend = min(nks, (c + 1) * nres);
+    if (kch) {
+      // buffer (c + 1) & 1 was last read in chunk c - 1, and every wave has passed the barrier behind that chunk
+      if (kend < nks) dma_chunk(c + 1, Bs + ((c + 1) & 1) * bufbytes);
+      bp = Bs + (c & 1) * bufbytes + lane * 16 - (size_t)c * bufbytes;     // mma() indexes by the absolute step
+    }
+    for (; kk + PF <= kend; kk += PF) quad(kk, std::false_type{});
+    if (kk < kend) { quad(kk, std::true_type{}); kk = kend; }
+    if (kch && kend < nks) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of chunk c + 1 has landed ...
+      __syncthreads();                                       // ... everyone's; and everyone is done with chunk c
+    }
+  }
 }
 
 // PIPE: 0 generic K loop, 1 pipelined, 4 pipelined with 64-channel stages (1x1 convs).
@@ -1204,7 +1225,7 @@ extern "C" int pmf_conv_multi_ok(const pmf_conv_desc_t* d) {
   return d && d->ndst > 0 && d->ndst <= PMF_MAX_SRC && !d->bias && multi_tile(d) != 0;
 }
 
-static int conv_direct_lds(const pmf_conv_desc_t* d, int BN);
+static int conv_direct_lds(const pmf_conv_desc_t* d, int BN, int* kchunk = nullptr);
 static bool conv_s3_fits(const pmf_conv_desc_t* d, int MT);
 static bool conv_s3_stride2(const pmf_conv_desc_t* d);
 static void conv_config_(const pmf_conv_desc_t* d, int* BN, int* MT);
@@ -1293,8 +1314,10 @@ static int conv_pipe_mode(const pmf_conv_desc_t* d, const ConvGeom& g, int gathe
 // PIPE 11 (conv_kloop_direct): LDS bytes of the launch, or 0 when the layer does not qualify -- one tap, split-bf16
 // weights, operands multiples of 16 channels with the same H x W, all weight fragments of one output-channel tile
 // resident in LDS.  PMF_NO_DIRECT=1 switches the variant off.
-static int conv_direct_lds(const pmf_conv_desc_t* d, int BN) {
+static int conv_direct_lds(const pmf_conv_desc_t* d, int BN, int* kchunk) {
   static const bool off = getenv("PMF_NO_DIRECT") != nullptr;
+  static const int stream_kib = getenv("PMF_DIRECT_STREAM_KIB") ? atoi(getenv("PMF_DIRECT_STREAM_KIB")) : 96;
+  if (kchunk) *kchunk = 0;
   if (off || !d->w_s3 || d->ntaps != 1 || d->gather || (d->ldw & 31)) return 0;
   int Ktot = 0;
   for (int i = 0; i < d->nsrc; ++i) {
@@ -1303,9 +1326,21 @@ static int conv_direct_lds(const pmf_conv_desc_t* d, int BN) {
     if ((int64_t)d->N * d->src[i].H * d->src[i].W * d->src[i].ldc * 4 >= (1ll << 31)) return 0;
     Ktot += d->src[i].C;
   }
-  int lds = (Ktot / 16) * (BN / 32) * 3 * 1024 + 16 * Ktot + 256;
+  const int NT = BN / 32, tab = 16 * Ktot + 256;
+  int lds = (Ktot / 16) * NT * 3 * 1024 + tab;
   if (lds < 2 * 4 * 64 * 2 * 8) lds = 2 * 4 * 64 * 2 * 8;
-  return lds <= 160 * 1024 ? lds : 0;
+  if (lds > 160 * 1024) return 0;
+  // layers whose resident fragments exceed 96 KiB (768 input channels) stream them in chunks sized so that TWO workgroups
+  // fit a CU and the weight DMA runs under the MFMAs instead of in front of them: 768 -> 256 at 16x512 70 -> 59 us
+  // (PMF_DIRECT_STREAM_KIB=n moves the threshold, 0 switches the streaming off; from 64 KiB it is neutral to 4 % slower)
+  if (stream_kib > 0 && lds > stream_kib * 1024) {
+    const int kch = ((76 * 1024 - tab) / (2 * NT * 3 * 1024)) & ~3;
+    if (kch >= 8 && kch < Ktot / 16) {
+      if (kchunk) *kchunk = kch;
+      return 2 * kch * NT * 3 * 1024 + tab;
+    }
+  }
+  return lds;
 }
 
 // split-bf16 path: 16-channel slabs per stage (1, 2 or 4) -- see conv_kloop_s3
@@ -1358,7 +1393,8 @@ static int launch(const pmf_conv_desc_t* d, hipStream_t s) {
   }
   const int co_tiles = cdiv(d->Cout, BN);
   int mode = conv_pipe_mode(d, g, gather, MT);
-  if (const int dl = conv_direct_lds(d, BN)) {   // 1x1 on split-bf16 weights: no input tile in LDS, no K split
+  g.kchunk = 0;
+  if (const int dl = conv_direct_lds(d, BN, &g.kchunk)) {   // 1x1 on split-bf16 weights: no input tile in LDS, no K split
     mode = 11;
     lds = dl;
     nchunks = 1;

@@ -109,6 +109,10 @@ CONVS = [
     ("c1x1_to1024", 2, 8, 32, [256], 1024, 1, 1, 0, 1, False, "bn_norelu", True),
     ("c1x1_k1040_cat", 1, 8, 32, [1024, 16], 64, 1, 1, 0, 1, True, "act_bn", True),
     ("c1x1s2_k1024", 2, 8, 32, [1024], 2048, 1, 1, 0, 2, False, "bn_norelu", True),
+    # 768 / 784 input channels: the direct variant streams the weight fragments in chunks through two LDS buffers (two
+    # workgroups per CU); ragged last chunk
+    ("c1x1_k768_cat", 2, 16, 64, [256, 256, 256], 256, 1, 1, 0, 1, True, "act_bn", True),
+    ("c1x1_k784", 1, 16, 64, [784], 64, 1, 1, 0, 1, False, "bn_relu", True),
 ]
 
 
@@ -132,7 +136,8 @@ def test_conv_unit_fwd_bwd(case):
 
 
 DIRECT_1X1 = [c for c in CONVS if c[0] in ("c1x1cat3", "c1x1_plain_lrelu", "c1x1s2", "c1x1cat3_big", "c1x1_odd_big",
-                                            "c1x1_c20_big", "c1x1_wide_big", "c1x1_odd_wide", "c1x1_to1024")]
+                                            "c1x1_c20_big", "c1x1_wide_big", "c1x1_odd_wide", "c1x1_to1024", "c1x1_k768_cat",
+                                            "c1x1_k784")]
 
 
 @pytest.mark.parametrize("case", DIRECT_1X1, ids=[c[0] for c in DIRECT_1X1])
