@@ -14,6 +14,8 @@ CASES = [  # name, N, H, W, Cin, Cout, k, dil
     ("full_32_32_1x1", 2, 64, 2048, 32, 32, 1, 1),
     ("full_192_64_1x1", 2, 64, 2048, 192, 64, 1, 1),
     ("full_64_64_1x1", 2, 64, 2048, 64, 64, 1, 1),
+    ("full_64_192_1x1", 2, 64, 2048, 64, 192, 1, 1),
+    ("half_128_384_1x1", 2, 32, 1024, 128, 384, 1, 1),
     ("half_384_128_1x1", 2, 32, 1024, 384, 128, 1, 1),
     ("quar_768_256_1x1", 2, 16, 512, 768, 256, 1, 1),
     ("full_64_64_2x2d2", 2, 64, 2048, 64, 64, 2, 2),
