@@ -55,7 +55,9 @@ def run(which, filt):
             print("fwd   %-22s %8.1f us  %6.1f TF/s" % (name, us, gf / us * 1e3), flush=True)
         if which == "s3":      # split-bf16 path, every tile configuration, next to the fp32 MFMA path
             w3 = G.pack_fwd_s3(w, ci, ldw)
-            for cfg in (0, 32 | (1 << 8) | (1 << 16), 64 | (1 << 8) | (1 << 16), 32 | (2 << 8) | (1 << 16), 64 | (2 << 8) | (1 << 16)):
+            cfgs = (0, 32 | (1 << 8) | (1 << 16), 64 | (1 << 8) | (1 << 16), 32 | (2 << 8) | (1 << 16), 64 | (2 << 8) | (1 << 16))
+            if os.environ.get("S3_CFGS"): cfgs = tuple(int(x, 0) for x in os.environ["S3_CFGS"].split(","))
+            for cfg in cfgs:
                 if (cfg & 0xff) == 64 and co <= 32: continue
                 res = []
                 for kind in ("f32", "s3"):
