@@ -89,6 +89,7 @@ struct ConvGeom {
   int kc_alloc;     // rows per tap reserved in the LDS weight tile
   int a_floats;     // floats reserved for the input tile
   int tap_group;    // taps per weight sub-stage
+  int one;          // split loops: single operand and no K split -> the operand scalars are fetched once (conv_kloop_s3 ONE)
   int kchunk;       // direct 1x1 variant: 16-channel steps per weight chunk (two LDS buffers); 0 = all fragments resident
   int ksplit;       // split-K factor (K chunks dealt round-robin to ksplit workgroups; partials go to ws)
   int ws_ld;        // channel stride of the partial slabs

@@ -450,7 +450,11 @@ __device__ __forceinline__ void s3_half(f32x16 (&acc)[MT][BN / 32], const char* 
 // three barriers.  Stages are sized so that virtual taps <= 9 and the staging slots per thread <= 8.
 // NTAPS: 9 = the 3x3 case with its tap count known at compile time (no dispatch on the half sizes inside the stage
 // loop: the branches end scheduling regions and cost accumulator copies at their joins), 0 = read from the descriptor
-template <int BN, int MT, int SL, int NTAPS = 0, int IS = 1>      // IS: input stride (2: the stride-2 3x3 layers, MT = 1 only)
+// ONE: a single operand and no K split (most 3x3 layers): the operand's scalars are fetched once, in front of the loop.
+// The generic stage iterator re-reads them from the kernel arguments every stage -- s_load -> s_waitcnt round trips
+// (settle: the channel count; head: pointers, pitch, flags) that sit between barrier Y and the first MFMA of the stage,
+// on the critical path of a one-wave-per-SIMD schedule.
+template <int BN, int MT, int SL, int NTAPS = 0, int IS = 1, bool ONE = false>      // IS: input stride (2: the stride-2 3x3 layers, MT = 1 only)
 __device__ __forceinline__ void conv_kloop_s3(const pmf_conv_desc_t& d, const ConvGeom& g, f32x16 (&acc)[MT][BN / 32],
                                               char* __restrict__ As, char* __restrict__ Bs, const int (&segrow)[MT],
                                               const int (&segcol)[MT], int tid, int li, int lh, int n, int n0, int ks,
@@ -507,7 +511,18 @@ __device__ __forceinline__ void conv_kloop_s3(const pmf_conv_desc_t& d, const Co
   for (int m = 0; m < MT; ++m) abase[m] = (segrow[m] * IS * in_cols + (segcol[m] * 32 + li) * IS) * S3_APB + lh * 16;
 
   int si = 0, c0 = 0, kb = 0, cn = 0;
+  // ONE: the operand, once
+  const float* o_x = nullptr; const float* o_sc = nullptr; const float* o_sh = nullptr; const float* o_cm = nullptr;
+  int o_C = 0, o_ld = 0, o_fl = 0;
+  if (ONE) {
+    o_x = d.src[0].x; o_sc = d.src[0].scale; o_sh = d.src[0].shift; o_cm = d.src[0].cmul;
+    o_C = d.src[0].C; o_ld = d.src[0].ldc; o_fl = d.src[0].flags;
+    const int o_cl = d.src[0].cmul_ld;
+    PMF_SGPR_BATCH("s"(o_x), "s"(o_sc), "s"(o_sh), "s"(o_cm), "s"(o_C), "s"(o_ld), "s"(o_fl), "s"(o_cl));
+    if (o_cm) o_cm += (size_t)n * o_cl;
+  }
   auto settle = [&]() {
+    if (ONE) return c0 < o_C;
     for (;;) {
       if (si >= d.nsrc) return false;
       if (c0 >= d.src[si].C) { kb += d.src[si].C; ++si; c0 = 0; continue; }
@@ -524,6 +539,23 @@ __device__ __forceinline__ void conv_kloop_s3(const pmf_conv_desc_t& d, const Co
   const char* __restrict__ nw = nullptr;   // fragment (tap 0, slab 0, plane 0) of the stage being fetched, first output tile
   const size_t tap_stride = (size_t)KS * CT * 3 * 1024, slab_stride = (size_t)CT * 3 * 1024;
   auto head = [&]() {
+    if (ONE) {
+      nrs = __builtin_amdgcn_make_buffer_rsrc((void*)o_x, 0, d.N * sH * sW * o_ld * 4, 0x00020000);
+      nld = o_ld; ncch = c0 + q * 4;
+      cur_flags = o_fl;
+      cur_aff = o_sc != nullptr;
+      cur_plain = !o_sc && !o_cm && !(o_fl & PMF_SRC_RELU);
+      if (SL == 1) {
+        sc4 = f32x4{1.f, 1.f, 1.f, 1.f}; sh4 = f32x4{0.f, 0.f, 0.f, 0.f}; cm4 = f32x4{1.f, 1.f, 1.f, 1.f};
+        if (cur_aff) { sc4 = *(const f32x4*)(o_sc + ncch); sh4 = *(const f32x4*)(o_sh + ncch); }
+        if (o_cm) cm4 = *(const f32x4*)(o_cm + ncch);
+      } else {
+        cur_sc = cur_aff ? o_sc + ncch : nullptr; cur_sh = cur_aff ? o_sh + ncch : nullptr;
+        cur_cm = o_cm ? o_cm + ncch : nullptr;
+      }
+      nw = (const char*)d.w_s3 + ((size_t)(c0 >> 4) * CT + (n0 >> 5)) * 3 * 1024;
+      return;
+    }
     const float* sx = d.src[si].x;
     const float* ssc = d.src[si].scale;
     const float* ssh = d.src[si].shift;
@@ -926,11 +958,20 @@ __global__ __launch_bounds__(256) void conv_fwd_k(const pmf_conv_desc_t d, const
   } else if constexpr (PIPE == 11) {  // 1x1, split-bf16, activations straight from global memory
     conv_kloop_direct<BN, MT>(d, g, acc, (char*)smem, segrow, segcol, tid, li, lh, n, n0, oy0, ox0);
   } else if constexpr (PIPE == 8) {   // one slab per stage, 9 taps at compile time
-    conv_kloop_s3<BN, MT, 1, 9>(d, g, acc, (char*)smem, (char*)(smem + g.a_floats), segrow, segcol, tid, li, lh, n, n0, ks, oy0, ox0, tri_);
+    if (g.one)
+      conv_kloop_s3<BN, MT, 1, 9, 1, true>(d, g, acc, (char*)smem, (char*)(smem + g.a_floats), segrow, segcol, tid, li, lh, n, n0, ks, oy0, ox0, tri_);
+    else
+      conv_kloop_s3<BN, MT, 1, 9>(d, g, acc, (char*)smem, (char*)(smem + g.a_floats), segrow, segcol, tid, li, lh, n, n0, ks, oy0, ox0, tri_);
   } else if constexpr (PIPE == 10) {  // two slabs per stage, 4 taps at compile time (the 2x2 dilated layers)
-    conv_kloop_s3<BN, MT, 2, 4>(d, g, acc, (char*)smem, (char*)(smem + g.a_floats), segrow, segcol, tid, li, lh, n, n0, ks, oy0, ox0, tri_);
+    if (g.one)
+      conv_kloop_s3<BN, MT, 2, 4, 1, true>(d, g, acc, (char*)smem, (char*)(smem + g.a_floats), segrow, segcol, tid, li, lh, n, n0, ks, oy0, ox0, tri_);
+    else
+      conv_kloop_s3<BN, MT, 2, 4>(d, g, acc, (char*)smem, (char*)(smem + g.a_floats), segrow, segcol, tid, li, lh, n, n0, ks, oy0, ox0, tri_);
   } else if constexpr (PIPE >= 5) {          // 5, 6, 7: 1, 2, 4 slabs per stage, tap count from the descriptor
-    conv_kloop_s3<BN, MT, (1 << (PIPE - 5))>(d, g, acc, (char*)smem, (char*)(smem + g.a_floats), segrow, segcol, tid, li, lh, n, n0, ks, oy0, ox0, tri_);
+    if (g.one)
+      conv_kloop_s3<BN, MT, (1 << (PIPE - 5)), 0, 1, true>(d, g, acc, (char*)smem, (char*)(smem + g.a_floats), segrow, segcol, tid, li, lh, n, n0, ks, oy0, ox0, tri_);
+    else
+      conv_kloop_s3<BN, MT, (1 << (PIPE - 5))>(d, g, acc, (char*)smem, (char*)(smem + g.a_floats), segrow, segcol, tid, li, lh, n, n0, ks, oy0, ox0, tri_);
   } else if constexpr (PIPE != 0) {
     conv_kloop_pipe<BN, MT, (PIPE > 1 ? PIPE : 1)>(d, g, acc, As, Bs, segrow, segcol, tid, li, lh, n, n0, ks, oy0, ox0, tri_);
   } else {
@@ -1431,6 +1472,8 @@ static int launch(const pmf_conv_desc_t* d, hipStream_t s) {
   g.ksplit = d->ndst > 0 ? 1 : choose_ksplit(d, g.tiles_x * g.tiles_y * d->N * co_tiles, nchunks, d->ntaps * 8 * MT * (BN / 32));
   g.ws = d->splitk_ws;
   g.ws_ld = round_up(d->Cout, 4);
+  static const bool no_one = getenv("PMF_NO_ONE") != nullptr;
+  g.one = (d->nsrc == 1 && g.ksplit == 1 && !no_one) ? 1 : 0;
   dim3 grid(g.tiles_x * g.tiles_y, co_tiles * g.ksplit, d->N);
   if (mode == 12) {
     if constexpr (MT == 1) hipLaunchKernelGGL((conv_fwd_k<BN, 1, 12>), grid, dim3(256), lds, s, dd, g);
