@@ -474,7 +474,10 @@ typedef struct {
   int32_t kind;
   int32_t pad_;    /* scheduling bits for pmf_plan_run: bits 0-1 = lane (0 = the caller's stream; a side lane forks from it
                     * at its first op of the range and is joined at the end of the range); bits 8-15 = e+1: the op's lane
-                    * first waits for plan event e; bits 16-23 = e+1: record plan event e on the op's lane after the op */
+                    * first waits for plan event e; bits 16-23 = e+1: record plan event e on the op's lane after the op;
+                    * bits 24-30 = duration estimate in units of 4 us (0 = unknown): pmf_plan_run hands the ops to the lanes'
+                    * streams in the order of a simulated parallel execution (per-lane order and events are kept; only the
+                    * interleaving of the lanes changes, which decides how a captured graph replays) */
   union {
     pmf_conv_desc_t conv;
     pmf_wgrad_desc_t wgrad;
@@ -485,14 +488,20 @@ typedef struct {
 /* runs ops[0..n) in order on stream s; returns 0 or the first error (index in *failed_at if non-NULL) */
 int pmf_plan_run(const pmf_op_t* ops, int32_t n, pmf_stream_t s, int32_t* failed_at);
 int pmf_plan_run_range(const pmf_op_t* ops, int32_t begin, int32_t end, pmf_stream_t s, int32_t* failed_at);
-/* hipGraph capture of ops[begin..end): one hipGraphLaunch replays the whole range (the plan allocates nothing, copies
+/* hipGraph capture of ops[begin..end): pmf_graph_launch replays the whole range (the plan allocates nothing, copies
  * nothing, never synchronises, and all its pointers are fixed).  Run the range eagerly once before capturing.  The
- * executable graph is bound to the pointer values inside `ops` at capture time. */
+ * handle is bound to the pointer values inside `ops` at capture time.  It holds one linear hipGraph per stretch of a
+ * lane between cross-lane edges; a replay launches them on the lanes' streams with stream events between them
+ * (PMF_GRAPH_MODE=single: one multi-branch hipGraph instead, see csrc/plan.cpp for why that is not the default). */
 int pmf_plan_capture(const pmf_op_t* ops, int32_t begin, int32_t end, void** graph_exec, int32_t* failed_at);
 int pmf_graph_launch(void* graph_exec, pmf_stream_t s);
+int pmf_graph_pieces(void* graph_exec);   /* linear hipGraphs behind the handle */
 /* lanes (pmf_op_t.pad_): on = 0 run every op on the caller's stream, 1 honour the lane bits (default; PMF_LANES=0 in the
  * environment starts with 0), < 0 query only; returns the previous setting */
 int pmf_plan_lanes(int on);
+/* the order in which pmf_plan_run_range / pmf_plan_capture hand ops [begin, end) to the lanes' streams (pmf_op_t.pad_
+ * bits 24-30); out: end - begin op indices.  Host-only, launches nothing. */
+int pmf_plan_issue_order(const pmf_op_t* ops, int32_t begin, int32_t end, int32_t* out);
 int pmf_graph_destroy(void* graph_exec);
 /* pixel splits pmf_conv_wgrad will use for this descriptor (sizes `partial`) */
 int pmf_conv_wgrad_nsplit(const pmf_wgrad_desc_t* d);

@@ -1,6 +1,7 @@
 // Plan executor: a whole forward or backward pass of the network is a flat array of pmf_op_t built once on the
 // host (static shapes, static buffers); running it is ONE C call that enqueues every kernel on the caller's
 // HIP stream -- no Python between launches, and the array can be captured into a hipGraph by the caller.
+#include <vector>
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include "../../include/pmf_amd.h"
@@ -128,7 +129,18 @@ static int lane_device_ok() {
 static int lane_stream(int lane, hipStream_t* out) {
   if (int rc = lane_device_ok()) return rc;
   if (!g_lane[lane]) {
-    hipError_t e = hipStreamCreateWithFlags(&g_lane[lane], hipStreamNonBlocking);
+    // PMF_LANE_PRIO=<mask>: the lanes in the mask get the LOWEST stream priority (weight-gradient lanes: leaves of the
+    // backward graph, they should fill what the critical path leaves idle, not compete with it)
+    static const int low_mask = [] { const char* m = getenv("PMF_LANE_PRIO"); return m ? atoi(m) : 0; }();
+    hipError_t e;
+    if ((low_mask >> lane) & 1) {
+      int least = 0, greatest = 0;
+      e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+      if (e != hipSuccess) return (int)e;
+      e = hipStreamCreateWithPriority(&g_lane[lane], hipStreamNonBlocking, least);
+    } else {
+      e = hipStreamCreateWithFlags(&g_lane[lane], hipStreamNonBlocking);
+    }
     if (e != hipSuccess) return (int)e;
     e = hipEventCreateWithFlags(&g_join[lane], hipEventDisableTiming);
     if (e != hipSuccess) return (int)e;
@@ -163,14 +175,97 @@ extern "C" int pmf_plan_lanes(int on) {
   return prev;
 }
 
+// Issue order of a range.  The lane bits and events define the dependencies; the ORDER in which the ops are handed to
+// the streams is free as long as every lane keeps its own order and an event is recorded before it is awaited -- and it
+// matters: hipGraph replay (ROCm 7.2) enqueues the nodes in capture order and resolves an edge between two of its
+// internal streams against the TAIL of the source stream at the moment the dependent node is enqueued.  Captured in list
+// order (the camera encoder's backward behind the whole LiDAR backward, a deferred weight-gradient batch in front of the
+// home lane's next op), a consumer therefore waited for everything its producer's lane had been handed by then: the
+// camera encoder's backward ran AFTER the LiDAR backward instead of under it (3.5 ms of latency-bound launches alone on
+// the chip, profiles/r03_lanes_*.txt).  The ops are issued in the order of a simulated parallel execution instead:
+// per-lane clocks advanced by the ops' cost hints (pad_ bits 24-30, units of 4 us, from the plan builder's flop / byte
+// counts), an op starts at max(its lane's clock, the record time of the event it waits for), and the op with the
+// earliest start goes next.  PMF_PLAN_ORDER=list keeps the list order (A/B).
+static void issue_order(const pmf_op_t* ops, int32_t begin, int32_t end, bool lanes, std::vector<int32_t>& order) {
+  const int32_t n = end - begin;
+  order.resize(n > 0 ? n : 0);
+  static const bool keep_list = [] { const char* e = getenv("PMF_PLAN_ORDER"); return e && e[0] == 'l'; }();
+  if (!lanes || keep_list || n <= 0) {
+    for (int32_t i = 0; i < n; ++i) order[i] = begin + i;
+    return;
+  }
+  std::vector<int32_t> q[PMF_MAX_LANES];
+  size_t cur[PMF_MAX_LANES] = {0, 0, 0, 0};
+  double clock[PMF_MAX_LANES] = {0.0, 0.0, 0.0, 0.0};
+  int32_t rec_at[PMF_MAX_EVENTS];
+  bool rec_done[PMF_MAX_EVENTS] = {};
+  double rec_clock[PMF_MAX_EVENTS] = {};
+  for (int e = 0; e < PMF_MAX_EVENTS; ++e) rec_at[e] = -1;
+  for (int32_t k = begin; k < end; ++k) {
+    q[ops[k].pad_ & 3].push_back(k);
+    const int r = ((ops[k].pad_ >> 16) & 0xff) - 1;
+    if (r >= 0 && rec_at[r] < 0) rec_at[r] = k;
+  }
+  // fork of a side lane: it must see every main-lane op that precedes its first op in the list
+  int32_t need_main[PMF_MAX_LANES] = {0, 0, 0, 0};
+  double fork_clock[PMF_MAX_LANES] = {0.0, 0.0, 0.0, 0.0};
+  bool forked[PMF_MAX_LANES] = {true, false, false, false};
+  for (int l = 1; l < PMF_MAX_LANES; ++l) {
+    if (q[l].empty()) continue;
+    for (int32_t k : q[0]) if (k < q[l][0]) ++need_main[l];
+    if (need_main[l] == 0) forked[l] = true;
+  }
+  for (int32_t out = 0; out < n; ++out) {
+    int best = -1;
+    double best_t = 0.0;
+    for (int l = 0; l < PMF_MAX_LANES; ++l) {
+      if (cur[l] >= q[l].size()) continue;
+      const int32_t k = q[l][cur[l]];
+      double t = clock[l];
+      if (cur[l] == 0 && l > 0) {
+        if (!forked[l]) continue;
+        if (fork_clock[l] > t) t = fork_clock[l];
+      }
+      const int w = ((ops[k].pad_ >> 8) & 0xff) - 1;
+      if (w >= 0 && rec_at[w] >= 0 && rec_at[w] < k) {     // (a wait for an event not recorded earlier in the range is void)
+        if (!rec_done[w]) continue;
+        if (rec_clock[w] > t) t = rec_clock[w];
+      }
+      if (best < 0 || t < best_t || (t == best_t && k < q[best][cur[best]])) { best = l; best_t = t; }
+    }
+    // (never -1: the unissued op with the smallest list index is always ready)
+    const int32_t k = q[best][cur[best]++];
+    order[out] = k;
+    const int cost = (ops[k].pad_ >> 24) & 0x7f;
+    clock[best] = best_t + (cost ? cost : 1);
+    const int r = ((ops[k].pad_ >> 16) & 0xff) - 1;
+    if (r >= 0) { rec_done[r] = true; rec_clock[r] = clock[best]; }
+    if (best == 0)
+      for (int l = 1; l < PMF_MAX_LANES; ++l)
+        if (!forked[l] && !q[l].empty() && (int32_t)cur[0] >= need_main[l]) { forked[l] = true; fork_clock[l] = clock[0]; }
+  }
+}
+
+// the order in which pmf_plan_run_range / pmf_plan_capture hand ops [begin, end) to the streams (host-only: no launch)
+extern "C" int pmf_plan_issue_order(const pmf_op_t* ops, int32_t begin, int32_t end, int32_t* out) {
+  if (!ops || !out || begin < 0 || end < begin) return PMF_E_ARG;
+  std::vector<int32_t> order;
+  issue_order(ops, begin, end, lanes_enabled(), order);
+  for (size_t i = 0; i < order.size(); ++i) out[i] = order[i];
+  return 0;
+}
+
 static int run_range(const pmf_op_t* ops, int32_t begin, int32_t end, hipStream_t main_s, int32_t* failed_at) {
   const bool lanes = lanes_enabled();
   bool used[PMF_MAX_LANES] = {true, false, false, false};
   bool ev_valid[PMF_MAX_EVENTS] = {};      // events recorded inside THIS range (a wait never reaches back further)
   hipStream_t st[PMF_MAX_LANES] = {main_s, nullptr, nullptr, nullptr};
   int rc = 0;
+  std::vector<int32_t> order;
+  issue_order(ops, begin, end, lanes, order);
   int32_t k = begin;
-  for (; k < end && rc == 0; ++k) {
+  for (size_t oi = 0; oi < order.size() && rc == 0; ++oi) {
+    k = order[oi];
     const int bits = ops[k].pad_;
     const int lane = lanes ? (bits & 3) : 0;
     const int wait_e = ((bits >> 8) & 0xff) - 1, rec_e = ((bits >> 16) & 0xff) - 1;
@@ -218,11 +313,64 @@ extern "C" int pmf_plan_run_range(const pmf_op_t* ops, int32_t begin, int32_t en
 // ---- hipGraph capture of a plan range --------------------------------------------------------------------------
 // A plan performs no allocation, memcpy or synchronisation and every pointer it uses is fixed at build time, so a
 // range of ops can be captured ONCE (on a private capture stream: the legacy default stream cannot capture) and
-// replayed with a single hipGraphLaunch.  Issuing the ~1200 kernels of one training iteration one by one costs
-// ~19 ms of host time per step on this stack -- about as much as the GPU needs to run them -- so without the graph the
-// GPU starves whenever the host thread does anything else (optimiser, loss, next batch).
+// replayed.  Issuing the ~900 kernels of one training iteration one by one costs ~19 ms of host time per step on
+// this stack -- about as much as the GPU needs to run them -- so without the graph the GPU starves whenever the host
+// thread does anything else (optimiser, loss, next batch).
 // The caller must have run the range eagerly once before (kernel attributes are set on first launch, which is not
 // allowed inside a capture).
+//
+// Two forms (PMF_GRAPH_MODE):
+//  * "single": the whole range, lanes included, is ONE multi-branch hipGraph.  Measured on ROCm 7.2: the replay resolves
+//    an edge between two branches against whatever the source branch has been handed when the runtime reaches the
+//    dependent node in ITS traversal of the DAG, which walks one branch to its end before the next -- the camera
+//    encoder's backward (waiting for the image gradient of the deepest fusion block, a third of the way into the LiDAR
+//    backward) started when the LiDAR backward had finished, and a deferred weight-gradient batch stalled the lane it
+//    was taken off (profiles/r03_lanes_single.txt).
+//  * "segments" (default): every lane is cut at its cross-lane edges (event waits, event records, fork points) into
+//    LINEAR pieces; each piece is its own single-branch hipGraph, and a replay launches the pieces on the lanes' real
+//    HIP streams with real events between them, in the issue order of the simulated parallel execution above.  A
+//    linear graph is a batch of packets on one queue, and a stream event names exactly the piece it was recorded
+//    behind, so the DAG executes as written.
+struct PlanSeg {
+  int lane;
+  std::vector<int32_t> ops;
+  hipGraphExec_t exec;
+};
+enum { ACT_START = 0, ACT_WAIT_FORK, ACT_WAIT_EV, ACT_LAUNCH, ACT_REC_EV, ACT_REC_FORK };
+struct PlanAct { int kind, lane, arg; };
+struct PlanProgram {
+  std::vector<PlanSeg> segs;
+  std::vector<PlanAct> acts;
+  bool used[PMF_MAX_LANES];
+  hipGraphExec_t single;     // "single" mode
+};
+static hipEvent_t g_forkev[PMF_MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
+
+static void program_destroy(PlanProgram* p) {
+  if (!p) return;
+  for (auto& sg : p->segs) if (sg.exec) (void)hipGraphExecDestroy(sg.exec);
+  if (p->single) (void)hipGraphExecDestroy(p->single);
+  delete p;
+}
+
+static int capture_linear(const pmf_op_t* ops, const std::vector<int32_t>& idx, hipStream_t cap, hipGraphExec_t* out,
+                          int32_t* failed_at) {
+  hipError_t e = hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal);
+  if (e != hipSuccess) return (int)e;
+  int rc = 0;
+  for (int32_t k : idx) {
+    rc = run_one(ops[k], (pmf_stream_t)cap);
+    if (rc) { if (failed_at) *failed_at = k; break; }
+  }
+  hipGraph_t graph = nullptr;
+  e = hipStreamEndCapture(cap, &graph);
+  if (rc != 0) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+  if (e != hipSuccess) return (int)e;
+  e = hipGraphInstantiate(out, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  return (int)e;
+}
+
 extern "C" int pmf_plan_capture(const pmf_op_t* ops, int32_t begin, int32_t end, void** graph_exec, int32_t* failed_at) {
   static hipStream_t cap = nullptr;
   if (!graph_exec) return PMF_E_ARG;
@@ -232,29 +380,133 @@ extern "C" int pmf_plan_capture(const pmf_op_t* ops, int32_t begin, int32_t end,
     e = hipStreamCreateWithFlags(&cap, hipStreamNonBlocking);
     if (e != hipSuccess) return (int)e;
   }
-  e = hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal);
-  if (e != hipSuccess) return (int)e;
-  int rc = run_range(ops, begin, end, cap, failed_at);   // side-lane ops fork / join inside the capture
-  hipGraph_t graph = nullptr;
-  e = hipStreamEndCapture(cap, &graph);
-  if (rc != 0) { if (graph) (void)hipGraphDestroy(graph); return rc; }
-  if (e != hipSuccess) return (int)e;
-  hipGraphExec_t exec = nullptr;
-  e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-  (void)hipGraphDestroy(graph);
-  if (e != hipSuccess) return (int)e;
-  *graph_exec = (void*)exec;
+  static const bool single = [] { const char* m = getenv("PMF_GRAPH_MODE"); return m && m[0] == 's' && m[1] == 'i'; }();
+  PlanProgram* prog = new PlanProgram();
+  prog->single = nullptr;
+  for (int l = 0; l < PMF_MAX_LANES; ++l) prog->used[l] = (l == 0);
+  if (single) {
+    e = hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) { delete prog; return (int)e; }
+    int rc = run_range(ops, begin, end, cap, failed_at);   // side-lane ops fork / join inside the capture
+    hipGraph_t graph = nullptr;
+    e = hipStreamEndCapture(cap, &graph);
+    if (rc != 0) { if (graph) (void)hipGraphDestroy(graph); delete prog; return rc; }
+    if (e != hipSuccess) { delete prog; return (int)e; }
+    e = hipGraphInstantiate(&prog->single, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) { delete prog; return (int)e; }
+    *graph_exec = (void*)prog;
+    return 0;
+  }
+  // ---- cut the lanes into linear pieces, in issue order
+  const bool lanes = lanes_enabled();
+  std::vector<int32_t> order;
+  issue_order(ops, begin, end, lanes, order);
+  int32_t rec_at[PMF_MAX_EVENTS];
+  for (int i = 0; i < PMF_MAX_EVENTS; ++i) rec_at[i] = -1;
+  int32_t first_of[PMF_MAX_LANES] = {-1, -1, -1, -1}, fork_after[PMF_MAX_LANES] = {-1, -1, -1, -1};
+  for (int32_t k = begin; k < end; ++k) {
+    const int l = lanes ? (ops[k].pad_ & 3) : 0;
+    if (first_of[l] < 0) first_of[l] = k;
+    const int r = ((ops[k].pad_ >> 16) & 0xff) - 1;
+    if (lanes && r >= 0 && rec_at[r] < 0) rec_at[r] = k;
+  }
+  for (int l = 1; l < PMF_MAX_LANES; ++l) {       // the main-lane op a side lane forks behind (list order), if any
+    if (first_of[l] < 0) continue;
+    for (int32_t k = begin; k < first_of[l]; ++k)
+      if ((lanes ? (ops[k].pad_ & 3) : 0) == 0) fork_after[l] = k;
+  }
+  int open[PMF_MAX_LANES] = {-1, -1, -1, -1};
+  prog->acts.push_back({ACT_START, 0, 0});
+  for (int32_t k : order) {
+    const int bits = ops[k].pad_;
+    const int l = lanes ? (bits & 3) : 0;
+    int w = lanes ? ((bits >> 8) & 0xff) - 1 : -1;
+    const int r = lanes ? ((bits >> 16) & 0xff) - 1 : -1;
+    if (w >= 0 && !(rec_at[w] >= 0 && rec_at[w] < k)) w = -1;     // (not recorded earlier in this range: void)
+    if (l > 0 && !prog->used[l]) {
+      prog->used[l] = true;
+      prog->acts.push_back({ACT_WAIT_FORK, l, fork_after[l] >= 0 ? l : 0});
+    }
+    if (w >= 0 && open[l] >= 0) open[l] = -1;
+    if (open[l] < 0) {
+      if (w >= 0) prog->acts.push_back({ACT_WAIT_EV, l, w});
+      open[l] = (int)prog->segs.size();
+      prog->segs.push_back(PlanSeg{l, {}, nullptr});
+      prog->acts.push_back({ACT_LAUNCH, l, open[l]});
+    }
+    prog->segs[open[l]].ops.push_back(k);
+    if (r >= 0) {
+      open[l] = -1;
+      prog->acts.push_back({ACT_REC_EV, l, r});
+    }
+    if (l == 0)
+      for (int sl = 1; sl < PMF_MAX_LANES; ++sl)
+        if (fork_after[sl] == k) {
+          open[0] = -1;
+          prog->acts.push_back({ACT_REC_FORK, 0, sl});
+        }
+  }
+  for (auto& sg : prog->segs) {
+    int rc = capture_linear(ops, sg.ops, cap, &sg.exec, failed_at);
+    if (rc) { program_destroy(prog); return rc; }
+  }
+  *graph_exec = (void*)prog;
   return 0;
 }
 
 extern "C" int pmf_graph_launch(void* graph_exec, pmf_stream_t s) {
   if (!graph_exec) return PMF_E_ARG;
-  return (int)hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)s);
+  PlanProgram* prog = (PlanProgram*)graph_exec;
+  hipStream_t main_s = (hipStream_t)s;
+  if (prog->single) return (int)hipGraphLaunch(prog->single, main_s);
+  hipStream_t st[PMF_MAX_LANES] = {main_s, nullptr, nullptr, nullptr};
+  int rc = 0;
+  for (int l = 1; l < PMF_MAX_LANES && rc == 0; ++l) {
+    if (!prog->used[l]) continue;
+    rc = lane_stream(l, &st[l]);
+    if (rc == 0 && !g_forkev[l]) rc = (int)hipEventCreateWithFlags(&g_forkev[l], hipEventDisableTiming);
+  }
+  if (rc == 0 && !g_fork) rc = (int)hipEventCreateWithFlags(&g_fork, hipEventDisableTiming);
+  if (rc == 0) rc = lane_device_ok();
+  for (size_t i = 0; i < prog->acts.size() && rc == 0; ++i) {
+    const PlanAct& a = prog->acts[i];
+    hipEvent_t ev;
+    switch (a.kind) {
+      case ACT_START: rc = (int)hipEventRecord(g_fork, main_s); break;
+      case ACT_WAIT_FORK: rc = (int)hipStreamWaitEvent(st[a.lane], a.arg ? g_forkev[a.arg] : g_fork, 0); break;
+      case ACT_WAIT_EV:
+        rc = plan_event(a.arg, &ev);
+        if (rc == 0) rc = (int)hipStreamWaitEvent(st[a.lane], ev, 0);
+        break;
+      case ACT_LAUNCH: rc = (int)hipGraphLaunch(prog->segs[a.arg].exec, st[a.lane]); break;
+      case ACT_REC_EV:
+        rc = plan_event(a.arg, &ev);
+        if (rc == 0) rc = (int)hipEventRecord(ev, st[a.lane]);
+        break;
+      case ACT_REC_FORK: rc = (int)hipEventRecord(g_forkev[a.arg], main_s); break;
+      default: rc = PMF_E_ARG;
+    }
+  }
+  for (int l = 1; l < PMF_MAX_LANES; ++l) {      // join (also on failure)
+    if (!prog->used[l] || !st[l]) continue;
+    hipError_t e = hipEventRecord(g_join[l], st[l]);
+    if (e == hipSuccess) e = hipStreamWaitEvent(main_s, g_join[l], 0);
+    if (e != hipSuccess && rc == 0) rc = (int)e;
+  }
+  return rc;
 }
 
 extern "C" int pmf_graph_destroy(void* graph_exec) {
-  if (!graph_exec) return 0;
-  return (int)hipGraphExecDestroy((hipGraphExec_t)graph_exec);
+  program_destroy((PlanProgram*)graph_exec);
+  return 0;
+}
+
+// number of linear pieces of a captured range (1 in "single" mode); tests / diagnostics
+extern "C" int pmf_graph_pieces(void* graph_exec) {
+  if (!graph_exec) return PMF_E_ARG;
+  PlanProgram* prog = (PlanProgram*)graph_exec;
+  return prog->single ? 1 : (int)prog->segs.size();
 }
 
 // ABI self-check for language bindings: sizes of the structs a binding has to mirror

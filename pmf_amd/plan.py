@@ -168,13 +168,31 @@ class Plan:
         # lanes: independent branches of the network on separate HIP streams (csrc/plan.cpp); ``lane`` is the lane ops
         # are being emitted on; cross-lane edges are plan events (record after one op, wait before another)
         self.lane = 0
-        self.n_lanes = 3
+        self.n_lanes = 4
         # weight gradients are leaves of the backward graph (only the optimiser / the gradient all-reduce reads them):
-        # PMF_WGRAD_LANE=2 runs them on their own lane behind an event of the op that produced dz.  Measured slower
-        # (25.1 vs 23.3 ms per step: 110 cross-queue edges cost more than the tails they fill), so off by default.
-        self.wgrad_lane = int(_os.environ.get("PMF_WGRAD_LANE", "0"))
-        self.wgrad_batch = int(_os.environ.get("PMF_WGRAD_BATCH", "8"))
+        # they run on lanes of their own (lane 0 -> 2, lane 1 -> 3; PMF_WGRAD_LANE=2: one shared lane, 0: inline on
+        # the home lane), in batches of PMF_WGRAD_BATCH behind ONE event of the home lane, so that the input-gradient
+        # chain -- the critical path -- is not queued behind them and their machine-filling launches run under its
+        # latency-bound ones.  (Round 2 measured this slower and kept it off: what it measured was the multi-branch
+        # hipGraph replay, see csrc/plan.cpp; with the range replayed as linear pieces on real streams it is worth
+        # 1.0 ms of 17.7 ms per step.)
+        self.wgrad_lane = int(_os.environ.get("PMF_WGRAD_LANE", "23"))
+        self._wgrad_lane_of = (lambda home: 2 + (home & 1)) if self.wgrad_lane == 23 else (lambda home: self.wgrad_lane)
+        self.wgrad_batch = int(_os.environ.get("PMF_WGRAD_BATCH", "4"))
         self._wg_deferred = {}
+        # PMF_WGRAD_POLICY=phase: only the weight gradients of the FIRST full-resolution stretch of a lane's backward
+        # are deferred; they are released in one batch at the lane's first small-map layer (<= PMF_WGRAD_THIN_PIX output
+        # pixels), whose latency-bound launches leave most of the chip to them; everything after runs inline
+        self.wgrad_policy = _os.environ.get("PMF_WGRAD_POLICY", "batch")
+        self.wgrad_homes = int(_os.environ.get("PMF_WGRAD_HOMES", "3"))      # bit h: lane h defers its weight gradients
+        self.wgrad_thin_pix = int(_os.environ.get("PMF_WGRAD_THIN_PIX", "16384"))
+        self._wg_phase_done = {}
+        # PMF_WGRAD_DELAY=n: a released batch is emitted n home-lane ops AFTER its release point (it still waits only for
+        # the event at the release point).  hipGraph replay enqueues nodes in capture order and resolves a cross-stream
+        # edge against the source stream's tail at that moment: a batch captured directly behind its release point makes
+        # the home lane's next op wait for the batch's first launches (measured: 0.5 ms stalls of the critical path).
+        self.wgrad_delay = int(_os.environ.get("PMF_WGRAD_DELAY", "0"))
+        self._wg_armed = {}                 # home lane -> [closures, event, home ops still to emit first]
         self.n_events = 0
         self._event_pos = {}                # event -> list position of its record op
         self._last_op = {}                  # (id(op list), lane) -> last entry emitted on that lane
@@ -210,6 +228,12 @@ class Plan:
     def emit(self, lst, kind, fill):
         """fill(op) populates a zeroed L.Op at finalise time (pointers are known only then).  The op runs on the
         current lane; a wait registered for this lane (wait_event) is attached to it."""
+        arm = self._wg_armed.get(self.lane) if (self._wg_armed and lst is self.bwd) else None
+        if arm is not None:
+            if arm[2] > 0:
+                arm[2] -= 1
+            else:
+                self._release_armed(self.lane)
         ent = [kind, fill, self.lane]       # [kind, fill, scheduling bits (pmf_amd.h)]
         key = (id(lst), self.lane)
         w = self._pending_wait.pop(key, None)
@@ -301,8 +325,8 @@ class Plan:
                     first[2] = (first[2] & ~0xff00) | ((wait[0] + 1) << 8)
             for g in touched:
                 g._last_touch = (lane, last)
-        for home in sorted(self._wg_deferred):
-            self.flush_wgrads(home)
+        for home in sorted(set(self._wg_deferred) | set(self._wg_armed)):
+            self.flush_wgrads(home, final=True)
         for lane in sorted(self.pending_reds):
             self.flush_reds(lane)
         self.lane = 0
@@ -935,7 +959,9 @@ class Plan:
                 d.dbias_out = self.pgrad_buf.at(boff)
         boff = self.pgrad(conv.bias) if dbias_rows else None
         home = self.lane
-        lane = self.wgrad_lane if (self.wgrad_lane and self.wgrad_lane != home) else home
+        lane = self._wgrad_lane_of(home) if (self.wgrad_lane and self._wgrad_lane_of(home) != home) else home
+        if not (self.wgrad_homes >> home) & 1:
+            lane = home
         self.n_wgrad += 1
         meta = dict(family="conv_wgrad", flops=2.0 * dz.N * dz.H * dz.W * Cout * conv.in_channels * len(taps), name=name,
                     shape="%dx%dx%d %d->%d t%d" % (dz.N, dz.H, dz.W, conv.in_channels, Cout, len(taps)))
@@ -966,6 +992,12 @@ class Plan:
                 self.grad_done[id(conv.weight)] = len(self.bwd) - 1
                 if dbias_rows:
                     self.grad_done[id(conv.bias)] = len(self.bwd) - 1
+        if lane != home and self.wgrad_policy == "phase":
+            if self._wg_phase_done.get(home) or dz.N * dz.H * dz.W <= self.wgrad_thin_pix:
+                if not self._wg_phase_done.get(home):
+                    self._wg_phase_done[home] = True
+                    self.flush_wgrads(home)
+                lane = home
         if lane == home:
             emit_ops()
         else:
@@ -973,16 +1005,30 @@ class Plan:
             # dz stays alive in the arena until the end of the pass, so running a weight gradient late is always legal)
             q = self._wg_deferred.setdefault(home, [])
             q.append(emit_ops)
-            if len(q) >= self.wgrad_batch:
+            if len(q) >= self.wgrad_batch and self.wgrad_policy != "phase":
                 self.flush_wgrads(home)
 
-    def flush_wgrads(self, home):
+    def flush_wgrads(self, home, final=False):
+        if final or self.wgrad_delay <= 0:
+            self._release_armed(home)
         q = self._wg_deferred.pop(home, [])
         if not q:
             return
-        prev = self.lane
         ready = self.record_event(self.bwd, lane=home)      # everything the batch reads is complete after this op
-        self.lane = self.wgrad_lane
+        if self.wgrad_delay > 0 and not final:
+            self._release_armed(home)
+            self._wg_armed[home] = [q, ready, self.wgrad_delay]
+            return
+        self._emit_batch(home, q, ready)
+
+    def _release_armed(self, home):
+        arm = self._wg_armed.pop(home, None)
+        if arm is not None:
+            self._emit_batch(home, arm[0], arm[1])
+
+    def _emit_batch(self, home, q, ready):
+        prev = self.lane
+        self.lane = self._wgrad_lane_of(home)
         self.wait_event(self.bwd, ready)
         for fn in q:
             fn()
@@ -1409,7 +1455,15 @@ class Plan:
         self.n_pack_jobs = len(self.pack_jobs)
         self.n_pack_blocks = sum(t[3] for t in self.pack_tables)
 
-        def build(lst, prologue):
+        def cost_hint(m):
+            """duration estimate of an op for the issue-order simulation of pmf_plan_run (pad_ bits 24-30, units of 4 us):
+            matrix work at 100 TFLOP/s fp32-equivalent, everything else at 3 TB/s, 6 us per launch at least"""
+            us = 6.0
+            if m:
+                us = max(us, m.get("flops", 0.0) / 100e12 * 1e6, m.get("bytes", 0.0) / 3e12 * 1e6)
+            return max(1, min(127, int(round(us / 4.0))))
+
+        def build(lst, prologue, meta):
             n = len(lst) + len(prologue)
             arr = (L.Op * max(n, 1))()
             k = 0
@@ -1417,6 +1471,7 @@ class Plan:
                 kind, fill = ent[0], ent[1]
                 arr[k].kind = kind
                 arr[k].pad_ = ent[2] if len(ent) > 2 else 0     # lane / wait / record bits (pmf_amd.h)
+                arr[k].pad_ |= cost_hint(meta.get(k - len(prologue)) if k >= len(prologue) else None) << 24
                 fill(arr[k])
                 k += 1
             return arr, n
@@ -1440,7 +1495,7 @@ class Plan:
         if self.zero_fwd.size:
             pro_f.insert(0, (L.OP_FILL, zero_arena(self.zero_fwd)))
         self.fwd_shift = len(pro_f)
-        self.fwd_ops, self.n_fwd = build(self.fwd, pro_f)
+        self.fwd_ops, self.n_fwd = build(self.fwd, pro_f, self.meta_fwd)
         if self.training:
             pro_b = [(L.OP_FILL, zero_arena(self.zero_bwd))]
             if self.flat is not None:
@@ -1449,7 +1504,7 @@ class Plan:
                     a.p[0], a.f[0], a.l[0] = g.data_ptr(), 0.0, g.numel()
                 pro_b.append((L.OP_FILL, zero_flat))
             self.bwd_shift = len(pro_b)
-            self.bwd_ops, self.n_bwd = build(self.bwd, pro_b)
+            self.bwd_ops, self.n_bwd = build(self.bwd, pro_b, self.meta_bwd)
         else:
             self.bwd_ops, self.n_bwd, self.bwd_shift = None, 0, 0
         self.fwd_kinds = [e[0] for e in pro_f + self.fwd]

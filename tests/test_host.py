@@ -126,7 +126,11 @@ def test_plan_builds_and_is_consistent(training):
         assert len(wait) == 4 and all(l == 0 for _, l in wait) and {e for e, _ in wait} == rec
         bl = [(bk[i], P.bwd_ops[i].pad_) for i in range(P.n_bwd)]
         bwait = [(k, b & 3) for k, b in bl if (b >> 8) & 0xff]
-        assert bwait == [("OP_ADD_ACT", 1)] * 4
+        assert [w for w in bwait if w[1] < 2] == [("OP_ADD_ACT", 1)] * 4
+        # weight gradients: batches on lanes 2 / 3, each batch behind one event of its home lane
+        side = [w for w in bwait if w[1] >= 2]
+        assert side and all(k == "OP_WGRAD_PART" for k, _ in side) and {l for _, l in side} == {2, 3}
+        assert all((b & 3) >= 2 for k, b in bl if k in ("OP_WGRAD_PART", "OP_WGRAD_RED"))
         for ops, n in ((P.fwd_ops, P.n_fwd), (P.bwd_ops, P.n_bwd)):      # an event is recorded before it is awaited
             seen = set()
             for i in range(n):
@@ -142,6 +146,54 @@ def test_plan_builds_and_is_consistent(training):
             assert o1 + n1 <= o2
         # dropout multiplier table covers the 15 application sites + 3 derived products
         assert len(P.mask_sites) == 15 and len(P.mask_derived) == 3
+
+
+def _issue_order(ops, n):
+    out = (C.c_int32 * n)()
+    assert L.lib().pmf_plan_issue_order(C.cast(ops, C.c_void_p), 0, n, C.cast(out, C.c_void_p)) == 0
+    return list(out)
+
+
+@pytest.mark.parametrize("wgrad_lane", ["0", "2", "23"])
+def test_plan_issue_order_keeps_lane_order_and_events(wgrad_lane, monkeypatch):
+    """pmf_plan_run / pmf_plan_capture hand the ops to the streams in the order of a simulated parallel execution
+    (csrc/plan.cpp issue_order): a permutation of the range that keeps every lane's own order, issues the record of an
+    event before its wait, and forks a side lane only behind the main-lane ops that precede its first op in the list."""
+    monkeypatch.setenv("PMF_WGRAD_LANE", wgrad_lane)
+    m = PMFNet(imagenet_pretrained=False).train(True)
+    P = m._build(2, 32, 64, True, torch.device("cpu"))
+    for ops, n in ((P.fwd_ops, P.n_fwd), (P.bwd_ops, P.n_bwd)):
+        order = _issue_order(ops, n)
+        assert sorted(order) == list(range(n))
+        pos = {k: i for i, k in enumerate(order)}
+        lanes = {}
+        for k in range(n):
+            lanes.setdefault(ops[k].pad_ & 3, []).append(k)
+        for lane, ks in lanes.items():                      # per-lane order
+            assert [pos[k] for k in ks] == sorted(pos[k] for k in ks)
+        rec = {}
+        for k in range(n):
+            r = ((ops[k].pad_ >> 16) & 0xff) - 1
+            if r >= 0:
+                rec.setdefault(r, k)
+        nwait = 0
+        for k in range(n):
+            w = ((ops[k].pad_ >> 8) & 0xff) - 1
+            if w >= 0 and w in rec and rec[w] < k:
+                assert pos[rec[w]] < pos[k]
+                nwait += 1
+        assert nwait >= 4
+        for lane, ks in lanes.items():                      # fork point
+            if lane:
+                for k0 in lanes[0]:
+                    if k0 < ks[0]:
+                        assert pos[k0] < pos[ks[0]]
+        # the lanes really interleave: the camera lane's ops are not one block behind the LiDAR lane's
+        seq = [ops[k].pad_ & 3 for k in order if (ops[k].pad_ & 3) < 2]
+        assert sum(1 for a, b in zip(seq, seq[1:]) if a != b) > 40
+    if wgrad_lane != "0":
+        bl = [P.bwd_ops[i].pad_ & 3 for i in range(P.n_bwd) if P.bwd_kinds[i] == L.OP_WGRAD_PART]
+        assert set(bl) <= {2, 3} and (wgrad_lane == "2") == (set(bl) == {2})
 
 
 def test_salsanext_plan_builds():
