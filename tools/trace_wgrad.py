@@ -59,6 +59,8 @@ def main(filt, ns):
             name, wd.nsplit, len(t), cnt, span, int(np.median(t[:, cnt - 1] - t[:, 0]))))
         names = ["prologue"]
         per = ["X barrier", "split+store X", "Y barrier", "fetch + dz wait + B prep", "108 MFMAs"]
+        if os.environ.get("PMF_WG_SWP", "1") != "0":     # software-pipelined body: three stamps per tile
+            per = ["barrier", "dz wait + B prep", "108 MFMAs + split(t+1)", "fetch(t+2)"]
         ntile = (cnt - 1 - 1 - 2) // len(per)
         for i in range(ntile): names += ["t%d %s" % (i, p) for p in per]
         names += ["loop exit", "reduce+write"]
