@@ -1074,6 +1074,301 @@ __global__ __launch_bounds__(256) void conv_wgrad_s3_swp_k(const pmf_wgrad_desc_
   conv_wgrad_s3_swp_body<TB, XSL>(d, g, smem);
 }
 
+// ---- eight waves per workgroup (W8): two waves per SIMD ----------------------------------------------------------------
+// What bounds conv_wgrad_s3_swp_body is the instruction stream of the ONE wave a SIMD holds (144 accumulator registers
+// per wave): ~770 instructions per tile at one issue slot every four cycles plus dependent-issue latency -- the loop
+// takes the same time with the MFMAs compiled out.  Here the taps of a 16-pixel slab are dealt to TWO waves (taps
+// [0, TBW) and [TBW, TB): 80 accumulator registers each), 512 threads per workgroup, so that every SIMD holds two
+// waves whose instruction streams interleave and the per-thread share of the split halves.
+//   * input tile: double-buffered in LDS as in the SWP body, 512 threads x XSL slots (4 or 5);
+//   * dz: both halves of a tile are 16 DMA instructions of 1 KiB, two per wave, into a double-buffered slab pair
+//     (a slab is read by the two waves that own its pixels: the barrier at the top of an iteration publishes it);
+//   * one barrier per tile.
+template <int TB, int XSL>
+__device__ __forceinline__ void conv_wgrad_s3_w8_body(const pmf_wgrad_desc_t& d, const WgGeom& g, float* __restrict__ smem) {
+  constexpr int BN = 32;
+  constexpr int HPX = 64;
+  constexpr int TBW = (TB + 1) / 2;             // taps of the first wave of a pair; the second takes TB - TBW
+  constexpr int NT = 512;
+  char* __restrict__ Xs0 = (char*)smem;
+  char* __restrict__ Xs1 = Xs0 + g.x_floats * 4;
+  float* __restrict__ Zb0 = (float*)(Xs1 + g.x_floats * 4);      // [2 halves][64 pixels][32 co], three tiles in flight
+  float* __restrict__ Zb1 = Zb0 + 2 * HPX * BN;
+  float* __restrict__ Zb2 = Zb1 + 2 * HPX * BN;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int slab = wave & 3, tset = wave >> 2;
+  const int li = lane & 31, lh = lane >> 5;
+  const int split = blockIdx.x, chunk = blockIdx.y;
+  const int co0 = (int)blockIdx.z * BN;
+  const int in_cols = g.in_cols;
+  int wtri_ = 0;
+  (void)wtri_;
+  WTR();
+
+  int si = 0, c0 = 0, k0 = 0;
+  {
+    int rem = chunk;
+    for (;;) {
+      const int nch = (d.src[si].C + WG_CI - 1) / WG_CI;     // (a 16-channel operand is one half-empty chunk)
+      if (rem < nch) { c0 = rem * WG_CI; k0 += c0; break; }
+      rem -= nch; k0 += d.src[si].C; ++si;
+    }
+  }
+  const int sld = d.src[si].ldc, sflags = d.src[si].flags;
+  const int sH = d.OH, sW = d.OW;
+  const bool aff = d.src[si].scale != nullptr, has_cm = d.src[si].cmul != nullptr;
+  const int q = tid & 7, cch = c0 + q * 4;
+  const int kc = min(WG_CI, d.src[si].C - c0);      // channels of this chunk that exist
+  const bool qok = q * 4 < kc;                      // this thread's four channels exist (else: zeros)
+  const int totalX = g.in_rows * in_cols * 8;
+  int rc[XSL], so[XSL];
+#pragma unroll
+  for (int j = 0; j < XSL; ++j) {
+    const int f = tid + NT * j, pix = f >> 3;
+    const int r = pix / in_cols, c = pix - r * in_cols;
+    rc[j] = (f < totalX && qok) ? (r << 8 | c) : (0x7fff << 8);
+    so[j] = ((r * sW + c) * sld + cch) * 4;
+  }
+  // dz: chunk k (0..15) of a tile = 8 pixels x 32 channels (1 KiB); wave w DMAs chunks 2 w and 2 w + 1
+  int offZ[2];
+#pragma unroll
+  for (int jj = 0; jj < 2; ++jj) {
+    const int p = (2 * wave + jj) * 8 + lane / 8;            // pixel 0..127 of the tile: row p / 32, column p % 32
+    offZ[jj] = ((p >> 5) * d.OW + (p & 31)) * d.dz_ldc + (lane % 8) * 4;
+  }
+  // own taps
+  const int t0 = tset ? TBW : 0;
+  int toff[TBW];
+#pragma unroll
+  for (int j = 0; j < TBW; ++j) {
+    const int t = min(t0 + j, TB - 1);
+    toff[j] = (((int)d.tdy[t] - g.dy_min) * in_cols + ((int)d.tdx[t] - g.dx_min)) * WS3_XPB;
+  }
+  const int trofs = (((lane >> 5) * 8 + ((lane & 15) >> 2)) * WS3_XPB) + ((((lane >> 4) & 1) * 16 + (lane & 3) * 4) * 2);
+
+  f32x16 acc[TBW];
+#pragma unroll
+  for (int j = 0; j < TBW; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  const __amdgpu_buffer_rsrc_t xrs_on =
+      __builtin_amdgcn_make_buffer_rsrc((void*)d.src[si].x, 0, d.N * sH * sW * sld * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t xrs_off = __builtin_amdgcn_make_buffer_rsrc((void*)d.src[si].x, 0, 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(has_cm ? d.src[si].cmul : d.src[si].x), 0, (has_cm && qok) ? d.N * d.src[si].cmul_ld * 4 : 0, 0x00020000);
+  f32x4 sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
+  if (aff && qok) { sc4 = *(const f32x4*)(d.src[si].scale + cch); sh4 = *(const f32x4*)(d.src[si].shift + cch); }
+  f32x4 rX[XSL], rC;
+  unsigned okX = 0u;
+  const int tiles_per_n = g.tiles_x * g.tiles_y;
+  int f_by = 0, f_bx = 0, f_base = 0, f_n = 0, f_ty = 0, f_tx = 0;
+  bool f_on = false;
+  auto fetch_coords = [&](int tile, bool on) {
+    const int n = tile / tiles_per_n, rem = tile - n * tiles_per_n;
+    const int ty = rem / g.tiles_x, tx = rem - ty * g.tiles_x;
+    f_by = ty * WG_ROWS + g.dy_min; f_bx = tx * 32 + g.dx_min;
+    f_base = ((n * sH + f_by) * sW + f_bx) * sld * 4;
+    f_n = n; f_on = on; f_ty = ty; f_tx = tx;
+  };
+  auto fetch_slot = [&](int j) {
+    const unsigned iy = (unsigned)(f_by + (rc[j] >> 8)), ix = (unsigned)(f_bx + (rc[j] & 255));
+    const bool ok = iy < (unsigned)sH && ix < (unsigned)sW;
+    okX = (okX & ~(1u << j)) | (ok ? (1u << j) : 0u);
+    const unsigned off = ok ? (unsigned)(f_base + so[j]) : 0x80000000u;
+    rX[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(f_on ? xrs_on : xrs_off, off, 0, 0));
+    if (j == XSL - 1)
+      rC = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(crs, (f_n * d.src[si].cmul_ld + cch) * 4, 0, 0));
+  };
+  auto dma_z = [&](int n, int ty, int tx, float* __restrict__ Zb) {
+    const float* src = d.dz + ((size_t)(n * d.OH + ty * WG_ROWS) * d.OW + tx * 32) * d.dz_ldc + co0;
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+      __builtin_amdgcn_global_load_lds(src + offZ[jj], (lds_ptr_t)(Zb + (2 * wave + jj) * 256), 16, 0, 0);
+  };
+  typedef __attribute__((address_space(3))) ws16x4* lds_tr_t;
+  auto afrag = [&](const char* __restrict__ base, wbf16x8 (&a)[3]) {   // 8-pixel A fragment of one tap, three planes
+#ifdef PMF_WG_NOTR       /* ablation build: no transposing LDS reads */
+#pragma unroll
+    for (int p = 0; p < 3; ++p) { wu32x4 t = {(unsigned)(size_t)base, (unsigned)p, 1u, 2u}; asm volatile("" : "+v"(t)); a[p] = __builtin_bit_cast(wbf16x8, t); }
+    return;
+#endif
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      const ws16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_t)(base + p * 64));
+      const ws16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_t)(base + p * 64 + 4 * WS3_XPB));
+      a[p] = __builtin_bit_cast(wbf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    }
+  };
+  // the slab's pixels: half h = tile rows 2 h, 2 h + 1; slab s = row s / 2 of the half, pixels 16 (s % 2) ..
+  const int rr = slab >> 1, xs = (slab & 1) * 16;
+  auto prep = [&](const float* __restrict__ Zh, wbf16x8 (&bf)[3]) {
+    const float* zp = Zh + (rr * 32 + xs + lh * 8) * BN + li;
+    float z[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) z[e] = zp[e * BN];
+    wu32x4 b0, b1, b2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      unsigned p0, p1, p2;
+      ws3_split2(z[2 * e], z[2 * e + 1], p0, p1, p2);
+      b0[e] = p0; b1[e] = p1; b2[e] = p2;
+    }
+    bf[0] = __builtin_bit_cast(wbf16x8, b0); bf[1] = __builtin_bit_cast(wbf16x8, b1); bf[2] = __builtin_bit_cast(wbf16x8, b2);
+  };
+  const int trash = g.in_rows * in_cols;
+  f32x4 cmS = {1.f, 1.f, 1.f, 1.f};
+  const float lo = (sflags & PMF_SRC_RELU) ? 0.f : -__builtin_inff();
+  auto store_slot = [&](int j, char* __restrict__ Xd) {
+    const bool ok = (okX >> j) & 1u;
+    f32x4 t;
+    t.x = ws3_fma(rX[j].x, sc4.x, sh4.x); t.y = ws3_fma(rX[j].y, sc4.y, sh4.y);
+    t.z = ws3_fma(rX[j].z, sc4.z, sh4.z); t.w = ws3_fma(rX[j].w, sc4.w, sh4.w);
+    t.x = ws3_vmax(t.x, lo); t.y = ws3_vmax(t.y, lo); t.z = ws3_vmax(t.z, lo); t.w = ws3_vmax(t.w, lo);
+    const float m = ok ? 1.f : 0.f;
+    t.x = ws3_mul(t.x, ws3_mul(cmS.x, m)); t.y = ws3_mul(t.y, ws3_mul(cmS.y, m));
+    t.z = ws3_mul(t.z, ws3_mul(cmS.z, m)); t.w = ws3_mul(t.w, ws3_mul(cmS.w, m));
+    unsigned l0, l1, l2, h0, h1, h2;
+    ws3_split2_np(t.x, t.y, l0, l1, l2);
+    ws3_split2_np(t.z, t.w, h0, h1, h2);
+    const int pix = (tid + NT * j) < totalX ? ((tid + NT * j) >> 3) : trash;
+    char* o = Xd + pix * WS3_XPB + q * 8;
+    *(wu32x2*)(o) = wu32x2{l0, h0};
+    *(wu32x2*)(o + 64) = wu32x2{l1, h1};
+    *(wu32x2*)(o + 128) = wu32x2{l2, h2};
+  };
+  // one tile: 2 halves x TBW taps; the A fragments of the next (half, tap) are read while this one multiplies; the slots
+  // of the next tile's split follow the taps one by one.  The second wave of a pair has one tap less when TB is odd: its
+  // last tap position is skipped (wave-uniform branch).
+  constexpr int NGT = 2 * TBW;
+  const bool last_tap = (t0 + TBW - 1) < TB;
+  wbf16x8 bf0[3], bf1[3];          // B fragments of the tile being multiplied
+  // Between the taps of tile t: split + store of tile t + 1, the loads of tile t + 2 into the registers a slot has
+  // freed, and the B fragments of tile t + 1 from the dz slabs the barrier at the top of the iteration has published.
+  auto tile_mma = [&](const char* __restrict__ Xc, char* __restrict__ Xn, const float* __restrict__ Zp) {
+    constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PB[6] = {2, 1, 0, 1, 0, 0};   // smallest terms first
+    wbf16x8 a[2][3], bn0[3], bn1[3];
+    const char* xb0 = Xc + ((0 + rr) * in_cols + xs) * WS3_XPB + trofs;
+    const char* xb1 = Xc + ((2 + rr) * in_cols + xs) * WS3_XPB + trofs;
+    afrag(xb0 + toff[0], a[0]);
+#pragma unroll
+    for (int gt = 0; gt < NGT; ++gt) {
+      const int cur = gt & 1, nxt = cur ^ 1;
+      const int h = gt / TBW, k = gt % TBW;
+      if (gt + 1 < NGT) afrag(((gt + 1) / TBW ? xb1 : xb0) + toff[(gt + 1) % TBW], a[nxt]);
+      if (k < TBW - 1 || last_tap) {
+#pragma unroll
+        for (int pr = 0; pr < 6; ++pr)
+          acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][PA[pr]], (h ? bf1 : bf0)[PB[pr]], acc[k], 0, 0, 0);
+      }
+#ifndef PMF_WG_NOSPLIT
+#pragma unroll
+      for (int j = gt * XSL / NGT; j < (gt + 1) * XSL / NGT; ++j) { store_slot(j, Xn); fetch_slot(j); }
+#endif
+      if (gt == NGT / 2 - 1) prep(Zp, bn0);
+      if (gt == NGT - 2) prep(Zp + HPX * BN, bn1);
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p) { bf0[p] = bn0[p]; bf1[p] = bn1[p]; }
+  };
+
+  // Vector-memory queue of a wave, oldest first, at the top of iteration t: [input t+1 (XSL + 1)]; my share of dz(t+1)
+  // has landed (the barrier publishes it)
+  int tile = split;
+  int cur = 0;
+  float* Zq0 = Zb0;   // dz(t)   -- consumed (B fragments prepared during iteration t - 1)
+  float* Zq1 = Zb1;   // dz(t+1) -- read during iteration t
+  float* Zq2 = Zb2;   // dz(t+2) -- DMA'd during iteration t
+  if (tile < g.total_tiles) {
+    fetch_coords(tile, true);
+#pragma unroll
+    for (int j = 0; j < XSL; ++j) fetch_slot(j);
+    dma_z(f_n, f_ty, f_tx, Zq0);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2) : "memory");            // the first input tile landed
+    if (has_cm) cmS = rC;
+#pragma unroll
+    for (int j = 0; j < XSL; ++j) store_slot(j, Xs0);
+    const int n1 = tile + d.nsplit;
+    fetch_coords(n1 < g.total_tiles ? n1 : tile, n1 < g.total_tiles);
+#pragma unroll
+    for (int j = 0; j < XSL; ++j) fetch_slot(j);
+    dma_z(f_n, f_ty, f_tx, Zq1);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XSL + 1 + 2) : "memory");  // my share of dz(t) landed
+    __syncthreads();
+    prep(Zq0, bf0);
+    prep(Zq0 + HPX * BN, bf1);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XSL + 1) : "memory");      // ... of dz(t + 1); queue: [input t+1]
+  }
+  WTR();
+  while (tile < g.total_tiles) {
+    const int next = tile + d.nsplit;
+    const char* Xc = cur ? Xs1 : Xs0;
+    char* Xn = cur ? Xs0 : Xs1;
+    const int n2 = next + d.nsplit;
+    const bool have2 = n2 < g.total_tiles;
+    fetch_coords(have2 ? n2 : tile, have2);
+    __syncthreads();                       // input tile t and dz(t + 1) complete; everyone finished with tile t - 1
+    WTR();
+    dma_z(f_n, f_ty, f_tx, Zq2);           // dz(t + 2); queue: [input t+1][dz t+2 (2)]
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2) : "memory");            // input tile t + 1 landed in registers
+    cmS.x = has_cm ? rC.x : 1.f; cmS.y = has_cm ? rC.y : 1.f; cmS.z = has_cm ? rC.z : 1.f; cmS.w = has_cm ? rC.w : 1.f;
+    WTR();
+    tile_mma(Xc, Xn, Zq1);                 // queue afterwards: [dz t+2 (2)][input t+2]
+    WTR();
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XSL + 1) : "memory");      // my share of dz(t + 2) landed (published by the next barrier)
+    WTR();
+    tile = next;
+    cur ^= 1;
+    float* zt = Zq0; Zq0 = Zq1; Zq1 = Zq2; Zq2 = zt;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  WTR();
+
+  // ---- sum the four pixel groups (fixed order) and write this workgroup's partial slab: per tap set, slabs 1..3 hand
+  // their accumulators to slab 0 through LDS
+  {
+    float* red = smem + tset * (3 * 16 * 64);   // [3 slabs][16][64] per tap set
+#pragma unroll
+    for (int j = 0; j < TBW; ++j) {
+      __syncthreads();
+      if (slab > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[((slab - 1) * 16 + r) * 64 + lane] = acc[j][r];
+      }
+      __syncthreads();
+      if (slab == 0) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[j][r] += red[(p * 16 + r) * 64 + lane];
+      }
+    }
+  }
+  if (slab == 0) {
+    float* part = d.partial + (size_t)split * d.ntaps * g.Ktot * g.Cout32;
+    const int co = co0 + li;
+#pragma unroll
+    for (int j = 0; j < TBW; ++j) {
+      if (t0 + j < TB) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ci = (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (ci < kc) part[((size_t)(t0 + j) * g.Ktot + k0 + ci) * g.Cout32 + co] = acc[j][r];
+        }
+      }
+    }
+  }
+  WTR();
+  WTR_END();
+}
+
+template <int TB, int XSL>
+__global__ __launch_bounds__(512) void conv_wgrad_s3_w8_k(const pmf_wgrad_desc_t d, const WgGeom g) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  conv_wgrad_s3_w8_body<TB, XSL>(d, g, smem);
+}
+
 template <int TB, int XSL>
 __global__ __launch_bounds__(256) void conv_wgrad_s3_k(const pmf_wgrad_desc_t d, const WgGeom g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1866,9 +2161,28 @@ static int wg_launch(const pmf_wgrad_desc_t* d, hipStream_t s, int phase) {
       g.x_floats = g.in_rows * g.in_cols * (WS3_XPB / 4);
       int lds3 = (g.x_floats + WG_ROWS * 32 * 32) * 4;
       if (lds3 < 16 * 1024) lds3 = 16 * 1024;
-      static const bool swp = !(getenv("PMF_WG_SWP") && getenv("PMF_WG_SWP")[0] == '0');
+      // (read per launch, not cached: the tests switch variants; a replayed graph never comes here)
+      const char* e_swp = getenv("PMF_WG_SWP");
+      const char* e_w8 = getenv("PMF_WG_W8");
+      const bool swp = !(e_swp && e_swp[0] == '0');
       const bool small7 = g.in_rows * g.in_cols * 8 <= 256 * 7;
-      if (swp) {      // input tile double-buffered: tile t + 1 is split while tile t is multiplied
+      const bool w8 = e_w8 && e_w8[0] == '1';
+      // eight waves (the taps of a slab on two waves, two waves per SIMD): 3-10 % faster launch by launch, but 110 KiB
+      // of LDS and 512 threads leave no room for the input-gradient launches the weight gradients run next to:
+      // 16.08 vs 15.97 ms per step -- off unless PMF_WG_W8=1
+      if (swp && w8 && TB > 1) {
+        if constexpr (TB > 1) {
+          static unsigned long long attr5 = 0ull;
+          if (pmf_first_on_device(&attr5)) {
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_s3_w8_k<TB, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_s3_w8_k<TB, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+          }
+          g.x_floats += WS3_XPB / 4;           // the spare pixel that slots beyond the tile write to
+          const int lds5 = (2 * g.x_floats + 3 * WG_ROWS * 32 * 32) * 4;
+          if (g.in_rows * g.in_cols * 8 <= 512 * 4) hipLaunchKernelGGL((conv_wgrad_s3_w8_k<TB, 4>), grid, dim3(512), lds5, s, *d, g);
+          else hipLaunchKernelGGL((conv_wgrad_s3_w8_k<TB, 5>), grid, dim3(512), lds5, s, *d, g);
+        }
+      } else if (swp) {      // input tile double-buffered: tile t + 1 is split while tile t is multiplied
         static unsigned long long attr4 = 0ull;
         if (pmf_first_on_device(&attr4)) {
           (void)hipFuncSetAttribute((const void*)conv_wgrad_s3_swp_k<TB, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -135,6 +135,21 @@ def test_conv_unit_fwd_bwd(case):
     _conv_case(case, 0)
 
 
+@pytest.mark.parametrize("env", [{"PMF_WG_SWP": "0"}, {"PMF_WG_W8": "1"}], ids=["staged", "eight_waves"])
+def test_conv_unit_wgrad_variants(env, monkeypatch):
+    """the split-bf16 weight-gradient kernel's other forms (conv_wgrad.hip): the two-barrier staged loop that the
+    software-pipelined default replaced (PMF_WG_SWP=0) and the 512-thread form with the taps of a slab on two waves
+    (PMF_WG_W8=1); same cases, same float64 bars"""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    ran = 0
+    for case in CONVS:
+        if case[6] in (2, 3) and case[9] == 1:      # 2x2 / 3x3, stride 1
+            _conv_case(case, 0)
+            ran += 1
+    assert ran >= 2
+
+
 DIRECT_1X1 = [c for c in CONVS if c[0] in ("c1x1cat3", "c1x1_plain_lrelu", "c1x1s2", "c1x1cat3_big", "c1x1_odd_big",
                                             "c1x1_c20_big", "c1x1_wide_big", "c1x1_odd_wide", "c1x1_to1024", "c1x1_k768_cat",
                                             "c1x1_k784")]

@@ -61,6 +61,8 @@ def main(filt, ns):
         per = ["X barrier", "split+store X", "Y barrier", "fetch + dz wait + B prep", "108 MFMAs"]
         if os.environ.get("PMF_WG_SWP", "1") != "0":     # software-pipelined body: three stamps per tile
             per = ["barrier", "dz wait + B prep", "108 MFMAs + split(t+1)", "fetch(t+2)"]
+            if os.environ.get("PMF_WG_W8", "0") == "1":
+                per = ["barrier", "dz DMA + input wait", "MFMAs + split(t+1) + fetch(t+2) + B prep(t+1)", "dz wait"]
         ntile = (cnt - 1 - 1 - 2) // len(per)
         for i in range(ntile): names += ["t%d %s" % (i, p) for p in per]
         names += ["loop exit", "reduce+write"]
