@@ -510,7 +510,10 @@ def plan_rooflines(plan, prof, model_tag):
             "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_FP32_MFMA, 4),
             "peak_note": "peak = dense fp32 MFMA (the arithmetic type); achieved = algorithmic fp32 flops / launch time; "
-                         "launch time = HIP events around 3 back-to-back launches of every conv op, one lane",
+                         "launch time = HIP events around 3 back-to-back launches of every conv op, one lane "
+                         "(the kernel alone on the chip: profiles/*_bench_kernel_stats_one_lane.csv is the rocprofv3 "
+                         "view of the same; in the timed 4-lane replay 2-4 kernels share the chip and each launch "
+                         "stretches, profiles/*_bench_kernel_stats.csv)",
             "bf16_pipe": {"executed_tflops": round(achieved * (6.0 * share), 1), "peak": PEAK_BF16_MFMA,
                           "frac": round(achieved * 6.0 * share / PEAK_BF16_MFMA, 4),
                           "fp32_equivalent_ceiling_tflops": round(PEAK_BF16_MFMA / 6.0, 1)},
