@@ -17,8 +17,8 @@ python $ROOT/tools/rocpd_join.py /tmp/p2/j_results.db $OUT/ops.txt 14 $OUT/${TAG
 # (the same one-lane run as per-kernel statistics: every kernel alone on the chip -- what bench.py's roofline divides by)
 python $ROOT/tools/rocpd_stats.py /tmp/p2/j_results.db $OUT/${TAG}_bench_kernel_stats_one_lane.csv 0.5 > /dev/null
 # 2b. who runs next to whom in the replayed step: per-queue timeline of the last full step + concurrency histogram
-python $ROOT/tools/rocpd_lanes.py /tmp/p1/r_results.db $OUT/${TAG}_lanes_segments.txt
-python $ROOT/tools/rocpd_overlap.py /tmp/p1/r_results.db 0.4 | tail -6 > $OUT/${TAG}_overlap.txt
+rm -rf /tmp/p2b; rocprofv3 --kernel-trace -d /tmp/p2b -o l -- python $ROOT/bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-f32-ref --no-roofline --no-parity > /dev/null 2>&1
+python $ROOT/tools/rocpd_lanes.py /tmp/p2b/l_results.db $OUT/${TAG}_lanes_segments.txt
 # 3. HBM-side traffic of the conv launches: FETCH_SIZE and WRITE_SIZE in separate passes
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/p_$c; rocprofv3 --kernel-trace --pmc $c -d /tmp/p_$c -o t -- python $ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-f32-ref --no-parity > /dev/null 2>&1

@@ -21,8 +21,15 @@ def main(db, out):
     step = rows[a:b]
     t0 = step[0][0]
     qs = sorted({r[2] for r in step})
+    ev = sorted([(r[0], 1) for r in step] + [(r[1], -1) for r in step])
+    wall, depth, prev = [0.0] * 5, 0, ev[0][0]
+    for x, k in ev:
+        wall[min(depth, 4)] += (x - prev) / 1e3
+        prev, depth = x, depth + k
     with open(out, "w") as f:
         f.write("step span %.1f us, %d kernels, queues %s\n" % ((step[-1][1] - t0) / 1e3, len(step), qs))
+        f.write("wall time by kernels in flight (us): " + "  ".join("%d%s: %.0f" % (k, "+" if k == 4 else "", wall[k]) for k in range(5))
+                + "   sum of kernel durations %.0f\n" % (sum(r[1] - r[0] for r in step) / 1e3))
         for r in step:
             depth = sum(1 for x in step if x[0] <= r[0] < x[1])
             name = re.sub(r"\(.*", "", r[3]).replace("void ", "")
