@@ -827,12 +827,14 @@ __device__ __forceinline__ void conv_wgrad_s3_swp_body(const pmf_wgrad_desc_t& d
   // per slot, fixed for the life of the workgroup: (row, column) inside the input tile and the byte offset of the
   // slot's 16 bytes relative to the tile's first pixel; a slot beyond the tile (or channels that do not exist) gets a
   // row no image has
-  int rc[XSL], so[XSL];
+  int sr[XSL], sc[XSL], so[XSL];
+  const float rcols = 1.f / (float)in_cols;
 #pragma unroll
   for (int j = 0; j < XSL; ++j) {
     const int f = tid + 256 * j, pix = f >> 3;
-    const int r = pix / in_cols, c = pix - r * in_cols;
-    rc[j] = (f < totalX && qok) ? (r << 8 | c) : (0x7fff << 8);
+    const int r = pmf_fdiv(pix, in_cols, rcols), c = pix - r * in_cols;
+    sr[j] = (f < totalX && qok) ? r : 0x7fff;
+    sc[j] = c;
     so[j] = ((r * sW + c) * sld + cch) * 4;
   }
   int offZ[ZPW];
@@ -863,7 +865,7 @@ __device__ __forceinline__ void conv_wgrad_s3_swp_body(const pmf_wgrad_desc_t& d
   f32x4 sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
   if (aff && qok) { sc4 = *(const f32x4*)(d.src[si].scale + cch); sh4 = *(const f32x4*)(d.src[si].shift + cch); }
   f32x4 rX[XSL], rC;
-  unsigned okX = 0u;
+  float mX[XSL];                           // 1 where the slot's element exists, 0 where it is padding
   const int tiles_per_n = g.tiles_x * g.tiles_y;
   // dz of a tile from its (sample, tile row, tile column): the coordinates are computed once per tile (fetch_coords)
   // and handed down -- every scalar instruction is an issue slot of the only wave on this SIMD
@@ -906,12 +908,11 @@ __device__ __forceinline__ void conv_wgrad_s3_swp_body(const pmf_wgrad_desc_t& d
   f32x4 cmS = {1.f, 1.f, 1.f, 1.f};        // channel multiplier of the tile being split (set once per tile)
   const float lo = (sflags & PMF_SRC_RELU) ? 0.f : -__builtin_inff();
   auto store_slot = [&](int j, char* __restrict__ Xd) {
-    const bool ok = (okX >> j) & 1u;
     f32x4 t;                                // (scale 1, shift 0 without a BatchNorm view; no packed-f32 forms here)
     t.x = ws3_fma(rX[j].x, sc4.x, sh4.x); t.y = ws3_fma(rX[j].y, sc4.y, sh4.y);
     t.z = ws3_fma(rX[j].z, sc4.z, sh4.z); t.w = ws3_fma(rX[j].w, sc4.w, sh4.w);
     t.x = ws3_vmax(t.x, lo); t.y = ws3_vmax(t.y, lo); t.z = ws3_vmax(t.z, lo); t.w = ws3_vmax(t.w, lo);
-    const float m = ok ? 1.f : 0.f;
+    const float m = mX[j];
     t.x = ws3_mul(t.x, ws3_mul(cmS.x, m)); t.y = ws3_mul(t.y, ws3_mul(cmS.y, m));
     t.z = ws3_mul(t.z, ws3_mul(cmS.z, m)); t.w = ws3_mul(t.w, ws3_mul(cmS.w, m));
     unsigned l0, l1, l2, h0, h1, h2;
@@ -931,21 +932,39 @@ __device__ __forceinline__ void conv_wgrad_s3_swp_body(const pmf_wgrad_desc_t& d
   // Vector-memory queue of a wave, oldest first, at the top of iteration t:  [dz0 t][dz1 t][input t+1]
   constexpr int G = TB % 3 == 0 ? 3 : (TB % 2 == 0 ? 2 : 1), NG = TB / G;
   constexpr int NGT = 2 * NG;                                 // groups per tile
+  // (sample, tile row, tile column) of the tile being fetched advance by the workgroup's stride without a division: every
+  // scalar instruction is an issue slot of the only wave on this SIMD
   int f_by = 0, f_bx = 0, f_base = 0, f_n = 0, f_ty = 0, f_tx = 0;
   bool f_on = false;
-  auto fetch_coords = [&](int tile, bool on) {
-    const int n = tile / tiles_per_n, rem = tile - n * tiles_per_n;
-    const int ty = rem / g.tiles_x, tx = rem - ty * g.tiles_x;
-    f_by = ty * WG_ROWS + g.dy_min; f_bx = tx * 32 + g.dx_min;
-    f_base = ((n * sH + f_by) * sW + f_bx) * sld * 4;
-    f_n = n; f_on = on; f_ty = ty; f_tx = tx;
+  const int st_n = d.nsplit / tiles_per_n, st_r = d.nsplit - st_n * tiles_per_n;
+  const int st_ty = st_r / g.tiles_x, st_tx = st_r - st_ty * g.tiles_x;
+  auto coords_set = [&]() {
+    f_by = f_ty * WG_ROWS + g.dy_min; f_bx = f_tx * 32 + g.dx_min;
+    f_base = ((f_n * sH + f_by) * sW + f_bx) * sld * 4;
+  };
+  auto fetch_first = [&](int tile) {
+    f_n = tile / tiles_per_n;
+    const int rem = tile - f_n * tiles_per_n;
+    f_ty = rem / g.tiles_x; f_tx = rem - f_ty * g.tiles_x;
+    f_on = true;
+    coords_set();
+  };
+  auto fetch_next = [&](bool on) {            // on: the next tile exists (else the current coordinates are requested again)
+    if (on) {
+      f_tx += st_tx;
+      if (f_tx >= g.tiles_x) { f_tx -= g.tiles_x; ++f_ty; }
+      f_ty += st_ty;
+      if (f_ty >= g.tiles_y) { f_ty -= g.tiles_y; ++f_n; }
+      f_n += st_n;
+      coords_set();
+    }
+    f_on = on;
   };
   // branch-free: the tile's first pixel is one scalar, the per-slot part is precomputed; a padding / non-existent
   // element gets an offset beyond every resource (the load returns 0 without touching memory)
   auto fetch_slot = [&](int j) {
-    const unsigned iy = (unsigned)(f_by + (rc[j] >> 8)), ix = (unsigned)(f_bx + (rc[j] & 255));
-    const bool ok = iy < (unsigned)sH && ix < (unsigned)sW;
-    okX = (okX & ~(1u << j)) | (ok ? (1u << j) : 0u);
+    const bool ok = (unsigned)(f_by + sr[j]) < (unsigned)sH && (unsigned)(f_bx + sc[j]) < (unsigned)sW;
+    mX[j] = ok ? 1.f : 0.f;
     const unsigned off = ok ? (unsigned)(f_base + so[j]) : 0x80000000u;
     rX[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(f_on ? xrs_on : xrs_off, off, 0, 0));
     if (j == XSL - 1)
@@ -983,7 +1002,7 @@ __device__ __forceinline__ void conv_wgrad_s3_swp_body(const pmf_wgrad_desc_t& d
   int tile = split;
   int cur = 0;
   if (tile < g.total_tiles) {
-    fetch_coords(tile, true);
+    fetch_first(tile);
 #pragma unroll
     for (int j = 0; j < XSL; ++j) fetch_slot(j);
     dma(zsrc_c(f_n, f_ty, f_tx, 0), Z0);
@@ -992,8 +1011,7 @@ __device__ __forceinline__ void conv_wgrad_s3_swp_body(const pmf_wgrad_desc_t& d
     if (has_cm) cmS = rC;
 #pragma unroll
     for (int j = 0; j < XSL; ++j) store_slot(j, Xs0);
-    const int n1 = tile + d.nsplit;
-    fetch_coords(n1 < g.total_tiles ? n1 : tile, n1 < g.total_tiles);
+    fetch_next(tile + d.nsplit < g.total_tiles);
 #pragma unroll
     for (int j = 0; j < XSL; ++j) fetch_slot(j);
   }
@@ -1021,9 +1039,7 @@ __device__ __forceinline__ void conv_wgrad_s3_swp_body(const pmf_wgrad_desc_t& d
     // harmless, and one code path keeps the accumulators in place)
     tile_mma(Xc, Xn, bf0, bf1);
     WTR();
-    const int n2 = next + d.nsplit;
-    const bool have2 = n2 < g.total_tiles;
-    fetch_coords(have2 ? n2 : tile, have2);
+    fetch_next(next + d.nsplit < g.total_tiles);
     z_n = f_n; z_ty = f_ty; z_tx = f_tx;
 #pragma unroll
     for (int j = 0; j < XSL; ++j) fetch_slot(j);
