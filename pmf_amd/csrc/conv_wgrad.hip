@@ -887,11 +887,13 @@ __device__ __forceinline__ void conv_wgrad_s3_swp_body(const pmf_wgrad_desc_t& d
     }
   };
   const int rr = wave >> 1, xs = (wave & 1) * 16;
-  auto prep = [&](const float* __restrict__ Zh, wbf16x8 (&bf)[3]) {
+  // B fragment dz[pixel 8 lh + e][co li], e = 0..7, of the wave's slab: read (prep_load), then split in registers
+  auto prep_load = [&](const float* __restrict__ Zh, float (&z)[8]) {
     const float* zp = Zh + (rr * 32 + xs + lh * 8) * BN + li;
-    float z[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) z[e] = zp[e * BN];
+  };
+  auto prep_split = [&](const float (&z)[8], wbf16x8 (&bf)[3]) {
     wu32x4 b0, b1, b2;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -1024,14 +1026,15 @@ __device__ __forceinline__ void conv_wgrad_s3_swp_body(const pmf_wgrad_desc_t& d
     __syncthreads();                       // tile t complete in Xc; everyone finished reading Xn (tile t - 1)
     WTR();
     wbf16x8 bf0[3], bf1[3];
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XSL + 1 + ZPW) : "memory");    // my dz slab of half 0 landed
-    prep(Z0, bf0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // slab read: the DMA below may overwrite it
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XSL + 1) : "memory");      // my dz slabs (both halves) landed
+    float z0[8], z1[8];
+    prep_load(Z0, z0);
+    prep_load(Z1, z1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // slabs read: the DMAs below may overwrite them
     dma(zsrc_c(z_n, z_ty, z_tx, 0), Z0);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XSL + 1 + ZPW) : "memory");    // ... of half 1
-    prep(Z1, bf1);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     dma(zsrc_c(z_n, z_ty, z_tx, 1), Z1);
+    prep_split(z0, bf0);                    // (both halves' splits interleave, under the DMA issue)
+    prep_split(z1, bf1);
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * ZPW) : "memory");      // input tile t + 1 landed in registers
     cmS.x = has_cm ? rC.x : 1.f; cmS.y = has_cm ? rC.y : 1.f; cmS.z = has_cm ? rC.z : 1.f; cmS.w = has_cm ? rC.w : 1.f;
     WTR();
