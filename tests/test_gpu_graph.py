@@ -50,3 +50,46 @@ def test_graph_replay_with_fresh_input_addresses():
         keep = a.clone()
         b = m(pcd2.cuda(), rgb2.cuda())[0]
     assert torch.equal(a, keep) and not torch.equal(a, b)
+
+
+def test_replay_pieces_match_eager_and_single_graph(tmp_path):
+    """A captured range is replayed as linear hipGraph pieces on the lanes' streams (csrc/plan.cpp).  Three processes
+    train the same model on the same batches for six iterations -- kernels issued one by one (PMF_GRAPH=0), the default
+    replay, and round 2's single multi-branch graph in list order: losses and parameters must agree bit for bit (the
+    lanes and events define the dependencies; only the interleaving differs), and the default replay really consists of
+    several pieces per pass."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import json, sys, hashlib, ctypes as C, torch
+sys.path.insert(0, %r)
+from pmf_amd import _lib as L
+from pmf_amd.engine import TrainEngine
+from pmf_amd.models import PMFNet
+from pmf_amd.utils.detinit import deterministic_init, synthetic_batch
+m = deterministic_init(PMFNet(5, 3, 20, 32, imagenet_pretrained=False, image_backbone="resnet34")).cuda()
+eng = TrainEngine(m, 20, lr=1e-3, warmup_steps=2, max_steps=20)
+pcd, rgb, label, mask = synthetic_batch(2, 32, 64, 20, seed=11, fill=0.5)
+feat = torch.cat((pcd, rgb), 1).cuda(); mask, label = mask.cuda(), label.cuda()
+torch.manual_seed(5); torch.cuda.manual_seed(5)
+losses = [eng.train_step(feat.clone(), mask, label)[0].item() for _ in range(6)]
+h = hashlib.sha256()
+for k, v in sorted(m.state_dict().items()):
+    h.update(v.detach().cpu().numpy().tobytes())
+plan = next(iter(m._plans.values()))
+print(json.dumps(dict(losses=losses, state=h.hexdigest(), pieces=[L.lib().pmf_graph_pieces(g) for g in plan._graphs.values()])))
+''' % root
+    out = {}
+    for name, env in (("eager", {"PMF_GRAPH": "0"}), ("pieces", {}),
+                      ("single", {"PMF_GRAPH_MODE": "single", "PMF_PLAN_ORDER": "list", "PMF_WGRAD_LANE": "0"})):
+        e = dict(os.environ, PMF_AUTOTUNE="0", **env)
+        r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[name] = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["eager"]["pieces"] == [] and out["single"]["pieces"] == [1, 1]
+    assert len(out["pieces"]["pieces"]) == 2 and min(out["pieces"]["pieces"]) >= 4
+    assert out["pieces"]["losses"] == out["eager"]["losses"] == out["single"]["losses"]
+    assert out["pieces"]["state"] == out["eager"]["state"] == out["single"]["state"]
