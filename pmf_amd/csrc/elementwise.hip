@@ -577,16 +577,31 @@ extern "C" int pmf_fusion_gate_bwd(const float* gout, int32_t g_ldc, const pmf_v
 
 // ------------------------------------------------------------------ channel softmax, NHWC logits <-> NCHW probabilities
 #define SM_MAXC 32
+// VEC: the NHWC side moves as 16-byte vectors (ldc a multiple of 4, base 16-byte aligned): a thread owns one pixel, so a
+// scalar access per channel touches as many cache lines per instruction as a vector access that moves four channels
+template <bool VEC>
 __global__ void softmax_k(const float* __restrict__ lg, int ldc, int N, int HW, int C, float* __restrict__ prob) {
   const int64_t total = (int64_t)N * HW;
   for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < total; p += (int64_t)gridDim.x * blockDim.x) {
     const int n = (int)(p / HW);
     const int64_t hw = p - (int64_t)n * HW;
     float v[SM_MAXC];
+    if (VEC) {
+#pragma unroll
+      for (int q = 0; q < SM_MAXC / 4; ++q)
+        if (q * 4 < C) {
+          const f32x4 t = *(const f32x4*)(lg + p * ldc + q * 4);
+          v[q * 4] = t.x; v[q * 4 + 1] = t.y; v[q * 4 + 2] = t.z; v[q * 4 + 3] = t.w;
+        }
+    } else {
+#pragma unroll
+      for (int c = 0; c < SM_MAXC; ++c)
+        if (c < C) v[c] = lg[p * ldc + c];
+    }
     float m = -INFINITY;
 #pragma unroll
     for (int c = 0; c < SM_MAXC; ++c)
-      if (c < C) { v[c] = lg[p * ldc + c]; m = fmaxf(m, v[c]); }
+      if (c < C) m = fmaxf(m, v[c]);
     float sum = 0.f;
 #pragma unroll
     for (int c = 0; c < SM_MAXC; ++c)
@@ -600,11 +615,15 @@ __global__ void softmax_k(const float* __restrict__ lg, int ldc, int N, int HW, 
 extern "C" int pmf_softmax_nhwc_to_nchw(const float* logits, int32_t ldc, int32_t N, int32_t HW, int32_t C,
                                         float* prob_nchw, pmf_stream_t s) {
   if (C > SM_MAXC || C < 1) return PMF_E_UNSUPPORTED;
-  hipLaunchKernelGGL(softmax_k, dim3(ew_grid((int64_t)N * HW)), dim3(EW_BLOCK), 0, (hipStream_t)s, logits, ldc, N, HW, C,
-                     prob_nchw);
+  const bool vec = (ldc & 3) == 0 && ((uintptr_t)logits & 15) == 0 && ((C + 3) & ~3) <= ldc;
+  if (vec) hipLaunchKernelGGL(softmax_k<true>, dim3(ew_grid((int64_t)N * HW)), dim3(EW_BLOCK), 0, (hipStream_t)s, logits, ldc,
+                              N, HW, C, prob_nchw);
+  else hipLaunchKernelGGL(softmax_k<false>, dim3(ew_grid((int64_t)N * HW)), dim3(EW_BLOCK), 0, (hipStream_t)s, logits, ldc, N,
+                          HW, C, prob_nchw);
   PMF_LAUNCH_CHECK();
   return 0;
 }
+template <bool VEC>
 __global__ void softmax_bwd_k(const float* __restrict__ prob, const float* __restrict__ g, int N, int HW, int C,
                               float* __restrict__ dl, int ldc) {
   const int64_t total = (int64_t)N * HW;
@@ -620,16 +639,32 @@ __global__ void softmax_bwd_k(const float* __restrict__ prob, const float* __res
         gv[c] = g[((int64_t)n * C + c) * HW + hw];
         dot += pv[c] * gv[c];
       }
+    if (VEC) {
 #pragma unroll
-    for (int c = 0; c < SM_MAXC; ++c)
-      if (c < ldc) dl[p * ldc + c] = c < C ? pv[c] * (gv[c] - dot) : 0.f;
+      for (int q = 0; q < SM_MAXC / 4; ++q)
+        if (q * 4 < ldc) {
+          f32x4 t;
+          t.x = q * 4 + 0 < C ? pv[q * 4 + 0] * (gv[q * 4 + 0] - dot) : 0.f;
+          t.y = q * 4 + 1 < C ? pv[q * 4 + 1] * (gv[q * 4 + 1] - dot) : 0.f;
+          t.z = q * 4 + 2 < C ? pv[q * 4 + 2] * (gv[q * 4 + 2] - dot) : 0.f;
+          t.w = q * 4 + 3 < C ? pv[q * 4 + 3] * (gv[q * 4 + 3] - dot) : 0.f;
+          *(f32x4*)(dl + p * ldc + q * 4) = t;
+        }
+    } else {
+#pragma unroll
+      for (int c = 0; c < SM_MAXC; ++c)
+        if (c < ldc) dl[p * ldc + c] = c < C ? pv[c] * (gv[c] - dot) : 0.f;
+    }
   }
 }
 extern "C" int pmf_softmax_bwd_nchw_to_nhwc(const float* prob_nchw, const float* g_nchw, int32_t N, int32_t HW,
                                             int32_t C, float* dlogits, int32_t ldc, pmf_stream_t s) {
   if (C > SM_MAXC || ldc > SM_MAXC) return PMF_E_UNSUPPORTED;
-  hipLaunchKernelGGL(softmax_bwd_k, dim3(ew_grid((int64_t)N * HW)), dim3(EW_BLOCK), 0, (hipStream_t)s, prob_nchw, g_nchw,
-                     N, HW, C, dlogits, ldc);
+  const bool vec = (ldc & 3) == 0 && ((uintptr_t)dlogits & 15) == 0;
+  if (vec) hipLaunchKernelGGL(softmax_bwd_k<true>, dim3(ew_grid((int64_t)N * HW)), dim3(EW_BLOCK), 0, (hipStream_t)s, prob_nchw,
+                              g_nchw, N, HW, C, dlogits, ldc);
+  else hipLaunchKernelGGL(softmax_bwd_k<false>, dim3(ew_grid((int64_t)N * HW)), dim3(EW_BLOCK), 0, (hipStream_t)s, prob_nchw,
+                          g_nchw, N, HW, C, dlogits, ldc);
   PMF_LAUNCH_CHECK();
   return 0;
 }
@@ -641,7 +676,18 @@ __global__ void nchw2nhwc_k(const float* __restrict__ x, int64_t sn, int64_t sc,
   for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < total; p += (int64_t)gridDim.x * blockDim.x) {
     const int n = (int)(p / HW);
     const int64_t hw = p - (int64_t)n * HW;
-    for (int c = 0; c < ldc; ++c) out[p * ldc + c] = c < C ? x[n * sn + c * sc + hw] : 0.f;
+    if ((ldc & 3) == 0 && ((uintptr_t)out & 15) == 0) {     // (one 16-byte store per channel quad instead of four strided ones)
+      for (int q = 0; q < ldc; q += 4) {
+        f32x4 t;
+        t.x = q + 0 < C ? x[n * sn + (q + 0) * sc + hw] : 0.f;
+        t.y = q + 1 < C ? x[n * sn + (q + 1) * sc + hw] : 0.f;
+        t.z = q + 2 < C ? x[n * sn + (q + 2) * sc + hw] : 0.f;
+        t.w = q + 3 < C ? x[n * sn + (q + 3) * sc + hw] : 0.f;
+        *(f32x4*)(out + p * ldc + q) = t;
+      }
+    } else {
+      for (int c = 0; c < ldc; ++c) out[p * ldc + c] = c < C ? x[n * sn + c * sc + hw] : 0.f;
+    }
   }
 }
 extern "C" int pmf_nchw_to_nhwc(const float* x, int64_t stride_n, int64_t stride_c, int32_t N, int32_t C, int32_t HW,
