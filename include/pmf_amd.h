@@ -283,6 +283,10 @@ int pmf_global_mean_bwd(const float* gout, int32_t N, int32_t HW, int32_t C, con
 /* column sums: out[z][c] += sum over the npix pixels of sample z of x[z][p][c], z < nz (x advances npix*ldc,
  * out advances C per sample).  Bias gradients (nz = 1) and broadcast-operand gradients (nz = N). */
 int pmf_colsum(const float* x, int32_t ldc, int64_t npix, int32_t C, float* out, int32_t nz, pmf_stream_t s);
+/* the same sums, deterministic (partial rows + fixed-order fold instead of float atomics); scratch: nz * PMF_COL_ROWS * C
+ * floats the call may overwrite */
+int pmf_colsum_rows(const float* x, int32_t ldc, int64_t npix, int32_t C, float* out, int32_t nz, float* scratch,
+                    pmf_stream_t s);
 /* per-pixel validity masks of EPMF's SparseVariantConv / ResContextBlock (epmf_net.py:30-50, 66-80):
  * mask[p] = (sum_c |x[p][c]| != 0); dilated mask = max-pool of the zero-padded mask with the conv's kernel/stride/
  * dilation; y = view(x) * mask and its gradient gx (+)= gy * mask (gx == gy, acc = 0: in place); out = a + b (b may be

@@ -73,7 +73,8 @@ static int run_one(const pmf_op_t& o, pmf_stream_t s) {
     case PMF_OP_GMEAN_BWD:  // p: gout cmul gin | i: N HW C cmul_ld gin_ldc acc
       return pmf_global_mean_bwd((const float*)a.p[0], i[0], i[1], i[2], (const float*)a.p[1], i[3], (float*)a.p[2],
                                  i[4], i[5], s);
-    case PMF_OP_COLSUM:  // p: x out | i: ldc C nz | l0 npix
+    case PMF_OP_COLSUM:  // p: x out [scratch] | i: ldc C nz | l0 npix
+      if (a.p[2]) return pmf_colsum_rows((const float*)a.p[0], i[0], a.l[0], i[1], (float*)a.p[1], i[2], (float*)a.p[2], s);
       return pmf_colsum((const float*)a.p[0], i[0], a.l[0], i[1], (float*)a.p[1], i[2], s);
     case PMF_OP_SOFTMAX:  // p: logits prob | i: ldc N HW C
       return pmf_softmax_nhwc_to_nchw((const float*)a.p[0], i[0], i[1], i[2], i[3], (float*)a.p[1], s);

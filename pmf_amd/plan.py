@@ -688,9 +688,11 @@ class Plan:
                 if has_bias:
                     boff = self.pgrad(conv.bias)
 
-                    def rb(op, dz=dz, boff=boff):
+                    crows = self.act.alloc(COL_ROWS * _ru(Cout, 4) * 4)      # partial rows of the deterministic column sum
+
+                    def rb(op, dz=dz, boff=boff, crows=crows):
                         a = op.u.sm
-                        a.p[0], a.p[1] = dz.buf.ptr, self.pgrad_buf.at(boff)
+                        a.p[0], a.p[1], a.p[2] = dz.buf.ptr, self.pgrad_buf.at(boff), crows.ptr
                         a.i[0], a.i[1], a.i[2] = dz.ldc, Cout, 1
                         a.l[0] = dz.npix
                     self.emit(self.bwd, L.OP_COLSUM, rb)
@@ -910,9 +912,11 @@ class Plan:
                         family="conv_dgrad", flops=2.0 * dz.N * mh * mw * s.t.C * Cout * len(sub), name=name,
                         shape="%dx%dx%d %d->%d t%d s%d" % (dz.N, mh, mw, Cout, s.t.C, len(sub), stride))
                 if tmp is not None:
-                    def fc(op, tmp=tmp, g=r.t.g):
+                    crows = self.act.alloc(COL_ROWS * tmp.N * _ru(r.t.g.ldc, 4) * 4)
+
+                    def fc(op, tmp=tmp, g=r.t.g, crows=crows):
                         a = op.u.sm
-                        a.p[0], a.p[1] = tmp.buf.ptr, g.buf.ptr
+                        a.p[0], a.p[1], a.p[2] = tmp.buf.ptr, g.buf.ptr, crows.ptr
                         a.i[0], a.i[1], a.i[2] = tmp.ldc, g.ldc, tmp.N
                         a.l[0] = tmp.H * tmp.W
                     self.emit(self.bwd, L.OP_COLSUM, fc)
