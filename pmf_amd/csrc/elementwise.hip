@@ -112,17 +112,35 @@ __global__ void act_bwd_k(float* __restrict__ g, int g_ldc, const float* __restr
   __shared__ f32x4 sh[256];
   COL_SETUP(Q)
   f32x4 part = zero4();
-  if (active_)
-    for (int64_t p = (int64_t)blockIdx.x * rows_ + row_; p < npix; p += (int64_t)gridDim.x * rows_) {
-      f32x4 v = *(const f32x4*)(g + p * g_ldc + c);
-      if (act != PMF_ACT_NONE) {
-        f32x4 x = *(const f32x4*)(a + p * a_ldc + c);
-        const float sl = act == PMF_ACT_LRELU ? 0.01f : 0.f;
-        v.x *= x.x > 0.f ? 1.f : sl; v.y *= x.y > 0.f ? 1.f : sl; v.z *= x.z > 0.f ? 1.f : sl; v.w *= x.w > 0.f ? 1.f : sl;
-        *(f32x4*)(g + p * g_ldc + c) = v;
+  if (active_) {
+    // four pixels per trip: eight loads in flight per thread (one pixel per trip left the 512 workgroups of this launch
+    // with 4 MB in flight chip-wide, a quarter of what HBM needs); same order of the column sum
+    const int64_t step = (int64_t)gridDim.x * rows_;
+    const float sl = act == PMF_ACT_LRELU ? 0.01f : 0.f;
+    for (int64_t p = (int64_t)blockIdx.x * rows_ + row_; p < npix; p += 4 * step) {
+      f32x4 v[4], x[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t pp = p + u * step;
+        if (pp < npix) {
+          v[u] = *(const f32x4*)(g + pp * g_ldc + c);
+          if (act != PMF_ACT_NONE) x[u] = *(const f32x4*)(a + pp * a_ldc + c);
+        }
       }
-      part += v;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t pp = p + u * step;
+        if (pp < npix) {
+          if (act != PMF_ACT_NONE) {
+            v[u].x *= x[u].x > 0.f ? 1.f : sl; v[u].y *= x[u].y > 0.f ? 1.f : sl;
+            v[u].z *= x[u].z > 0.f ? 1.f : sl; v[u].w *= x[u].w > 0.f ? 1.f : sl;
+            *(f32x4*)(g + pp * g_ldc + c) = v[u];
+          }
+          part += v[u];
+        }
+      }
     }
+  }
   if (dbias_rows) {
     sh[row_ * Qg_max_(Q) + cql_] = part;
     __syncthreads();
