@@ -85,6 +85,94 @@ extern "C" int pmf_knn_vote(const float* proj_range, const float* unproj_range, 
   return 0;
 }
 
+// ---- all frames of a batch in ONE launch (BASELINE configs[1]: bs = 4) ------------------------------------------------
+// Range images / argmax maps are [B, H, W]; the points of all frames are concatenated, frame b owning
+// [offsets[b], offsets[b+1]).  64-thread workgroups (one wave): a 25 k-point frame is 391 workgroups instead of 98, so four
+// frames fill the 256 CUs ~6x over and the ~50 dependent-address loads per lane of one wave overlap with its
+// neighbours' on the CU.  Same arithmetic as knn_k (bit-identical labels).
+template <int S>
+__global__ __launch_bounds__(64) void knn_batch_k(const float* __restrict__ pr, const float* __restrict__ ur,
+                                                  const int64_t* __restrict__ am, const int64_t* __restrict__ px,
+                                                  const int64_t* __restrict__ py, const int64_t* __restrict__ offsets,
+                                                  int B, int H, int W, int64_t P, int knn, const float* __restrict__ invg,
+                                                  float cutoff, int nclasses, int64_t* __restrict__ labels) {
+  constexpr int S2 = S * S, PAD = (S - 1) / 2, CENTER = (S2 - 1) / 2;
+  __shared__ float wsh[S2];
+  if (threadIdx.x < S2) wsh[threadIdx.x] = invg[threadIdx.x];
+  __syncthreads();
+  const int64_t i = blockIdx.x * (int64_t)64 + threadIdx.x;
+  if (i >= P) return;
+  int b = 0;
+  for (int k = 1; k < B; ++k) b += offsets[k] <= i;     // B is small (a batch): wave-uniform scalar loads
+  const float* __restrict__ prb = pr + (size_t)b * H * W;
+  const int64_t* __restrict__ amb = am + (size_t)b * H * W;
+  const int cx = (int)px[i], cy = (int)py[i];
+  const float r = ur[i];
+  float dist[S2];
+  int lab[S2];
+#pragma unroll
+  for (int t = 0; t < S2; ++t) {
+    const int y = cy + t / S - PAD, x = cx + t % S - PAD;
+    float v = 0.f;
+    int l = 0;
+    if (y >= 0 && y < H && x >= 0 && x < W) {
+      v = prb[(size_t)y * W + x];
+      l = (int)amb[(size_t)y * W + x];
+      if (v < 0.f) v = INFINITY;
+    }
+    if (t == CENTER) v = r;
+    dist[t] = fabsf(v - r) * wsh[t];
+    lab[t] = l;
+  }
+  unsigned long long used = 0ull;
+  int sel[8];
+  int nsel = knn < 8 ? knn : 8;
+  for (int k = 0; k < nsel; ++k) {
+    float best = 0.f;
+    int bi = -1;
+#pragma unroll
+    for (int t = 0; t < S2; ++t) {
+      const bool free_ = !((used >> t) & 1ull);
+      if (free_ && (bi < 0 || dist[t] < best)) { best = dist[t]; bi = t; }
+    }
+    used |= 1ull << bi;
+    int l = 0;
+#pragma unroll
+    for (int t = 0; t < S2; ++t) if (t == bi) l = lab[t];
+    if (cutoff > 0.f && best > cutoff) l = nclasses;
+    sel[k] = l;
+  }
+  int best_cnt = 0, best_cls = 1;
+  for (int a = 0; a < nsel; ++a) {
+    const int cls = sel[a];
+    if (cls < 1 || cls >= nclasses) continue;
+    int cnt = 0;
+    for (int c = 0; c < nsel; ++c) cnt += sel[c] == cls;
+    if (cnt > best_cnt || (cnt == best_cnt && cls < best_cls)) { best_cnt = cnt; best_cls = cls; }
+  }
+  labels[i] = best_cls;
+}
+
+extern "C" int pmf_knn_vote_batch(const float* proj_range, const float* unproj_range, const int64_t* proj_argmax,
+                                  const int64_t* px, const int64_t* py, const int64_t* offsets, int32_t B, int32_t H,
+                                  int32_t W, int64_t P_total, int32_t knn, int32_t search, const float* inv_gauss,
+                                  float cutoff, int32_t nclasses, int64_t* labels, pmf_stream_t s) {
+  if (search % 2 == 0) return PMF_E_ARG;
+  if (B < 1 || B > 1024 || !offsets) return PMF_E_ARG;
+  if (knn < 1 || knn > 8 || knn > search * search) return PMF_E_UNSUPPORTED;
+  if (P_total <= 0) return 0;
+  dim3 grid((unsigned)cdiv64(P_total, 64)), block(64);
+  hipStream_t st = (hipStream_t)s;
+  switch (search) {
+    case 3: hipLaunchKernelGGL(knn_batch_k<3>, grid, block, 0, st, proj_range, unproj_range, proj_argmax, px, py, offsets, B, H, W, P_total, knn, inv_gauss, cutoff, nclasses, labels); break;
+    case 5: hipLaunchKernelGGL(knn_batch_k<5>, grid, block, 0, st, proj_range, unproj_range, proj_argmax, px, py, offsets, B, H, W, P_total, knn, inv_gauss, cutoff, nclasses, labels); break;
+    case 7: hipLaunchKernelGGL(knn_batch_k<7>, grid, block, 0, st, proj_range, unproj_range, proj_argmax, px, py, offsets, B, H, W, P_total, knn, inv_gauss, cutoff, nclasses, labels); break;
+    default: return PMF_E_UNSUPPORTED;
+  }
+  PMF_LAUNCH_CHECK();
+  return 0;
+}
+
 // ---- multi-camera merge (tasks/pmf_eval_nuscenes/infer.py:18-38 getMergePred) --------------------------------------
 // Per LiDAR point the prediction of the camera with the highest confidence; a camera that does not see the point
 // counts as confidence 0 / label -1, torch.argmax breaks ties towards the FIRST camera.  One 64-bit atomicMax per

@@ -276,7 +276,7 @@ __global__ __launch_bounds__(LV_BLOCK) void lovasz2_sums_k(const IT* __restrict_
   float s = 0.f;
 #pragma unroll
   for (int k = 0; k < LV_PER_THREAD; ++k)
-    s += (cls != 0 && pix[k] >= 0 && label[pix[k]] == cls) ? 1.f : 0.f;
+    s += (cls != 0 && pix[k] >= 0 && pix[k] < P && label[pix[k]] == cls) ? 1.f : 0.f;
   sh[threadIdx.x] = s;
   __syncthreads();
   for (int o = LV_BLOCK / 2; o > 0; o >>= 1) {
@@ -332,6 +332,7 @@ __global__ __launch_bounds__(LV_BLOCK) void lovasz2_grad_k(const IT* __restrict_
     for (int k = 0; k < LV_PER_THREAD; ++k) {
       const int64_t i = cb + k * LV_BLOCK + threadIdx.x;
       pl[k] = i < lim ? (int64_t)row[i] : -1;
+      if (pl[k] >= P) pl[k] = -1;                  // (never with a well-formed permutation: no out-of-range scatter)
       el[k] = i < lim ? krow[i] : 0.f;
     }
 #pragma unroll
@@ -543,7 +544,7 @@ __global__ __launch_bounds__(RS_TILE) void rs_hist_k(const float* __restrict__ k
       if (i < n) {
         unsigned k;
         bool ok = true;
-        if (FIRST) { const float e = key[(int64_t)r * P + i]; ok = e >= 0.f; k = rs_key_of(e); }
+        if (FIRST) { const float e = key[(int64_t)r * P + i]; ok = !(e < 0.f); k = rs_key_of(e); }   // (NaN is kept: see rs_scatter_k)
         else k = kin[(int64_t)r * P + i];
         if (ok) atomicAdd(&h[(k >> shift) & 255u], 1u);
       }
@@ -608,7 +609,11 @@ __global__ __launch_bounds__(RS_TILE) void rs_scatter_k(const float* __restrict_
     bool ok = i < n;
     ks[s] = 0u; vs[s] = 0u;
     if (ok) {
-      if (FIRST) { const float e = key[ro + i]; ok = e >= 0.f; ks[s] = rs_key_of(e); vs[s] = (unsigned)i; }
+      if (FIRST) {
+        // dropped: exactly the -1 sentinel of ignored pixels.  NOT "e >= 0": a NaN error (diverged training) must stay, or
+        // fewer than P - cnt[0] keys survive and the row tails every later pass / the Lovasz kernels read are never written
+        const float e = key[ro + i]; ok = !(e < 0.f); ks[s] = rs_key_of(e); vs[s] = (unsigned)i;
+      }
       else { ks[s] = kin[ro + i]; vs[s] = vin[ro + i]; }
     }
     okm |= ok ? (1u << s) : 0u;

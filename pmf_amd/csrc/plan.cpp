@@ -187,13 +187,13 @@ extern "C" int pmf_plan_lanes(int on) {
 // per-lane clocks advanced by the ops' cost hints (pad_ bits 24-30, units of 4 us, from the plan builder's flop / byte
 // counts), an op starts at max(its lane's clock, the record time of the event it waits for), and the op with the
 // earliest start goes next.  PMF_PLAN_ORDER=list keeps the list order (A/B).
-static void issue_order(const pmf_op_t* ops, int32_t begin, int32_t end, bool lanes, std::vector<int32_t>& order) {
+static int issue_order(const pmf_op_t* ops, int32_t begin, int32_t end, bool lanes, std::vector<int32_t>& order) {
   const int32_t n = end - begin;
   order.resize(n > 0 ? n : 0);
   static const bool keep_list = [] { const char* e = getenv("PMF_PLAN_ORDER"); return e && e[0] == 'l'; }();
   if (!lanes || keep_list || n <= 0) {
     for (int32_t i = 0; i < n; ++i) order[i] = begin + i;
-    return;
+    return 0;
   }
   std::vector<int32_t> q[PMF_MAX_LANES];
   size_t cur[PMF_MAX_LANES] = {0, 0, 0, 0};
@@ -234,7 +234,10 @@ static void issue_order(const pmf_op_t* ops, int32_t begin, int32_t end, bool la
       }
       if (best < 0 || t < best_t || (t == best_t && k < q[best][cur[best]])) { best = l; best_t = t; }
     }
-    // (never -1: the unissued op with the smallest list index is always ready)
+    // a well-formed op array always has a ready op (the unissued op with the smallest list index); event bits that do
+    // not come from the plan builder (a wait and its record on ops of one lane in the wrong order, a foreign binding) may
+    // not: refuse instead of indexing q[-1]
+    if (best < 0) return PMF_E_ARG;
     const int32_t k = q[best][cur[best]++];
     order[out] = k;
     const int cost = (ops[k].pad_ >> 24) & 0x7f;
@@ -245,13 +248,14 @@ static void issue_order(const pmf_op_t* ops, int32_t begin, int32_t end, bool la
       for (int l = 1; l < PMF_MAX_LANES; ++l)
         if (!forked[l] && !q[l].empty() && (int32_t)cur[0] >= need_main[l]) { forked[l] = true; fork_clock[l] = clock[0]; }
   }
+  return 0;
 }
 
 // the order in which pmf_plan_run_range / pmf_plan_capture hand ops [begin, end) to the streams (host-only: no launch)
 extern "C" int pmf_plan_issue_order(const pmf_op_t* ops, int32_t begin, int32_t end, int32_t* out) {
   if (!ops || !out || begin < 0 || end < begin) return PMF_E_ARG;
   std::vector<int32_t> order;
-  issue_order(ops, begin, end, lanes_enabled(), order);
+  if (int rc = issue_order(ops, begin, end, lanes_enabled(), order)) return rc;
   for (size_t i = 0; i < order.size(); ++i) out[i] = order[i];
   return 0;
 }
@@ -263,7 +267,13 @@ static int run_range(const pmf_op_t* ops, int32_t begin, int32_t end, hipStream_
   hipStream_t st[PMF_MAX_LANES] = {main_s, nullptr, nullptr, nullptr};
   int rc = 0;
   std::vector<int32_t> order;
-  issue_order(ops, begin, end, lanes, order);
+  if ((rc = issue_order(ops, begin, end, lanes, order)) != 0) { if (failed_at) *failed_at = begin; return rc; }
+  int32_t rec_at[PMF_MAX_EVENTS];          // list position of an event's record op inside this range (-1: none)
+  for (int i = 0; i < PMF_MAX_EVENTS; ++i) rec_at[i] = -1;
+  for (int32_t j = begin; j < end; ++j) {
+    const int r = ((ops[j].pad_ >> 16) & 0xff) - 1;
+    if (r >= 0 && rec_at[r] < 0) rec_at[r] = j;
+  }
   int32_t k = begin;
   for (size_t oi = 0; oi < order.size() && rc == 0; ++oi) {
     k = order[oi];
@@ -277,7 +287,9 @@ static int run_range(const pmf_op_t* ops, int32_t begin, int32_t end, hipStream_
       if (rc) break;
       used[lane] = true;
     }
-    if (lanes && wait_e >= 0 && ev_valid[wait_e]) {
+    // (a wait counts only for a record EARLIER IN LIST ORDER, the rule of issue_order and pmf_plan_capture: the eager run
+    // and the captured replay build the same dependency graph)
+    if (lanes && wait_e >= 0 && rec_at[wait_e] >= 0 && rec_at[wait_e] < k && ev_valid[wait_e]) {
       hipEvent_t ev;
       rc = plan_event(wait_e, &ev);
       if (rc == 0) rc = (int)hipStreamWaitEvent(st[lane], ev, 0);
@@ -402,7 +414,7 @@ extern "C" int pmf_plan_capture(const pmf_op_t* ops, int32_t begin, int32_t end,
   // ---- cut the lanes into linear pieces, in issue order
   const bool lanes = lanes_enabled();
   std::vector<int32_t> order;
-  issue_order(ops, begin, end, lanes, order);
+  if (int rc = issue_order(ops, begin, end, lanes, order)) { delete prog; return rc; }
   int32_t rec_at[PMF_MAX_EVENTS];
   for (int i = 0; i < PMF_MAX_EVENTS; ++i) rec_at[i] = -1;
   int32_t first_of[PMF_MAX_LANES] = {-1, -1, -1, -1}, fork_after[PMF_MAX_LANES] = {-1, -1, -1, -1};
@@ -468,13 +480,18 @@ extern "C" int pmf_graph_launch(void* graph_exec, pmf_stream_t s) {
     rc = lane_stream(l, &st[l]);
     if (rc == 0 && !g_forkev[l]) rc = (int)hipEventCreateWithFlags(&g_forkev[l], hipEventDisableTiming);
   }
-  if (rc == 0 && !g_fork) rc = (int)hipEventCreateWithFlags(&g_fork, hipEventDisableTiming);
-  if (rc == 0) rc = lane_device_ok();
+  // the lane streams and their events belong to ONE device (the first that used a side lane in this process); a range
+  // without side lanes (PMF_LANES=0, or a plan on a second GPU of the process) touches none of them and replays anywhere,
+  // as its eager run does
+  bool any_side = false;
+  for (int l = 1; l < PMF_MAX_LANES; ++l) any_side = any_side || prog->used[l];
+  if (rc == 0 && any_side && !g_fork) rc = (int)hipEventCreateWithFlags(&g_fork, hipEventDisableTiming);
+  if (rc == 0 && any_side) rc = lane_device_ok();
   for (size_t i = 0; i < prog->acts.size() && rc == 0; ++i) {
     const PlanAct& a = prog->acts[i];
     hipEvent_t ev;
     switch (a.kind) {
-      case ACT_START: rc = (int)hipEventRecord(g_fork, main_s); break;
+      case ACT_START: if (any_side) rc = (int)hipEventRecord(g_fork, main_s); break;
       case ACT_WAIT_FORK: rc = (int)hipStreamWaitEvent(st[a.lane], a.arg ? g_forkev[a.arg] : g_fork, 0); break;
       case ACT_WAIT_EV:
         rc = plan_event(a.arg, &ev);

@@ -228,10 +228,23 @@ class PerspectiveViewLoader(Dataset):
         self.out_h = s["proj_ht"] if is_train else s["proj_h"]
         self.out_w = s["proj_wt"] if is_train else s["proj_w"]
         self._own_aug = False
+        # __getitem__ may run on several prefetch threads at once (tasks/pmf/trainer.py Prefetcher): what it leaves behind for
+        # the caller (last_keep) is per thread, and the device-constant cache is filled under a lock
+        import threading
+        self._tls, self._const_lock = threading.local(), threading.Lock()
         if is_train and aug_ops is None:
             # RandomCrop(size=(proj_ht - 2*h_pad, proj_wt - 2*w_pad)) then Pad((w_pad, h_pad)), both inside the gather
             self.aug_ops = FlipRotateCrop(s["proj_ht"] - 2 * self.h_pad, s["proj_wt"] - 2 * self.w_pad, self.h_pad, self.w_pad)
             self._own_aug = True
+
+    @property
+    def last_keep(self):
+        """bool[P] of the frame THIS thread projected last: the points behind x_data / y_data, in file order"""
+        return getattr(self._tls, "keep", None)
+
+    @last_keep.setter
+    def last_keep(self, keep):
+        self._tls.keep = keep
 
     def __getitem__(self, index):
         pointcloud, sem_label, _ = self.dataset.loadDataByIndex(index)
@@ -263,14 +276,15 @@ class PerspectiveViewLoader(Dataset):
 
     def _const(self, kind, seq_id):
         """the sequence's projection matrix / the label LUT as device tensors, uploaded once"""
-        cache = self.__dict__.setdefault("_dev_const", {})
         key = (kind, seq_id)
-        if key not in cache:
-            if kind == "mat":
-                cache[key] = torch.as_tensor(np.ascontiguousarray(self.dataset.proj_matrix[seq_id], np.float64).reshape(12)).to(self.device)
-            else:
-                cache[key] = torch.as_tensor(np.ascontiguousarray(self.dataset.class_map_lut, np.int32)).to(self.device)
-        return cache[key]
+        with self._const_lock:
+            cache = self.__dict__.setdefault("_dev_const", {})
+            if key not in cache:
+                if kind == "mat":
+                    cache[key] = torch.as_tensor(np.ascontiguousarray(self.dataset.proj_matrix[seq_id], np.float64).reshape(12)).to(self.device)
+                else:
+                    cache[key] = torch.as_tensor(np.ascontiguousarray(self.dataset.class_map_lut, np.int32)).to(self.device)
+            return cache[key]
 
     def __len__(self):
         if 0 < self.data_len < len(self.dataset):

@@ -230,9 +230,32 @@ class TrainEngine:
                 self._frontier[g] = f
 
     def _finish_allreduce(self):
+        """make the training stream wait for the collectives still in flight (``wait`` orders the streams; it does not
+        block the host).  With ``time_allreduce`` set (bench.py) a HIP event pair brackets the waits: the elapsed time
+        between them is what the compute stream idled for the all-reduce AFTER the backward plan had finished -- the
+        EXPOSED part of the collective, the figure that decides the 1 -> 8 GPU scaling."""
+        timed = getattr(self, "time_allreduce", False) and self._pending and self._pending[0] is not None \
+            and torch.cuda.is_available()
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         for h in self._pending:
             h.wait()
+        if timed:
+            e1.record()
+            self.__dict__.setdefault("allreduce_events", []).append((e0, e1))
         self._pending, self._frontier = [], None
+
+    def exposed_allreduce_ms(self, reset=True):
+        """mean exposed all-reduce time per step over the steps recorded since the last reset (see _finish_allreduce)"""
+        evs = self.__dict__.get("allreduce_events", [])
+        if not evs:
+            return None
+        torch.cuda.synchronize()
+        ms = sum(a.elapsed_time(b) for a, b in evs) / len(evs)
+        if reset:
+            self.allreduce_events = []
+        return ms
 
     def sync_buffers(self):
         """rank 0's BatchNorm running statistics / counters to every rank, as two coalesced broadcasts.
@@ -424,6 +447,7 @@ class SalsaNextEngine:
 
     _allreduce_ready_ranges = TrainEngine._allreduce_ready_ranges
     _finish_allreduce = TrainEngine._finish_allreduce
+    exposed_allreduce_ms = TrainEngine.exposed_allreduce_ms
 
     def forward_loss(self, feature, label, mask):
         """(feature, label, mask): the order SalsaNextLoader yields and the reference loop unpacks

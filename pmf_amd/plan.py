@@ -776,6 +776,27 @@ class Plan:
                   and all(s.t.needs_grad and not s.bcast and s.t.C % 32 == 0 for s in srcs)
                   and dz.N * dz.H * dz.W >= int(os.environ.get("PMF_DGRAD_MERGE_MINPIX", "1024")) and os.environ.get("PMF_DGRAD_MERGE", "1") != "0")
         if merged:
+            # torch.cat of one tensor (or one root) twice: two destinations would be ONE gradient buffer, written with
+            # accumulate 0 and 1 by workgroups of one launch in unspecified order -- such a concat keeps the per-operand
+            # launches (stream order)
+            holders = [(s.root() if s.root().bn is not None else s.root().t) for s in srcs]
+            merged = len({id(h_) for h_ in holders}) == len(holders)
+        if merged:
+            # the library's own eligibility rule, on the shape-only descriptor (a mismatch would otherwise only surface as
+            # PMF_E_ARG when the plan runs)
+            probe = L.ConvDesc()
+            probe.N, probe.OH, probe.OW = dz.N, ref.t.H, ref.t.W
+            probe.Cout, probe.nsrc = sum(s.t.C for s in srcs), 1
+            probe.src[0].C, probe.src[0].ldc, probe.src[0].H, probe.src[0].W = Kd, dz.ldc, dz.H, dz.W
+            probe.ntaps = len(classes[0][2])
+            for i, (dy, dx, _) in enumerate(classes[0][2]):
+                probe.tdy[i], probe.tdx[i] = dy, dx
+            probe.in_stride, probe.gather, probe.out_sy, probe.out_sx, probe.w_s3 = 1, gather, 1, 1, 1
+            probe.ndst = len(srcs)
+            for k_, s in enumerate(srcs):
+                probe.dst[k_].C = s.t.C
+            merged = bool(L.lib().pmf_conv_multi_ok(C.byref(probe)))
+        if merged:
             (_, _, sub), wT = classes[0], packs[0]
             parts = []
             for s in srcs:
@@ -1391,6 +1412,10 @@ class Plan:
             self._emit_tape()
         self.tape = None
         if self.dry:
+            # enough of the final layout for the data-parallel range scheduler (segment_cuts / grad_frontier are pure
+            # host logic over op indices: tests/test_ddp_gloo.py runs them on a CPU-only host)
+            self.bwd_shift = (1 + (self.flat is not None)) if self.training else 0
+            self.n_bwd = (len(self.bwd) + self.bwd_shift) if self.training else 0
             return self
         if self.flat is not None and self.training:
             self.pgrad_buf = ExternalBuf(self.flat.grad)
@@ -1629,19 +1654,40 @@ class Plan:
         return x
 
     def segment_cuts(self, k):
-        """op indices that split the backward plan into k segments of similar algorithmic work (by op count where no
-        flop estimate exists)."""
+        """op indices that split the backward plan into at most k segments for the data-parallel engine: after every
+        segment the gradient ranges that became final are handed to RCCL while the next segment computes.
+        Flat training state: a weight gradient is final when the batched stage-2 reduction of its layer group has run
+        (OP_WGRAD_RED_MULTI, a handful per pass), so the cuts sit RIGHT BEHIND those ops -- a cut placed a few ops in front
+        of one (round 3: segments of equal flops) leaves its whole payload (84 MB of the 146 MB at 64x2048) to the end of
+        the pass, fully exposed.  Of more candidates than k - 1 the ones with the largest payload are kept; a reduction in
+        the last 2 % of the list is not a cut (nothing left to overlap with).  PMF_DP_CUTS=flops: equal-work segments."""
         if getattr(self, "_cuts", None) is not None and self._cuts[0] == k:
             return self._cuts[1]
         n = self.n_bwd
-        w = [1.0 + self.meta_bwd.get(i - self.bwd_shift, {}).get("flops", 0.0) / 2e9 for i in range(n)]
-        tot, acc, cuts = sum(w), 0.0, [0]
-        for i in range(n):
-            acc += w[i]
-            if len(cuts) < k and acc >= tot * len(cuts) / k:
-                cuts.append(i + 1)
-        if cuts[-1] != n:
-            cuts.append(n)
+        kinds = getattr(self, "bwd_kinds", None)
+        if not kinds:       # dry plan: the entry list is still there
+            kinds = [None] * self.bwd_shift + [e[0] for e in self.bwd]
+        cuts = None
+        if self.flat is not None and k > 1 and os.environ.get("PMF_DP_CUTS", "reds") != "flops":
+            cand = [i + 1 for i in range(n) if kinds[i] == L.OP_WGRAD_RED_MULTI and i + 1 <= n - max(4, n // 50)]
+            if cand:
+                self.__dict__.pop("_frontiers", None)
+                prev, gain = [a for (a, _) in self.flat.ranges], []
+                for c in cand:
+                    f = self.grad_frontier(c)
+                    gain.append(sum(x - p for x, p in zip(f, prev)))
+                    prev = f
+                keep = sorted(sorted(range(len(cand)), key=lambda j: -gain[j])[:k - 1])
+                cuts = [0] + [cand[j] for j in keep if gain[j] > 0] + [n]
+        if cuts is None:
+            w = [1.0 + self.meta_bwd.get(i - self.bwd_shift, {}).get("flops", 0.0) / 2e9 for i in range(n)]
+            tot, acc, cuts = sum(w), 0.0, [0]
+            for i in range(n):
+                acc += w[i]
+                if len(cuts) < k and acc >= tot * len(cuts) / k:
+                    cuts.append(i + 1)
+            if cuts[-1] != n:
+                cuts.append(n)
         self._cuts = (k, cuts)
         return cuts
 

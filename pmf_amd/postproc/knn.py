@@ -7,6 +7,7 @@
 import ctypes as C
 import math
 
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -62,3 +63,41 @@ class KNN(nn.Module):
                               C.c_void_p(stream))
         L.check(rc, "pmf_knn_vote")
         return out
+
+    def forward_batch(self, proj_range, proj_argmax, unproj_range, px, py, offsets):
+        """all frames of a batch in ONE launch (pmf_knn_vote_batch): proj_range f32[B,H,W], proj_argmax i64[B,H,W]; the
+        points of all frames concatenated (unproj_range f32[P], px / py i64[P]), frame b owning [offsets[b], offsets[b+1])
+        (offsets: int64[B+1], device).  Returns labels i64[P]; bit-identical to B calls of forward()."""
+        if self.search % 2 == 0:
+            raise ValueError("Nearest neighbor kernel must be odd number")
+        if not proj_range.is_cuda:
+            raise RuntimeError("pmf_amd KNN runs on the GPU only (no CPU fallback)")
+        dev = proj_range.device
+        B, H, W = proj_range.shape
+        P = unproj_range.shape[0]
+        if px.shape[0] != P or py.shape[0] != P or offsets.shape[0] != B + 1 or tuple(proj_argmax.shape) != (B, H, W):
+            raise ValueError("forward_batch: inconsistent shapes")
+        if self._w is None or self._w.device != dev:
+            self._w = inverse_gaussian_window(self.search, self.sigma).to(dev)
+        pr, am = proj_range.contiguous().float(), proj_argmax.contiguous().long()
+        ur, pxx, pyy = unproj_range.contiguous().float(), px.contiguous().long(), py.contiguous().long()
+        off = offsets.contiguous().long()
+        out = torch.empty(P, dtype=torch.int64, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        rc = L.lib().pmf_knn_vote_batch(pr.data_ptr(), ur.data_ptr(), am.data_ptr(), pxx.data_ptr(), pyy.data_ptr(),
+                                        off.data_ptr(), B, H, W, P, int(self.knn), int(self.search), self._w.data_ptr(),
+                                        C.c_float(float(self.cutoff)), int(self.nclasses), out.data_ptr(),
+                                        C.c_void_p(stream))
+        L.check(rc, "pmf_knn_vote_batch")
+        return out
+
+    def batch(self, frames):
+        """frames: list of (proj_range[H,W], unproj_range[P_b], proj_argmax[H,W], px[P_b], py[P_b]) of equal H, W -> list of
+        label tensors, one launch for all of them."""
+        n = [f[1].shape[0] for f in frames]
+        dev = frames[0][0].device
+        off = torch.tensor([0] + list(np.cumsum(n)), dtype=torch.int64, device=dev)
+        out = self.forward_batch(torch.stack([f[0] for f in frames]), torch.stack([f[2] for f in frames]),
+                                 torch.cat([f[1] for f in frames]), torch.cat([f[3] for f in frames]),
+                                 torch.cat([f[4] for f in frames]), off)
+        return list(out.split(n))

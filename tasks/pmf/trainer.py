@@ -68,10 +68,15 @@ class Prefetcher(object):
     The producers stop when the consumer stops: leaving the loop early (debug break, exception, generator collected) sets
     a flag they check between items, so no thread -- and none of the device batches it holds -- outlives an epoch."""
 
+    MAX_WORKERS = 3      # the reference's n_threads (DataLoader processes, 4-8) would mean that many device-resident batches
+
     def __init__(self, loader, depth=2, workers=1):
-        self.loader, self.depth = loader, depth
+        self.loader = loader
+        workers = min(int(workers), self.MAX_WORKERS)
         self.workers = workers if (workers > 1 and isinstance(loader, DataLoader) and loader.num_workers == 0
                                    and loader.batch_sampler is not None) else 1
+        # ``depth`` batches ahead IN TOTAL (not per thread): at least one slot per worker
+        self.depth = max(1, -(-int(depth) // self.workers))
 
     def __len__(self):
         return len(self.loader)

@@ -1,0 +1,184 @@
+"""-m gpu: parity of the TIMED plans at BASELINE.json's own sizes (VERDICT r03 "what's missing" 3 and 4).
+
+* backward of configs[2] (PMF-ResNet34, 2 x 64 x 2048), configs[3] (PMF-ResNet50, 17 classes, 2 x 32 x 1024) and
+  configs[4] (EPMF-ResNet34, 2 x 64 x 2048): every parameter gradient of the flat training state -- the path bench.py
+  times: TrainEngine, fused objective, lanes, hipGraph replay -- against the CPU oracle in float64 with the fp32 CPU
+  oracle as the yardstick, with the heuristic tile configurations and with the autotuner on
+  (tasks/pmf/trainer.py:214-219 is the reference's backward);
+* configs[1] at its batch size: eval logits of 4 frames + the KNN labels of every frame against the oracle
+  (tasks/pmf_eval_semantickitti/infer.py:67-160).
+
+At these sizes train-mode BatchNorm normalises over >= 1024 values per channel even at the 4 x 128 bottleneck, so the
+whole backward is well conditioned and the bars can be tight everywhere (they could not at 2 x 32 x 64).
+"""
+import copy
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from pmf_amd.utils.detinit import deterministic_init, synthetic_batch  # noqa: E402
+from tests import gpu_helpers as G  # noqa: E402
+
+# parameters whose gradient never passes through a low-resolution stage or a second BatchNorm: the float64 unit-test
+# yardstick of tests/test_gpu_ops.py applies to them directly
+TAIL = ("lidar_stream.logits.", "lidar_stream.upBlock4.conv4.", "camera_stream_decoder.conv.")
+
+_ORACLE = {}
+
+
+def _build(kind):
+    from oracle import pmf_torch as O
+    if kind == "epmf":
+        from pmf_amd.models import EPMFNet
+        from oracle import epmf_torch as E
+        return (lambda: deterministic_init(EPMFNet(5, 3, 20, 32, False, "resnet34")),
+                lambda: deterministic_init(E.EPMFNet(5, 3, 20, 32, False, "resnet34")), 20, (2, 64, 2048), 0.3)
+    from pmf_amd.models import PMFNet
+    if kind == "r50":
+        return (lambda: deterministic_init(PMFNet(5, 3, 17, 32, False, "resnet50")),
+                lambda: deterministic_init(O.PMFNet(5, 3, 17, 32, False, "resnet50")), 17, (2, 32, 1024), 0.25)
+    return (lambda: deterministic_init(PMFNet(5, 3, 20, 32, False, "resnet34")),
+            lambda: deterministic_init(O.PMFNet(5, 3, 20, 32, False, "resnet34")), 20, (2, 64, 2048), 0.25)
+
+
+def _oracle_grads(kind):
+    """fp32 and float64 CPU oracle gradients of the 5-term objective (cached: the two tile-configuration runs share them)"""
+    if kind in _ORACLE:
+        return _ORACLE[kind]
+    from oracle import pmf_torch as O
+    from oracle import losses_ref
+    _, mk_ref, ncls, (n, h, w), fill = _build(kind)
+    ref = mk_ref().train()
+    g = torch.Generator().manual_seed(3)
+    masks = {nm: (torch.rand(n, c, generator=g) > 0.2).float() / 0.8 for nm, _, c in O.dropout_sites(ref)}
+    pcd, rgb, label, _ = synthetic_batch(n, h, w, ncls, seed=21, fill=fill)
+    alpha = torch.linspace(0.2, 1.0, ncls)
+    alpha[0] = 0
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    out = {}
+    for tag, dt in (("f32", torch.float32), ("f64", torch.float64)):
+        m = copy.deepcopy(ref).to(dt)
+        O.set_dropout_masks(m, {k: v.to(dt) for k, v in masks.items()})
+        a, b = m(pcd.to(dt), rgb.to(dt))
+        tot, _ = losses_ref.pmf_total_loss(a, b, label, alpha.to(dt))
+        tot.backward()
+        out[tag] = ({k: p.grad.detach().clone() for k, p in m.named_parameters()}, float(tot),
+                    m.lidar_stream.last_logits.detach().clone())
+        del m, a, b, tot
+    _ORACLE[kind] = (out, masks, (pcd, rgb, label), alpha)
+    return _ORACLE[kind]
+
+
+@pytest.mark.parametrize("tune", ["0", "1"], ids=["heuristic", "autotuned"])
+@pytest.mark.parametrize("kind", ["pmf_r34", "r50", "epmf"])
+def test_full_size_backward_vs_oracle(kind, tune):
+    from pmf_amd.engine import TrainEngine
+    from pmf_amd import plan as PL
+    mk_hip, _, ncls, (n, h, w), _ = _build(kind)
+    (out, masks, (pcd, rgb, label), alpha) = _oracle_grads(kind)
+    g64, loss64, logits64 = out["f64"]
+    g32, _, _ = out["f32"]
+    old = os.environ.get("PMF_AUTOTUNE")
+    os.environ["PMF_AUTOTUNE"] = tune
+    try:
+        hip = mk_hip().cuda().train()
+        eng = TrainEngine(hip, ncls, alpha=alpha.numpy(), warmup_steps=10, max_steps=100)
+        assert eng.flat is not None
+        hip.set_dropout_masks({k: v.cuda() for k, v in masks.items()})
+        d_pcd, d_rgb, d_label = pcd.cuda(), rgb.cuda(), label.cuda()
+        # three passes: eager, eager + capture, hipGraph replay -- the gradients compared are those of the replay
+        for _ in range(3):
+            total = eng.forward_loss(d_pcd, d_rgb, d_label.long())[0]
+            total.backward()
+        torch.cuda.synchronize()
+        plan = next(p for k, p in hip._plans.items() if k[3])
+        assert len(plan._graphs) >= 2, "the compared pass did not run on captured graphs"
+        if tune == "1":
+            assert len(PL._TUNED) > 20
+    finally:
+        if old is None:
+            os.environ.pop("PMF_AUTOTUNE", None)
+        else:
+            os.environ["PMF_AUTOTUNE"] = old
+    assert abs(float(total) - loss64) < 1e-4 * max(1.0, abs(loss64))
+    assert G.rel_err(plan.read(plan.tensors["logits"]).cpu().numpy(), logits64.float().numpy()) < 1e-3
+    rows = []
+    for k, p in hip.named_parameters():
+        assert p.grad is not None, k
+        ref = g64[k]
+        wk = k.rsplit(".", 1)[0] + ".weight"
+        # (a conv bias in front of a train-mode BatchNorm has a true gradient of exactly 0: measure it on the scale of
+        # its layer's weight gradient instead of on its own rounding noise)
+        floor = 1e-6 * g64[wk].norm().item() if wk in g64 else 0.0
+        den = max(ref.norm().item(), floor, 1e-30)
+        rows.append((k, (p.grad.cpu().double() - ref).norm().item() / den, (g32[k].double() - ref).norm().item() / den))
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(os.path.join("gpurun_out", "fullsize_grads_%s_tune%s.txt" % (kind, tune)), "w") as f:
+        for r in rows:
+            f.write("%-60s %.3e %.3e\n" % r)
+    ratio = np.array([r[1] / max(r[2], 1e-12) for r in rows if r[2] > 1e-7])
+    gmean, p90 = float(np.exp(np.log(np.maximum(ratio, 1e-6)).mean())), float(np.percentile(ratio, 90))
+    worst = max(rows, key=lambda r: r[1])
+    print("[fullsize %s tune=%s] worst %s %.2e (cpu fp32 %.2e), ratio gmean %.2f p90 %.2f" % (
+        kind, tune, worst[0], worst[1], worst[2], gmean, p90))
+    # (1) tail layers: the float64 unit-test yardstick
+    for k, e_h, _ in rows:
+        if k.startswith(TAIL):
+            assert e_h < 1e-4, (k, e_h)
+    # (2) every parameter: as close to float64 as the fp32 CPU oracle is (x4, floor 2e-4) and never beyond 5e-3
+    bad = [r for r in rows if not (r[1] <= max(4 * r[2], 2e-4) and r[1] < 5e-3)]
+    assert not bad, "gradient error vs float64 (hip, cpu-fp32):\n" + "\n".join("%-55s %.3e %.3e" % r for r in bad[:30])
+    # (3) no systematic excess over the fp32 CPU path
+    assert gmean < 1.5 and p90 < 2.5, (gmean, p90)
+
+
+def test_infer_bs4_logits_and_knn_vs_oracle():
+    """BASELINE configs[1]: eval forward of FOUR 64 x 2048 frames in one call + the KNN vote of every frame"""
+    from pmf_amd.models import PMFNet
+    from pmf_amd.postproc import KNN
+    from oracle import pmf_torch as O
+    from oracle import knn_ref
+    hip = deterministic_init(PMFNet(5, 3, 20, 32, False, "resnet34")).cuda().eval()
+    ref = deterministic_init(O.PMFNet(5, 3, 20, 32, False, "resnet34")).eval()
+    bs, h, w = 4, 64, 2048
+    pcd, rgb, _, mask = synthetic_batch(bs, h, w, 20, seed=31, fill=0.3)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    with torch.no_grad():
+        rl, rc = ref(pcd, rgb)
+        both = torch.cat((pcd, rgb), 1).cuda()
+        lp, cp = hip(both[:, 0:5], both[:, 5:8])
+    plan = next(iter(hip._plans.values()))
+    assert G.rel_err(plan.read(plan.tensors["logits"]).cpu().numpy(), ref.lidar_stream.last_logits.numpy()) < 1e-3
+    assert (lp.cpu() - rl).abs().max() < 1e-4 and (cp.cpu() - rc).abs().max() < 1e-4
+    am_h, am_r = lp.argmax(1), rl.argmax(1)
+    # argmax may legitimately differ where two classes tie to within the probability bar: the KNN vote is compared on
+    # the ORACLE's argmax map (the kernel under test is the vote) and, separately, end to end with a mismatch budget
+    knn = KNN({"knn": 5, "search": 5, "sigma": 1.0, "cutoff": 1.0}, 20)
+    rng = np.random.default_rng(5)
+    frames, total, diff = [], 0, 0
+    for b in range(bs):
+        pr = np.where(mask[b].numpy() > 0, np.abs(pcd[b, 0].numpy()) + 2.0, -1.0).astype(np.float32)
+        occ = np.argwhere(mask[b].numpy() > 0)
+        sel = rng.integers(0, occ.shape[0], 25000)
+        py, px = occ[sel, 0].astype(np.int64), occ[sel, 1].astype(np.int64)
+        ur = (pr[py, px] + rng.random(sel.size).astype(np.float32) * 0.2).astype(np.float32)
+        frames.append((pr, ur, px, py))
+        want = knn_ref.knn_vote(pr, ur, am_r[b].numpy(), px, py)
+        t = lambda a: torch.from_numpy(a).cuda()
+        got = knn(t(pr), t(ur), am_r[b].cuda(), t(px), t(py)).cpu().numpy()
+        np.testing.assert_array_equal(got, want)
+        e2e = knn(t(pr), t(ur), am_h[b], t(px), t(py)).cpu().numpy()
+        total += want.size
+        diff += int((e2e != want).sum())
+    assert int((am_h.cpu() != am_r).sum()) <= 1e-4 * am_r.numel()
+    assert diff <= 1e-4 * total + 2, (diff, total)
+    # all frames in ONE call (batched entry point) give the same labels as frame-by-frame calls
+    if hasattr(knn, "batch"):
+        t = lambda a: torch.from_numpy(a).cuda()
+        outs = knn.batch([(t(pr), t(ur), am_r[b].cuda(), t(px), t(py)) for b, (pr, ur, px, py) in enumerate(frames)])
+        for b, (pr, ur, px, py) in enumerate(frames):
+            np.testing.assert_array_equal(outs[b].cpu().numpy(), knn_ref.knn_vote(pr, ur, am_r[b].numpy(), px, py))
