@@ -100,7 +100,10 @@ def infer_bench(args, model, dev):
         plan.run_profiled("forward")             # (first reading discarded: see the training line's roofline block)
         roof, hbm, _ = plan_rooflines(plan, plan.run_profiled("forward"), args.model)
         am = model(feat[:, 0:5], feat[:, 5:8])[0].argmax(1)
-        ms = timed_ms(lambda: knn.forward_batch(pr_all, am, ur_all, px_all, py_all, off), 20)
+        knn_fn, _ = knn.bind_batch(pr_all, am, ur_all, px_all, py_all, off)      # the launch alone (no wrapper overhead)
+        for _ in range(200):
+            knn_fn()
+        ms = timed_ms(knn_fn, 200)
         nb = bs * 12.0 * args.height * args.width + 28.0 * ur_all.numel()    # 12 H W + 28 P bytes per frame
         pr, ur, px, py = frames[0]
         ms1 = timed_ms(lambda: knn(pr, ur, am[0], px, py), 20)
@@ -434,12 +437,17 @@ def cpu_baseline(bs, h, w, model="pmf", backbone="resnet34", nclasses=20, mode="
                           "oracle/pmf_torch.py + oracle/knn_ref.py, torch %s"
                           % (bs, h, w, dt_f, threads, os.cpu_count() or 1, ur.shape[0], dt_k, torch.__version__)}
     eng = Engine(net, nclasses, feature_mean=KITTI_MEAN, feature_std=KITTI_STD, warmup_steps=10, max_steps=100)
-    # warm-up on a 1/8-area slice (thread pools, oneDNN primitive caches), then ONE timed iteration at the full size
+    # warm-up: one iteration on a 1/8-area slice (thread pools) and one at the full size (oneDNN primitive caches for these
+    # shapes), then THREE timed iterations at the full size (warm-up + several); the median is reported
     fw, mw, lw = make_batch(1, h, max(w // 4, 64), 2, "cpu", nclasses)
     eng.train_step(fw.clone(), mw, lw)
-    t0 = time.time()
     eng.train_step(feat.clone(), mask, label)
-    dt = time.time() - t0
+    times = []
+    for _ in range(3):
+        t0 = time.time()
+        eng.train_step(feat.clone(), mask, label)
+        times.append(time.time() - t0)
+    dt = sorted(times)[1]
     # single thread, bounded: 1/16 of the pixels
     torch.set_num_threads(1)
     sw = max(w // 8, 64)
@@ -451,12 +459,26 @@ def cpu_baseline(bs, h, w, model="pmf", backbone="resnet34", nclasses=20, mode="
     d1 = (time.time() - t1) * (bs * h * w) / float(h * sw)
     torch.set_num_threads(threads)
     return {"value": 1.0 / dt, "unit": "iter/s", "cores": threads, "kind": "port",
-            "sample": "1 timed full train iteration at the full configuration bs=%d %dx%d (after a warm-up iteration on a "
-                      "1/8-area slice): %.2f s; oracle + torch %s on %d of %d host threads (more threads are slower)"
-                      % (bs, h, w, dt, torch.__version__, threads, os.cpu_count() or 1),
+            "sample": "median of 3 timed full train iterations at the full configuration bs=%d %dx%d (%s s; after one warm-up "
+                      "iteration on a 1/8-area slice and one at the full size); oracle + torch %s on %d of %d host threads "
+                      "(more threads are slower)"
+                      % (bs, h, w, " / ".join("%.2f" % t for t in times), torch.__version__, threads, os.cpu_count() or 1),
             "single_thread": {"value": 1.0 / d1, "unit": "iter/s", "cores": 1,
                               "sample": "1 iteration at bs=1 %dx%d on one thread, scaled by pixel count to the full "
                                         "configuration (%.1f s)" % (h, sw, d1)}}
+
+
+def _detach_dp_hooks(model):
+    """rank-local measurements must not issue collectives: take the data-parallel hooks off the model, return them"""
+    saved = {k: getattr(model, k, None) for k in ("_bwd_segment_hook", "_bwd_gated_hook")}
+    for k in saved:
+        setattr(model, k, None)
+    return saved
+
+
+def _attach_dp_hooks(model, saved):
+    for k, v in saved.items():
+        setattr(model, k, v)
 
 
 def parity_block(args, eng, model, feat0, mask, label):
@@ -485,8 +507,7 @@ def parity_block(args, eng, model, feat0, mask, label):
     model.set_dropout_masks({k: v.to(dev) for k, v in masks.items()})
     try:
         eng.model.train()
-        hook = getattr(model, "_bwd_segment_hook", None)
-        model._bwd_segment_hook = None      # (world 1 only: no collective between the backward segments here)
+        hooks = _detach_dp_hooks(model)     # (world 1 only: no collective inside this backward)
         pcd, rgb = eng.prepare(feat0.clone(), mask)
         total = eng.forward_loss(pcd, rgb, label.long())[0]
         total.backward()                    # the timed backward plan (flat state: writes every p.grad in place)
@@ -501,17 +522,42 @@ def parity_block(args, eng, model, feat0, mask, label):
         graphs = len(plan._graphs)
     finally:
         model.set_dropout_masks(None)
-        model._bwd_segment_hook = hook
+        _attach_dp_hooks(model, hooks)
     f = feat0.detach().cpu().clone()
     pc, rc = ref_eng.prepare(f, mask.cpu())
     tot_r = ref_eng.forward_loss(pc, rc, label.cpu().long())[0]
-    loss_r = float(tot_r)
-    tot_r.backward()                        # tasks/pmf/trainer.py:214-219 on the CPU oracle
+    loss_r = float(tot_r.detach())
+    tot_r.backward()                        # tasks/pmf/trainer.py:214-219 on the CPU oracle, fp32
     ref_named = dict(net.named_parameters())
-    grad_rel = {}
+    del tot_r
+    # ... and the same pass in FLOAT64: two fp32 paths with different rounding points are each ~1e-2 away from the exact
+    # gradient in this network (the BatchNorm backward subtracts two per-channel means from gy in ~90 layers; measured in
+    # tests/test_gpu_fullsize.py), so "HIP vs fp32 oracle" alone cannot tell a rounding difference from a defect -- the
+    # yardstick of a parameter is the fp32 CPU oracle's own distance from float64
+    import copy
+    net64 = copy.deepcopy(net).double()
+    for p in net64.parameters():
+        p.grad = None
+    O.set_dropout_masks(net64, {k: v.double() for k, v in masks.items()})
+    for k, v in net.state_dict().items():      # the fp32 pass above updated the running statistics: restore
+        if "running_" in k or "num_batches" in k:
+            net64.state_dict()[k].copy_(sd[k])
+    eng64 = Engine(net64, args.nclasses, lambda_=1.0, gamma=0.5, tau=0.7, feature_mean=KITTI_MEAN, feature_std=KITTI_STD,
+                   warmup_steps=10, max_steps=100)
+    eng64.focal.double()
+    if args.model == "epmf":
+        eng64.mt_loss.double()
+        with torch.no_grad():
+            eng64.mt_loss.sigma.copy_(eng.mt_loss.sigma.detach().cpu().double())
+    p64, r64 = eng64.prepare(feat0.detach().cpu().double(), mask.cpu().double())
+    eng64.forward_loss(p64, r64, label.cpu().long())[0].backward()
+    named64 = dict(net64.named_parameters())
+    grad_rel, grad_rel_cpu = {}, {}
     for k in picks:
-        gr = ref_named[k].grad.detach()
-        grad_rel[k] = float((grads_h[k] - gr).norm() / gr.norm().clamp_min(1e-30))
+        g64 = named64[k].grad.detach()
+        den = g64.norm().clamp_min(1e-30)
+        grad_rel[k] = float((grads_h[k].double() - g64).norm() / den)
+        grad_rel_cpu[k] = float((ref_named[k].grad.detach().double() - g64).norm() / den)
     ref_logits = net.lidar_stream.last_logits.detach()
     if logits.shape != ref_logits.shape:                       # the plan stores NHWC
         logits = logits.permute(0, 3, 1, 2)[:, :ref_logits.shape[1]]
@@ -521,17 +567,23 @@ def parity_block(args, eng, model, feat0, mask, label):
         if "running_" in k:
             rrel = max(rrel, float((rs_h[k] - v).abs().max() / max(float(v.abs().max()), 1.0)))
     lossrel = abs(loss_h - loss_r) / max(abs(loss_r), 1.0)
-    gworst = max(grad_rel.values()) if grad_rel else None
-    return {"logits_rel": lrel, "loss_rel": lossrel, "running_stat_rel": rrel, "grad_rel_worst": gworst, "grad_rel": grad_rel,
+    gratio = max(grad_rel[k] / max(grad_rel_cpu[k], 1e-12) for k in picks if max(grad_rel[k], grad_rel_cpu[k]) > 2e-4) \
+        if any(max(grad_rel[k], grad_rel_cpu[k]) > 2e-4 for k in picks) else 0.0
+    gok = all(grad_rel[k] <= max(3.0 * grad_rel_cpu[k], 2e-4) for k in picks)
+    return {"logits_rel": lrel, "loss_rel": lossrel, "running_stat_rel": rrel,
+            "grad_rel_vs_float64": {k: {"hip": grad_rel[k], "cpu_fp32_oracle": grad_rel_cpu[k]} for k in picks},
+            "grad_rel_worst": max(grad_rel.values()) if picks else None,
+            "grad_rel_worst_ratio_to_cpu_fp32": gratio,
             "loss_hip": loss_h, "loss_oracle": loss_r,
-            "bars": {"logits_rel": 1e-3, "loss_rel": 1e-4, "running_stat_rel": 1e-4, "grad_rel_worst": 5e-3},
-            "ok": bool(lrel < 1e-3 and lossrel < 1e-4 and rrel < 1e-4 and (gworst is None or gworst < 5e-3)),
+            "bars": {"logits_rel": 1e-3, "loss_rel": 1e-4, "running_stat_rel": 1e-4,
+                     "grad_rel": "hip <= max(3 x cpu_fp32_oracle, 2e-4) for every listed parameter"},
+            "ok": bool(lrel < 1e-3 and lossrel < 1e-4 and rrel < 1e-4 and gok),
             "what": "train-mode forward + objective + BACKWARD of the plan that was timed (PMF_AUTOTUNE %s, lanes, %d captured "
-                    "graphs) against the fp32 CPU oracle: model state after the timed iterations copied into oracle/ (%d host "
-                    "threads), same Dropout2d multipliers, same batch; grad_rel = |g_hip - g_oracle|_2 / |g_oracle|_2 of the "
-                    "named parameter gradients (first / last layer of each stream and one layer per kernel family; both "
-                    "sides fp32, so the figure holds both paths' rounding -- tests/test_gpu_fullsize.py has the float64 "
-                    "yardstick)" % (os.environ.get("PMF_AUTOTUNE", "on"), graphs, torch.get_num_threads())}
+                    "graphs) against the CPU oracle: model state after the timed iterations copied into oracle/ (%d host "
+                    "threads), same Dropout2d multipliers, same batch; logits / loss / running statistics against the fp32 "
+                    "oracle; grad_rel_vs_float64 = |g - g64|_2 / |g64|_2 of the named parameter gradients (first / last "
+                    "layer of each stream, one layer per kernel family) for the HIP path and for the fp32 CPU oracle, both "
+                    "against the oracle in float64" % (os.environ.get("PMF_AUTOTUNE", "on"), graphs, torch.get_num_threads())}
 
 
 # parameter gradients the parity block reports: first / last layer of each stream, one layer per kernel family
@@ -851,8 +903,7 @@ def main():
         plan = next(iter(model._plans.values()))
         eng.model.train()
         # rank-local measurement: no collective may be issued here (the other ranks are not taking part)
-        hook = getattr(model, "_bwd_segment_hook", None)
-        model._bwd_segment_hook = None
+        hooks = _detach_dp_hooks(model)
         pcd, rgb = eng.prepare(feat0.clone(), mask)
         total = eng.forward_loss(pcd, rgb, label.long())[0]
         # (each pass is profiled twice and the second reading kept: the block may follow seconds of CPU-only work --
@@ -863,7 +914,7 @@ def main():
         total.backward()                             # normal backward (stages the upstream gradients) ...
         plan.run_profiled("backward")
         prof_b = plan.run_profiled("backward")      # ... then the backward plan again, op by op
-        model._bwd_segment_hook = hook
+        _attach_dp_hooks(model, hooks)
         if args.profile_out:
             with open(args.profile_out, "w") as f:
                 for ph, prof in (("fwd", prof_f), ("bwd", prof_b)):

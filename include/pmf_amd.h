@@ -508,6 +508,10 @@ int pmf_plan_run_range(const pmf_op_t* ops, int32_t begin, int32_t end, pmf_stre
 int pmf_plan_capture(const pmf_op_t* ops, int32_t begin, int32_t end, void** graph_exec, int32_t* failed_at);
 int pmf_graph_launch(void* graph_exec, pmf_stream_t s);
 int pmf_graph_pieces(void* graph_exec);   /* linear hipGraphs behind the handle */
+/* stream `s` waits for plan event `e` (pad_ bits 16-23 of the op that records it) as recorded by the most recently ENQUEUED
+ * run / replay: how a caller hangs work of its own -- the gradient all-reduce -- behind one op of a running plan.
+ * PMF_E_UNSUPPORTED: the event was never recorded (lanes off): order behind the whole range instead. */
+int pmf_plan_event_wait(int32_t e, pmf_stream_t s);
 /* lanes (pmf_op_t.pad_): on = 0 run every op on the caller's stream, 1 honour the lane bits (default; PMF_LANES=0 in the
  * environment starts with 0), < 0 query only; returns the previous setting */
 int pmf_plan_lanes(int on);

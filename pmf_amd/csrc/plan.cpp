@@ -520,6 +520,16 @@ extern "C" int pmf_graph_destroy(void* graph_exec) {
   return 0;
 }
 
+// make stream `s` wait for plan event `e` as last recorded by a plan run / graph replay that has ALREADY been enqueued (the
+// data-parallel engine gates the all-reduce of a gradient range on the event behind the launch that finalises it, instead
+// of cutting the backward plan into segments).  PMF_E_UNSUPPORTED when the event has never been recorded (lanes off).
+extern "C" int pmf_plan_event_wait(int32_t e, pmf_stream_t s) {
+  if (e < 0 || e >= PMF_MAX_EVENTS) return PMF_E_ARG;
+  if (e >= g_nev || !lanes_enabled()) return PMF_E_UNSUPPORTED;
+  if (int rc = lane_device_ok()) return rc;
+  return (int)hipStreamWaitEvent((hipStream_t)s, g_ev[e], 0);
+}
+
 // number of linear pieces of a captured range (1 in "single" mode); tests / diagnostics
 extern "C" int pmf_graph_pieces(void* graph_exec) {
   if (!graph_exec) return PMF_E_ARG;

@@ -172,7 +172,7 @@ class TrainEngine:
             if distributed:
                 import torch.distributed as dist
                 self._pending, self._frontier = [], None
-                model._bwd_segment_hook = self._allreduce_ready_ranges
+                self._attach_dp_hooks(model)
                 # what DistributedDataParallel does at construction: every rank starts from rank 0's state
                 dist.broadcast(self.flat.param, 0)
                 for b in model.buffers():
@@ -214,6 +214,44 @@ class TrainEngine:
         self.iteration = 0
 
     # ---- data parallel over the flat gradient buffer ---------------------------------------------------------
+    def _attach_dp_hooks(self, model):
+        """PMF_DP_MODE=events (default): the backward plan runs as ONE range and every gradient range is all-reduced behind
+        the plan events that finalise it; PMF_DP_MODE=segments: the plan is cut into PMF_DP_SEGMENTS ranges with an
+        all-reduce of the finished ranges between them (round 2/3)."""
+        if os.environ.get("PMF_DP_MODE", "events") == "segments":
+            model._bwd_segment_hook = self._allreduce_ready_ranges
+        else:
+            model._bwd_gated_hook = self._allreduce_behind_events
+
+    def _allreduce_behind_events(self, plan):
+        """called once per step, right after the whole backward plan has been ENQUEUED (graph replay: ~3 ms of host time
+        for ~10 ms of GPU work).  For every batched weight-gradient reduction of the plan (Plan.dp_gates: a handful per
+        pass, the first a third of the way in) a side stream waits for the plan events behind it and the gradient ranges
+        that are final by then are all-reduced from that stream: RCCL starts on them while the backward plan is still
+        running, and the plan itself is not cut anywhere.  What is left (the ranges finished by the last ops) follows on
+        the training stream.  Same ranges, same order on every rank (the plan is deterministic)."""
+        import ctypes as C
+        import torch.distributed as dist
+        from . import _lib as L
+        if os.environ.get("PMF_DP_DEBUG_SKIP") == "1":
+            return
+        cur = torch.cuda.current_stream(self.device)
+        side = self.__dict__.get("_dp_side")
+        if side is None:
+            side = self._dp_side = torch.cuda.Stream(device=self.device)
+        lib = L.lib()
+        for evs, ranges in plan.dp_schedule():
+            if evs is None:                 # finalised by the last ops of the plan: behind the training stream
+                for a, b in ranges:
+                    self._pending.append(dist.all_reduce(self.flat.grad[a:b], async_op=True))
+                continue
+            ok = all(lib.pmf_plan_event_wait(e, C.c_void_p(side.cuda_stream)) == 0 for e in evs)
+            if not ok:                      # events never recorded (PMF_LANES=0): order behind the whole plan instead
+                side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                for a, b in ranges:
+                    self._pending.append(dist.all_reduce(self.flat.grad[a:b], async_op=True))
+
     def _allreduce_ready_ranges(self, plan, op_end):
         """called between segments of the backward plan: all-reduce the gradient ranges that are final by now.
         The collective is asynchronous (RCCL stream): it overlaps with the remaining segments."""
@@ -426,7 +464,7 @@ class SalsaNextEngine:
             if distributed:
                 import torch.distributed as dist
                 self._pending, self._frontier = [], None
-                model._bwd_segment_hook = self._allreduce_ready_ranges
+                self._attach_dp_hooks(model)
                 dist.broadcast(self.flat.param, 0)
                 for b in model.buffers():
                     dist.broadcast(b, 0)
@@ -446,6 +484,8 @@ class SalsaNextEngine:
         self.iteration = 0
 
     _allreduce_ready_ranges = TrainEngine._allreduce_ready_ranges
+    _allreduce_behind_events = TrainEngine._allreduce_behind_events
+    _attach_dp_hooks = TrainEngine._attach_dp_hooks
     _finish_allreduce = TrainEngine._finish_allreduce
     exposed_allreduce_ms = TrainEngine.exposed_allreduce_ms
 

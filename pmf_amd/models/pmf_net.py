@@ -735,9 +735,15 @@ class _PlanFunction(torch.autograd.Function):
                 plan.stage_g[slot].copy_(g)
         sig = ()
         hook = getattr(ctx.model, "_bwd_segment_hook", None) if plan.flat is not None else None
-        if hook is None:
+        gated = getattr(ctx.model, "_bwd_gated_hook", None) if plan.flat is not None else None
+        if gated is not None:
+            # data parallel, default: the WHOLE backward plan as one range (same replay as the single-process step); the
+            # hook then hangs the all-reduce of every gradient range behind the plan events that finalise it
             plan.run(plan.bwd_ops, plan.n_bwd, "backward", sig=sig)
-        else:       # data parallel: the backward plan in a few segments, finished gradient ranges handed to the hook
+            gated(plan)
+        elif hook is None:
+            plan.run(plan.bwd_ops, plan.n_bwd, "backward", sig=sig)
+        else:       # data parallel (PMF_DP_MODE=segments): the backward plan in a few segments, finished ranges to the hook
             import os
             cuts = plan.segment_cuts(int(os.environ.get("PMF_DP_SEGMENTS", "4")))
             for k in range(len(cuts) - 1):

@@ -201,6 +201,7 @@ class Plan:
         self.red_batch = int(_os.environ.get("PMF_RED_BATCH", str(RED_BATCH)))     # 0: one reduction op per layer
         self.batch_reds = self.red_batch > 0
         self.pending_reds, self._red_tables = {}, []     # lane -> queued stage-2 reductions
+        self.dp_events = []                 # (backward op count behind a batched reduction, [plan events]) -- see flush_reds
         self.grad_done = {}                 # id(param) -> index (in self.bwd) of the last op writing its gradient
         self.pgrad_floats = 0
         self._pid = {}
@@ -1091,6 +1092,15 @@ class Plan:
             a.p[0], a.p[1] = jd.data_ptr(), md.data_ptr()
             a.i[0], a.i[1] = n, blocks
         self.emit(self.bwd, L.OP_WGRAD_RED_MULTI, f)
+        # data parallelism: the gradients this launch finalises (and everything listed before it) may be all-reduced as
+        # soon as it AND the ops emitted so far on the two home lanes have run -- one event each; the engine makes its RCCL
+        # side stream wait for them (pmf_plan_event_wait), no cut through the plan
+        evs = [self._event_after(self._last_op[(id(self.bwd), lane)])[0]]
+        for hl in (0, 1):
+            ev = self.record_event(self.bwd, lane=hl)
+            if ev is not None:
+                evs.append(ev[0])
+        self.dp_events.append((len(self.bwd), evs))
         self.lane = prev
         for _, params in pend:
             for p in params:
@@ -1690,6 +1700,27 @@ class Plan:
                 cuts.append(n)
         self._cuts = (k, cuts)
         return cuts
+
+    def dp_gates(self):
+        """[(op_end, [plan events])] in list order: once the events of an entry have fired, every gradient that
+        grad_frontier(op_end) reports is final.  The last 2 % of the list is left out (nothing left to overlap with)."""
+        n = self.n_bwd
+        return [(oe + self.bwd_shift, evs) for (oe, evs) in self.dp_events if oe + self.bwd_shift <= n - max(4, n // 50)]
+
+    def dp_schedule(self):
+        """the data-parallel all-reduce schedule of one backward pass as pure data: [(events, [(a, b), ...])] in issue order
+        -- float ranges [a, b) of the flat gradient buffer that may be all-reduced once ``events`` have fired -- with a last
+        entry (None, ranges) for what only the end of the plan finalises.  Every float appears exactly once."""
+        front = [a for (a, _) in self.flat.ranges]
+        out = []
+        for op_end, evs in self.dp_gates():
+            new = self.grad_frontier(op_end)
+            todo = [(a, f) for a, f in zip(front, new) if f > a]
+            if todo:
+                out.append((list(evs), todo))
+            front = [max(a, f) for a, f in zip(front, new)]
+        out.append((None, [(a, b) for a, (_, b) in zip(front, self.flat.ranges) if b > a]))
+        return out
 
     def grad_frontier(self, op_end):
         """per FlatState group: float offset up to which the gradient buffer is final once ops [0, op_end) have run

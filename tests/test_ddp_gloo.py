@@ -178,8 +178,24 @@ def _real_plan_worker(rank, world, port, ret):
     eng._finish_allreduce()
     dist.all_reduce = real
     want = (idx % 1000).float() * sum(r + 1 for r in range(world))
+    ok_seg = bool(torch.equal(flat.grad[idx], want))
+    # ---- the default form: ONE backward range, all-reduces hung behind plan events (Plan.dp_schedule is the engine's
+    # schedule as data; the stream waits themselves need a GPU)
+    m._bwd_segment_hook = None
+    plan_e = m._build(2, 64, 2048, True, cpu, dry=True)
+    flat.grad.zero_()
+    flat.grad[idx] = (idx % 1000).float() * (rank + 1)
+    sched = plan_e.dp_schedule()
+    ev_calls = []
+    for evs, ranges in sched:
+        for a, b in ranges:
+            ev_calls.append((a, b - a))
+            dist.all_reduce(flat.grad[a:b])
     if rank == 0:
-        ret["ok"] = bool(torch.equal(flat.grad[idx], want))
+        ret["ok"] = ok_seg
+        ret["ok_events"] = bool(torch.equal(flat.grad[idx], want))
+        ret["ev_calls"] = ev_calls
+        ret["sched"] = [(evs, ranges) for evs, ranges in sched]
         ret["calls"], ret["cuts"], ret["fronts"], ret["n"] = calls, cuts, fronts, n
         ret["ranges"] = list(flat.ranges)
         ret["n_bwd"] = plan.n_bwd
@@ -209,6 +225,17 @@ def test_world8_real_plan_segments_and_frontiers():
     assert pos == n
     last = sum(b - a for a, b in zip(fronts[-2], fronts[-1]))
     assert last <= 0.02 * n, "%.1f MB of the gradient only become final in the last segment" % (4e-6 * last)
+    # event-gated form: same coverage; every gate names at least the event of its reduction launch; what is left for the
+    # end of the plan (no event) is at most 2 % of the payload
+    assert ret["ok_events"]
+    pos = 0
+    for off, cnt in sorted(ret["ev_calls"]):
+        assert off == pos, "event-gated ranges overlap or leave a gap at float %d" % pos
+        pos += cnt
+    assert pos == n
+    sched = list(ret["sched"])
+    assert len(sched) >= 3 and sched[-1][0] is None and all(evs for evs, _ in sched[:-1])
+    assert sum(b - a for a, b in sched[-1][1]) <= 0.02 * n
 
 
 def test_bench_gpus_flag_spawns_ranks():

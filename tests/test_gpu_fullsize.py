@@ -8,8 +8,8 @@
 * configs[1] at its batch size: eval logits of 4 frames + the KNN labels of every frame against the oracle
   (tasks/pmf_eval_semantickitti/infer.py:67-160).
 
-At these sizes train-mode BatchNorm normalises over >= 1024 values per channel even at the 4 x 128 bottleneck, so the
-whole backward is well conditioned and the bars can be tight everywhere (they could not at 2 x 32 x 64).
+No outlier allowance and no "worst error anywhere" yardstick: every parameter is held to the fp32 CPU
+oracle's own distance from float64 for THAT parameter.
 """
 import copy
 import os
@@ -23,9 +23,8 @@ pytestmark = pytest.mark.gpu
 from pmf_amd.utils.detinit import deterministic_init, synthetic_batch  # noqa: E402
 from tests import gpu_helpers as G  # noqa: E402
 
-# parameters whose gradient never passes through a low-resolution stage or a second BatchNorm: the float64 unit-test
-# yardstick of tests/test_gpu_ops.py applies to them directly
-TAIL = ("lidar_stream.logits.", "lidar_stream.upBlock4.conv4.", "camera_stream_decoder.conv.")
+# the two heads: no BatchNorm lies behind them in backward order
+HEADS = ("lidar_stream.logits.", "camera_stream_decoder.conv.")
 
 _ORACLE = {}
 
@@ -66,7 +65,7 @@ def _oracle_grads(kind):
         a, b = m(pcd.to(dt), rgb.to(dt))
         tot, _ = losses_ref.pmf_total_loss(a, b, label, alpha.to(dt))
         tot.backward()
-        out[tag] = ({k: p.grad.detach().clone() for k, p in m.named_parameters()}, float(tot),
+        out[tag] = ({k: p.grad.detach().clone() for k, p in m.named_parameters()}, float(tot.detach()),
                     m.lidar_stream.last_logits.detach().clone())
         del m, a, b, tot
     _ORACLE[kind] = (out, masks, (pcd, rgb, label), alpha)
@@ -125,15 +124,20 @@ def test_full_size_backward_vs_oracle(kind, tune):
     worst = max(rows, key=lambda r: r[1])
     print("[fullsize %s tune=%s] worst %s %.2e (cpu fp32 %.2e), ratio gmean %.2f p90 %.2f" % (
         kind, tune, worst[0], worst[1], worst[2], gmean, p90))
-    # (1) tail layers: the float64 unit-test yardstick
+    # Measured at 2 x 64 x 2048 (PMF-R34, hash init): the fp32 CPU oracle itself sits 1e-6 (heads) ... 1.5e-2 (camera
+    # encoder) ... 1.6e-1 (a conv bias in front of a train-mode BatchNorm, true gradient ~0) away from float64 -- the
+    # BatchNorm backward subtracts two per-channel means from gy (cancellation) in every one of ~90 layers -- and the HIP
+    # path tracks it parameter by parameter (ratio geometric mean 0.90, 90th percentile 1.07).  So the yardstick for a
+    # parameter is the fp32 CPU oracle's own distance from float64:
+    # (1) the two heads (no BatchNorm behind them in backward order): fp32 rounding level
     for k, e_h, _ in rows:
-        if k.startswith(TAIL):
-            assert e_h < 1e-4, (k, e_h)
-    # (2) every parameter: as close to float64 as the fp32 CPU oracle is (x4, floor 2e-4) and never beyond 5e-3
-    bad = [r for r in rows if not (r[1] <= max(4 * r[2], 2e-4) and r[1] < 5e-3)]
+        if k.startswith(HEADS):
+            assert e_h < 2e-5, (k, e_h)
+    # (2) EVERY parameter: at most 3x as far from float64 as the fp32 CPU oracle (floor 2e-4); no outlier allowance
+    bad = [r for r in rows if not r[1] <= max(3 * r[2], 2e-4)]
     assert not bad, "gradient error vs float64 (hip, cpu-fp32):\n" + "\n".join("%-55s %.3e %.3e" % r for r in bad[:30])
     # (3) no systematic excess over the fp32 CPU path
-    assert gmean < 1.5 and p90 < 2.5, (gmean, p90)
+    assert gmean < 1.25 and p90 < 1.6, (gmean, p90)
 
 
 def test_infer_bs4_logits_and_knn_vs_oracle():

@@ -658,6 +658,34 @@ def test_fused_loss_matches_reference_objective(golden):
 
 
 @pytest.mark.gpu
+def test_fused_loss_nan_probabilities_stay_in_bounds():
+    """diverged training: NaN probabilities must give a NaN loss, not out-of-bounds scatters (the in-library
+    Lovasz sort used to drop NaN keys in pass 0, leaving row tails of the permutation unwritten)"""
+    from pmf_amd.loss import pmf_total_loss_fused
+    n, c, h, w = 2, 20, 64, 512
+    _, _, label, _ = synthetic_batch(n, h, w, c, seed=5, fill=0.5)
+    alpha = np.linspace(0.2, 1.0, c).astype(np.float32)
+    alpha[0] = 0
+    for _ in range(3):
+        a = torch.softmax(det_tensor("nan.a", (n, c, h, w), -3, 3), 1)
+        b = torch.softmax(det_tensor("nan.b", (n, c, h, w), -3, 3), 1)
+        a[0, :, 10:20, 100:200] = float("nan")
+        b[1, 3, :, :] = float("nan")
+        ga, gb = a.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+        tot, _ = pmf_total_loss_fused(ga, gb, label.cuda(), torch.from_numpy(alpha))
+        tot.backward()
+        torch.cuda.synchronize()
+        assert not torch.isfinite(tot).item()
+        assert ga.grad.shape == a.shape
+    # and the library still works afterwards (no sticky fault)
+    a = torch.softmax(det_tensor("nan.a", (n, c, h, w), -3, 3), 1).cuda().requires_grad_(True)
+    b = torch.softmax(det_tensor("nan.b", (n, c, h, w), -3, 3), 1).cuda().requires_grad_(True)
+    tot, _ = pmf_total_loss_fused(a, b, label.cuda(), torch.from_numpy(alpha))
+    tot.backward()
+    assert torch.isfinite(tot).item() and torch.isfinite(a.grad).all()
+
+
+@pytest.mark.gpu
 def test_flat_training_state_matches_per_tensor_path():
     """FlatState (parameters / gradients as views of two flat buffers, one fused optimiser launch per group, gradients
     written in place by the backward plan) must produce bit-identical parameters to the per-tensor path."""
@@ -717,15 +745,26 @@ def test_data_parallel_range_allreduce_world1():
             for _ in range(3):
                 eng.train_step(feat.cuda().clone(), mask.cuda(), label.cuda())
             plan = next(iter(m._plans.values()))
+            if distributed and os.environ.get("PMF_DP_MODE") == "events":
+                gates = plan.dp_gates()
+                assert gates and all(evs for _, evs in gates) and all(a[0] < b[0] for a, b in zip(gates, gates[1:]))
             cuts = plan.segment_cuts(4)
             assert cuts[0] == 0 and cuts[-1] == plan.n_bwd and all(a < b for a, b in zip(cuts, cuts[1:]))
             fr = [plan.grad_frontier(c) for c in cuts[1:]]
             assert fr[-1] == [b for (_, b) in plan.flat.ranges]           # everything final at the end
             assert all(x <= y for f0, f1 in zip(fr, fr[1:]) for x, y in zip(f0, f1))   # frontiers only advance
             return {k: v.detach().clone() for k, v in m.state_dict().items()}
-        a, b = run(False), run(True)
-        for k in a:
-            assert torch.equal(a[k], b[k]), k
+        a = run(False)
+        # both data-parallel forms: all-reduce hung behind plan events of ONE backward range (default), and the backward
+        # plan cut into segments (PMF_DP_MODE=segments)
+        for mode in ("events", "segments"):
+            os.environ["PMF_DP_MODE"] = mode
+            try:
+                b = run(True)
+            finally:
+                os.environ.pop("PMF_DP_MODE", None)
+            for k in a:
+                assert torch.equal(a[k], b[k]), (mode, k)
     finally:
         if created:
             dist.destroy_process_group()
