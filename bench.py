@@ -534,14 +534,10 @@ def parity_block(args, eng, model, feat0, mask, label):
     # gradient in this network (the BatchNorm backward subtracts two per-channel means from gy in ~90 layers; measured in
     # tests/test_gpu_fullsize.py), so "HIP vs fp32 oracle" alone cannot tell a rounding difference from a defect -- the
     # yardstick of a parameter is the fp32 CPU oracle's own distance from float64
-    import copy
-    net64 = copy.deepcopy(net).double()
-    for p in net64.parameters():
-        p.grad = None
+    net64 = _oracle_model(args.model, args.backbone, args.nclasses)
+    net64.load_state_dict(sd)                  # (the state before the fp32 pass above touched the running statistics)
+    net64 = net64.double().train()
     O.set_dropout_masks(net64, {k: v.double() for k, v in masks.items()})
-    for k, v in net.state_dict().items():      # the fp32 pass above updated the running statistics: restore
-        if "running_" in k or "num_batches" in k:
-            net64.state_dict()[k].copy_(sd[k])
     eng64 = Engine(net64, args.nclasses, lambda_=1.0, gamma=0.5, tau=0.7, feature_mean=KITTI_MEAN, feature_std=KITTI_STD,
                    warmup_steps=10, max_steps=100)
     eng64.focal.double()

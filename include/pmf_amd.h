@@ -209,8 +209,17 @@ int pmf_bn_finalize(const double* stats, int32_t nrows, float count, const float
 int pmf_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                        float eps, float* scale, float* shift, float* save_mean, float* save_invstd, int32_t C,
                        pmf_stream_t s);
+/* small maps (pmf_bn_bwd_small_ok: <= 2048 pixels, C % 4 == 0): the whole train-mode BatchNorm backward of a layer --
+ * column sums, dgamma += / dbeta +=, dz = coef-form of salsanext.py:27-33's BatchNorm2d backward times act'(a), and the
+ * exact column sum of dz (the conv-bias gradient) as ONE row -- in one launch, one read of gy and a. */
+int pmf_bn_bwd_small_ok(int64_t npix, int32_t C);
+int pmf_bn_bwd_small(const float* gy, int32_t gy_ldc, const float* a, int32_t a_ldc, int64_t npix, int32_t C,
+                     const float* save_mean, const float* gamma, const float* save_invstd, int32_t train, int32_t act,
+                     float* dz, int32_t dz_ldc, float* dbias_row, float* dgamma, float* dbeta, pmf_stream_t s);
 /* number of partial rows the column-reduction kernels (bn_bwd_reduce/apply, act_bwd) write for npix pixels, C channels */
 int pmf_col_rows(int64_t npix, int32_t C);
+/* tuning hook (tools/bench_elem.py): workgroup cap (> 0) and pixels per trip (4 / 8) of the column kernels; returns the cap */
+int pmf_debug_col(int32_t cap, int32_t unroll);
 /* backward pass 1 + fold: partial rows of sum gy, sum gy*(a-mean) into `part` (float64 [rows][2][C] scratch), then
  * dgamma += invstd*sum gy*(a-mean), dbeta += sum gy, coef[3][C] = {gamma*invstd, invstd^2*mean(gy*(a-mean)), mean(gy)}
  * (train == 0, eval-mode BN: coef[1] = coef[2] = 0). */
@@ -470,7 +479,7 @@ enum {
   PMF_OP_MAXPOOL, PMF_OP_MAXPOOL_BWD, PMF_OP_BILINEAR, PMF_OP_BILINEAR_BWD, PMF_OP_PSHUFFLE, PMF_OP_PSHUFFLE_BWD,
   PMF_OP_GATE, PMF_OP_GATE_BWD, PMF_OP_GMEAN, PMF_OP_GMEAN_BWD, PMF_OP_COLSUM, PMF_OP_SOFTMAX, PMF_OP_SOFTMAX_BWD,
   PMF_OP_NCHW2NHWC, PMF_OP_FILL, PMF_OP_PMASK_FROM, PMF_OP_PMASK_POOL, PMF_OP_PMASK_MUL, PMF_OP_PMASK_MUL_BWD,
-  PMF_OP_VEC_ADD, PMF_OP_WGRAD_PART, PMF_OP_WGRAD_RED, PMF_OP_WGRAD_RED_MULTI, PMF_OP_BN_BWD_FOLD
+  PMF_OP_VEC_ADD, PMF_OP_WGRAD_PART, PMF_OP_WGRAD_RED, PMF_OP_WGRAD_RED_MULTI, PMF_OP_BN_BWD_FOLD, PMF_OP_BN_BWD_SMALL
 };
 
 /* generic argument record for the small ops (slot meaning documented next to each dispatcher case in plan.cpp) */

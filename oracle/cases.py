@@ -141,3 +141,70 @@ def merge_case(seed, pc_size, n_cams=6, ncls=17):
     put(5, 4, 0.25, 0)                 # label 0 from the last view
     put(0, 5, 0.3, 2); put(1, 5, 0.9, 11)  # higher confidence wins
     return idx, conf, lab              # points 0, 6, 7 unseen
+
+
+class SyntheticNus(object):
+    """A devkit-free stand-in for pc_processor/dataset/nuScenes/dataset_nuscenes.py:74-282 with the attributes
+    NusPerspectiveViewLoader (tasks/pmf_eval_nuscenes/nus_perspective_loader.py) and the inference loop
+    (tasks/pmf_eval_nuscenes/infer.py:110-200) use: six consecutive indices = the six camera views of ONE sweep
+    (token_list[i] = {lidar_token, cam_token}), loadDataByIndex -> (f32[P,4] x/y/z/intensity, uint8[P,1] raw labels, int32[P]),
+    loadImage -> uint8[h,w,3], labelMapping (the vectorised dictionary of dataset_nuscenes.py:181-186) and
+    mapLidar2Camera(index, xyz, img_h=<image width>, img_w=<image height>) -> ((row, col) float of the kept points, keep
+    mask): same masks as :268-276 (depth > 1 m, one pixel margin), the devkit's chain of four rigid transforms replaced by
+    ONE yaw rotation per camera (cameras 60 degrees apart, 80-degree horizontal field of view: neighbouring views overlap,
+    the merge has to decide) and a pinhole model.  TEST INFRASTRUCTURE: the reference loader class is executed against
+    this object to produce tests/golden/g15_nus.npz, the HIP loader and the numpy oracle are compared on it."""
+
+    N_CAM = 6
+
+    def __init__(self, seed=0, sweeps=2, npts=6000, h=80, w=160, nclasses=17):
+        rng = np.random.Generator(np.random.PCG64(seed))
+        self.h, self.w, self.nclasses = h, w, nclasses
+        self.sweeps, self.images = [], []
+        for s in range(sweeps):
+            pts, _, _ = lidar_sweep(100 * seed + s, npts)
+            raw = rng.integers(0, 32, (npts, 1)).astype(np.uint8)
+            self.sweeps.append((pts, raw))
+            self.images.append([rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for _ in range(self.N_CAM)])
+        # general index (0..31) -> segmentation index (0..16), as map_name_from_general_index_to_segmentation_index
+        self.map_name_from_general_index_to_segmentation_index = {i: int(rng.integers(0, nclasses)) for i in range(32)}
+        self.mapped_cls_name = {i: "class_%d" % i for i in range(nclasses)}
+        self.token_list = [{"lidar_token": "sweep%03d" % (i // self.N_CAM), "cam_token": "sweep%03d_cam%d" % (
+            i // self.N_CAM, i % self.N_CAM)} for i in range(sweeps * self.N_CAM)]
+        self.fx = 0.6 * w
+
+    def __len__(self):
+        return len(self.token_list)
+
+    def parsePathInfoByIndex(self, index):
+        return index, ""
+
+    def loadDataByIndex(self, index):
+        pts, raw = self.sweeps[index // self.N_CAM]
+        return pts, raw, np.zeros(pts.shape[0], dtype=np.int32)
+
+    def loadImage(self, index):
+        return self.images[index // self.N_CAM][index % self.N_CAM]
+
+    def labelMapping(self, sem_label):
+        sem_label = np.vectorize(self.map_name_from_general_index_to_segmentation_index.__getitem__)(sem_label)
+        assert sem_label.shape[-1] == 1
+        return sem_label[:, 0]
+
+    def mapLidar2Camera(self, index, pointcloud, img_h, img_w, min_dist=1.0):
+        yaw = np.deg2rad(60.0 * (index % self.N_CAM))
+        x, y, z = (pointcloud[:, k].astype(np.float64) for k in range(3))
+        fwd = np.cos(yaw) * x + np.sin(yaw) * y          # camera z (depth)
+        right = np.sin(yaw) * x - np.cos(yaw) * y        # camera x
+        down = -z - 0.3                                  # camera y
+        with np.errstate(divide="ignore", invalid="ignore"):
+            u = self.fx * right / fwd + 0.5 * self.w
+            v = self.fx * down / fwd + 0.5 * self.h
+        mask = np.ones(fwd.shape[0], dtype=bool)
+        mask = np.logical_and(mask, fwd > min_dist)
+        mask = np.logical_and(mask, u > 1)
+        mask = np.logical_and(mask, u < img_h - 1)       # (the reference passes the image WIDTH as img_h, :272-273)
+        mask = np.logical_and(mask, v > 1)
+        mask = np.logical_and(mask, v < img_w - 1)
+        mapped = np.stack([v, u], 1)                     # fliplr: (row, col)
+        return mapped[mask, :], mask

@@ -717,10 +717,57 @@ def epmf_trace(R):
     print("g14_epmf_trace: %d arrays" % len(out))
 
 
+def nus(R):
+    """G15: the reference's NusPerspectiveViewLoader class (tasks/pmf_eval_nuscenes/nus_perspective_loader.py, imported from
+    its source file: numpy + torch only) on oracle.cases.SyntheticNus -- the six views of sweep 0 -- and its getMergePred
+    (infer.py:18-38, compiled from source as in merge()) on per-view confidences / labels derived from those views.
+    Stored per view: depth / xyz / intensity / mask / label planes, the index arrays, and of the three image planes (the
+    uint8 image / 255, 154 KB per view) a float64 checksum plus 256 sampled values."""
+    import ast
+    from oracle.cases import SyntheticNus
+    mod = _load("ref_nus_loader", "tasks/pmf_eval_nuscenes/nus_perspective_loader.py")
+    ds = SyntheticNus(seed=0, sweeps=2, npts=6000, h=80, w=160, nclasses=17)
+    ld = mod.NusPerspectiveViewLoader(dataset=ds, config={})
+    out = {}
+    rng = np.random.Generator(np.random.PCG64(15))
+    samp = rng.integers(0, 3 * 80 * 160, 256)
+    idx_l, conf_l, lab_l = [], [], []
+    for v in range(6):
+        feat, mask, label, xd, yd, dep, pidx, psize = ld[v]
+        feat = feat.numpy()
+        out["v%d.geom" % v] = feat[:5]
+        out["v%d.rgb_sum" % v] = np.array([feat[5:8].astype(np.float64).sum()])
+        out["v%d.rgb_samples" % v] = feat[5:8].reshape(-1)[samp]
+        out["v%d.mask" % v], out["v%d.label" % v] = mask.numpy(), label.numpy()
+        out["v%d.x" % v], out["v%d.y" % v] = xd.numpy(), yd.numpy()
+        out["v%d.depth" % v], out["v%d.pidx" % v] = dep.numpy(), pidx.numpy()
+        out["v%d.psize" % v] = psize.numpy()
+        # a deterministic stand-in for the network: confidence / label of a point from its view and pixel
+        conf = ((xd.numpy() * 31 + yd.numpy() * 17 + v * 7) % 97).astype(np.float32) / 97.0
+        lab = ((xd.numpy() * 5 + yd.numpy() * 3 + v) % 16 + 1).astype(np.int64)
+        idx_l.append(pidx.numpy()), conf_l.append(conf), lab_l.append(lab)
+    out["rgb_sample_index"] = samp
+    path = os.path.join(REF, "tasks/pmf_eval_nuscenes/infer.py")
+    tree = ast.parse(open(path).read())
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "getMergePred"]
+    ns = {"torch": torch}
+    exec(compile(ast.Module(body=fn, type_ignores=[]), path, "exec"), ns)
+    keep = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        t = lambda xs: [torch.from_numpy(x) for x in xs]
+        out["merged"] = ns["getMergePred"](t(idx_l), t(conf_l), t(lab_l), 6000).numpy()
+    finally:
+        torch.Tensor.cuda = keep
+    np.savez_compressed(os.path.join(OUT, "g15_nus.npz"), **out)
+    print("g15_nus:", {k: v.shape for k, v in out.items() if k.startswith("v0.") or k == "merged"},
+          "unseen points:", int((out["merged"] < 0).sum()), "kept per view:", [out["v%d.x" % v].shape[0] for v in range(6)])
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     R = import_reference()
-    which = sys.argv[1:] or ["blocks", "whole_net", "losses_metrics", "knn", "loader", "trainer_trace", "epmf", "loader_v2", "range_loader", "kitti_formats", "merge", "loader_train", "epmf_trace"]
+    which = sys.argv[1:] or ["blocks", "whole_net", "losses_metrics", "knn", "loader", "trainer_trace", "epmf", "loader_v2", "range_loader", "kitti_formats", "merge", "loader_train", "epmf_trace", "nus"]
     for name in which:
         globals()[name](R)

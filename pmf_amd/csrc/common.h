@@ -14,6 +14,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
   } while (0)
 
 #define PMF_COL_ROWS 512   // max partial rows written by the column-reduction kernels (one per workgroup)
+extern int g_pmf_col_cap;      // tuning hook (pmf_debug_col): workgroup cap of the column kernels, <= the rows the caller sized
+extern int g_pmf_col_unroll;   // ... and pixels per trip (4 or 8)
 
 // true the first time it is called with `mask` on the current device: per-device one-time work (the dynamic-LDS function
 // attribute is a property of the (function, device) pair)

@@ -77,7 +77,7 @@ static ColLaunch col_launch(int64_t npix, int Q, int nz) {
   int Qg = Q < 256 ? Q : 256;
   int rows = 256 / Qg;
   int64_t gx = cdiv64(npix, (int64_t)rows * 4);   // same rule as bn.hip col_l / pmf_col_rows
-  if (gx > PMF_COL_ROWS) gx = PMF_COL_ROWS;
+  if (gx > g_pmf_col_cap) gx = g_pmf_col_cap;
   if (gx < 1) gx = 1;
   ColLaunch L;
   L.grid = dim3((unsigned)gx, (unsigned)cdiv(Q, 256), (unsigned)nz);

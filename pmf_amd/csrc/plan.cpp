@@ -34,6 +34,10 @@ static int run_one(const pmf_op_t& o, pmf_stream_t s) {
     case PMF_OP_BN_BWD_FOLD:  // p: part gamma save_invstd coef dgamma dbeta | i: C nrows train | l0 npix
       return pmf_bn_bwd_fold((const double*)a.p[0], i[1], i[0], a.l[0], i[2], (const float*)a.p[1], (const float*)a.p[2],
                              (float*)a.p[3], (float*)a.p[4], (float*)a.p[5], s);
+    case PMF_OP_BN_BWD_SMALL:  // p: gy a save_mean gamma save_invstd dz dbias_row dgamma dbeta | i: gy_ldc a_ldc C train act dz_ldc | l0 npix
+      return pmf_bn_bwd_small((const float*)a.p[0], i[0], (const float*)a.p[1], i[1], a.l[0], i[2], (const float*)a.p[2],
+                              (const float*)a.p[3], (const float*)a.p[4], i[3], i[4], (float*)a.p[5], i[5], (float*)a.p[6],
+                              (float*)a.p[7], (float*)a.p[8], s);
     case PMF_OP_BN_BWD_APPLY:  // p: gy a coef save_mean dz dbias_rows | i: gy_ldc a_ldc C act dz_ldc dbias_ld | l0 npix
       return pmf_bn_bwd_apply((const float*)a.p[0], i[0], (const float*)a.p[1], i[1], a.l[0], i[2], (const float*)a.p[2],
                               (const float*)a.p[3], i[3], (float*)a.p[4], i[4], (float*)a.p[5], i[5], s);

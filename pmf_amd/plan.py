@@ -618,7 +618,28 @@ class Plan:
                 self.colrows_max = max(self.colrows_max, _ru(Cout, 4))
 
                 lw = getattr(view, "_gy_last", None)
-                if lw is not None and lw["lane"] == lane:
+                # small maps (<= 2048 pixels: the 4x128 stage and below, a fifth of the BatchNorm layers): column sums,
+                # fold and apply in ONE launch (bn.hip bn_bwd_small_k) instead of three latency-bound ones; the
+                # input-gradient epilogue then carries no partial sums either (its hook stays empty)
+                small = (os.environ.get("PMF_BN_SMALL", "1") != "0" and Cout % 4 == 0
+                         and bool(L.lib().pmf_bn_bwd_small_ok(out.npix, Cout)))
+                if small:
+                    one_row = has_bias and pmask is None
+
+                    def rs(op):
+                        a = op.u.sm
+                        ps = (gyt.buf.ptr, out.buf.ptr, info["mean"].ptr, bn.weight.data_ptr(), info["invstd"].ptr,
+                              dz.buf.ptr, dbr.ptr if (dbr is not None and one_row) else None, self.pgrad_buf.at(dgam),
+                              self.pgrad_buf.at(dbet))
+                        for i, p in enumerate(ps):
+                            a.p[i] = p
+                        a.i[0], a.i[1], a.i[2], a.i[3], a.i[4], a.i[5] = gyt.ldc, out.ldc, Cout, bn_train_flag, k_act, dz.ldc
+                        a.l[0] = out.npix
+                    self.emit(self.bwd, L.OP_BN_BWD_SMALL, rs)
+                    self.note_bytes(self.bwd, "bn_bwd_small", 12.0 * out.npix * Cout)
+                    self.grad_done[id(bn.weight)] = self.grad_done[id(bn.bias)] = len(self.bwd) - 1
+                    dbias_rows = 1 if one_row else 0
+                elif lw is not None and lw["lane"] == lane:
                     # the last writer of gy was an input-gradient launch on this lane: it carried the reduction
                     # (sum gy, sum gy*(a - mean) per tile row) in its epilogue; only the fold is left
                     probe = L.ConvDesc()
@@ -649,7 +670,8 @@ class Plan:
                         a.l[0] = out.npix
                     self.emit(self.bwd, L.OP_BN_BWD_REDUCE, r1)
                     self.note_bytes(self.bwd, "bn_bwd_reduce", 8.0 * out.npix * Cout)
-                self.grad_done[id(bn.weight)] = self.grad_done[id(bn.bias)] = len(self.bwd) - 1
+                if not small:
+                    self.grad_done[id(bn.weight)] = self.grad_done[id(bn.bias)] = len(self.bwd) - 1
 
                 def r2(op):
                     a = op.u.sm
@@ -659,9 +681,10 @@ class Plan:
                         a.p[i] = p
                     a.i[0], a.i[1], a.i[2], a.i[3], a.i[4], a.i[5] = gyt.ldc, out.ldc, Cout, k_act, dz.ldc, dbr_ld
                     a.l[0] = out.npix
-                self.emit(self.bwd, L.OP_BN_BWD_APPLY, r2)
-                self.note_bytes(self.bwd, "bn_bwd_apply", 12.0 * out.npix * Cout)
-                dbias_rows = L.lib().pmf_col_rows(out.npix, Cout) if (has_bias and pmask is None) else 0
+                if not small:
+                    self.emit(self.bwd, L.OP_BN_BWD_APPLY, r2)
+                    self.note_bytes(self.bwd, "bn_bwd_apply", 12.0 * out.npix * Cout)
+                    dbias_rows = L.lib().pmf_col_rows(out.npix, Cout) if (has_bias and pmask is None) else 0
             else:
                 dz = self.tgrad(out)
                 dbias_rows = 0

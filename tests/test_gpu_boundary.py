@@ -624,3 +624,115 @@ def test_tasks_salsanext_train_and_resume(tmp_path):
         yaml.safe_dump(cfg, f)
     out = _run_task(main, conf)
     assert "E[003|003]" in out and "E[003|001]" not in out
+
+
+# ---- nuScenes: six camera views per sweep ----------------------------------------------------------
+def _nus_settings(tmp_path, knn, nclasses=17, proj_h=64):
+    import types
+    cfg = {"sensor": {"proj_h": proj_h, "proj_w": 160, "img_mean": [16.51, 0.10, -0.21, -0.21, 21.18],
+                      "img_stds": [14.16, 14.35, 16.09, 2.34, 22.45]},
+           "post": {"KNN": {"use": knn, "params": {"knn": 5, "search": 5, "sigma": 1.0, "cutoff": 1.0}}}}
+    rec = types.SimpleNamespace(logger=types.SimpleNamespace(info=lambda *a, **k: None))
+    s = types.SimpleNamespace(config=cfg, n_classes=nclasses, save_path=str(tmp_path), has_label=True, is_debug=False,
+                              dataset="nuScenes", data_root="")
+    return s, rec
+
+
+def test_nus_view_loader_matches_reference_fixture(golden):
+    """NusPerspectiveViewLoader on the GPU (one upload + pmf_project_v2_scatter) against g15_nus -- the reference's own class
+    executed on the same synthetic dataset -- bit for bit, and getMergePred (pmf_merge_pred) on the fixture's views"""
+    from oracle.cases import SyntheticNus
+    from pmf_amd.dataset.nuScenes import NusPerspectiveViewLoader
+    from pmf_amd.postproc import getMergePred
+    g = golden("g15_nus")
+    ds = SyntheticNus(seed=0, sweeps=2, npts=6000, h=80, w=160, nclasses=17)
+    ld = NusPerspectiveViewLoader(ds, {})
+    assert len(ld) == 12
+    samp = g["rgb_sample_index"]
+    idx_l, conf_l, lab_l = [], [], []
+    for v in range(6):
+        feat, mask, label, xd, yd, dep, pidx, psize = ld[v]
+        f = feat.cpu().numpy()
+        assert np.array_equal(f[:5], g["v%d.geom" % v])
+        assert np.array_equal(f[5:8].reshape(-1)[samp], g["v%d.rgb_samples" % v])
+        assert abs(f[5:8].astype(np.float64).sum() - g["v%d.rgb_sum" % v][0]) < 1e-6
+        assert np.array_equal(mask.cpu().numpy(), g["v%d.mask" % v])
+        assert np.array_equal(label.cpu().numpy(), g["v%d.label" % v])
+        assert np.array_equal(xd.cpu().numpy(), g["v%d.x" % v]) and np.array_equal(yd.cpu().numpy(), g["v%d.y" % v])
+        assert np.array_equal(dep.cpu().numpy(), g["v%d.depth" % v])
+        assert np.array_equal(pidx.cpu().numpy(), g["v%d.pidx" % v]) and int(psize.item()) == 6000
+        conf = ((xd.long() * 31 + yd.long() * 17 + v * 7) % 97).float() / 97.0
+        lab = (xd.long() * 5 + yd.long() * 3 + v) % 16 + 1
+        idx_l.append(pidx), conf_l.append(conf), lab_l.append(lab)
+    merged = getMergePred(idx_l, conf_l, lab_l, 6000).cpu().numpy()
+    assert np.array_equal(merged, g["merged"])
+    with pytest.raises(RuntimeError):
+        NusPerspectiveViewLoader(ds, {}, device="cpu")[0]
+
+
+@pytest.mark.parametrize("knn,fallback", [(False, False), (True, False), (False, True)])
+def test_nus_six_camera_inference_loop(tmp_path, knn, fallback):
+    """tasks/pmf_eval_nuscenes/infer.py on two synthetic sweeps x six views: per view crop -> normalise -> PMFNet -> pad ->
+    confidence / argmax -> point labels (pixel lookup or KNN) -> after six views the merge (+ SalsaNext labels for the points
+    no camera sees) -> <token>_lidarseg.bin.  Everything behind the networks is compared EXACTLY: the oracle chain
+    (oracle/nus_infer_ref.py) is fed the probability maps the HIP model produced; end to end against the CPU oracle network
+    a point may differ only where two classes tie to within the probability bar."""
+    import importlib.util
+    import sys
+    from oracle import nus_infer_ref, pmf_torch as O
+    from oracle.cases import SyntheticNus
+    from pmf_amd.models import PMFNet, SalsaNext
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tdir = os.path.join(repo, "tasks", "pmf_eval_nuscenes")
+    sys.path.insert(0, tdir)
+    try:
+        for m in ("option", "nus_perspective_loader"):
+            sys.modules.pop(m, None)
+        spec = importlib.util.spec_from_file_location("nus_infer_task", os.path.join(tdir, "infer.py"))
+        task = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(task)
+    finally:
+        sys.path.remove(tdir)
+        for m in ("option", "nus_perspective_loader"):
+            sys.modules.pop(m, None)
+    ds = SyntheticNus(seed=3, sweeps=2, npts=5000, h=80, w=160, nclasses=17)
+    settings, rec = _nus_settings(tmp_path, knn)
+    hip = deterministic_init(PMFNet(5, 3, 17, 32, False, "resnet34")).cuda().eval()
+    fb = None
+    if fallback:
+        salsa = deterministic_init(SalsaNext(5, 17, 32)).cuda().eval()
+        fb = task.LidarOnlyFallback(salsa, {"fov_up": 10, "fov_down": -30, "proj_h": 32, "proj_w": 256,
+                                            "img_mean": settings.config["sensor"]["img_mean"],
+                                            "img_stds": settings.config["sensor"]["img_stds"]}, torch.device("cuda", 0))
+    inf = task.Inference(settings, hip, rec, dataset=ds, fallback=fb)
+    written = inf.run()
+    assert sorted(written) == ["sweep000", "sweep001"]
+    got = {k: np.fromfile(p, dtype=np.int32) for k, p in written.items()}
+    assert all(v.shape == (5000,) for v in got.values())
+
+    def predict_hip(pcd, rgb):
+        with torch.no_grad():
+            return hip(pcd.cuda(), rgb.cuda())[0].cpu()
+    fb_ref = None
+    if fallback:
+        fb_ref = lambda i: fb(ds.loadDataByIndex(i)[0]).cpu().numpy()
+    kp = dict(knn=5, search=5, sigma=1.0, cutoff=1.0) if knn else None
+    sensor = settings.config["sensor"]
+    want = nus_infer_ref.infer_sweeps(ds, predict_hip, 64, sensor["img_mean"], sensor["img_stds"], kp, 17, fb_ref)
+    for k in want:
+        np.testing.assert_array_equal(got[k], want[k])
+        if not fallback:
+            assert (want[k] == 0).sum() > 100            # points no camera sees: -1 -> 0 (infer.py:183-184)
+        else:
+            assert (got[k] == 0).sum() < (5000 // 50)    # ... now carry the LiDAR-only model's labels
+    if not knn and not fallback:
+        ref = deterministic_init(O.PMFNet(5, 3, 17, 32, False, "resnet34")).eval()
+
+        def predict_ref(pcd, rgb):
+            with torch.no_grad():
+                return ref(pcd, rgb)[0]
+        e2e = nus_infer_ref.infer_sweeps(ds, predict_ref, 64, sensor["img_mean"], sensor["img_stds"], None, 17)
+        for k in e2e:
+            assert (got[k] != e2e[k]).sum() <= 5, (k, int((got[k] != e2e[k]).sum()))
+        # the evaluator saw every sweep once
+        assert int(inf.evaluator.conf_matrix.sum()) == 2 * 5000

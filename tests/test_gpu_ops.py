@@ -135,6 +135,15 @@ def test_conv_unit_fwd_bwd(case):
     _conv_case(case, 0)
 
 
+@pytest.mark.parametrize("name", ["c3x3", "c3x3d2", "c1x1cat3", "c3x3_big", "c3x3s2", "c2x2d2_wpipe"])
+def test_conv_unit_bn_backward_three_launch_form(name, monkeypatch):
+    """maps of <= 2048 pixels run their BatchNorm backward as ONE launch (bn_bwd_small_k) by default -- which is what the
+    cases above exercise; PMF_BN_SMALL=0 keeps them on the reduce / fold / apply kernels and on the input-gradient epilogue
+    that carries the column sums, the form every larger map uses"""
+    monkeypatch.setenv("PMF_BN_SMALL", "0")
+    _conv_case(next(c for c in CONVS if c[0] == name), 0)
+
+
 @pytest.mark.parametrize("env", [{"PMF_WG_SWP": "0"}, {"PMF_WG_W8": "1"}], ids=["staged", "eight_waves"])
 def test_conv_unit_wgrad_variants(env, monkeypatch):
     """the split-bf16 weight-gradient kernel's other forms (conv_wgrad.hip): the two-barrier staged loop that the
