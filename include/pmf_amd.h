@@ -101,7 +101,10 @@ typedef struct {
   float* splitk_ws;          /* optional scratch for deterministic split-K on small maps (NULL = never split) */
   int64_t splitk_ws_bytes;
   int32_t cfg;               /* 0 = built-in heuristics; else tile configuration chosen by the caller's autotuner:
-                              * BN (32|64) | MT (1|2) << 8 | K splits (1 = none) << 16, see pmf_conv_fwd_stat_rows */
+                              * BN (32|64) | MT (1|2) << 8 | K splits (1 = none) << 16, see pmf_conv_fwd_stat_rows;
+                              * bit 24 (PMF_CFG_DIRECT_TAPS): a 2..9-tap launch with w_s3 runs the direct variant -- activations
+                              * straight from global memory per tap, no input tile in LDS (conv_fwd.hip PIPE 13) -- where its
+                              * weight fragments fit; ignored elsewhere */
   int32_t ep_flags;          /* PMF_EP_STAT_X_ONLY: ep_relu_x feeds ep_stat_mean only (no ReLU mask) */
   const float* ep_stat_mean; /* optional [Cout], needs stats + ep_relu_x: the second statistics column becomes
                               * sum out * (ep_relu_x - mean) instead of sum out^2 -- the BatchNorm-backward reduction
@@ -119,6 +122,7 @@ typedef struct {
 /* 1 when a descriptor with ndst > 0 can run as one launch (channel ranges on tile boundaries, no split-K workspace needed) */
 int pmf_conv_multi_ok(const pmf_conv_desc_t* d);
 #define PMF_EP_STAT_X_ONLY 1
+#define PMF_CFG_DIRECT_TAPS (1 << 24)
 /* 1 when the descriptor runs the software-pipelined K loop (stride 1 -- or a stride-2 3x3 with all nine taps --, one halo tile,
  * every operand a multiple of 16 channels, same H x W, no broadcast): the class pmf_conv_fwd accepts w_s3 for.
  * 2 for one-tap descriptors (1x1 layers, any stride) that qualify for the direct variant (conv_fwd.hip PIPE 11:

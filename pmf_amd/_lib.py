@@ -14,6 +14,7 @@ ACT_NONE, ACT_LRELU, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
 SRC_RELU, SRC_BCAST = 1, 2
 EP_STAT_X_ONLY = 1
 WGRAD_S3 = 1
+CFG_DIRECT_TAPS = 1 << 24      # pmf_conv_desc_t.cfg: direct multi-tap variant (PMF_CFG_DIRECT_TAPS)
 
 (OP_CONV, OP_WGRAD, OP_PACK, OP_BN_FINALIZE, OP_BN_EVAL, OP_BN_BWD_REDUCE, OP_BN_BWD_APPLY, OP_ADD_ACT,
  OP_ADD_ACT_BWD, OP_ACT_BWD, OP_AVGPOOL, OP_AVGPOOL_BWD, OP_MAXPOOL, OP_MAXPOOL_BWD, OP_BILINEAR,

@@ -712,14 +712,21 @@ __device__ __forceinline__ void conv_kloop_s3(const pmf_conv_desc_t& d, const Co
 // [K] x {scale, shift, relu floor, channel multiplier}, splits into three bf16 planes in registers and multiplies.
 // PF k-steps of loads are in flight per wave; the split of step k + 1 is issued next to the MFMAs of step k.
 // Host conditions: conv_direct_lds().
-template <int BN, int MT>
+// MTAP (PIPE 13): the same loop over VIRTUAL k-steps v = tap * (K / 16) + k of a multi-tap convolution (2x2 / 3x3, any
+// dilation, stride 1 or 2; <= 9 taps): the weight fragments are already packed tap-major ([tap][K/16][Cout/32][plane]), so
+// the fragment index is v itself; a lane's pixel moves by (dy, dx) of the tap when the channel counter wraps; taps that fall
+// outside the image address the buffer out of range (hardware zero) and -- for operands seen through a BatchNorm / ReLU /
+// multiplier view, whose transform would turn that 0 into `shift` -- are zeroed again behind the transform (zero padding of
+// the TRANSFORMED map).  No input tile in LDS, no barrier per stage; every tap re-reads its pixels through L1 / L2.
+// Selected by the caller (pmf_conv_desc_t.cfg bit 24: the plan autotuner tries it next to the LDS-staged loop).
+template <int BN, int MT, bool MTAP = false>
 __device__ __forceinline__ void conv_kloop_direct(const pmf_conv_desc_t& d, const ConvGeom& g, f32x16 (&acc)[MT][BN / 32],
                                                   char* __restrict__ Bs, const int (&segrow)[MT], const int (&segcol)[MT],
                                                   int tid, int li, int lh, int n, int n0, int oy0, int ox0) {
   constexpr int NT = BN / 32;
   constexpr int PF = 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  const int Ktot = g.Ktot, nks = Ktot >> 4, CT = d.ldw >> 5;
+  const int Ktot = g.Ktot, KS = Ktot >> 4, nks = MTAP ? KS * d.ntaps : KS, CT = d.ldw >> 5;
   const int is = d.in_stride, sH = d.src[0].H, sW = d.src[0].W;
   // weights: every fragment of this output-channel tile resident in LDS (kchunk 0), or streamed in chunks of kchunk
   // 16-channel steps through two buffers: chunk c + 1 is DMA'd while chunk c is multiplied, one wait + barrier per chunk
@@ -754,15 +761,23 @@ __device__ __forceinline__ void conv_kloop_direct(const pmf_conv_desc_t& d, cons
       tab[3 * Ktot + k] = scm ? scm[(size_t)n * d.src[si].cmul_ld + c] : 1.f;
     }
   }
-  // ---- load stream: (source, channel) of the next k-step to fetch
+  // ---- load stream: (tap, source, channel) of the next k-step to fetch
   int pix[MT];
+  unsigned okcur = 0u;                 // bit m: the current tap of segment m lies inside the image
+  int ltap = 0;
+  auto set_tap = [&](int t) {
+    const int ty = (int)d.tdy[t], tx = (int)d.tdx[t];
+    okcur = 0u;
 #pragma unroll
-  for (int m = 0; m < MT; ++m) {
-    const int oy = oy0 + segrow[m], ox = ox0 + segcol[m] * 32 + li;
-    const int iy = oy * is + (int)d.tdy[0], ix = ox * is + (int)d.tdx[0];
-    const bool ok = oy < d.OH && ox < d.OW && iy >= 0 && iy < sH && ix >= 0 && ix < sW;
-    pix[m] = ok ? (n * sH + iy) * sW + ix : -1;
-  }
+    for (int m = 0; m < MT; ++m) {
+      const int oy = oy0 + segrow[m], ox = ox0 + segcol[m] * 32 + li;
+      const int iy = oy * is + ty, ix = ox * is + tx;
+      const bool ok = oy < d.OH && ox < d.OW && iy >= 0 && iy < sH && ix >= 0 && ix < sW;
+      pix[m] = ok ? (n * sH + iy) * sW + ix : -1;
+      okcur |= ok ? (1u << m) : 0u;
+    }
+  };
+  set_tap(0);
   int lsi = 0, lc0 = 0, lC = 0;
   unsigned lbase[MT];
   __amdgpu_buffer_rsrc_t lrs;
@@ -781,6 +796,7 @@ __device__ __forceinline__ void conv_kloop_direct(const pmf_conv_desc_t& d, cons
     }
   };
   f32x4 raw[PF][MT][2];
+  unsigned okslot[PF] = {0u, 0u, 0u, 0u};
   auto issue = [&](auto slot_c) {
     constexpr int j = decltype(slot_c)::value;
 #pragma unroll
@@ -788,8 +804,13 @@ __device__ __forceinline__ void conv_kloop_direct(const pmf_conv_desc_t& d, cons
       raw[j][m][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(lrs, lbase[m] + lc0 * 4, 0, 0));
       raw[j][m][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(lrs, lbase[m] + lc0 * 4 + 16, 0, 0));
     }
+    if (MTAP) okslot[j] = okcur;
     lc0 += 16;
-    if (lc0 >= lC) { ++lsi; lc0 = 0; lhead(); }
+    if (lc0 >= lC) {
+      ++lsi; lc0 = 0;
+      if (MTAP && lsi >= d.nsrc && ltap + 1 < d.ntaps) { ++ltap; lsi = 0; set_tap(ltap); }   // next tap: same channels
+      lhead();
+    }
   };
   lhead();
   issue(std::integral_constant<int, 0>{});
@@ -804,7 +825,8 @@ __device__ __forceinline__ void conv_kloop_direct(const pmf_conv_desc_t& d, cons
     constexpr int j = decltype(slot_c)::value;
     f32x4 sc[2], sh[2], lo[2], cm[2];
     if (!plain) {
-      const float* t0 = tab + kk * 16 + lh * 8;
+      const int kc = MTAP ? kk - (kk / KS) * KS : kk;       // channel step inside the tap
+      const float* t0 = tab + kc * 16 + lh * 8;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         sc[h] = *(const f32x4*)(t0 + h * 4); sh[h] = *(const f32x4*)(t0 + Ktot + h * 4);
@@ -821,6 +843,10 @@ __device__ __forceinline__ void conv_kloop_direct(const pmf_conv_desc_t& d, cons
           t = t * sc[h] + sh[h];
           t.x = s3_vmax(t.x, lo[h].x); t.y = s3_vmax(t.y, lo[h].y); t.z = s3_vmax(t.z, lo[h].z); t.w = s3_vmax(t.w, lo[h].w);
           t = t * cm[h];
+          if (MTAP) {           // zero padding of the transformed map
+            const bool ok = (okslot[j] >> m) & 1u;
+            t.x = ok ? t.x : 0.f; t.y = ok ? t.y : 0.f; t.z = ok ? t.z : 0.f; t.w = ok ? t.w : 0.f;
+          }
         }
         unsigned a0, a1, a2, b0, b1, b2;
         s3_split2(t.x, t.y, a0, a1, a2);
@@ -915,7 +941,7 @@ __global__ __launch_bounds__(256) void conv_fwd_k(const pmf_conv_desc_t d, const
     if ((total & 7u) == 0u) lin = (lin & 7u) * (total >> 3) + (lin >> 3);
   }
   int tile, bz, by;
-  if constexpr (PIPE == 11) {
+  if constexpr (PIPE == 11 || PIPE == 13) {
     // no input tile in LDS to share: the output-channel tiles of one pixel tile run back to back on one XCD, so the
     // activations come from HBM once and from that XCD's L2 for the other tiles
     by = lin % gridDim.y;
@@ -957,6 +983,8 @@ __global__ __launch_bounds__(256) void conv_fwd_k(const pmf_conv_desc_t d, const
       conv_kloop_s3<BN, 1, 1, 9, 2>(d, g, acc, (char*)smem, (char*)(smem + g.a_floats), segrow, segcol, tid, li, lh, n, n0, ks, oy0, ox0, tri_);
   } else if constexpr (PIPE == 11) {  // 1x1, split-bf16, activations straight from global memory
     conv_kloop_direct<BN, MT>(d, g, acc, (char*)smem, segrow, segcol, tid, li, lh, n, n0, oy0, ox0);
+  } else if constexpr (PIPE == 13) {  // the same for 2 .. 9 taps (virtual k-steps)
+    conv_kloop_direct<BN, MT, true>(d, g, acc, (char*)smem, segrow, segcol, tid, li, lh, n, n0, oy0, ox0);
   } else if constexpr (PIPE == 8) {   // one slab per stage, 9 taps at compile time
     if (g.one)
       conv_kloop_s3<BN, MT, 1, 9, 1, true>(d, g, acc, (char*)smem, (char*)(smem + g.a_floats), segrow, segcol, tid, li, lh, n, n0, ks, oy0, ox0, tri_);
@@ -1274,7 +1302,7 @@ static void conv_config(const pmf_conv_desc_t* d, int* BN, int* MT) {
   conv_config_(d, BN, MT);
   // 1x1 on split-bf16 weights: the direct variant was promised for the 32-wide tile (pmf_conv_s3_eligible); a 64-wide
   // tile whose weight fragments do not fit LDS falls back to it
-  if (d->w_s3 && d->ntaps == 1 && *BN == 64 && !conv_direct_lds(d, 64) && conv_direct_lds(d, 32)) *BN = 32;
+  if (d->w_s3 && (d->ntaps == 1 || ((d->cfg >> 24) & 1)) && *BN == 64 && !conv_direct_lds(d, 64) && conv_direct_lds(d, 32)) *BN = 32;
   // LDS-staged split loop: the 256-pixel tile may not qualify where the 128-pixel one does (dilated 3x3 on a 4-row map)
   if (d->w_s3 && d->ntaps > 1 && *MT == 2 && !conv_s3_fits(d, 2)) *MT = 1;
   if (d->w_s3 && d->in_stride == 2 && d->ntaps > 1) *MT = 1;      // the stride-2 split loop: 128-pixel tiles
@@ -1359,7 +1387,10 @@ static int conv_direct_lds(const pmf_conv_desc_t* d, int BN, int* kchunk) {
   static const bool off = getenv("PMF_NO_DIRECT") != nullptr;
   static const int stream_kib = getenv("PMF_DIRECT_STREAM_KIB") ? atoi(getenv("PMF_DIRECT_STREAM_KIB")) : 96;
   if (kchunk) *kchunk = 0;
-  if (off || !d->w_s3 || d->ntaps != 1 || d->gather || (d->ldw & 31)) return 0;
+  // more than one tap: only on request (cfg bit 24, set by the plan autotuner when the variant measured faster), <= 9 taps
+  const bool mtap = d->ntaps > 1;
+  if (mtap && (!((d->cfg >> 24) & 1) || d->ntaps > TAPG)) return 0;
+  if (off || !d->w_s3 || d->gather || (d->ldw & 31)) return 0;
   int Ktot = 0;
   for (int i = 0; i < d->nsrc; ++i) {
     if (d->src[i].C % 16 || (d->src[i].flags & PMF_SRC_BCAST)) return 0;
@@ -1367,21 +1398,21 @@ static int conv_direct_lds(const pmf_conv_desc_t* d, int BN, int* kchunk) {
     if ((int64_t)d->N * d->src[i].H * d->src[i].W * d->src[i].ldc * 4 >= (1ll << 31)) return 0;
     Ktot += d->src[i].C;
   }
-  const int NT = BN / 32, tab = 16 * Ktot + 256;
-  int lds = (Ktot / 16) * NT * 3 * 1024 + tab;
+  const int NT = BN / 32, tab = 16 * Ktot + 256, steps = (Ktot / 16) * d->ntaps;
+  int lds = steps * NT * 3 * 1024 + tab;
   if (lds < 2 * 4 * 64 * 2 * 8) lds = 2 * 4 * 64 * 2 * 8;
-  if (lds > 160 * 1024) return 0;
+  if (lds > 160 * 1024 && !mtap) return 0;           // (multi-tap: streamed below or refused)
   // layers whose resident fragments exceed 96 KiB (768 input channels) stream them in chunks sized so that TWO workgroups
   // fit a CU and the weight DMA runs under the MFMAs instead of in front of them: 768 -> 256 at 16x512 70 -> 59 us
   // (PMF_DIRECT_STREAM_KIB=n moves the threshold, 0 switches the streaming off; from 64 KiB it is neutral to 4 % slower)
   if (stream_kib > 0 && lds > stream_kib * 1024) {
     const int kch = ((76 * 1024 - tab) / (2 * NT * 3 * 1024)) & ~3;
-    if (kch >= 8 && kch < Ktot / 16) {
+    if (kch >= 8 && kch < steps) {
       if (kchunk) *kchunk = kch;
       return 2 * kch * NT * 3 * 1024 + tab;
     }
   }
-  return lds;
+  return lds > 160 * 1024 ? 0 : lds;
 }
 
 // split-bf16 path: 16-channel slabs per stage (1, 2 or 4) -- see conv_kloop_s3
@@ -1429,6 +1460,7 @@ static int launch(const pmf_conv_desc_t* d, hipStream_t s) {
     (void)hipFuncSetAttribute((const void*)conv_fwd_k<BN, MT, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)conv_fwd_k<BN, MT, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)conv_fwd_k<BN, MT, 11>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_fwd_k<BN, MT, 13>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if constexpr (MT == 1)
       (void)hipFuncSetAttribute((const void*)conv_fwd_k<BN, 1, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
@@ -1436,7 +1468,7 @@ static int launch(const pmf_conv_desc_t* d, hipStream_t s) {
   int mode = conv_pipe_mode(d, g, gather, MT);
   g.kchunk = 0;
   if (const int dl = conv_direct_lds(d, BN, &g.kchunk)) {   // 1x1 on split-bf16 weights: no input tile in LDS, no K split
-    mode = 11;
+    mode = d->ntaps > 1 ? 13 : 11;
     lds = dl;
     nchunks = 1;
   } else if (d->w_s3 && d->in_stride == 2) {     // stride-2 3x3
@@ -1479,6 +1511,8 @@ static int launch(const pmf_conv_desc_t* d, hipStream_t s) {
     if constexpr (MT == 1) hipLaunchKernelGGL((conv_fwd_k<BN, 1, 12>), grid, dim3(256), lds, s, dd, g);
   } else if (mode == 11) {
     hipLaunchKernelGGL((conv_fwd_k<BN, MT, 11>), grid, dim3(256), lds, s, dd, g);
+  } else if (mode == 13) {
+    hipLaunchKernelGGL((conv_fwd_k<BN, MT, 13>), grid, dim3(256), lds, s, dd, g);
   } else if (mode == 5) {
     hipLaunchKernelGGL((conv_fwd_k<BN, MT, 5>), grid, dim3(256), lds, s, dd, g);
   } else if (mode == 6) {

@@ -1649,6 +1649,12 @@ class Plan:
                         for ks in (1, 2, 4, 8, 16):
                             if ks == 1 or (ks <= stages // 2 and d.N * d.OH * d.OW <= 65536):
                                 cands.append(bn | (1 << 8) | (ks << 16))
+                    if d.w_s3 and 1 < d.ntaps <= 9 and os.environ.get("PMF_TUNE_DIRECT", "1") != "0":
+                        # the direct multi-tap variant (no input tile in LDS, conv_fwd.hip PIPE 13): a candidate wherever the
+                        # launch runs on split-bf16 weights
+                        for bn in ((32, 64) if d.Cout > 32 else (32,)):
+                            for mt in (1, 2):
+                                cands.append(bn | (mt << 8) | (1 << 16) | L.CFG_DIRECT_TAPS)
                     best_t, best = float("inf"), 0
                     for cfg in cands:
                         d.cfg = cfg

@@ -1,5 +1,7 @@
 """GPU tests of the drop-in boundary: the reference trainers' own call sequences through the ``pc_processor`` shim
 (tasks/pmf/trainer.py:33-39,80-98,139-147; tasks/epmf/trainer.py:195-198) and the pieces they need."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -7,6 +9,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from oracle import loader_ref  # noqa: E402
+from pmf_amd.utils.detinit import deterministic_init  # noqa: E402
 from tests.test_oracle_golden import LOADER_TRAIN_CASES, loader_train_oracle, _all_colours  # noqa: E402
 
 

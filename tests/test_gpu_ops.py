@@ -117,16 +117,19 @@ CONVS = [
 
 
 TILE_CFGS = [bn | (2 << 8) | (1 << 16) for bn in (32, 64)] + \
-            [bn | (1 << 8) | (ks << 16) for bn in (32, 64) for ks in (1, 2, 4, 8, 16)]
+            [bn | (1 << 8) | (ks << 16) for bn in (32, 64) for ks in (1, 2, 4, 8, 16)] + \
+            [bn | (mt << 8) | (1 << 16) | L.CFG_DIRECT_TAPS for bn in (32, 64) for mt in (1, 2)]     # direct multi-tap variant
 
 
-@pytest.mark.parametrize("cfg", TILE_CFGS, ids=["bn%d_mt%d_ks%d" % (c & 255, (c >> 8) & 255, c >> 16) for c in TILE_CFGS])
+@pytest.mark.parametrize("cfg", TILE_CFGS, ids=["bn%d_mt%d_ks%d%s" % (c & 255, (c >> 8) & 255, (c >> 16) & 255, "_direct" if c >> 24 else "")
+                                              for c in TILE_CFGS])
 def test_conv_tile_configs(cfg):
     """every tile configuration the plan autotuner may write into a conv op (output-channel tile 32/64, 128/256-pixel
     tile, 1-16 K splits), forward + input gradient + BatchNorm statistics, against float64 -- on a 3x3 dilated conv
     with BN, a 3-operand 1x1 (64-channel stages), a stride-2 3x3 (parity-class input gradients) and a deep small map"""
     for case in CONVS:
-        if case[0] in ("c3x3d2", "c1x1cat3", "c3x3s2", "c3x3_big", "c7x7"):
+        if case[0] in ("c3x3d2", "c1x1cat3", "c3x3s2", "c3x3_big", "c7x7") or \
+                (cfg >> 24 and case[0] in ("c3x3", "c2x2d2", "c3x3cat2", "c1x1_512_cat", "c3x3_wpipe", "c2x2d2_wpipe", "c3x3d6")):
             _conv_case(case, cfg)
 
 

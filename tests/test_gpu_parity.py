@@ -94,7 +94,8 @@ S3_CASES = [c for c in CONV_CASES if c[0] in ("3x3_32_32", "3x3d2_64_64_xf", "2x
 
 
 @pytest.mark.parametrize("cfg", [0, 32 | (1 << 8) | (1 << 16), 64 | (1 << 8) | (1 << 16), 32 | (2 << 8) | (1 << 16),
-                                 64 | (2 << 8) | (1 << 16), 64 | (1 << 8) | (2 << 16)])
+                                 64 | (2 << 8) | (1 << 16), 64 | (1 << 8) | (2 << 16),
+                                 32 | (1 << 8) | (1 << 16) | (1 << 24), 64 | (2 << 8) | (1 << 16) | (1 << 24)])
 @pytest.mark.parametrize("case", S3_CASES, ids=[c[0] for c in S3_CASES])
 def test_conv_fwd_split_bf16_vs_float64(case, cfg):
     """the same convolutions on the bf16 matrix pipe with three-way split operands (conv_fwd.hip PIPE 5): fp32-class

@@ -20,6 +20,9 @@ CASES = [  # name, N, H, W, Cin, Cout, k, dil
     ("quar_768_256_1x1", 2, 16, 512, 768, 256, 1, 1),
     ("full_64_64_2x2d2", 2, 64, 2048, 64, 64, 2, 2),
     ("half_128_128_2x2d2", 2, 32, 1024, 128, 128, 2, 2),
+    ("full_32_32_2x2d2", 2, 64, 2048, 32, 32, 2, 2),
+    ("quar_256_256_2x2d2", 2, 16, 512, 256, 256, 2, 2),
+    ("8th_256_256_2x2d2", 2, 8, 256, 256, 256, 2, 2),
     ("half_64_64_3x3", 2, 32, 1024, 64, 64, 3, 1),
     ("half_128_128_3x3d2", 2, 32, 1024, 128, 128, 3, 2),
     ("quar_128_128_3x3", 2, 16, 512, 128, 128, 3, 1),
