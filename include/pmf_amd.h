@@ -125,6 +125,8 @@ int pmf_conv_multi_ok(const pmf_conv_desc_t* d);
 #define PMF_CFG_DIRECT_TAPS (1 << 24)
 /* 1 when the descriptor runs the software-pipelined K loop (stride 1 -- or a stride-2 3x3 with all nine taps --, one halo tile,
  * every operand a multiple of 16 channels, same H x W, no broadcast): the class pmf_conv_fwd accepts w_s3 for.
+ * 3 for stem-class descriptors (ONE operand of 8 padded channels, 2..49 taps, e.g. the 7x7 RGB stem): the direct variant
+ * with two taps per 16-deep MFMA step (conv_fwd.hip PIPE 14), weights in pmf_pack_job_t format 2;
  * 2 for one-tap descriptors (1x1 layers, any stride) that qualify for the direct variant (conv_fwd.hip PIPE 11:
  * activations straight from global memory, all weight fragments of an output-channel tile resident in LDS; operands
  * multiples of 16 channels, same H x W, no broadcast, Ktot * 32 * 6 bytes + tables within 160 KiB); 0 otherwise */
@@ -189,7 +191,9 @@ typedef struct {
   float* dst;
   int32_t Cout, Cin, KHW, ntaps, transpose, K_pad, ldw, CT, tiles_ci, block_start;
   int8_t tap_idx[PMF_MAX_TAPS + 3];
-  int32_t format;            /* 0: fp32 slabs [tap][K_pad][ldw]; 1: split-bf16 fragments (pmf_conv_desc_t.w_s3) */
+  int32_t format;            /* 0: fp32 slabs [tap][K_pad][ldw]; 1: split-bf16 fragments (pmf_conv_desc_t.w_s3); 2: the same
+                              * fragments for a stem-class layer (one operand of 8 padded channels, many taps): ONE virtual tap
+                              * with K index = tap * 8 + channel, K_pad = ntaps * 8 rounded up to 16 (transpose 0 only) */
   int32_t w_ld;              /* input channels per output-channel row of w when the job packs a channel sub-range
                               * (w then points at its first channel, Cin = channels of the range); 0: Cin */
 } pmf_pack_job_t;

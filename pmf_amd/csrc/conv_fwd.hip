@@ -719,14 +719,18 @@ __device__ __forceinline__ void conv_kloop_s3(const pmf_conv_desc_t& d, const Co
 // multiplier view, whose transform would turn that 0 into `shift` -- are zeroed again behind the transform (zero padding of
 // the TRANSFORMED map).  No input tile in LDS, no barrier per stage; every tap re-reads its pixels through L1 / L2.
 // Selected by the caller (pmf_conv_desc_t.cfg bit 24: the plan autotuner tries it next to the LDS-staged loop).
-template <int BN, int MT, bool MTAP = false>
+// MODE 2 (PIPE 14, the stem class: ONE operand of 8 padded channels, many taps -- the 7x7 RGB stem): a 16-deep MFMA step holds
+// the 8 channels of TWO taps; lane (pixel, half) loads the 32 bytes of its pixel shifted by tap 2 v + half, which is
+// exactly its A fragment.  Weights: pmf_pack_job_t format 2 (K index = tap * 8 + channel).
+template <int BN, int MT, int MODE = 0>
 __device__ __forceinline__ void conv_kloop_direct(const pmf_conv_desc_t& d, const ConvGeom& g, f32x16 (&acc)[MT][BN / 32],
                                                   char* __restrict__ Bs, const int (&segrow)[MT], const int (&segcol)[MT],
                                                   int tid, int li, int lh, int n, int n0, int oy0, int ox0) {
   constexpr int NT = BN / 32;
   constexpr int PF = 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  const int Ktot = g.Ktot, KS = Ktot >> 4, nks = MTAP ? KS * d.ntaps : KS, CT = d.ldw >> 5;
+  constexpr bool MTAP = MODE != 0, HALF = MODE == 2;
+  const int Ktot = g.Ktot, KS = Ktot >> 4, nks = HALF ? (d.ntaps + 1) >> 1 : (MTAP ? KS * d.ntaps : KS), CT = d.ldw >> 5;
   const int is = d.in_stride, sH = d.src[0].H, sW = d.src[0].W;
   // weights: every fragment of this output-channel tile resident in LDS (kchunk 0), or streamed in chunks of kchunk
   // 16-channel steps through two buffers: chunk c + 1 is DMA'd while chunk c is multiplied, one wait + barrier per chunk
@@ -766,13 +770,22 @@ __device__ __forceinline__ void conv_kloop_direct(const pmf_conv_desc_t& d, cons
   unsigned okcur = 0u;                 // bit m: the current tap of segment m lies inside the image
   int ltap = 0;
   auto set_tap = [&](int t) {
-    const int ty = (int)d.tdy[t], tx = (int)d.tdx[t];
+    int ty, tx;
+    bool tap_ok = true;
+    if (HALF) {                      // step t: taps 2 t (lower half wave) and 2 t + 1 (upper half)
+      const int t0 = 2 * t, t1 = min(2 * t + 1, d.ntaps - 1);
+      const int y0 = (int)d.tdy[t0], x0 = (int)d.tdx[t0], y1 = (int)d.tdy[t1], x1 = (int)d.tdx[t1];
+      ty = lh ? y1 : y0; tx = lh ? x1 : x0;
+      tap_ok = 2 * t + lh < d.ntaps;
+    } else {
+      ty = (int)d.tdy[t]; tx = (int)d.tdx[t];
+    }
     okcur = 0u;
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
       const int oy = oy0 + segrow[m], ox = ox0 + segcol[m] * 32 + li;
       const int iy = oy * is + ty, ix = ox * is + tx;
-      const bool ok = oy < d.OH && ox < d.OW && iy >= 0 && iy < sH && ix >= 0 && ix < sW;
+      const bool ok = tap_ok && oy < d.OH && ox < d.OW && iy >= 0 && iy < sH && ix >= 0 && ix < sW;
       pix[m] = ok ? (n * sH + iy) * sW + ix : -1;
       okcur |= ok ? (1u << m) : 0u;
     }
@@ -789,7 +802,7 @@ __device__ __forceinline__ void conv_kloop_direct(const pmf_conv_desc_t& d, cons
       lrs = __builtin_amdgcn_make_buffer_rsrc((void*)sx, 0, d.N * sH * sW * sld * 4, 0x00020000);
       lC = sC;
 #pragma unroll
-      for (int m = 0; m < MT; ++m) lbase[m] = pix[m] >= 0 ? (unsigned)(pix[m] * sld * 4 + lh * 32) : 0x80000000u;
+      for (int m = 0; m < MT; ++m) lbase[m] = pix[m] >= 0 ? (unsigned)(pix[m] * sld * 4 + (HALF ? 0 : lh * 32)) : 0x80000000u;
     } else {          // past the last k-step: the range check returns zeros without touching memory
       lrs = __builtin_amdgcn_make_buffer_rsrc((void*)d.src[0].x, 0, 0, 0x00020000);
       lC = 1 << 30;
@@ -805,6 +818,12 @@ __device__ __forceinline__ void conv_kloop_direct(const pmf_conv_desc_t& d, cons
       raw[j][m][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(lrs, lbase[m] + lc0 * 4 + 16, 0, 0));
     }
     if (MTAP) okslot[j] = okcur;
+    if (HALF) {                      // the 8 channels are one load pair: every step moves to the next two taps
+      ++ltap;
+      if (ltap < nks) { set_tap(ltap); } else { lsi = d.nsrc; }
+      lhead();
+      return;
+    }
     lc0 += 16;
     if (lc0 >= lC) {
       ++lsi; lc0 = 0;
@@ -825,8 +844,8 @@ __device__ __forceinline__ void conv_kloop_direct(const pmf_conv_desc_t& d, cons
     constexpr int j = decltype(slot_c)::value;
     f32x4 sc[2], sh[2], lo[2], cm[2];
     if (!plain) {
-      const int kc = MTAP ? kk - (kk / KS) * KS : kk;       // channel step inside the tap
-      const float* t0 = tab + kc * 16 + lh * 8;
+      const int kc = HALF ? 0 : (MTAP ? kk - (kk / KS) * KS : kk);       // channel step inside the tap
+      const float* t0 = tab + (HALF ? 0 : kc * 16 + lh * 8);
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         sc[h] = *(const f32x4*)(t0 + h * 4); sh[h] = *(const f32x4*)(t0 + Ktot + h * 4);
@@ -941,7 +960,7 @@ __global__ __launch_bounds__(256) void conv_fwd_k(const pmf_conv_desc_t d, const
     if ((total & 7u) == 0u) lin = (lin & 7u) * (total >> 3) + (lin >> 3);
   }
   int tile, bz, by;
-  if constexpr (PIPE == 11 || PIPE == 13) {
+  if constexpr (PIPE == 11 || PIPE == 13 || PIPE == 14) {
     // no input tile in LDS to share: the output-channel tiles of one pixel tile run back to back on one XCD, so the
     // activations come from HBM once and from that XCD's L2 for the other tiles
     by = lin % gridDim.y;
@@ -984,7 +1003,9 @@ __global__ __launch_bounds__(256) void conv_fwd_k(const pmf_conv_desc_t d, const
   } else if constexpr (PIPE == 11) {  // 1x1, split-bf16, activations straight from global memory
     conv_kloop_direct<BN, MT>(d, g, acc, (char*)smem, segrow, segcol, tid, li, lh, n, n0, oy0, ox0);
   } else if constexpr (PIPE == 13) {  // the same for 2 .. 9 taps (virtual k-steps)
-    conv_kloop_direct<BN, MT, true>(d, g, acc, (char*)smem, segrow, segcol, tid, li, lh, n, n0, oy0, ox0);
+    conv_kloop_direct<BN, MT, 1>(d, g, acc, (char*)smem, segrow, segcol, tid, li, lh, n, n0, oy0, ox0);
+  } else if constexpr (PIPE == 14) {  // stem class: 8 padded channels, two taps per MFMA step
+    conv_kloop_direct<BN, MT, 2>(d, g, acc, (char*)smem, segrow, segcol, tid, li, lh, n, n0, oy0, ox0);
   } else if constexpr (PIPE == 8) {   // one slab per stage, 9 taps at compile time
     if (g.one)
       conv_kloop_s3<BN, MT, 1, 9, 1, true>(d, g, acc, (char*)smem, (char*)(smem + g.a_floats), segrow, segcol, tid, li, lh, n, n0, ks, oy0, ox0, tri_);
@@ -1295,6 +1316,7 @@ extern "C" int pmf_conv_multi_ok(const pmf_conv_desc_t* d) {
 }
 
 static int conv_direct_lds(const pmf_conv_desc_t* d, int BN, int* kchunk = nullptr);
+static bool conv_stem_class(const pmf_conv_desc_t* d);
 static bool conv_s3_fits(const pmf_conv_desc_t* d, int MT);
 static bool conv_s3_stride2(const pmf_conv_desc_t* d);
 static void conv_config_(const pmf_conv_desc_t* d, int* BN, int* MT);
@@ -1302,9 +1324,9 @@ static void conv_config(const pmf_conv_desc_t* d, int* BN, int* MT) {
   conv_config_(d, BN, MT);
   // 1x1 on split-bf16 weights: the direct variant was promised for the 32-wide tile (pmf_conv_s3_eligible); a 64-wide
   // tile whose weight fragments do not fit LDS falls back to it
-  if (d->w_s3 && (d->ntaps == 1 || ((d->cfg >> 24) & 1)) && *BN == 64 && !conv_direct_lds(d, 64) && conv_direct_lds(d, 32)) *BN = 32;
+  if (d->w_s3 && (d->ntaps == 1 || ((d->cfg >> 24) & 1) || conv_stem_class(d)) && *BN == 64 && !conv_direct_lds(d, 64) && conv_direct_lds(d, 32)) *BN = 32;
   // LDS-staged split loop: the 256-pixel tile may not qualify where the 128-pixel one does (dilated 3x3 on a 4-row map)
-  if (d->w_s3 && d->ntaps > 1 && *MT == 2 && !conv_s3_fits(d, 2)) *MT = 1;
+  if (d->w_s3 && d->ntaps > 1 && *MT == 2 && !conv_stem_class(d) && !((d->cfg >> 24) & 1) && !conv_s3_fits(d, 2)) *MT = 1;
   if (d->w_s3 && d->in_stride == 2 && d->ntaps > 1) *MT = 1;      // the stride-2 split loop: 128-pixel tiles
   if (d->ndst > 0 && *BN == 64 && multi_tile(d) == 32) *BN = 32;   // a 32-channel destination: no tile may straddle two
 }
@@ -1383,14 +1405,25 @@ static int conv_pipe_mode(const pmf_conv_desc_t* d, const ConvGeom& g, int gathe
 // PIPE 11 (conv_kloop_direct): LDS bytes of the launch, or 0 when the layer does not qualify -- one tap, split-bf16
 // weights, operands multiples of 16 channels with the same H x W, all weight fragments of one output-channel tile
 // resident in LDS.  PMF_NO_DIRECT=1 switches the variant off.
+static bool conv_stem_class(const pmf_conv_desc_t* d) {
+  static const bool off = getenv("PMF_NO_STEM_DIRECT") != nullptr;
+  return !off && d->nsrc == 1 && d->src[0].C == 8 && d->ntaps >= 2 && d->ntaps <= PMF_MAX_TAPS &&
+         !(d->src[0].flags & PMF_SRC_BCAST);
+}
 static int conv_direct_lds(const pmf_conv_desc_t* d, int BN, int* kchunk) {
   static const bool off = getenv("PMF_NO_DIRECT") != nullptr;
   static const int stream_kib = getenv("PMF_DIRECT_STREAM_KIB") ? atoi(getenv("PMF_DIRECT_STREAM_KIB")) : 96;
   if (kchunk) *kchunk = 0;
   // more than one tap: only on request (cfg bit 24, set by the plan autotuner when the variant measured faster), <= 9 taps
   const bool mtap = d->ntaps > 1;
-  if (mtap && (!((d->cfg >> 24) & 1) || d->ntaps > TAPG)) return 0;
-  if (off || !d->w_s3 || d->gather || (d->ldw & 31)) return 0;
+  const bool stem = conv_stem_class(d);       // 8 padded channels, many taps: two taps per MFMA step (PIPE 14)
+  if (mtap && !stem && (!((d->cfg >> 24) & 1) || d->ntaps > TAPG)) return 0;
+  if (off || !d->w_s3 || (d->gather && !stem) || (d->ldw & 31)) return 0;
+  if (stem) {
+    if ((int64_t)d->N * d->src[0].H * d->src[0].W * d->src[0].ldc * 4 >= (1ll << 31)) return 0;
+    const int lds_ = ((d->ntaps + 1) / 2) * (BN / 32) * 3 * 1024 + 16 * 8 + 256;
+    return lds_ > 160 * 1024 ? 0 : (lds_ < 2 * 4 * 64 * 2 * 8 ? 2 * 4 * 64 * 2 * 8 : lds_);
+  }
   int Ktot = 0;
   for (int i = 0; i < d->nsrc; ++i) {
     if (d->src[i].C % 16 || (d->src[i].flags & PMF_SRC_BCAST)) return 0;
@@ -1461,6 +1494,7 @@ static int launch(const pmf_conv_desc_t* d, hipStream_t s) {
     (void)hipFuncSetAttribute((const void*)conv_fwd_k<BN, MT, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)conv_fwd_k<BN, MT, 11>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)conv_fwd_k<BN, MT, 13>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_fwd_k<BN, MT, 14>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if constexpr (MT == 1)
       (void)hipFuncSetAttribute((const void*)conv_fwd_k<BN, 1, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
@@ -1468,7 +1502,7 @@ static int launch(const pmf_conv_desc_t* d, hipStream_t s) {
   int mode = conv_pipe_mode(d, g, gather, MT);
   g.kchunk = 0;
   if (const int dl = conv_direct_lds(d, BN, &g.kchunk)) {   // 1x1 on split-bf16 weights: no input tile in LDS, no K split
-    mode = d->ntaps > 1 ? 13 : 11;
+    mode = conv_stem_class(d) ? 14 : (d->ntaps > 1 ? 13 : 11);
     lds = dl;
     nchunks = 1;
   } else if (d->w_s3 && d->in_stride == 2) {     // stride-2 3x3
@@ -1513,6 +1547,8 @@ static int launch(const pmf_conv_desc_t* d, hipStream_t s) {
     hipLaunchKernelGGL((conv_fwd_k<BN, MT, 11>), grid, dim3(256), lds, s, dd, g);
   } else if (mode == 13) {
     hipLaunchKernelGGL((conv_fwd_k<BN, MT, 13>), grid, dim3(256), lds, s, dd, g);
+  } else if (mode == 14) {
+    hipLaunchKernelGGL((conv_fwd_k<BN, MT, 14>), grid, dim3(256), lds, s, dd, g);
   } else if (mode == 5) {
     hipLaunchKernelGGL((conv_fwd_k<BN, MT, 5>), grid, dim3(256), lds, s, dd, g);
   } else if (mode == 6) {
@@ -1563,6 +1599,12 @@ extern "C" int pmf_conv_fwd_stat_rows(const pmf_conv_desc_t* d) {
 }
 
 extern "C" int pmf_conv_s3_eligible(const pmf_conv_desc_t* d) {
+  if (conv_stem_class(d)) {   // 3: weights in pack format 2
+    pmf_conv_desc_t t = *d;
+    t.w_s3 = (const void*)1;
+    if (!t.ldw) t.ldw = 64;
+    return conv_direct_lds(&t, 32) ? 3 : 0;
+  }
   if (d->ntaps == 1) {       // 1x1: only the direct variant (2), judged on the narrow tile; the caller sets w_s3 afterwards
     pmf_conv_desc_t t = *d;
     t.w_s3 = (const void*)1;

@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void pack_k(const pmf_pack_job_t* __restrict__
     T[col][j] = J.w[((size_t)(co0 + col) * wld + ci0) * J.KHW + j];
   }
   __syncthreads();
-  if (J.format == 1) {
+  if (J.format >= 1) {
     // split-bf16 fragments: GEMM element (tap t, k, n) -> plane p of fragment (t, k/16, n/32) at lane (n%32) + 32 ((k%16)/8),
     // element k%8 (the B-operand layout of v_mfma_f32_32x32x16_bf16); planes are 512 bf16 apart
     unsigned short* __restrict__ dst = (unsigned short*)J.dst;
@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void pack_k(const pmf_pack_job_t* __restrict__
     // n), three 16-byte stores per thread, consecutive threads -> consecutive lanes of the fragment (coalesced)
     const int kdim = J.transpose ? nco : ct, ndim = J.transpose ? ct : nco;
     const int kbase = J.transpose ? co0 : ci0, nbase = J.transpose ? ci0 : co0;
-    if ((kdim & 7) == 0 && (kbase & 7) == 0) {
+    if (J.format == 1 && (kdim & 7) == 0 && (kbase & 7) == 0) {
       typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
       const int noct = kdim >> 3, totalv = J.ntaps * noct * ndim;
       for (int i = threadIdx.x; i < totalv; i += 256) {
@@ -74,7 +74,11 @@ __global__ __launch_bounds__(256) void pack_k(const pmf_pack_job_t* __restrict__
       if (!J.transpose) { col = i % nco; const int r = i / nco; cil = r % ct; t = r / ct; }
       else { cil = i % ct; const int r = i / ct; col = r % nco; t = r / nco; }
       const float x = T[col][cil * J.KHW + J.tap_idx[t]];
-      const int k = J.transpose ? co0 + col : ci0 + cil, nn = J.transpose ? ci0 + cil : co0 + col;
+      int k = J.transpose ? co0 + col : ci0 + cil;
+      const int nn = J.transpose ? ci0 + cil : co0 + col;
+      // format 2 (few-channel stem, conv_fwd.hip PIPE 14): ONE virtual tap whose K index is tap * 8 + channel, so that a
+      // 16-deep MFMA step holds the 8 padded channels of TWO taps
+      if (J.format == 2) { k += t * 8; t = 0; }
       const unsigned u0 = __builtin_bit_cast(unsigned short, (__bf16)x);
       const float r1 = x - __builtin_bit_cast(float, u0 << 16);
       const unsigned u1 = __builtin_bit_cast(unsigned short, (__bf16)r1);

@@ -434,7 +434,8 @@ class Plan:
     def add_pack(self, weight, taps_widx, transpose, K_pad, ldw, fmt=0, cin=None):
         """register a pack job; returns the Buf of the packed slab [ntaps][K_pad][ldw] (fmt 0, fp32) or of the split-bf16
         fragments [ntaps][K_pad/16][ldw/32][3][64][8] (fmt 1, 6 bytes per weight; pmf_conv_desc_t.w_s3)."""
-        buf = self.persist.alloc((6 if fmt else 4) * len(taps_widx) * K_pad * ldw)
+        # (fmt 2, the stem class: ONE virtual tap, K_pad = taps * 8 rounded up to 16)
+        buf = self.persist.alloc((6 if fmt else 4) * (1 if fmt == 2 else len(taps_widx)) * K_pad * ldw)
         # forward packs: index of the conv op about to be emitted (the first reader); input-gradient packs: none (they are
         # read by the backward graph only)
         owner = len(self.fwd) if (not transpose and self.fwd is not None) else None
@@ -455,7 +456,7 @@ class Plan:
                     and L.lib().pmf_conv_s3_eligible(C.byref(probe)) == 2)
         if probe.ntaps < self.s3_min_taps:
             return False
-        return bool(L.lib().pmf_conv_s3_eligible(C.byref(probe)))
+        return int(L.lib().pmf_conv_s3_eligible(C.byref(probe)))     # (3: the stem class, weights in pack format 2)
 
     def conv(self, srcs, conv, act=L.ACT_NONE, bn=None, order="act_bn", relu_view=False, name="", pmask=None,
              extra_bias=None):
@@ -519,7 +520,11 @@ class Plan:
             d.out_sy = d.out_sx = 1
             d.splitk_ws, d.splitk_ws_bytes = 1, SPLITK_BYTES      # non-NULL: same split decision as the real launch
         fwd_s3 = self.s3_ok(shape_fill)
-        wbuf = self.add_pack(conv.weight, [t[2] for t in taps], 0, Ktot, ldw, int(fwd_s3))
+        if fwd_s3 == 3:
+            # the 7x7 RGB stem: 8 padded channels x 49 taps, two taps per 16-deep MFMA step (conv_fwd.hip PIPE 14)
+            wbuf = self.add_pack(conv.weight, [t[2] for t in taps], 0, _ru(len(taps) * 8, 16), ldw, 2)
+        else:
+            wbuf = self.add_pack(conv.weight, [t[2] for t in taps], 0, Ktot, ldw, int(bool(fwd_s3)))
         stat_rows = 0
         if train_bn:
             probe = L.ConvDesc()

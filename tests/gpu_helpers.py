@@ -51,6 +51,20 @@ def pack_fwd_s3(w, k_pad, ldw):
     return f.cuda()
 
 
+def pack_fwd_s3_stem(w, ldw):
+    """stem class (one operand of 8 padded channels, many taps): pmf_pack_job_t format 2 -- ONE virtual tap whose K index is
+    tap * 8 + channel, K padded to a multiple of 16"""
+    co, ci, kh, kw = w.shape
+    kp = (kh * kw * 8 + 15) // 16 * 16
+    p = torch.zeros(1, kp, ldw)
+    q = torch.zeros(kh * kw, 8, co)
+    q[:, :ci, :] = w.permute(2, 3, 1, 0).reshape(kh * kw, ci, co)
+    p[0, :kh * kw * 8, :co] = q.reshape(kh * kw * 8, co)
+    planes = torch.stack([h.view(torch.int16) for h in split_bf16(p)], 0)
+    f = planes.view(3, 1, kp // 16, 2, 8, ldw // 32, 32).permute(1, 2, 5, 0, 3, 6, 4).contiguous()
+    return f.cuda()
+
+
 def stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 

@@ -33,6 +33,7 @@ CONV_CASES = [
     ("3x3_cat2_80_32", 1, 16, 96, [16, 64], 32, 3, 1, 1, 1, 1, True),
     ("1x1_8_32", 2, 16, 32, [8], 32, 1, 1, 0, 1, 1, False),
     ("7x7_8_64", 1, 16, 48, [8], 64, 7, 1, 3, 1, 0, False),
+    ("7x7_8_64_xf", 2, 19, 70, [8], 64, 7, 1, 3, 1, 1, True),      # stem class through an operand view (zero padding!)
     ("3x3s2_64_128", 2, 16, 32, [64], 128, 3, 1, 1, 2, 0, False),
     ("1x1s2_64_128", 2, 16, 32, [64], 128, 1, 1, 0, 2, 0, False),
     ("3x3d6_64_64", 1, 8, 40, [64], 64, 3, 6, 6, 1, 0, False),
@@ -90,7 +91,7 @@ def test_conv_fwd_vs_torch_cpu(case):
 
 S3_CASES = [c for c in CONV_CASES if c[0] in ("3x3_32_32", "3x3d2_64_64_xf", "2x2d2_32", "1x1_cat3", "3x3_cat2_80_32",
                                                "3x3_16_20", "3x3_256_256_small", "1x1_cat2_80_48_xf", "1x1_32_20",
-                                               "1x1s2_64_128", "3x3s2_64_128")]
+                                               "1x1s2_64_128", "3x3s2_64_128", "7x7_8_64", "7x7_8_64_xf")]
 
 
 @pytest.mark.parametrize("cfg", [0, 32 | (1 << 8) | (1 << 16), 64 | (1 << 8) | (1 << 16), 32 | (2 << 8) | (1 << 16),
@@ -128,14 +129,16 @@ def test_conv_fwd_split_bf16_vs_float64(case, cfg):
     errs = {}
     for kind in ("f32", "s3"):
         out = torch.zeros(N, OH, OW, (Cout + 7) // 8 * 8, device="cuda")
-        wpk = G.pack_fwd(w, sum(cins), ldw) if kind == "f32" else G.pack_fwd_s3(w, sum(cins), ldw)
+        stem = k == 7 and cins == [8]
+        wpk = G.pack_fwd(w, sum(cins), ldw) if kind == "f32" else (
+            G.pack_fwd_s3_stem(w, ldw) if stem else G.pack_fwd_s3(w, sum(cins), ldw))
         d = G.conv_desc(srcs, wpk, ldw, b_dev, out, N, OH, OW, Cout, G.taps_of(k, k, dil, pad), stride, act)
         ws = torch.empty(8 << 20, dtype=torch.uint8, device="cuda")
         d.splitk_ws, d.splitk_ws_bytes = ws.data_ptr(), ws.numel()
         d.cfg = cfg
         if kind == "s3":
             d.w, d.w_s3 = None, wpk.data_ptr()
-            assert lib.pmf_conv_s3_eligible(C.byref(d)) == (2 if k == 1 else 1)      # 2: the direct 1x1 variant
+            assert lib.pmf_conv_s3_eligible(C.byref(d)) == (3 if stem else (2 if k == 1 else 1))   # 2: direct 1x1, 3: stem
         rows = lib.pmf_conv_fwd_stat_rows(C.byref(d))
         stats = torch.full((rows, 2, Cout), float("nan"), device="cuda", dtype=torch.float64)
         d.stats = stats.data_ptr()

@@ -8,6 +8,7 @@ from pmf_amd import _lib as L
 from tests import gpu_helpers as G
 lib = L.lib()
 CASES = [  # name, N, H, W, Cin, Cout, k, dil
+    ("full_stem_8_64_7x7", 2, 64, 2048, 8, 64, 7, 1),
     ("full_32_32_3x3", 2, 64, 2048, 32, 32, 3, 1),
     ("full_32_32_3x3d2", 2, 64, 2048, 32, 32, 3, 2),
     ("full_64_64_3x3d2", 2, 64, 2048, 64, 64, 3, 2),
@@ -57,7 +58,7 @@ def run(which, filt):
             us = timeit(lambda: lib.pmf_conv_fwd(C.byref(d), st))
             print("fwd   %-22s %8.1f us  %6.1f TF/s" % (name, us, gf / us * 1e3), flush=True)
         if which == "s3":      # split-bf16 path, every tile configuration, next to the fp32 MFMA path
-            w3 = G.pack_fwd_s3(w, ci, ldw)
+            w3 = G.pack_fwd_s3_stem(w, ldw) if (k == 7 and ci == 8) else G.pack_fwd_s3(w, ci, ldw)
             cfgs = (0, 32 | (1 << 8) | (1 << 16), 64 | (1 << 8) | (1 << 16), 32 | (2 << 8) | (1 << 16), 64 | (2 << 8) | (1 << 16))
             if os.environ.get("S3_CFGS"): cfgs = tuple(int(x, 0) for x in os.environ["S3_CFGS"].split(","))
             for cfg in cfgs:
