@@ -357,3 +357,23 @@ def test_prefetcher_workers_keep_sampler_order():
     it = iter(Prefetcher(dl, workers=3))
     assert next(it).tolist() == want[0]
     del it                                     # early exit with several workers: threads end (no hang at interpreter exit)
+
+
+def test_documented_knob_defaults_are_what_a_fresh_plan_uses(monkeypatch):
+    """DESIGN.md section 6 lists the PMF_* knobs and says "defaults are what the bench runs": a plan built in a clean
+    environment must carry exactly these values, and every knob named here must be documented there."""
+    from pmf_amd.plan import Plan
+    for k in list(os.environ):
+        if k.startswith("PMF_"):
+            monkeypatch.delenv(k)
+    got = Plan(torch.device("cpu"), True).knobs()
+    want = {"PMF_CONV_F32": False, "PMF_S3_MIN_TAPS": 2, "PMF_S3_DIRECT_MIN_PIX": 1, "PMF_BN_BWD_FUSED": True, "lanes": 4,
+            "PMF_WGRAD_LANE": 23, "PMF_WGRAD_BATCH": 4, "PMF_WGRAD_POLICY": "batch", "PMF_WGRAD_HOMES": 3, "PMF_WGRAD_DELAY": 0,
+            "PMF_RED_BATCH": 32, "PMF_BN_SMALL": True, "PMF_DGRAD_MERGE": True, "PMF_DGRAD_MERGE_MINPIX": 1024,
+            "PMF_AUTOTUNE": True, "PMF_TUNE_DIRECT": True, "PMF_GRAPH": True, "PMF_DP_MODE": "events", "PMF_DP_SEGMENTS": 4,
+            "PMF_PACK_EARLY": 8}
+    assert got == want
+    design = open(os.path.join(ROOT, "DESIGN.md")).read()
+    for k in want:
+        if k.startswith("PMF_"):
+            assert k in design, "%s is not documented in DESIGN.md" % k

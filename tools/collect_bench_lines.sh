@@ -1,7 +1,7 @@
 #!/bin/bash
-# Run ON the GPU box (gpurun -- 'bash tools/collect_bench_lines.sh r03'): the bench JSON line of every mode, one per line,
+# Run ON the GPU box (gpurun -- 'bash tools/collect_bench_lines.sh r04'): the bench JSON line of every mode, one per line,
 # into gpurun_out/<tag>_bench_lines.jsonl (copy to profiles/).
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out/${TAG}_bench_lines.jsonl
 : > $OUT
