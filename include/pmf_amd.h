@@ -370,6 +370,13 @@ int pmf_project_v2_scatter(const float* points, const int32_t* sem, const int32_
                            const int32_t* y_data, const float* depth, int32_t K, const uint8_t* image, int32_t ih,
                            int32_t iw, const int32_t* lut, int32_t nlut, int32_t x_min, int32_t y_min, int32_t h,
                            int32_t w, float* proj_out, int32_t* pix_idx, pmf_stream_t s);
+/* pmf_project_scatter in TWO launches and without the per-call memset (the loader's per-frame path): pix_tag u32[h*w] and
+ * slots u64[ceil(P/1024)] are PERSISTENT workspaces of the caller, zeroed once and again whenever `generation` (1..4095,
+ * +1 per call on the same workspaces) wraps; P <= 2^20.  Outputs bit-identical to pmf_project_scatter. */
+int pmf_project_scatter2(const float* points, const int32_t* sem, int64_t P, const uint8_t* image, int32_t h, int32_t w,
+                         const double* proj, const int32_t* lut, int32_t nlut, float* proj_out, uint8_t* keep,
+                         int32_t* x_data, int32_t* y_data, float* depth, int32_t* n_kept, uint32_t* pix_tag, uint64_t* slots,
+                         int32_t generation, pmf_stream_t s);
 /* validation crop/pad (perspective_view_loader.py:71-74,138-141): dst[c][oh][ow] window copy with zero fill */
 int pmf_crop_pad(const float* src, int32_t C, int32_t h, int32_t w, int32_t top, int32_t left, float* dst,
                  int32_t oh, int32_t ow, int32_t pad_top, int32_t pad_left, int32_t ch, int32_t cw, pmf_stream_t s);

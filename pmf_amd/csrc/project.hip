@@ -140,6 +140,105 @@ extern "C" int pmf_project_scatter(const float* points, const int32_t* sem, int6
   return 0;
 }
 
+// ---- the same in TWO launches and without the memset (the loader's per-frame path) ----------------------------------------
+// pmf_project_scatter is five enqueues (memset, count, scan, scatter, gather) for ~2 MB of data: launch latency, not work.
+// Here (1) ONE kernel projects, compacts and scatters: a block publishes its kept-point count in a slot tagged with the
+// call's generation (relaxed agent-scope atomics: the value travels in the same word as the tag, no fence needed) and reads
+// the slots of the blocks in front of it -- dispatch is in order and a frame is ~120 blocks, all resident, so the wait is
+// short and cannot deadlock; the winner of a pixel is an atomicMax over (generation << 20 | point index), so entries of
+// earlier frames lose against the current one and the per-pixel table is never cleared (the caller zeroes it once every
+// 4095 frames); (2) the gather pass.  Same outputs, bit for bit.
+__global__ __launch_bounds__(PB) void proj_fused_k(const float* __restrict__ pts, int64_t P, const double* __restrict__ m,
+                                                   int h, int w, uint8_t* __restrict__ keep, float* __restrict__ depth,
+                                                   int32_t* __restrict__ x_data, int32_t* __restrict__ y_data,
+                                                   unsigned* __restrict__ pix_tag, unsigned long long* __restrict__ slots,
+                                                   unsigned gen, int32_t* __restrict__ n_kept) {
+  __shared__ int wave_cnt[PB / 64];
+  __shared__ int red[PB / 64];
+  const int64_t i = blockIdx.x * (int64_t)PB + threadIdx.x;
+  int r = 0, c = 0;
+  const bool k = i < P && project_point(pts + i * 4, m, h, w, r, c);
+  if (i < P) {
+    keep[i] = (uint8_t)k;
+    const float x = pts[i * 4], y = pts[i * 4 + 1], z = pts[i * 4 + 2];
+    depth[i] = sqrtf((x * x + y * y) + z * z);
+  }
+  const unsigned long long bal = __ballot(k);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int before = __popcll(bal & ((1ull << lane) - 1ull));
+  if (lane == 0) wave_cnt[wv] = __popcll(bal);
+  __syncthreads();
+  int woff = 0, cnt = 0;
+  for (int j = 0; j < PB / 64; ++j) { if (j < wv) woff += wave_cnt[j]; cnt += wave_cnt[j]; }
+  if (threadIdx.x == 0)
+    __hip_atomic_store(slots + blockIdx.x, ((unsigned long long)gen << 32) | (unsigned)cnt, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  // counts of the blocks in front: thread t waits for slot t, t + 1024, ...
+  int part = 0;
+  for (int b = threadIdx.x; b < (int)blockIdx.x; b += PB) {
+    unsigned long long v;
+    do { v = __hip_atomic_load(slots + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((unsigned)(v >> 32) != gen);
+    part += (int)(unsigned)v;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+  if (lane == 0) red[wv] = part;
+  __syncthreads();
+  int boff = 0;
+  for (int j = 0; j < PB / 64; ++j) boff += red[j];
+  if (k) {
+    const int dst = boff + woff + before;
+    x_data[dst] = r;
+    y_data[dst] = c;
+    atomicMax(pix_tag + (size_t)r * w + c, (gen << 20) | (unsigned)i);
+  }
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *n_kept = boff + cnt;
+}
+
+__global__ void proj_gather_tag_k(const float* __restrict__ pts, const int32_t* __restrict__ sem,
+                                  const float* __restrict__ depth, const uint8_t* __restrict__ img,
+                                  const int32_t* __restrict__ lut, int nlut, const unsigned* __restrict__ pix_tag, unsigned gen,
+                                  int h, int w, float* __restrict__ out) {
+  const int64_t hw = (int64_t)h * w;
+  for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < hw; p += (int64_t)gridDim.x * blockDim.x) {
+    const unsigned tag = pix_tag[p];
+    const int i = (tag >> 20) == gen ? (int)(tag & 0xFFFFFu) : -1;
+    float d = 0.f, x = 0.f, y = 0.f, z = 0.f, it = 0.f, mk = 0.f, lb = 0.f;
+    if (i >= 0) {
+      const f32x4 q = *(const f32x4*)(pts + (size_t)i * 4);
+      x = q.x; y = q.y; z = q.z; it = q.w;
+      d = depth[i];
+      mk = 1.f;
+      const int sl = sem[i];
+      lb = (float)((sl >= 0 && sl < nlut) ? lut[sl] : 0);
+    }
+    out[0 * hw + p] = d; out[1 * hw + p] = x; out[2 * hw + p] = y; out[3 * hw + p] = z; out[4 * hw + p] = it;
+    out[5 * hw + p] = (float)img[p * 3 + 0] / 255.0f;
+    out[6 * hw + p] = (float)img[p * 3 + 1] / 255.0f;
+    out[7 * hw + p] = (float)img[p * 3 + 2] / 255.0f;
+    out[8 * hw + p] = mk;
+    out[9 * hw + p] = lb;
+  }
+}
+
+extern "C" int pmf_project_scatter2(const float* points, const int32_t* sem, int64_t P, const uint8_t* image, int32_t h,
+                                    int32_t w, const double* proj, const int32_t* lut, int32_t nlut, float* proj_out,
+                                    uint8_t* keep, int32_t* x_data, int32_t* y_data, float* depth, int32_t* n_kept,
+                                    uint32_t* pix_tag, uint64_t* slots, int32_t generation, pmf_stream_t s) {
+  hipStream_t st = (hipStream_t)s;
+  if (P < 0 || h < 1 || w < 1 || generation < 1 || generation > 4095 || !pix_tag || !slots) return PMF_E_ARG;
+  if (P > (1 << 20)) return PMF_E_UNSUPPORTED;            // 20 bits of point index in a pixel's tag
+  const int nblk = (int)cdiv64(P > 0 ? P : 1, PB);
+  hipLaunchKernelGGL(proj_fused_k, dim3(nblk), dim3(PB), 0, st, points, P, proj, h, w, keep, depth, x_data, y_data,
+                     (unsigned*)pix_tag, (unsigned long long*)slots, (unsigned)generation, n_kept);
+  const int64_t hw = (int64_t)h * w;
+  const int g = (int)cdiv64(hw, 256);
+  hipLaunchKernelGGL(proj_gather_tag_k, dim3(g > 2048 ? 2048 : g), dim3(256), 0, st, points, sem, depth, image, lut, nlut,
+                     (const unsigned*)pix_tag, (unsigned)generation, h, w, proj_out);
+  PMF_LAUNCH_CHECK();
+  return 0;
+}
+
 __global__ void crop_pad_k(const float* __restrict__ src, int C, int h, int w, int top, int left, float* __restrict__ dst,
                            int oh, int ow, int pad_top, int pad_left, int ch, int cw) {
   const int64_t total = (int64_t)C * oh * ow;

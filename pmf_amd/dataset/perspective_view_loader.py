@@ -19,6 +19,8 @@ torchvision's get_params order on torch's RNG, the four pixel operations run as 
 to Pillow exhaustively).
 """
 import ctypes as C
+import os
+import threading
 
 import numpy as np
 import torch
@@ -103,6 +105,38 @@ class ColorJitter(object):
         return self.apply(img, *self.draw())
 
 
+_PROJ_TLS = threading.local()      # per thread (prefetch workers run on streams of their own): persistent projection workspaces
+_CONST_CACHE = {}                  # small host constants (projection matrix, label LUT) already on the device, by content
+
+
+def _proj_workspace(dev, h, w, nblk):
+    """(pix_tag u32[h*w], slots u64[>= nblk], generation) of pmf_project_scatter2 for this thread: allocated once per image
+    size, zeroed once and whenever the generation counter wraps (4095 frames)"""
+    tab = _PROJ_TLS.__dict__.setdefault("ws", {})
+    ent = tab.get((str(dev), h, w))
+    if ent is None or ent[1].numel() < nblk:
+        ent = tab[(str(dev), h, w)] = [torch.zeros(h * w, dtype=torch.int32, device=dev),
+                                       torch.zeros(max(nblk, 256), dtype=torch.int64, device=dev), 0]
+    ent[2] += 1
+    if ent[2] > 4095:
+        ent[0].zero_()
+        ent[1].zero_()
+        ent[2] = 1
+    return ent
+
+
+def _device_const(a, dtype, dev):
+    """a small host array as a device tensor, uploaded once per distinct content"""
+    a = np.ascontiguousarray(a, dtype)
+    key = (str(dev), a.dtype.str, a.tobytes())
+    t = _CONST_CACHE.get(key)
+    if t is None:
+        if len(_CONST_CACHE) > 256:
+            _CONST_CACHE.clear()
+        t = _CONST_CACHE[key] = torch.from_numpy(a.reshape(-1).copy()).to(dev)
+    return t
+
+
 def project_frame_gpu(points, sem_label, image_u8, proj_matrix, label_lut, device="cuda", need_uproj=True):
     """-> (proj f32[10,h,w], x_data i32[K], y_data i32[K], depth f32[P], keep bool[P]) on `device`.
     need_uproj=False (training / validation items, which return only the image-plane tensors): x_data / y_data come back
@@ -117,25 +151,39 @@ def project_frame_gpu(points, sem_label, image_u8, proj_matrix, label_lut, devic
         torch.as_tensor(np.ascontiguousarray(sem_label, np.int32)).to(dev)
     img = image_to_device(image_u8, dev)
     # calibration matrix / label LUT: per-sequence constants -- callers that loop over frames pass device tensors
+    # calibration matrix / label LUT: per-sequence constants -- device tensors are taken as they are, host arrays are
+    # uploaded once per distinct content (_device_const)
     mat = proj_matrix.to(dev, torch.float64).reshape(12).contiguous() if isinstance(proj_matrix, torch.Tensor) else \
-        torch.as_tensor(np.ascontiguousarray(proj_matrix, np.float64).reshape(12)).to(dev)
+        _device_const(np.asarray(proj_matrix, np.float64).reshape(12), np.float64, dev)
     lut = label_lut.to(dev, torch.int32).contiguous() if isinstance(label_lut, torch.Tensor) else \
-        torch.as_tensor(np.ascontiguousarray(label_lut, np.int32)).to(dev)
+        _device_const(label_lut, np.int32, dev)
     P = pts.shape[0]
     h, w = img.shape[0], img.shape[1]
     out = torch.empty((10, h, w), dtype=torch.float32, device=dev)
-    keep = torch.empty(max(P, 1), dtype=torch.uint8, device=dev)
-    xd = torch.empty(max(P, 1), dtype=torch.int32, device=dev)
-    yd = torch.empty(max(P, 1), dtype=torch.int32, device=dev)
-    depth = torch.empty(max(P, 1), dtype=torch.float32, device=dev)
-    nk = torch.zeros(1, dtype=torch.int32, device=dev)
-    pix = torch.empty(h * w, dtype=torch.int32, device=dev)
-    blk = torch.empty((P + 1023) // 1024 + 1, dtype=torch.int32, device=dev)
+    # keep / x / y / depth / count: ONE allocation (they go back to the caller, so they cannot live in the cached workspace)
+    n1 = max(P, 1)
+    blob = torch.empty(3 * n1 + (n1 + 3) // 4 + 4, dtype=torch.int32, device=dev)
+    xd, yd = blob[:n1], blob[n1:2 * n1]
+    depth = blob[2 * n1:3 * n1].view(torch.float32)
+    keep = blob[3 * n1:3 * n1 + (n1 + 3) // 4].view(torch.uint8)[:n1]
+    nk = blob[3 * n1 + (n1 + 3) // 4:3 * n1 + (n1 + 3) // 4 + 1]
     stream = torch.cuda.current_stream(dev).cuda_stream
-    rc = lib.pmf_project_scatter(pts.data_ptr(), sem.data_ptr(), P, img.data_ptr(), h, w, mat.data_ptr(),
-                                 lut.data_ptr(), lut.shape[0], out.data_ptr(), keep.data_ptr(), xd.data_ptr(),
-                                 yd.data_ptr(), depth.data_ptr(), nk.data_ptr(), pix.data_ptr(), blk.data_ptr(),
-                                 C.c_void_p(stream))
+    rc = L.PMF_E_UNSUPPORTED if os.environ.get("PMF_PROJECT_LEGACY") == "1" else 0
+    if rc == 0:
+        # two launches, no memset, persistent per-thread workspace (csrc/project.hip pmf_project_scatter2)
+        nblk = (P + 1023) // 1024 + 1
+        pix, slots, gen = _proj_workspace(dev, h, w, nblk)
+        rc = lib.pmf_project_scatter2(pts.data_ptr(), sem.data_ptr(), P, img.data_ptr(), h, w, mat.data_ptr(),
+                                      lut.data_ptr(), lut.shape[0], out.data_ptr(), keep.data_ptr(), xd.data_ptr(),
+                                      yd.data_ptr(), depth.data_ptr(), nk.data_ptr(), pix.data_ptr(), slots.data_ptr(),
+                                      gen, C.c_void_p(stream))
+    if rc == L.PMF_E_UNSUPPORTED:      # more than 2^20 points (or PMF_PROJECT_LEGACY=1): the five-launch form
+        pix = torch.empty(h * w, dtype=torch.int32, device=dev)
+        blk = torch.empty((P + 1023) // 1024 + 1, dtype=torch.int32, device=dev)
+        rc = lib.pmf_project_scatter(pts.data_ptr(), sem.data_ptr(), P, img.data_ptr(), h, w, mat.data_ptr(),
+                                     lut.data_ptr(), lut.shape[0], out.data_ptr(), keep.data_ptr(), xd.data_ptr(),
+                                     yd.data_ptr(), depth.data_ptr(), nk.data_ptr(), pix.data_ptr(), blk.data_ptr(),
+                                     C.c_void_p(stream))
     L.check(rc, "pmf_project_scatter")
     if not need_uproj:
         return out, xd, yd, depth[:P], keep[:P].bool()

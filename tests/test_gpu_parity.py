@@ -582,6 +582,39 @@ def test_projection_scatter_exact(tag, seed, npts, h, w, golden):
         np.testing.assert_array_equal(got, loader_ref.center_crop_pad(rp, oh, ow, hp, wp))
 
 
+def test_projection_two_launch_form_reuses_its_workspace(monkeypatch):
+    """pmf_project_scatter2 (projection + ordered compaction + scatter in ONE kernel, gather in a second; the per-pixel
+    winner table is never cleared, entries carry the call's generation): a run of DIFFERENT frames of one image size through
+    the same persistent workspace -- incl. the generation wrap at 4095 and an empty sweep -- against the numpy oracle, and the
+    legacy five-launch form (PMF_PROJECT_LEGACY=1) on the same frames"""
+    from pmf_amd.dataset import project_frame_gpu, perspective_view_loader as PV
+    from oracle import loader_ref
+    h, w = 96, 320
+    frames = [loader_ref.synthetic_frame(seed, n, h, w) for seed, n in ((1, 30000), (2, 2500), (3, 61000), (4, 1100), (5, 9000))]
+    project_frame_gpu(*[frames[0][i] for i in (1, 2, 3, 0, 4)])              # creates this thread's workspace
+    ws = PV._PROJ_TLS.ws[(str(torch.device("cuda")), h, w)]
+    ws[2] = 4092                                                             # ... three calls before the wrap
+    for rep in range(2):
+        for k, (M, pts, sem, img, lut) in enumerate(frames):
+            if rep == 1 and k == 2:
+                pts, sem = pts[:0], sem[:0]                                    # a frame with no points at all
+            proj, xd, yd, depth, keep = project_frame_gpu(pts, sem, img, M, lut)
+            rp, rx, ry, rd = loader_ref.project_frame(pts, sem, img, M, lut)
+            np.testing.assert_array_equal(proj.cpu().numpy(), rp)
+            np.testing.assert_array_equal(xd.cpu().numpy(), rx)
+            np.testing.assert_array_equal(yd.cpu().numpy(), ry)
+            np.testing.assert_array_equal(depth.cpu().numpy(), rd)
+            assert int(keep.sum()) == rx.shape[0]
+    assert 1 <= ws[2] <= 10                                                   # the counter wrapped and restarted
+    monkeypatch.setenv("PMF_PROJECT_LEGACY", "1")
+    M, pts, sem, img, lut = frames[2]
+    a = project_frame_gpu(pts, sem, img, M, lut)
+    monkeypatch.delenv("PMF_PROJECT_LEGACY")
+    b = project_frame_gpu(pts, sem, img, M, lut)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+
+
 # ---------------------------------------------------------------------------------------------- losses
 def test_losses_gpu_match_cpu_and_fixture(golden):
     """product loss modules on the GPU (incl. the HIP Lovasz Jaccard-gradient kernel) vs the same ops on CPU and the
