@@ -1406,8 +1406,13 @@ static int conv_pipe_mode(const pmf_conv_desc_t* d, const ConvGeom& g, int gathe
 // weights, operands multiples of 16 channels with the same H x W, all weight fragments of one output-channel tile
 // resident in LDS.  PMF_NO_DIRECT=1 switches the variant off.
 static bool conv_stem_class(const pmf_conv_desc_t* d) {
-  static const bool off = getenv("PMF_NO_STEM_DIRECT") != nullptr;
-  return !off && d->nsrc == 1 && d->src[0].C == 8 && d->ntaps >= 2 && d->ntaps <= PMF_MAX_TAPS &&
+  // OPT-IN (PMF_STEM_DIRECT=1).  Per launch the variant is pinned against float64 like every other (tests), and it is faster
+  // (7x7 stem 172 -> 121-134 us).  But it sits on the camera lane, where it does not move the step (16.41 vs 16.40 ms), and
+  // with it the full-size gradient parity of the camera decoder's low-resolution layers goes from 1e-5 to 1e-3 against
+  // float64 (EPMF, and PMF-R34 with the 32-wide / 256-pixel tile; tests/test_gpu_fullsize.py) although every forward tensor
+  // agrees with the generic loop to rounding and the backward kernels are the same -- not understood yet, so: off.
+  static const bool on = [] { const char* e = getenv("PMF_STEM_DIRECT"); return e && e[0] == '1'; }();
+  return on && d->nsrc == 1 && d->src[0].C == 8 && d->ntaps >= 2 && d->ntaps <= PMF_MAX_TAPS &&
          !(d->src[0].flags & PMF_SRC_BCAST);
 }
 static int conv_direct_lds(const pmf_conv_desc_t* d, int BN, int* kchunk) {

@@ -129,7 +129,9 @@ def test_conv_fwd_split_bf16_vs_float64(case, cfg):
     errs = {}
     for kind in ("f32", "s3"):
         out = torch.zeros(N, OH, OW, (Cout + 7) // 8 * 8, device="cuda")
-        stem = k == 7 and cins == [8]
+        stem = k == 7 and cins == [8] and os.environ.get("PMF_STEM_DIRECT") == "1"      # (opt-in variant, PIPE 14)
+        if k == 7 and not stem and kind == "s3":
+            continue
         wpk = G.pack_fwd(w, sum(cins), ldw) if kind == "f32" else (
             G.pack_fwd_s3_stem(w, ldw) if stem else G.pack_fwd_s3(w, sum(cins), ldw))
         d = G.conv_desc(srcs, wpk, ldw, b_dev, out, N, OH, OW, Cout, G.taps_of(k, k, dil, pad), stride, act)
@@ -150,8 +152,23 @@ def test_conv_fwd_split_bf16_vs_float64(case, cfg):
         assert G.rel_err(st[0].numpy() / ref[0, 0].numel(), (ref.sum((0, 2, 3)) / ref[0, 0].numel()).numpy()) < 1e-5
     os.makedirs("gpurun_out", exist_ok=True)
     with open("gpurun_out/s3_conv_errors.txt", "a") as f:
-        f.write("%-22s cfg %#8x  f32 %.3e  s3 %.3e\n" % (name, cfg, errs["f32"], errs["s3"]))
+        f.write("%-22s cfg %#8x  f32 %.3e  s3 %.3e\n" % (name, cfg, errs["f32"], errs.get("s3", float("nan"))))
+    if "s3" not in errs:
+        pytest.skip("stem-class variant is opt-in (PMF_STEM_DIRECT=1)")
     assert errs["s3"] < 2e-6 and errs["s3"] <= 4 * errs["f32"] + 1e-7, errs
+
+
+def test_stem_direct_variant_opt_in():
+    """PIPE 14 (stem class: 8 padded channels, two taps per MFMA step, pack format 2) is opt-in (PMF_STEM_DIRECT=1, read once per
+    process): its float64 pins -- the 7x7 cases above, plain and through an operand view with zero padding, every tile
+    configuration -- run in a process of their own"""
+    import subprocess
+    import sys
+    env = dict(os.environ, PMF_STEM_DIRECT="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-k", "split_bf16_vs_float64 and 7x7"],
+                       env=env, capture_output=True, text=True, timeout=600,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and " passed" in r.stdout and "skipped" not in r.stdout.splitlines()[-1], r.stdout[-1500:]
 
 
 @pytest.mark.parametrize("transpose", [0, 1])
