@@ -608,11 +608,15 @@ def plan_rooflines(plan, prof, model_tag):
     """(mfma roofline of the conv kernel, per-family HBM rooflines, kernel-time breakdown) from one op-by-op profile"""
     fam = {}
     for kind, family, flops, ms, _, nbytes in prof:
-        a = fam.setdefault(family or kind, [0, 0.0, 0.0, 0.0])
+        a = fam.setdefault(family or kind, [0, 0.0, 0.0, 0.0, 0.0])
         a[0] += 1
         a[1] += flops
         a[2] += ms
         a[3] += nbytes
+        # what the launch would cost at the achievable copy rate (6.3 TB/s, MI355X_MICROARCH.md) with a 4 us floor: a kernel
+        # boundary in a replayed graph costs 3.6 us before the first byte moves, so a family of 1-8 MB launches cannot
+        # reach a large fraction of 8 TB/s however good its kernels are -- `frac_of_launch_floor` is the kernel-quality number
+        a[4] += max(nbytes / 6.3e12 * 1e3, 4e-3) if nbytes else 0.0
     convs = [k for k in ("conv_fwd", "conv_dgrad") if k in fam]
     mfma_ms = sum(fam[k][2] for k in convs)
     mfma_fl = sum(fam[k][1] for k in convs)
@@ -654,7 +658,8 @@ def plan_rooflines(plan, prof, model_tag):
             gbs = v[3] / (v[2] * 1e-3) / 1e9
             hbm.append({"kernel": k, "bound": "hbm", "launches": v[0], "achieved": round(gbs, 1), "peak": PEAK_HBM,
                         "unit": "GB/s", "frac": round(gbs / PEAK_HBM, 4), "algorithmic_mb_per_iter": round(v[3] / 1e6, 1),
-                        "ms_per_iter": round(v[2], 4)})
+                        "ms_per_iter": round(v[2], 4), "avg_mb_per_launch": round(v[3] / 1e6 / v[0], 2),
+                        "frac_of_launch_floor": round(v[4] / v[2], 4)})
     detail = {k: {"launches": v[0], "gflop": round(v[1] / 1e9, 1), "ms": round(v[2], 3),
                   "tflops": round(v[1] / max(v[2], 1e-9) / 1e9, 2) if v[1] else None}
               for k, v in sorted(fam.items(), key=lambda kv: -kv[1][2])}
