@@ -24,15 +24,15 @@ __global__ void bn_finalize_k(const double* __restrict__ stats, int nrows, float
     s1 += (a[0] + a[1]) + (a[2] + a[3]);
     s2 += (b[0] + b[1]) + (b[2] + b[3]);
   }
-  sh[0][threadIdx.x] = s1; sh[1][threadIdx.x] = s2;
+  // wave shuffles, then the four wave sums through LDS: one barrier instead of eight (this kernel is nothing but latency)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+  if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = s1; sh[1][threadIdx.x >> 6] = s2; }
   __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (threadIdx.x < o) { sh[0][threadIdx.x] += sh[0][threadIdx.x + o]; sh[1][threadIdx.x] += sh[1][threadIdx.x + o]; }
-    __syncthreads();
-  }
   if (threadIdx.x) return;
-  const double mean = sh[0][0] / (double)count;
-  double var = sh[1][0] / (double)count - mean * mean;
+  const double t1 = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]), t2 = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
+  const double mean = t1 / (double)count;
+  double var = t2 / (double)count - mean * mean;
   if (var < 0.0) var = 0.0;
   const float invstd = (float)(1.0 / sqrt(var + (double)eps));
   const float sc = gamma[c] * invstd;
@@ -161,14 +161,13 @@ __global__ void bn_bwd_fold_k(const double* __restrict__ part, int nrows, int C,
     s1 += (a[0] + a[1]) + (a[2] + a[3]);
     s2 += (b[0] + b[1]) + (b[2] + b[3]);
   }
-  sh[0][threadIdx.x] = s1; sh[1][threadIdx.x] = s2;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+  if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = s1; sh[1][threadIdx.x >> 6] = s2; }
   __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (threadIdx.x < o) { sh[0][threadIdx.x] += sh[0][threadIdx.x + o]; sh[1][threadIdx.x] += sh[1][threadIdx.x + o]; }
-    __syncthreads();
-  }
   if (threadIdx.x) return;
-  const float sg = (float)sh[0][0], sgc = (float)sh[1][0], r = save_invstd[c], g = gamma[c];
+  const float sg = (float)((sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3])), sgc = (float)((sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]));
+  const float r = save_invstd[c], g = gamma[c];
   const float dgam = r * sgc;
   dgamma[c] += dgam;
   dbeta[c] += sg;
