@@ -72,7 +72,14 @@ def infer_bench(args, model, dev):
         pr = torch.where(mask[b] > 0, feat[b, 0].abs() + 2.0, torch.full_like(feat[b, 0], -1.0))
         occ = torch.nonzero(mask[b] > 0)
         sel = torch.randint(0, occ.shape[0], (int(occ.shape[0] * 1.3),), generator=g).to(dev)
-        py, px = occ[sel, 0].contiguous(), occ[sel, 1].contiguous()
+        # file order of a spinning sensor: azimuth by azimuth (one firing = all lasers at one azimuth), i.e. column-major in
+        # the range image -- neighbouring points of a sweep file are neighbouring pixels; --knn-random-order keeps the draw
+        # order (no locality at all: the worst case for the window gather, reported beside the headline either way)
+        py, px = occ[sel, 0], occ[sel, 1]
+        if not getattr(args, "knn_random_order", False):
+            order = torch.argsort(px * args.height + py, stable=True)
+            sel, py, px = sel[order], py[order], px[order]
+        py, px = py.contiguous(), px.contiguous()
         ur = pr[py, px] + torch.rand(sel.numel(), generator=g).to(dev) * 0.2
         frames.append((pr.contiguous(), ur.contiguous(), px, py))
 
@@ -107,11 +114,23 @@ def infer_bench(args, model, dev):
         nb = bs * 12.0 * args.height * args.width + 28.0 * ur_all.numel()    # 12 H W + 28 P bytes per frame
         pr, ur, px, py = frames[0]
         ms1 = timed_ms(lambda: knn(pr, ur, am[0], px, py), 20)
+        # the same points in random order (no pixel locality between neighbouring lanes)
+        perm = torch.randperm(ur_all.numel(), device=dev)
+        counts_t = torch.tensor(counts, device=dev)
+        fidx = torch.repeat_interleave(torch.arange(bs, device=dev), counts_t)[perm]
+        perm = perm[torch.argsort(fidx, stable=True)]            # (shuffled inside every frame, frames still contiguous)
+        knn_rand, _ = knn.bind_batch(pr_all, am, ur_all[perm].contiguous(), px_all[perm].contiguous(),
+                                     py_all[perm].contiguous(), off)
+        for _ in range(200):
+            knn_rand()
+        ms_rand = timed_ms(knn_rand, 200)
         hbm.insert(0, {"kernel": "knn_batch_k (5x5 window, k=5 vote per point; all %d frames in one launch)" % bs,
                        "bound": "hbm", "launches": 1, "achieved": round(nb / ms / 1e6, 1), "peak": PEAK_HBM, "unit": "GB/s",
                        "frac": round(nb / ms / 1e6 / PEAK_HBM, 5), "algorithmic_mb_per_iter": round(nb / 1e6, 2),
                        "ms_per_iter": round(ms, 4), "points": int(ur_all.numel()),
-                       "per_frame_launch_us": round(1e3 * ms1, 2)})
+                       "per_frame_launch_us": round(1e3 * ms1, 2),
+                       "point_order": "random draw order" if args.knn_random_order else "sweep-file order (azimuth-major)",
+                       "random_point_order_us": round(1e3 * ms_rand, 2)})
     if not args.no_parity:
         parity = infer_parity(args, model, feat, mask, frames, knn, out.split(counts))
     if not args.no_cpu_baseline:
@@ -743,6 +762,8 @@ def main():
                          "a NEW device address every iteration -- what DataLoader + .cuda() hands the reference's trainer "
                          "(tasks/pmf/trainer.py:289-303); the captured graphs keep replaying through the plan's own "
                          "staging tensors.  The other mode's number is printed beside the headline either way")
+    ap.add_argument("--knn-random-order", action="store_true",
+                    help="--mode infer: KNN points in random order instead of sweep-file (azimuth-major) order")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle parity block of the timed plan")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
