@@ -1179,7 +1179,7 @@ __global__ __launch_bounds__(256) void conv_fwd_k(const pmf_conv_desc_t d, const
 }
 
 // Deterministic split-K tail: out = ep( act( sum_ks ws[ks] + bias ) ), optional BatchNorm statistics.
-__global__ void conv_finish_k(const pmf_conv_desc_t d, int ksplit, const float* __restrict__ ws, int ws_ld, int Q) {
+__global__ __launch_bounds__(256) void conv_finish_k(const pmf_conv_desc_t d, int ksplit, const float* __restrict__ ws, int ws_ld, int Q) {
   __shared__ double sh[2][256][4];
   const int Qm = Q < 256 ? Q : 256, Qg = min(Q - (int)blockIdx.y * 256, 256), rows = 256 / Qm;
   const int row = threadIdx.x / Qm, cql = threadIdx.x - row * Qm;
@@ -1193,44 +1193,59 @@ __global__ void conv_finish_k(const pmf_conv_desc_t d, int ksplit, const float* 
 #pragma unroll
       for (int k = 0; k < 4; ++k) if (c + k < d.Cout) bias[k] = d.bias[c + k];
     }
-    for (int64_t p = (int64_t)blockIdx.x * rows + row; p < npix; p += (int64_t)gridDim.x * rows) {
-      // slabs in batches of 8 independent loads (a load -> add loop exposes one L2 round trip per slab), summed in
-      // slab order: the result does not depend on the batching
-      f32x4 v = bias;
+    // PP pixels x 8 slabs of independent loads in flight (a load -> add loop exposes one L2 round trip per slab and
+    // per pixel: 8 round trips on a 16-way split with 4 pixels per thread).  Every pixel is still summed in slab order
+    // and the statistics still accumulate in pixel order: the result does not depend on the batching.
+    constexpr int PP = 4;
+    const int64_t pstride = (int64_t)gridDim.x * rows;
+    for (int64_t p0 = (int64_t)blockIdx.x * rows + row; p0 < npix; p0 += pstride * PP) {
+      f32x4 v[PP];
+#pragma unroll
+      for (int i = 0; i < PP; ++i) v[i] = bias;
       for (int s0 = 0; s0 < ksplit; s0 += 8) {
-        f32x4 t[8];
+        f32x4 t[PP][8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-          if (s0 + j < ksplit) t[j] = *(const f32x4*)(ws + ((int64_t)(s0 + j) * npix + p) * ws_ld + c);
+        for (int i = 0; i < PP; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-          if (s0 + j < ksplit) v += t[j];
+          for (int j = 0; j < 8; ++j)
+            if (s0 + j < ksplit && p0 + i * pstride < npix)
+              t[i][j] = *(const f32x4*)(ws + ((int64_t)(s0 + j) * npix + p0 + i * pstride) * ws_ld + c);
+#pragma unroll
+        for (int i = 0; i < PP; ++i)
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (s0 + j < ksplit && p0 + i * pstride < npix) v[i] += t[i][j];
       }
-      const int n = (int)(p / hw);
-      const int rem = (int)(p - (int64_t)n * hw), oy = rem / d.OW, ox = rem - oy * d.OW;
-      // strided / offset outputs (stride-2 input-gradient parity classes, pixel-shuffle style scatter)
-      const int64_t opix = (int64_t)(n * d.out_H + oy * d.out_sy + d.out_oy) * d.out_W + ox * d.out_sx + d.out_ox;
-      float* op = d.out + opix * d.out_ldc + c;
-      const bool vec = c + 3 < d.Cout && !d.accumulate && ((uintptr_t)op & 15) == 0;   // one 16-byte store
-      f32x4 xo;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        if (c + k >= d.Cout) continue;
-        float x = pmf_act(v[k], d.act);
-        if (d.ep_cmul) x *= d.ep_cmul[(size_t)n * d.ep_cmul_ld + c + k];
-        if (d.ep_pmask) x *= d.ep_pmask[opix];
-        float xraw = 0.f;
-        if (d.ep_relu_x) {
-          float xr = xraw = d.ep_relu_x[opix * d.ep_relu_ldc + c + k];
-          if (d.ep_relu_scale) xr = xr * d.ep_relu_scale[c + k] + d.ep_relu_shift[c + k];
-          if (!(xr > 0.f) && !(d.ep_flags & PMF_EP_STAT_X_ONLY)) x = 0.f;
+      for (int i = 0; i < PP; ++i) {
+        const int64_t p = p0 + i * pstride;
+        if (p >= npix) break;
+        const int n = (int)(p / hw);
+        const int rem = (int)(p - (int64_t)n * hw), oy = rem / d.OW, ox = rem - oy * d.OW;
+        // strided / offset outputs (stride-2 input-gradient parity classes, pixel-shuffle style scatter)
+        const int64_t opix = (int64_t)(n * d.out_H + oy * d.out_sy + d.out_oy) * d.out_W + ox * d.out_sx + d.out_ox;
+        float* op = d.out + opix * d.out_ldc + c;
+        const bool vec = c + 3 < d.Cout && !d.accumulate && ((uintptr_t)op & 15) == 0;   // one 16-byte store
+        f32x4 xo;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (c + k >= d.Cout) continue;
+          float x = pmf_act(v[i][k], d.act);
+          if (d.ep_cmul) x *= d.ep_cmul[(size_t)n * d.ep_cmul_ld + c + k];
+          if (d.ep_pmask) x *= d.ep_pmask[opix];
+          float xraw = 0.f;
+          if (d.ep_relu_x) {
+            float xr = xraw = d.ep_relu_x[opix * d.ep_relu_ldc + c + k];
+            if (d.ep_relu_scale) xr = xr * d.ep_relu_scale[c + k] + d.ep_relu_shift[c + k];
+            if (!(xr > 0.f) && !(d.ep_flags & PMF_EP_STAT_X_ONLY)) x = 0.f;
+          }
+          if (d.accumulate) x += op[k];
+          if (vec) xo[k] = x; else op[k] = x;
+          s1[k] += (double)x;
+          s2[k] += (double)x * (double)(d.ep_stat_mean ? xraw - d.ep_stat_mean[c + k] : x);
         }
-        if (d.accumulate) x += op[k];
-        if (vec) xo[k] = x; else op[k] = x;
-        s1[k] += (double)x;
-        s2[k] += (double)x * (double)(d.ep_stat_mean ? xraw - d.ep_stat_mean[c + k] : x);
+        if (vec) *(f32x4*)op = xo;
       }
-      if (vec) *(f32x4*)op = xo;
     }
   }
   if (d.stats) {
@@ -1285,16 +1300,18 @@ int pmf_conv_geometry(int OH, int OW, int ntaps, const int8_t* tdy, const int8_t
   }
 }
 
-static int finish_rows(const pmf_conv_desc_t* d) {
+static int finish_rows(const pmf_conv_desc_t* d, bool stats) {
   const int Q = round_up(d->Cout, 4) / 4, Qg = Q < 256 ? Q : 256, rows = 256 / Qg;
-  int64_t gx = cdiv64((int64_t)d->N * d->OH * d->OW, (int64_t)rows * 4);
+  // four pixels per thread row when the launch writes statistics rows (one per workgroup, read back by the BatchNorm
+  // finalize), one otherwise
+  int64_t gx = cdiv64((int64_t)d->N * d->OH * d->OW, (int64_t)rows * (stats ? 4 : 1));
   return (int)(gx > 1024 ? 1024 : (gx < 1 ? 1 : gx));
 }
 
 // deterministic split-K tail of a launch whose workgroups wrote g.ksplit partial slabs
 static int pmf_conv_finish_launch(const pmf_conv_desc_t* d, const ConvGeom& g, hipStream_t s) {
   const int Q = g.ws_ld / 4, Qg = Q < 256 ? Q : 256, rows = 256 / Qg;
-  const int gx = finish_rows(d);
+  const int gx = finish_rows(d, d->stats != nullptr);
   hipLaunchKernelGGL(conv_finish_k, dim3((unsigned)gx, (unsigned)cdiv(Q, 256), 1), dim3(rows * Qg), 0, s, *d, g.ksplit,
                      (const float*)g.ws, g.ws_ld, Q);
   PMF_LAUNCH_CHECK();
@@ -1600,7 +1617,7 @@ extern "C" int pmf_conv_fwd_stat_rows(const pmf_conv_desc_t* d) {
   }
   if (conv_direct_lds(d, BN)) nchunks = 1;
   if (d->ndst > 0) return tiles * d->N;
-  if (choose_ksplit(d, tiles * d->N * cdiv(d->Cout, BN), nchunks, d->ntaps * 8 * MT * (BN / 32)) > 1) return finish_rows(d);
+  if (choose_ksplit(d, tiles * d->N * cdiv(d->Cout, BN), nchunks, d->ntaps * 8 * MT * (BN / 32)) > 1) return finish_rows(d, true);
   return tiles * d->N;
 }
 

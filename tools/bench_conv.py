@@ -30,6 +30,9 @@ CASES = [  # name, N, H, W, Cin, Cout, k, dil
     ("quar_256_256_3x3d2", 2, 16, 512, 256, 256, 3, 2),
     ("8th_256_256_3x3", 2, 8, 256, 256, 256, 3, 1),
     ("16th_512_512_3x3", 2, 4, 128, 512, 512, 3, 1),
+    ("16th_1024_256_1x1", 2, 4, 128, 1024, 256, 1, 1),      # ResNet-50 bottlenecks: split-K launches + conv_finish_k
+    ("32nd_2048_512_1x1", 2, 2, 64, 2048, 512, 1, 1),
+    ("32nd_512_2048_1x1", 2, 2, 64, 512, 2048, 1, 1),
 ]
 def timeit(fn, n=200):
     # the shader clock needs tens of milliseconds of load to ramp from idle: warm up long enough, then time
@@ -57,6 +60,14 @@ def run(which, filt):
             st = G.stream()
             us = timeit(lambda: lib.pmf_conv_fwd(C.byref(d), st))
             print("fwd   %-22s %8.1f us  %6.1f TF/s" % (name, us, gf / us * 1e3), flush=True)
+        if which == "fwdst":   # with BatchNorm statistics rows (the split-K tail then writes them)
+            d = G.conv_desc([dict(x=x, C=ci)], wpk, ldw, None, out, N, H, W, co, taps, 1, 0)
+            d.splitk_ws, d.splitk_ws_bytes = ws.data_ptr(), ws.numel()
+            rows = lib.pmf_conv_fwd_stat_rows(C.byref(d))
+            stt = torch.empty(rows * 2 * co, dtype=torch.float64, device="cuda"); d.stats = stt.data_ptr()
+            st = G.stream()
+            us = timeit(lambda: lib.pmf_conv_fwd(C.byref(d), st))
+            print("fwdst %-22s %8.1f us  %6.1f TF/s  (%d stat rows)" % (name, us, gf / us * 1e3, rows), flush=True)
         if which == "s3":      # split-bf16 path, every tile configuration, next to the fp32 MFMA path
             w3 = G.pack_fwd_s3_stem(w, ldw) if (k == 7 and ci == 8) else G.pack_fwd_s3(w, ci, ldw)
             cfgs = (0, 32 | (1 << 8) | (1 << 16), 64 | (1 << 8) | (1 << 16), 32 | (2 << 8) | (1 << 16), 64 | (2 << 8) | (1 << 16))
