@@ -776,7 +776,7 @@ def main():
         raise SystemExit("bench.py: --gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # no launcher around us: become the launcher (one rank per GPU)
-        if not probe:
+        if not probe and os.environ.get("PMF_BENCH_SHARE_GPU") != "1":
             have = torch.cuda.device_count() if torch.cuda.is_available() else 0
             if have < args.gpus:
                 raise SystemExit("bench.py: --gpus %d asked for, %d device(s) visible" % (args.gpus, have))
@@ -791,6 +791,13 @@ def main():
         return dist_probe(world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an AMD GPU: the HIP hot path has no CPU fallback")
+    # PMF_BENCH_SHARE_GPU=1 + PMF_BENCH_BACKEND=gloo (tests/test_gpu_boundary.py): a dry run of the multi-rank path on a
+    # one-GPU box -- every rank on device 0, collectives over gloo (RCCL refuses two ranks on one device).  Not a
+    # measurement: the line says so in "config".
+    share_gpu = os.environ.get("PMF_BENCH_SHARE_GPU") == "1"
+    backend = os.environ.get("PMF_BENCH_BACKEND", "nccl")
+    if share_gpu:
+        local = 0
     if torch.cuda.device_count() <= local:
         raise SystemExit("bench.py: rank %d has no device %d (%d visible)" % (rank, local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
@@ -799,7 +806,7 @@ def main():
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group("nccl", init_method="env://", world_size=world, rank=rank)
+        dist.init_process_group(backend, init_method="env://", world_size=world, rank=rank)
     if args.mode == "loader":
         return loader_bench(args, dev)
     if args.model == "salsanext":
@@ -899,6 +906,15 @@ def main():
                     "gradient_payload_mb": round(4.0 * eng.flat.grad.numel() / 1e6, 1) if eng.flat is not None else None,
                     "note": "exposed all-reduce = HIP-event time the training stream waited for the RCCL stream after the "
                             "last backward segment; the earlier ranges were reduced under the remaining backward segments"}
+        if eng.flat is not None:
+            # every rank trained on its OWN data: the parameters stay bit-identical only if every gradient range really
+            # went through the all-reduce before the optimiser read it (a range reduced too early or left out diverges)
+            fp = eng.flat.param
+            sig = torch.stack([fp.double().sum(), fp.double().abs().sum(),
+                               fp.view(torch.int32).to(torch.int64).sum().double()])
+            sigs = [torch.zeros_like(sig) for _ in range(world)]
+            dist.all_gather(sigs, sig)
+            per_rank["parameters_identical_across_ranks"] = bool(all(torch.equal(x, sigs[0]) for x in sigs))
     dt = t.item()
     loss_val = float(loss)
     if not np.isfinite(loss_val):
@@ -1043,7 +1059,10 @@ def main():
                                       ", S_A" if (args.height, args.width) == (64, 2048) else "", args.bs,
                                       args.nclasses),
                        "global_batch": world * args.bs, "parallelism": "dp%d" % world,
-                       "rccl_ranks": (dist.get_world_size() if multi else 0),
+                       "rccl_ranks": (dist.get_world_size() if multi and backend == "nccl" else 0),
+                       **({"dry_run": "PMF_BENCH_SHARE_GPU=1: %d ranks share GPU 0, collectives over %s -- a functional "
+                                      "check of the multi-rank path, NOT a measurement" % (world, backend)}
+                          if share_gpu or backend != "nccl" else {}),
                        "samples_per_s": world * args.bs * args.steps / dt, "final_loss": loss_val,
                        "fresh_input_addresses": bool(args.fresh_inputs),
                        "init": "closed-form hash weights (pmf_amd.utils.detinit), %d training iterations before the parity block" % (args.warmup + args.steps + ko + 2),

@@ -739,3 +739,32 @@ def test_nus_six_camera_inference_loop(tmp_path, knn, fallback):
             assert (got[k] != e2e[k]).sum() <= 5, (k, int((got[k] != e2e[k]).sum()))
         # the evaluator saw every sweep once
         assert int(inf.evaluator.conf_matrix.sum()) == 2 * 5000
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dp_mode", ["events", "segments"])
+def test_bench_two_ranks_dry_run_on_one_gpu(dp_mode, tmp_path):
+    """The `--gpus N` path of bench.py (rank 0 tunes first and shares its choices through PMF_TUNE_CACHE, event-gated /
+    segmented gradient all-reduce on its own stream, per-rank timing block, ONE JSON line from rank 0) run end to end
+    with two ranks on THIS box's single GPU: PMF_BENCH_SHARE_GPU=1 puts every rank on device 0 and PMF_BENCH_BACKEND=gloo
+    carries the collectives (RCCL refuses two ranks on one device).  A functional check -- the line carries `dry_run`."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PMF_BENCH_SHARE_GPU="1", PMF_BENCH_BACKEND="gloo", PMF_DP_MODE=dp_mode, PMF_AUTOTUNE="1",
+               PMF_TUNE_CACHE=str(tmp_path / "tune.txt"), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "3",
+                        "--no-cpu-baseline", "--no-roofline", "--no-f32-ref"], env=env, capture_output=True, text=True,
+                       timeout=1500, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "dp2" and "dry_run" in line["config"]
+    assert np.isfinite(line["config"]["final_loss"])
+    dp = line["data_parallel"]
+    assert dp["parameters_identical_across_ranks"] is True      # ranks saw different data: only a complete all-reduce keeps them equal
+    assert dp["ms_per_step_max"] >= dp["ms_per_step_min"] > 0
+    assert dp["exposed_allreduce_ms_per_step"]["max"] >= 0
+    # both ranks built their plan from ONE tuning pass: the cache file exists and holds choices
+    assert os.path.getsize(str(tmp_path / "tune.txt")) > 0
