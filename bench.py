@@ -904,8 +904,11 @@ def main():
                                                       "mean": float(allr[:, 1].mean())},
                     "dp_segments": int(os.environ.get("PMF_DP_SEGMENTS", "4")),
                     "gradient_payload_mb": round(4.0 * eng.flat.grad.numel() / 1e6, 1) if eng.flat is not None else None,
-                    "note": "exposed all-reduce = HIP-event time the training stream waited for the RCCL stream after the "
-                            "last backward segment; the earlier ranges were reduced under the remaining backward segments"}
+                    "note": "exposed tail = HIP-event time on the training stream from the end of the backward plan to the "
+                            "point where every gradient range is all-reduced AND its parameters are updated (range "
+                            "optimiser, engine._behind_events); the earlier ranges were reduced and updated under the "
+                            "running backward plan.  PMF_OWN_OPTIM=0 / PMF_DP_MODE=segments: the stream waits for the "
+                            "collectives only"}
         if eng.flat is not None:
             # every rank trained on its OWN data: the parameters stay bit-identical only if every gradient range really
             # went through the all-reduce before the optimiser read it (a range reduced too early or left out diverges)

@@ -543,6 +543,19 @@ int pmf_plan_lanes(int on);
  * bits 24-30); out: end - begin op indices.  Host-only, launches nothing. */
 int pmf_plan_issue_order(const pmf_op_t* ops, int32_t begin, int32_t end, int32_t* out);
 int pmf_graph_destroy(void* graph_exec);
+/* ---- optimiser updates over a range of the flat training state -------------------------------------------------------
+ * Replaces: torch.optim.AdamW(lidar_stream.parameters()).step() and torch.optim.SGD(camera parameters, nesterov=True)
+ * .step() of the reference (tasks/pmf/trainer.py:80-98 construction, :336-337 the two step() calls), element by element
+ * the arithmetic of torch/optim/adamw.py / sgd.py in float32.  `n` consecutive floats starting at each pointer; a range
+ * launch lets the caller update the parameters whose gradients are already final (and all-reduced) while the backward
+ * plan is still running.  `step`: device float holding the 1-based count of THIS step (bias corrections are computed from
+ * it on the device, no host read).  pmf_sgd_range: first_step != 0 initialises the momentum buffer with the
+ * (weight-decayed) gradient as torch does; nesterov needs momentum > 0 and dampening == 0 (PMF_E_ARG otherwise, torch
+ * raises ValueError). */
+int pmf_adamw_range(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double lr,
+                    double beta1, double beta2, double eps, double weight_decay, const float* step, pmf_stream_t s);
+int pmf_sgd_range(float* param, const float* grad, float* momentum_buffer, int64_t n, double lr, double momentum,
+                  double dampening, double weight_decay, int32_t nesterov, int32_t first_step, pmf_stream_t s);
 /* pixel splits pmf_conv_wgrad will use for this descriptor (sizes `partial`) */
 int pmf_conv_wgrad_nsplit(const pmf_wgrad_desc_t* d);
 /* sizeof() of the structs above, for bindings to self-check: 0 src, 1 conv, 2 wgrad, 3 view, 4 small, 5 op, 6 pack job */

@@ -193,6 +193,10 @@ class TrainEngine:
         self.optimizer = torch.optim.AdamW(adam_groups, lr=lr, **adam_kw, **fused)
         self.aux_optimizer = torch.optim.SGD(camera_groups, lr=lr, nesterov=True, momentum=momentum,
                                              weight_decay=weight_decay, **fused)
+        if self.flat is not None:
+            # flat state: the updates run as range launches of libpmf_amd.so behind the backward plan's events
+            # (_behind_events); the torch optimisers stay as the holders of hyper-parameters and state tensors
+            self._setup_range_optim(model, [(self.optimizer, 0, "adamw"), (self.aux_optimizer, 0, "sgd")])
         # what a trainer / main.py holds as trainer.optimizer / trainer.aux_optimizer: reference checkpoint layout
         self.optimizer_view, self.aux_optimizer_view = self.optimizer, self.aux_optimizer
         if self.flat is not None:
@@ -213,7 +217,7 @@ class TrainEngine:
         self.std = None if feature_std is None else torch.tensor(feature_std, device=dev).view(1, -1, 1, 1).float()
         self.iteration = 0
 
-    # ---- data parallel over the flat gradient buffer ---------------------------------------------------------
+    # ---- data parallel + optimiser updates over ranges of the flat buffers -------------------------------------
     def _attach_dp_hooks(self, model):
         """PMF_DP_MODE=events (default): the backward plan runs as ONE range and every gradient range is all-reduced behind
         the plan events that finalise it; PMF_DP_MODE=segments: the plan is cut into PMF_DP_SEGMENTS ranges with an
@@ -221,36 +225,139 @@ class TrainEngine:
         if os.environ.get("PMF_DP_MODE", "events") == "segments":
             model._bwd_segment_hook = self._allreduce_ready_ranges
         else:
-            model._bwd_gated_hook = self._allreduce_behind_events
+            model._bwd_gated_hook = self._behind_events
 
-    def _allreduce_behind_events(self, plan):
-        """called once per step, right after the whole backward plan has been ENQUEUED (graph replay: ~3 ms of host time
-        for ~10 ms of GPU work).  For every batched weight-gradient reduction of the plan (Plan.dp_gates: a handful per
-        pass, the first a third of the way in) a side stream waits for the plan events behind it and the gradient ranges
-        that are final by then are all-reduced from that stream: RCCL starts on them while the backward plan is still
-        running, and the plan itself is not cut anywhere.  What is left (the ranges finished by the last ops) follows on
-        the training stream.  Same ranges, same order on every rank (the plan is deterministic)."""
-        import ctypes as C
-        import torch.distributed as dist
-        from . import _lib as L
-        if os.environ.get("PMF_DP_DEBUG_SKIP") == "1":
+    def _setup_range_optim(self, model, group_opts):
+        """group_opts[g] = (torch optimiser, index of its param_group, "adamw" | "sgd") for FlatState group g.
+        PMF_OWN_OPTIM=0 keeps the torch fused step() calls at the end of the iteration."""
+        self._ro, self._ro_armed, self._ro_done, self._ro_first = None, False, False, {}
+        if self.flat is None or self.device.type != "cuda" or os.environ.get("PMF_OWN_OPTIM", "1") == "0":
             return
+        for opt, gi, kind in group_opts:
+            pg = opt.param_groups[gi]
+            if pg.get("maximize") or pg.get("amsgrad") or len(pg["params"]) != 1:
+                return                       # not the configurations the reference builds: leave them to torch
+        self._ro = list(group_opts)
+        if not (self.distributed and os.environ.get("PMF_DP_MODE", "events") == "segments"):
+            model._bwd_gated_hook = self._behind_events
+        # (segmented all-reduce: the same kernels over the whole buffers once the last collective is in, _finish_range_optim)
+
+    def _arm_range_optim(self):
+        """before backward() of a training step: optimiser state tensors exist (torch creates them lazily inside step():
+        same names, dtypes and shapes, so state_dict()/load_state_dict() and FlatOptimizerView see no difference) and
+        AdamW's step counter counts this step."""
+        if self.__dict__.get("_ro") is None:
+            return False
+        for g, (opt, gi, kind) in enumerate(self._ro):
+            fp = opt.param_groups[gi]["params"][0]
+            st = opt.state[fp]
+            if kind == "adamw":
+                if "exp_avg" not in st:
+                    st["step"] = torch.zeros((), dtype=torch.float32, device=fp.device)
+                    st["exp_avg"] = torch.zeros_like(fp, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(fp, memory_format=torch.preserve_format)
+                if not (torch.is_tensor(st["step"]) and st["step"].is_cuda and st["step"].dtype == torch.float32):
+                    st["step"] = torch.as_tensor(float(st["step"]), dtype=torch.float32, device=fp.device)
+                st["step"] += 1
+            else:
+                self._ro_first[g] = st.get("momentum_buffer") is None
+                if self._ro_first[g]:
+                    st["momentum_buffer"] = torch.empty_like(fp, memory_format=torch.preserve_format)
+        self._ro_armed, self._ro_done = True, False
+        return True
+
+    def _range_update(self, a, b, stream):
+        """parameters [a, b) of the flat buffer <- one optimiser step from gradient [a, b) (final, all-reduced), on `stream`"""
+        import ctypes as C
+        from . import _lib as L
+        g = next(i for i, (lo, hi) in enumerate(self.flat.ranges) if lo <= a < hi)
+        lo, hi = self.flat.ranges[g]
+        if b > hi:
+            raise RuntimeError("range optimiser: [%d, %d) crosses the parameter groups" % (a, b))
+        opt, gi, kind = self._ro[g]
+        pg = opt.param_groups[gi]
+        st = opt.state[pg["params"][0]]
+        o, n = 4 * (a - lo), b - a
+        pp, gp = self.flat.param.data_ptr() + 4 * a, self.flat.grad.data_ptr() + 4 * a
+        sp = C.c_void_p(stream.cuda_stream)
+        if kind == "adamw":
+            rc = L.lib().pmf_adamw_range(pp, gp, st["exp_avg"].data_ptr() + o, st["exp_avg_sq"].data_ptr() + o, n,
+                                         float(pg["lr"]), float(pg["betas"][0]), float(pg["betas"][1]), float(pg["eps"]),
+                                         float(pg["weight_decay"]), st["step"].data_ptr(), sp)
+        else:
+            rc = L.lib().pmf_sgd_range(pp, gp, st["momentum_buffer"].data_ptr() + o, n, float(pg["lr"]),
+                                       float(pg["momentum"]), float(pg["dampening"]), float(pg["weight_decay"]),
+                                       int(bool(pg["nesterov"])), int(self._ro_first[g]), sp)
+        if rc != 0:
+            raise RuntimeError("libpmf_amd.so: %s range update failed (%d)" % (kind, rc))
+
+    def _behind_events(self, plan):
+        """called once per backward pass, right after the whole backward plan has been ENQUEUED (graph replay: ~3 ms of host
+        time for ~10 ms of GPU work).  For every batched weight-gradient reduction of the plan (Plan.dp_gates: a handful
+        per pass, the first a third of the way in) a side stream waits for the plan events behind it; the gradient ranges
+        that are final by then are all-reduced from that stream (data parallel) and, in a training step, the parameters
+        of those ranges are updated right behind it -- while the backward plan is still running, and without cutting the
+        plan anywhere.  What only the end of the plan finalises follows on the training stream.  Same ranges, same order
+        on every rank (the plan is deterministic)."""
+        import contextlib
+        import ctypes as C
+        from . import _lib as L
+        dist_on = self.distributed and os.environ.get("PMF_DP_DEBUG_SKIP") != "1"
+        armed = self.__dict__.get("_ro") is not None and self._ro_armed and not self._ro_done
+        if not dist_on and not armed:
+            return
+        if dist_on:
+            import torch.distributed as dist
         cur = torch.cuda.current_stream(self.device)
         side = self.__dict__.get("_dp_side")
         if side is None:
             side = self._dp_side = torch.cuda.Stream(device=self.device)
         lib = L.lib()
+        if getattr(self, "time_allreduce", False):
+            self._tail_e0 = torch.cuda.Event(enable_timing=True)
+            self._tail_e0.record(cur)                    # fires when the backward plan itself is through
+        used_side = False
         for evs, ranges in plan.dp_schedule():
-            if evs is None:                 # finalised by the last ops of the plan: behind the training stream
-                for a, b in ranges:
-                    self._pending.append(dist.all_reduce(self.flat.grad[a:b], async_op=True))
-                continue
-            ok = all(lib.pmf_plan_event_wait(e, C.c_void_p(side.cuda_stream)) == 0 for e in evs)
-            if not ok:                      # events never recorded (PMF_LANES=0): order behind the whole plan instead
-                side.wait_stream(cur)
-            with torch.cuda.stream(side):
-                for a, b in ranges:
-                    self._pending.append(dist.all_reduce(self.flat.grad[a:b], async_op=True))
+            if evs is not None:
+                ok = all(lib.pmf_plan_event_wait(e, C.c_void_p(side.cuda_stream)) == 0 for e in evs)
+                if not ok:                  # events never recorded (PMF_LANES=0): order behind the whole plan instead
+                    side.wait_stream(cur)
+                used_side = True
+            where = side if evs is not None else cur          # (None: finalised by the last ops of the plan)
+            with (torch.cuda.stream(side) if evs is not None else contextlib.nullcontext()):
+                hs = [dist.all_reduce(self.flat.grad[a:b], async_op=True) for a, b in ranges] if dist_on else []
+                if armed:
+                    for h in hs:
+                        h.wait()            # orders `where` behind the collective (no host block)
+                    for a, b in ranges:
+                        self._range_update(a, b, where)
+                else:
+                    self._pending += hs
+        if used_side and armed:
+            cur.wait_stream(side)
+        if armed:
+            self._ro_done = True
+
+    def _finish_range_optim(self):
+        """after backward(): every parameter range has been updated (or is queued behind its events).  If the hook did
+        not run (taken off the model, or a backward pass outside the plan's gated path) the whole buffers are updated
+        here on the training stream -- same kernels."""
+        if not self.__dict__.get("_ro") or not self._ro_armed:
+            return False
+        if not self._ro_done:
+            cur = torch.cuda.current_stream(self.device)
+            for lo, hi in self.flat.ranges:
+                if hi > lo:
+                    self._range_update(lo, hi, cur)
+        self._ro_armed = self._ro_done = False
+        e0 = self.__dict__.pop("_tail_e0", None)
+        if e0 is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            self.__dict__.setdefault("allreduce_events", []).append((e0, e1))
+        return True
+
+    _allreduce_behind_events = _behind_events        # (round-4 name)
 
     def _allreduce_ready_ranges(self, plan, op_end):
         """called between segments of the backward plan: all-reduce the gradient ranges that are final by now.
@@ -273,7 +380,7 @@ class TrainEngine:
         between them is what the compute stream idled for the all-reduce AFTER the backward plan had finished -- the
         EXPOSED part of the collective, the figure that decides the 1 -> 8 GPU scaling."""
         timed = getattr(self, "time_allreduce", False) and self._pending and self._pending[0] is not None \
-            and torch.cuda.is_available()
+            and torch.cuda.is_available() and self.__dict__.get("_tail_e0") is None
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -313,6 +420,18 @@ class TrainEngine:
             dist.broadcast(flat, 0)
             torch._foreach_copy_(bufs, [c.view(b.shape) for c, b in zip(flat.split([b.numel() for b in bufs]), bufs)])
 
+    def _step_extra_groups(self):
+        """parameters outside the flat buffers (EPMF: the six MultiTaskLoss sigmas in the AdamW's second group) keep the
+        torch step: the flat parameter is hidden from it for the call (step() skips parameters without a gradient)."""
+        if len(self.optimizer.param_groups) < 2:
+            return
+        fp = self.optimizer.param_groups[0]["params"][0]
+        g, fp.grad = fp.grad, None
+        try:
+            self.optimizer.step()
+        finally:
+            fp.grad = g
+
     def prepare(self, input_feature, input_mask):
         """trainer.py:291-297: normalise the 5 LiDAR channels in place, return the two channel-slice views."""
         if self.mean is not None:
@@ -348,6 +467,7 @@ class TrainEngine:
         if self.flat is None:
             self.optimizer.zero_grad(set_to_none=True)
             self.aux_optimizer.zero_grad(set_to_none=True)
+        own = self._arm_range_optim()
         if self.flat is not None and self.distributed:
             # mean over ranks = sum of gradients of loss / world: scale the upstream gradient (free: the objective's
             # backward multiplies by it anyway) instead of a pass over the 146 MB gradient buffer after the all-reduce
@@ -356,8 +476,12 @@ class TrainEngine:
             self._finish_allreduce()
         else:
             total.backward()        # flat state: the plan zero-fills and rewrites the gradient buffer itself
-        self.optimizer.step()
-        self.aux_optimizer.step()
+        if own:
+            self._finish_range_optim()
+            self._step_extra_groups()
+        else:
+            self.optimizer.step()
+            self.aux_optimizer.step()
         self.scheduler.step()
         self.aux_scheduler.step()
         if not metrics_done:
@@ -482,12 +606,18 @@ class SalsaNextEngine:
         self.metrics = IOUEval(nclasses, dev, ignore=list(ignore_class), is_distributed=distributed)
         self.scheduler = WarmupCosineLR(self.optimizer, lr, warmup_steps, momentum, max_steps)
         self.iteration = 0
+        if self.flat is not None:
+            self._setup_range_optim(model, [(self.optimizer, 0, "adamw")])
 
     _allreduce_ready_ranges = TrainEngine._allreduce_ready_ranges
-    _allreduce_behind_events = TrainEngine._allreduce_behind_events
+    _behind_events = TrainEngine._behind_events
     _attach_dp_hooks = TrainEngine._attach_dp_hooks
     _finish_allreduce = TrainEngine._finish_allreduce
     exposed_allreduce_ms = TrainEngine.exposed_allreduce_ms
+    _setup_range_optim = TrainEngine._setup_range_optim
+    _arm_range_optim = TrainEngine._arm_range_optim
+    _range_update = TrainEngine._range_update
+    _finish_range_optim = TrainEngine._finish_range_optim
 
     def forward_loss(self, feature, label, mask):
         """(feature, label, mask): the order SalsaNextLoader yields and the reference loop unpacks
@@ -505,13 +635,17 @@ class SalsaNextEngine:
         total, terms, output, label = self.forward_loss(feature, label, mask)
         if self.flat is None:
             self.optimizer.zero_grad(set_to_none=True)
+        own = self._arm_range_optim()
         if self.flat is not None and self.distributed:
             import torch.distributed as dist
             total.backward(torch.full_like(total, 1.0 / dist.get_world_size()))
             self._finish_allreduce()
         else:
             total.backward()
-        self.optimizer.step()
+        if own:
+            self._finish_range_optim()
+        else:
+            self.optimizer.step()
         self.scheduler.step()
         with torch.no_grad():
             self.metrics.addBatch(output.argmax(dim=1), label)

@@ -321,10 +321,16 @@ def test_checkpoint_roundtrip_in_reference_layout():
     assert ck["aux_optimizer"]["param_groups"][1]["params"][0] == n_enc
     assert "momentum_buffer" in ck["aux_optimizer"]["state"][0]
 
-    def same(m, loss):
+    def same(m, loss, exact=True):
+        # exact: the same update kernels on both sides (libpmf_amd.so range optimiser).  The per-parameter engine steps
+        # with torch's fused AdamW / SGD -- the same arithmetic evaluated by another kernel: equal to float32 rounding of
+        # one update (everything the step READS -- loss, BatchNorm statistics -- is still bit-identical)
         assert loss == lossA, (loss, lossA)
         for k, v in m.state_dict().items():
-            assert torch.equal(v, wantA[k]), k
+            if exact or not v.is_floating_point() or "running_" in k:
+                assert torch.equal(v, wantA[k]), k
+            else:
+                assert torch.allclose(v, wantA[k], rtol=1e-5, atol=1e-7), (k, (v - wantA[k]).abs().max().item())
 
     mB, eB = engine(True, seed_init=False)                 # (a) flat <- checkpoint
     restore(mB, eB, ck, 2)
@@ -333,7 +339,7 @@ def test_checkpoint_roundtrip_in_reference_layout():
     restore(mC, eC, ck, 2)
     ckC = save(mC, eC)                                     #     ... and their own state dict is the same layout
     assert ckC["optimizer"]["param_groups"][0]["params"] == ck["optimizer"]["param_groups"][0]["params"]
-    same(mC, step(eC))
+    same(mC, step(eC), exact=False)
     mD, eD = engine(True, seed_init=False)                 # (c) flat <- a checkpoint written by per-parameter optimisers
     restore(mD, eD, ckC, 2)
     same(mD, step(eD))
@@ -396,12 +402,18 @@ def test_epmf_checkpoint_in_reference_layout():
     assert tuple(ck["optimizer"]["state"][len(lidar)]["exp_avg"].shape) == (6,)
     assert all(tuple(ck["optimizer"]["state"][i]["exp_avg"].shape) == tuple(p.shape) for i, p in enumerate(lidar))
 
-    def same(m, e, loss):
+    def same(m, e, loss, exact=True):
         # bitwise, as in the PMF test: the bias gradients of EPMF's masked convolutions are column sums folded in a fixed
         # order (pmf_colsum_rows; the float-atomic form they used before differed run to run in the last bit)
+        # (exact=False: the per-parameter engine's torch fused step against the range kernels -- one update apart by rounding)
         assert loss == lossA, (loss, lossA)
         assert torch.equal(e.mt_loss.sigma.detach(), sigA)
-        bad = [k for k, v in m.state_dict().items() if not torch.equal(v, wantA[k])]
+        if exact:
+            bad = [k for k, v in m.state_dict().items() if not torch.equal(v, wantA[k])]
+        else:
+            bad = [k for k, v in m.state_dict().items()
+                   if not (torch.allclose(v, wantA[k], rtol=1e-5, atol=1e-7) if v.is_floating_point() and "running_" not in k
+                           else torch.equal(v, wantA[k]))]
         assert not bad, bad[:8]
 
     mB, eB = engine(True, seed_init=False)                 # flat <- checkpoint
@@ -411,7 +423,7 @@ def test_epmf_checkpoint_in_reference_layout():
     restore(mC, eC, ck, 2)
     ckC = save(mC, eC)
     assert [g["params"] for g in ckC["optimizer"]["param_groups"]] == [g["params"] for g in groups]
-    same(mC, eC, step(eC))
+    same(mC, eC, step(eC), exact=False)
     mD, eD = engine(True, seed_init=False)                 # flat <- a checkpoint written by per-parameter optimisers
     restore(mD, eD, ckC, 2)
     same(mD, eD, step(eD))

@@ -347,3 +347,64 @@ def test_maxpool_fwd_bwd():
     got, gin, _ = Hn.run([V(out)], [x], [go])
     _check("mp.out", got[0], ref.detach())
     _check("mp.gin", gin[0], xd.grad, 1e-5)
+
+
+# ---- optimiser range kernels (csrc/optim.hip) against torch.optim on the CPU ----------------------------------------
+@pytest.mark.parametrize("n,off", [(1, 0), (7, 0), (1024, 0), (4099, 64), (100003, 1), (262144, 128)])
+def test_adamw_range_matches_torch(n, off):
+    import ctypes as C
+    g = torch.Generator().manual_seed(n)
+    p0 = torch.randn(n + off, generator=g)
+    ref = torch.nn.Parameter(p0[off:].clone())
+    opt = torch.optim.AdamW([ref], lr=1e-3, weight_decay=0.01)
+    p = p0.clone().to(DEV)
+    m, v = torch.zeros(n + off, device=DEV), torch.zeros(n + off, device=DEV)
+    step = torch.zeros((), device=DEV)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for k in range(4):
+        gr = torch.randn(n + off, generator=g) * (10.0 ** (k - 2))
+        ref.grad = gr[off:].clone()
+        opt.param_groups[0]["lr"] = 1e-3 * (k + 1)
+        opt.step()
+        gd = gr.to(DEV)
+        step += 1
+        rc = L.lib().pmf_adamw_range(p.data_ptr() + 4 * off, gd.data_ptr() + 4 * off, m.data_ptr() + 4 * off,
+                                     v.data_ptr() + 4 * off, n, 1e-3 * (k + 1), 0.9, 0.999, 1e-8, 0.01, step.data_ptr(), st)
+        assert rc == 0
+        torch.cuda.synchronize()
+        assert torch.equal(p[:off].cpu(), p0[:off])                     # nothing outside the range is touched
+        assert torch.allclose(p[off:].cpu(), ref.data, rtol=2e-6, atol=2e-7), (k, (p[off:].cpu() - ref.data).abs().max().item())
+        s = opt.state[ref]
+        assert (m[off:].cpu() - s["exp_avg"]).abs().max() <= 1e-6 * s["exp_avg"].abs().max()
+        assert (v[off:].cpu() - s["exp_avg_sq"]).abs().max() <= 1e-6 * s["exp_avg_sq"].abs().max()
+
+
+@pytest.mark.parametrize("n,off,nesterov,wd", [(5, 0, True, 1e-5), (4099, 64, True, 1e-5), (100003, 3, False, 0.0),
+                                                 (65536, 0, True, 0.0)])
+def test_sgd_range_matches_torch(n, off, nesterov, wd):
+    import ctypes as C
+    g = torch.Generator().manual_seed(n + 1)
+    p0 = torch.randn(n + off, generator=g)
+    ref = torch.nn.Parameter(p0[off:].clone())
+    opt = torch.optim.SGD([ref], lr=1e-2, momentum=0.9, nesterov=nesterov, weight_decay=wd)
+    p = p0.clone().to(DEV)
+    buf = torch.full((n + off,), float("nan"), device=DEV)            # first step must not read it
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for k in range(4):
+        gr = torch.randn(n + off, generator=g)
+        ref.grad = gr[off:].clone()
+        opt.step()
+        gd = gr.to(DEV)
+        rc = L.lib().pmf_sgd_range(p.data_ptr() + 4 * off, gd.data_ptr() + 4 * off, buf.data_ptr() + 4 * off, n, 1e-2, 0.9,
+                                   0.0, wd, int(nesterov), int(k == 0), st)
+        assert rc == 0
+        torch.cuda.synchronize()
+        assert torch.allclose(p[off:].cpu(), ref.data, rtol=2e-6, atol=2e-7), (k, (p[off:].cpu() - ref.data).abs().max().item())
+        assert torch.allclose(buf[off:].cpu(), opt.state[ref]["momentum_buffer"], rtol=2e-6, atol=1e-7)
+    # momentum 0: no buffer at all; nesterov without momentum is an argument error (torch raises ValueError)
+    p2 = p0.clone().to(DEV)
+    gd = torch.ones(n + off, device=DEV)
+    assert L.lib().pmf_sgd_range(p2.data_ptr(), gd.data_ptr(), None, n + off, 0.5, 0.0, 0.0, 0.0, 0, 0, st) == 0
+    torch.cuda.synchronize()
+    assert torch.allclose(p2.cpu(), p0 - 0.5)
+    assert L.lib().pmf_sgd_range(p2.data_ptr(), gd.data_ptr(), None, n + off, 0.5, 0.0, 0.0, 0.0, 1, 0, st) == L.PMF_E_ARG

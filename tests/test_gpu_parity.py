@@ -741,18 +741,24 @@ def test_fused_loss_nan_probabilities_stay_in_bounds():
 
 @pytest.mark.gpu
 def test_flat_training_state_matches_per_tensor_path():
-    """FlatState (parameters / gradients as views of two flat buffers, one fused optimiser launch per group, gradients
-    written in place by the backward plan) must produce bit-identical parameters to the per-tensor path."""
+    """FlatState (parameters / gradients as views of two flat buffers, gradients written in place by the backward plan) must
+    produce bit-identical parameters to the per-tensor path when both step with the same optimiser kernels (torch's fused
+    AdamW / SGD: PMF_OWN_OPTIM=0 on the flat side).  With the range optimiser of libpmf_amd.so -- the default on the flat
+    state -- the same trajectory to float32 rounding of the update arithmetic."""
     from pmf_amd.engine import TrainEngine
     from pmf_amd.models import PMFNet
     from pmf_amd.utils.detinit import deterministic_init
 
-    def run(flat):
+    def run(flat, own="1"):
         torch.manual_seed(0)
         m = PMFNet(5, 3, 20, 32, imagenet_pretrained=False, image_backbone="resnet34")
         deterministic_init(m)
         m = m.cuda()
-        eng = TrainEngine(m, 20, lr=1e-3, warmup_steps=2, max_steps=10, flat_state=flat)
+        os.environ["PMF_OWN_OPTIM"] = own
+        try:
+            eng = TrainEngine(m, 20, lr=1e-3, warmup_steps=2, max_steps=10, flat_state=flat)
+        finally:
+            os.environ.pop("PMF_OWN_OPTIM", None)
         pcd, rgb, label, mask = synthetic_batch(2, 32, 64, 20, seed=11, fill=0.5)
         feat = torch.cat((pcd, rgb), 1)
         torch.manual_seed(123)                       # same dropout masks in both runs
@@ -765,11 +771,21 @@ def test_flat_training_state_matches_per_tensor_path():
         return losses, {k: v.detach().clone() for k, v in m.state_dict().items()}, conf
 
     l0, s0, c0 = run(False)
-    l1, s1, c1 = run(True)
+    l1, s1, c1 = run(True, own="0")
     assert l0 == l1, (l0, l1)
     assert torch.equal(c0, c1)
     for k in s0:
         assert torch.equal(s0[k], s1[k]), k
+    l2, s2, c2 = run(True)                       # range optimiser
+    assert l2[0] == l0[0] and all(abs(a - b) < 1e-4 * abs(b) for a, b in zip(l2, l0)), (l2, l0)
+    # camera stream (SGD: linear in the gradient) convolution weights stay within rounding; AdamW (LiDAR stream) turns the
+    # last-bit difference of a near-zero gradient element into a full +-lr step, so there only the bound that follows from
+    # three steps of at most lr each holds (one step: test_range_optimiser_equals_torch_fused_step compares everything)
+    errs = sorted(((((s2[k] - s0[k]).abs().max() / s0[k].abs().max().clamp_min(1e-6)).item(), k)
+                   for k in s0 if s0[k].dim() == 4 and k.startswith("camera_stream")), reverse=True)
+    assert errs and errs[0][0] < 1e-3, errs[:6]
+    lr_sum = 1e-3 * (1 + 2 + 2) / 2 * 1.05
+    assert all((s2[k] - s0[k]).abs().max().item() <= 2 * lr_sum for k in s0 if k.startswith("lidar_stream") and s0[k].dim() == 4)
 
 
 @pytest.mark.gpu
@@ -1460,3 +1476,59 @@ def test_engine_overfits_a_fixed_batch():
     assert all(torch.isfinite(p).all() for p in m.parameters())
     acc = eng.metrics.getAcc()[0].item()
     assert 0.0 <= acc <= 1.0
+
+
+DEV = "cuda"
+
+
+def test_range_optimiser_equals_torch_fused_step():
+    """TrainEngine with the range optimiser of libpmf_amd.so (updates queued behind the backward plan's events) against the
+    same engine with torch's fused AdamW / SGD step() at the end of the iteration (PMF_OWN_OPTIM=0): after ONE iteration
+    (identical gradients on both sides) the parameters and the optimiser state agree to float32 rounding of one update;
+    after three the checkpoint layout is identical.  (Parameter VALUES are not compared after three steps: a convolution
+    bias in front of a BatchNorm has a true gradient of zero, AdamW turns the rounding noise it receives instead into
+    +-lr steps, and two runs that differ in the last bit after step one take different signs there.)"""
+    import os
+    from pmf_amd.engine import TrainEngine
+    from pmf_amd.models import PMFNet
+    from pmf_amd.utils.detinit import deterministic_init
+    out = {}
+    for own in ("1", "0"):
+        os.environ["PMF_OWN_OPTIM"] = own
+        try:
+            torch.manual_seed(3)
+            model = deterministic_init(PMFNet(5, 3, 20, 32, imagenet_pretrained=False, image_backbone="resnet34")).to(DEV)
+            eng = TrainEngine(model, 20, lr=1e-3, momentum=0.9, weight_decay=1e-5, warmup_steps=2, max_steps=10)
+        finally:
+            os.environ.pop("PMF_OWN_OPTIM", None)
+        assert (eng._ro is not None) == (own == "1")
+        g = torch.Generator().manual_seed(5)
+        first = None
+        for it in range(3):
+            feat = torch.randn(2, 8, 32, 64, generator=g).to(DEV)
+            mask = (torch.rand(2, 32, 64, generator=g) > 0.2).float().to(DEV)
+            label = torch.randint(0, 20, (2, 32, 64), generator=g).to(DEV)
+            eng.train_step(feat, mask, label)
+            if it == 0:
+                torch.cuda.synchronize()
+                st = eng.optimizer.state[eng.optimizer.param_groups[0]["params"][0]]
+                sg = eng.aux_optimizer.state[eng.aux_optimizer.param_groups[0]["params"][0]]
+                first = (eng.flat.param.clone(), st["exp_avg"].clone(), st["exp_avg_sq"].clone(),
+                         sg["momentum_buffer"].clone(), float(st["step"]))
+        torch.cuda.synchronize()
+        out[own] = (first, eng.optimizer_view.state_dict(), eng.aux_optimizer_view.state_dict())
+    fa, fb = out["1"][0], out["0"][0]
+    assert fa[4] == fb[4] == 1.0
+    assert torch.allclose(fa[0], fb[0], rtol=1e-5, atol=1e-7), (fa[0] - fb[0]).abs().max().item()
+    for i in (1, 2, 3):
+        assert torch.allclose(fa[i], fb[i], rtol=1e-5, atol=1e-30 if i == 2 else 1e-12), i
+    for sa, sb in ((out["1"][1], out["0"][1]), (out["1"][2], out["0"][2])):
+        assert sa["param_groups"] == sb["param_groups"]
+        assert sa["state"].keys() == sb["state"].keys()
+        for k in sa["state"]:
+            assert sa["state"][k].keys() == sb["state"][k].keys()
+            for name, t in sa["state"][k].items():
+                u = sb["state"][k][name]
+                assert t.shape == u.shape and t.dtype == u.dtype, (k, name)
+                if name == "step":
+                    assert float(t) == float(u) == 3.0
