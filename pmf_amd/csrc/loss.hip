@@ -10,6 +10,21 @@
 #define LV_PER_THREAD 16
 #define LV_CHUNK (LV_BLOCK * LV_PER_THREAD)
 
+// (chunk b, row r) of a row-wise kernel.  2-D launch: (blockIdx.x, blockIdx.y).  1-D launch of 8 * ceil(R / 8) * nb
+// workgroups (rows_grid()): consecutive workgroup ids go round-robin over the 8 XCDs, so workgroup L runs on XCD L % 8 and
+// that XCD works through rows L % 8, L % 8 + 8, ... chunk by chunk -- every chunk of a row on ONE XCD at about the same
+// time.  The row-wise scatters (radix passes into the row's [0, n) range, the Lovasz gradient through the permutation
+// into the row's two gradient planes) then read-modify-write lines that sit in that XCD's L2, instead of every L2 holding
+// -- and writing back -- a part of every line.  Returns false for the padding rows.
+__device__ __forceinline__ bool rows_map(int nb, int R, int* b, int* r) {
+  if (gridDim.y > 1 || R <= 0) { *b = blockIdx.x; *r = blockIdx.y; return true; }
+  const int L = blockIdx.x, j = L >> 3, slot = j / nb;
+  *b = j - slot * nb;
+  *r = slot * 8 + (L & 7);
+  return *r < R;
+}
+static inline dim3 rows_grid(int nb, int R) { return dim3((unsigned)(8 * ((R + 7) / 8) * nb), 1, 1); }
+
 __global__ __launch_bounds__(LV_BLOCK) void lovasz_sums_k(const float* __restrict__ fg, int64_t P, int nb,
                                                           float* __restrict__ bsum) {
   __shared__ float sh[LV_BLOCK];
@@ -259,7 +274,9 @@ __global__ __launch_bounds__(LV_BLOCK) void lovasz2_sums_k(const IT* __restrict_
                                                            int64_t P, int C, int nb, float* __restrict__ bsum,
                                                            const unsigned long long* __restrict__ cnt) {
   __shared__ float sh[LV_BLOCK];
-  const int r = blockIdx.y, b = blockIdx.x, cls = r % C;
+  int r, b;
+  if (!rows_map(nb, 2 * C, &b, &r)) return;
+  const int cls = r % C;
   const int64_t lim = cnt ? P - (int64_t)cnt[0] : P;
   if (cnt && (cls == 0 || cnt[cls] == 0)) return;
   if ((int64_t)b * LV_CHUNK >= lim) {              // nothing ranked here
@@ -299,7 +316,9 @@ __global__ __launch_bounds__(LV_BLOCK) void lovasz2_grad_k(const IT* __restrict_
   __shared__ float sh[LV_BLOCK];
   __shared__ double shd[LV_BLOCK];
   __shared__ float carry_s, total_s;
-  const int r = blockIdx.y, b = blockIdx.x, cls = r % C, head = r / C;
+  int r, b;
+  if (!rows_map(nb, 2 * C, &b, &r)) return;
+  const int cls = r % C, head = r / C;
   const int64_t nvalid = P - (int64_t)cnt[0];
   const int64_t lim = LIMIT ? nvalid : P;
   if (LIMIT && (cls == 0 || cnt[cls] == 0)) return;          // (loss_fold_k skips these rows' dots as well)
@@ -555,13 +574,27 @@ __global__ __launch_bounds__(RS_TILE) void rs_hist_k(const float* __restrict__ k
 }
 
 // one workgroup per row: hist[r][chunk][digit] -> exclusive offsets in (digit, chunk) order, in place
-__global__ __launch_bounds__(256) void rs_scan_k(unsigned* __restrict__ hist, int C, int nb, const unsigned long long* __restrict__ cnt) {
+// (nb_all chunks per row in the table; after the compacting first pass only the chunks below P - cnt[0] keys hold anything:
+// P > 0 limits both loops to those -- 18 instead of 128 at the bench's fill)
+__global__ __launch_bounds__(256) void rs_scan_k(unsigned* __restrict__ hist, int C, int nb_all, const unsigned long long* __restrict__ cnt,
+                                                 int64_t P) {
   __shared__ unsigned tot[256];
   const int r = blockIdx.x, cls = r % C, d = threadIdx.x;
   if (cls == 0 || cnt[cls] == 0) return;
-  unsigned* hp = hist + (int64_t)r * nb * 256 + d;
+  int nb = nb_all;
+  if (P > 0) {
+    const int64_t na = (P - (int64_t)cnt[0] + RS_CHUNK - 1) / RS_CHUNK;
+    nb = na < nb_all ? (int)na : nb_all;
+  }
+  unsigned* hp = hist + (int64_t)r * nb_all * 256 + d;
   unsigned s = 0;
-  for (int b = 0; b < nb; ++b) s += hp[b * 256];
+  for (int b0 = 0; b0 < nb; b0 += 8) {          // eight independent loads per trip
+    unsigned c[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) c[u] = b0 + u < nb ? hp[(b0 + u) * 256] : 0u;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += c[u];
+  }
   tot[d] = s;
   __syncthreads();
   for (int o = 1; o < 256; o <<= 1) {
@@ -581,31 +614,38 @@ __global__ __launch_bounds__(256) void rs_scan_k(unsigned* __restrict__ hist, in
   }
 }
 
+// Stable scatter of one 4096-key chunk.  Wave w owns the contiguous quarter [w * 1024, (w + 1) * 1024) of the chunk, 16 rounds of
+// 64 consecutive keys: a key's rank among the equal digits of its OWN wave needs no workgroup barrier (ballot matching +
+// a wave-private running counter per digit in LDS; LDS operations of one wave execute in order), so the sixteen rounds run
+// back to back; ONE barrier later the per-wave digit totals are turned into the waves' start offsets and the keys go out.
+// (Round 3 ranked workgroup-wide round by round: three barriers in each of the 16 rounds -- 45 us per pass for 2.8 M keys.)
 template <bool FIRST>
 __global__ __launch_bounds__(RS_TILE) void rs_scatter_k(const float* __restrict__ key, const unsigned* __restrict__ kin,
                                                         const unsigned* __restrict__ vin, int64_t P, int C, int nb, int shift,
                                                         const unsigned long long* __restrict__ cnt,
                                                         const unsigned* __restrict__ offs, unsigned* __restrict__ kout,
                                                         unsigned* __restrict__ vout) {
-  __shared__ unsigned run[256];
-  __shared__ unsigned wc[RS_TILE / 64][256];
-  const int r = blockIdx.y, b = blockIdx.x, cls = r % C;
+  constexpr int NW = RS_TILE / 64;
+  __shared__ unsigned wc[NW][256];
+  int r, b;
+  if (!rows_map(nb, 2 * C, &b, &r)) return;
+  const int cls = r % C;
   if (cls == 0 || cnt[cls] == 0) return;
   const int64_t n = FIRST ? P : P - (int64_t)cnt[0];
   const int64_t base = (int64_t)b * RS_CHUNK;
   if (base >= n) return;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  run[t] = offs[((int64_t)r * nb + b) * 256 + t];
+  const unsigned run0 = offs[((int64_t)r * nb + b) * 256 + t];
 #pragma unroll
-  for (int w = 0; w < RS_TILE / 64; ++w) wc[w][t] = 0u;
+  for (int w = 0; w < NW; ++w) wc[w][t] = 0u;
   __syncthreads();
   const int64_t ro = (int64_t)r * P;
-  // the whole chunk first (16 independent loads per thread in flight), then the sixteen ranking rounds
-  unsigned ks[RS_SUB], vs[RS_SUB];
+  // the wave's 1024 keys first (16 independent loads per thread in flight), then the sixteen ranking rounds
+  unsigned ks[RS_SUB], vs[RS_SUB], pos[RS_SUB];
   unsigned okm = 0u;
 #pragma unroll
   for (int s = 0; s < RS_SUB; ++s) {
-    const int64_t i = base + s * RS_TILE + t;
+    const int64_t i = base + wave * (RS_CHUNK / NW) + s * 64 + lane;
     bool ok = i < n;
     ks[s] = 0u; vs[s] = 0u;
     if (ok) {
@@ -618,11 +658,11 @@ __global__ __launch_bounds__(RS_TILE) void rs_scatter_k(const float* __restrict_
     }
     okm |= ok ? (1u << s) : 0u;
   }
+  unsigned* __restrict__ mine = wc[wave];
 #pragma unroll
   for (int s = 0; s < RS_SUB; ++s) {
-    const unsigned k = ks[s], v = vs[s];
     const bool ok = (okm >> s) & 1u;
-    const unsigned d = (k >> shift) & 255u;
+    const unsigned d = (ks[s] >> shift) & 255u;
     unsigned long long m = __ballot(ok);
 #pragma unroll
     for (int bit = 0; bit < 8; ++bit) {
@@ -632,23 +672,26 @@ __global__ __launch_bounds__(RS_TILE) void rs_scatter_k(const float* __restrict_
     }
     const unsigned long long peers = ok ? m : 0ull;
     const unsigned rank = (unsigned)__popcll(peers & ((1ull << lane) - 1ull));
-    if (ok && rank == 0u) wc[wave][d] = (unsigned)__popcll(peers);       // the lowest lane of every digit group
-    __syncthreads();
-    if (ok) {
-      unsigned pre = run[d];
-      for (int w = 0; w < wave; ++w) pre += wc[w][d];
-      const int64_t dst = ro + pre + rank;
-      kout[dst] = k;
-      vout[dst] = v;
-    }
-    __syncthreads();
-    {
-      unsigned a = 0u;
+    const unsigned before = ok ? mine[d] : 0u;                    // equal digits of this wave in earlier rounds
+    pos[s] = before + rank;
+    __builtin_amdgcn_wave_barrier();                              // every lane has read before the group's first lane adds
+    if (ok && rank == 0u) mine[d] = before + (unsigned)__popcll(peers);
+    __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();
+  {   // digit t: chunk offset + the totals of the waves in front
+    unsigned a = run0;
 #pragma unroll
-      for (int w = 0; w < RS_TILE / 64; ++w) { a += wc[w][t]; wc[w][t] = 0u; }
-      run[t] += a;
+    for (int w = 0; w < NW; ++w) { const unsigned c = wc[w][t]; wc[w][t] = a; a += c; }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < RS_SUB; ++s) {
+    if ((okm >> s) & 1u) {
+      const int64_t dst = ro + mine[(ks[s] >> shift) & 255u] + pos[s];
+      kout[dst] = ks[s];
+      vout[dst] = vs[s];
     }
-    __syncthreads();
   }
 }
 
@@ -682,16 +725,18 @@ static int loss_lovasz_sort_impl(const float* key, const int64_t* label, int32_t
   unsigned* vB = vA + (int64_t)R * P;
   unsigned* hist = vB + (int64_t)R * P;
   const dim3 grid(nb, R), blk(RS_TILE);
+  static const bool xcd_rows = getenv("PMF_LOSS_XCD_ROWS") == nullptr || atoi(getenv("PMF_LOSS_XCD_ROWS")) != 0;   // A/B knob
+  const dim3 xgrid = xcd_rows ? rows_grid(nb, R) : grid;
   // pass 0 (bits 0-7): raw keys -> A (compaction); 1: A -> B; 2: B -> A; 3: A -> B
   hipLaunchKernelGGL(rs_hist_k<true>, grid, blk, 0, st, key, (const unsigned*)nullptr, P, C, nb, 0, cnt, hist);
-  hipLaunchKernelGGL(rs_scan_k, dim3(R), dim3(256), 0, st, hist, C, nb, cnt);
-  hipLaunchKernelGGL(rs_scatter_k<true>, grid, blk, 0, st, key, (const unsigned*)nullptr, (const unsigned*)nullptr, P, C, nb, 0,
+  hipLaunchKernelGGL(rs_scan_k, dim3(R), dim3(256), 0, st, hist, C, nb, cnt, (int64_t)0);
+  hipLaunchKernelGGL(rs_scatter_k<true>, xgrid, blk, 0, st, key, (const unsigned*)nullptr, (const unsigned*)nullptr, P, C, nb, 0,
                      cnt, (const unsigned*)hist, kA, vA);
   unsigned* ki = kA; unsigned* vi = vA; unsigned* ko = kB; unsigned* vo = vB;
   for (int pass = 1; pass < 4; ++pass) {
     hipLaunchKernelGGL(rs_hist_k<false>, grid, blk, 0, st, (const float*)nullptr, (const unsigned*)ki, P, C, nb, 8 * pass, cnt, hist);
-    hipLaunchKernelGGL(rs_scan_k, dim3(R), dim3(256), 0, st, hist, C, nb, cnt);
-    hipLaunchKernelGGL(rs_scatter_k<false>, grid, blk, 0, st, (const float*)nullptr, (const unsigned*)ki, (const unsigned*)vi, P, C,
+    hipLaunchKernelGGL(rs_scan_k, dim3(R), dim3(256), 0, st, hist, C, nb, cnt, P);
+    hipLaunchKernelGGL(rs_scatter_k<false>, xgrid, blk, 0, st, (const float*)nullptr, (const unsigned*)ki, (const unsigned*)vi, P, C,
                        nb, 8 * pass, cnt, (const unsigned*)hist, ko, vo);
     unsigned* t = ki; ki = ko; ko = t;
     t = vi; vi = vo; vo = t;
@@ -700,8 +745,9 @@ static int loss_lovasz_sort_impl(const float* key, const int64_t* label, int32_t
   float* es = (float*)ko;
   hipLaunchKernelGGL(rs_unkey_k, dim3(nb, R), dim3(256), 0, st, (const unsigned*)ki, es, P, C, cnt);
   const int nbl = (int)cdiv64(P, LV_CHUNK);
-  hipLaunchKernelGGL(lovasz2_sums_k<unsigned>, dim3(nbl, R), dim3(LV_BLOCK), 0, st, (const unsigned*)vi, label, P, C, nbl, bsum, cnt);
-  hipLaunchKernelGGL((lovasz2_grad_k<unsigned, true>), dim3(nbl, R), dim3(LV_BLOCK), 0, st, (const unsigned*)vi, (const float*)es,
+  const dim3 lgrid = xcd_rows ? rows_grid(nbl, R) : dim3(nbl, R);
+  hipLaunchKernelGGL(lovasz2_sums_k<unsigned>, lgrid, dim3(LV_BLOCK), 0, st, (const unsigned*)vi, label, P, C, nbl, bsum, cnt);
+  hipLaunchKernelGGL((lovasz2_grad_k<unsigned, true>), lgrid, dim3(LV_BLOCK), 0, st, (const unsigned*)vi, (const float*)es,
                      label, P, HW, C, nbl, (const float*)bsum, cnt, lambda, w6, grad_lidar, grad_camera, dots);
   hipLaunchKernelGGL(loss_fold_k, dim3(1), dim3(256), 0, st, rows, (int)cdiv64(P, LP_BLOCK), (const double*)dots, C, nbl, cnt,
                      lambda, gamma_per, w6, out8);
