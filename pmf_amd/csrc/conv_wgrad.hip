@@ -2095,10 +2095,14 @@ extern "C" int pmf_conv_wgrad_nsplit(const pmf_wgrad_desc_t* d) {
   wg_config(d, &TB, &NT);
   wg_geometry(d, TB, NT * 32, &g, &lds);
   int other = g.nchunks * g.co_tiles * g.tap_batches;
-  // workgroups per launch: one per CU.  Two per CU make the launch itself ~10 % faster in isolation (4.8 vs 5.4 ms over the
-  // 110 layers), but the weight gradients run on a side lane next to the input-gradient launches of the main lane, and
-  // half the partial slabs is half the stage-2 traffic: 18.64 vs 18.74 ms per training step (PMF_WGRAD_WGS=512: old rule)
-  static const int target = getenv("PMF_WGRAD_WGS") ? atoi(getenv("PMF_WGRAD_WGS")) : 256;
+  // workgroups per launch: one per TWO CUs.  More make the launch itself faster in isolation (512: 4.8 ms over the 110 layers,
+  // 256: 5.4 ms), but the weight gradients run on side lanes next to the input-gradient launches of the main lane -- which IS
+  // the step -- and a weight-gradient workgroup holds 80-110 KiB of its CU's LDS: with one on every CU a main-lane conv
+  // launch gets one workgroup per CU instead of the two it is tuned for.  Step time, alternating runs on one box (round 4):
+  // 64 workgroups 17.97 ms, 96: 16.25, 128: 15.13-15.17, 160: 15.79, 256: 15.41-15.48, 320: 16.40 (512, round 2: +0.1 over 256);
+  // PMF-ResNet50 32x1024 10.07 -> 9.79 ms, EPMF 14.66 -> 14.61, SalsaNext 11.33 -> 11.22.  Half the partial slabs is also half
+  // the stage-2 traffic.  PMF_WGRAD_WGS overrides.
+  static const int target = getenv("PMF_WGRAD_WGS") ? atoi(getenv("PMF_WGRAD_WGS")) : 128;
   int ns = target / (other > 0 ? other : 1);
   if (ns < 1) ns = 1;
   if (ns > g.total_tiles) ns = g.total_tiles;
