@@ -689,6 +689,12 @@ def plan_rooflines(plan, prof, model_tag):
     detail = {k: {"launches": v[0], "gflop": round(v[1] / 1e9, 1), "ms": round(v[2], 3),
                   "tflops": round(v[1] / max(v[2], 1e-9) / 1e9, 2) if v[1] else None}
               for k, v in sorted(fam.items(), key=lambda kv: -kv[1][2])}
+    if "conv_wgrad" in detail:
+        detail["conv_wgrad"]["note"] = ("weight-gradient launches are sized for the side lanes they run on in the timed step -- %s "
+                                        "workgroups, one per two CUs, so that the main lane's convolutions keep their LDS (step "
+                                        "15.4 -> 15.1 ms against 256; DESIGN.md section 4 'Round 4') -- which makes the launch "
+                                        "ALONE, what this line times, slower (256 workgroups: 4.7 ms / 100 TFLOP/s)"
+                                        % os.environ.get("PMF_WGRAD_WGS", "128"))
     return roof, hbm, detail
 
 
