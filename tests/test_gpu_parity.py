@@ -1532,3 +1532,22 @@ def test_range_optimiser_equals_torch_fused_step():
                 assert t.shape == u.shape and t.dtype == u.dtype, (k, name)
                 if name == "step":
                     assert float(t) == float(u) == 3.0
+
+
+def test_objective_row_mapping_is_bit_identical():
+    """the objective's row-wise kernels launched one XCD per row (default) against the 2-D (chunk, row) grids
+    (PMF_LOSS_XCD_ROWS=0): the mapping only decides WHERE a (chunk, row) pair runs -- loss and both gradient maps must be
+    bit-identical (the knob is read once per process: two processes)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = []
+    for v in ("1", "0"):
+        env = dict(os.environ, PMF_LOSS_XCD_ROWS=v)
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "bench_loss.py"), "3"], env=env, capture_output=True,
+                           text=True, timeout=600, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        fp = [ln for ln in r.stdout.splitlines() if ln.startswith("fingerprint")]
+        assert len(fp) == 1, r.stdout
+        out.append(fp[0])
+    assert out[0] == out[1], out

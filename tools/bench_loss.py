@@ -29,3 +29,7 @@ for _ in range(reps): t = step()
 e1.record(); torch.cuda.synchronize()
 print("fused objective fwd+bwd: %.1f us per call, labelled fraction %.3f, loss %.6f" % (
     e0.elapsed_time(e1) / reps * 1e3, (label > 0).float().mean().item(), t.item()))
+# exact fingerprints (the kernels are deterministic: equal across runs and across PMF_LOSS_XCD_ROWS=0 / 1)
+print("fingerprint loss %r grad_a %r %r grad_b %r %r" % (
+    t.item(), a.grad.double().sum().item(), a.grad.double().abs().sum().item(),
+    b.grad.double().sum().item(), b.grad.double().abs().sum().item()))
