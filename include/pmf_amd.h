@@ -556,6 +556,12 @@ int pmf_adamw_range(float* param, const float* grad, float* exp_avg, float* exp_
                     double beta1, double beta2, double eps, double weight_decay, const float* step, pmf_stream_t s);
 int pmf_sgd_range(float* param, const float* grad, float* momentum_buffer, int64_t n, double lr, double momentum,
                   double dampening, double weight_decay, int32_t nesterov, int32_t first_step, pmf_stream_t s);
+/* Replaces the four element-wise passes of tasks/pmf/trainer.py:291-295 (tasks/epmf/trainer.py likewise):
+ *   input_feature[:, 0:C] = (input_feature[:, 0:C] - mean) / std * mask.unsqueeze(1)      in place, one launch.
+ * x: [N, >= C, H, W] float32 with contiguous channel planes, stride_n floats between samples (8 * HW for the 8-channel
+ * feature tensor, C = 5); mask [N, HW]; mean / std [C].  Same float32 operation order as torch (bit-identical). */
+int pmf_normalise_inplace(float* x, int64_t stride_n, const float* mask, const float* mean, const float* stdv, int32_t N,
+                          int32_t C, int64_t HW, pmf_stream_t s);
 /* pixel splits pmf_conv_wgrad will use for this descriptor (sizes `partial`) */
 int pmf_conv_wgrad_nsplit(const pmf_wgrad_desc_t* d);
 /* sizeof() of the structs above, for bindings to self-check: 0 src, 1 conv, 2 wgrad, 3 view, 4 small, 5 op, 6 pack job */

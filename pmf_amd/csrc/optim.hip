@@ -98,3 +98,31 @@ extern "C" int pmf_sgd_range(float* param, const float* grad, float* momentum_bu
   PMF_LAUNCH_CHECK();
   return 0;
 }
+
+// ---- input normalisation of a training / validation batch, in place (tasks/pmf/trainer.py:291-295 of the reference:
+// input_feature[:, 0:5] = (input_feature[:, 0:5] - mean) / std * mask.unsqueeze(1)) -- the reference's four element-wise
+// passes as one launch; float32 subtract, IEEE divide, multiply in that order (fp contract off: same bits as torch).
+__global__ __launch_bounds__(256) void normalise_k(float* __restrict__ x, const float* __restrict__ mask,
+                                                   const float* __restrict__ mean, const float* __restrict__ stdv, int C,
+                                                   int64_t stride_n, int64_t HW, int64_t total) {
+  const int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x;       // over N * C * HW
+  if (i >= total) return;
+  const int64_t hw = i % HW, nc = i / HW;
+  const int c = (int)(nc % C);
+  const int64_t n = nc / C;
+  float* p = x + n * stride_n + (int64_t)c * HW + hw;
+  const float d = *p - mean[c];
+  const float q = d / stdv[c];
+  *p = q * mask[n * HW + hw];
+}
+
+extern "C" int pmf_normalise_inplace(float* x, int64_t stride_n, const float* mask, const float* mean, const float* stdv,
+                                     int32_t N, int32_t C, int64_t HW, pmf_stream_t s) {
+  if (!x || !mask || !mean || !stdv || N < 0 || C < 1 || HW < 1 || stride_n < (int64_t)C * HW) return PMF_E_ARG;
+  const int64_t total = (int64_t)N * C * HW;
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(normalise_k, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)s, x, mask, mean, stdv, C,
+                     stride_n, HW, total);
+  PMF_LAUNCH_CHECK();
+  return 0;
+}

@@ -435,7 +435,19 @@ class TrainEngine:
     def prepare(self, input_feature, input_mask):
         """trainer.py:291-297: normalise the 5 LiDAR channels in place, return the two channel-slice views."""
         if self.mean is not None:
-            input_feature[:, 0:5] = (input_feature[:, 0:5] - self.mean) / self.std * input_mask.unsqueeze(1)
+            x, m = input_feature, input_mask
+            if (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and m.is_cuda and m.dtype == torch.float32
+                    and m.is_contiguous() and x.dim() == 4 and x.shape[1] >= 5 and m.shape == (x.shape[0],) + x.shape[2:]):
+                # the same arithmetic as one launch of libpmf_amd.so (bit-identical; four ATen passes otherwise)
+                import ctypes as C
+                from . import _lib as L
+                hw = x.shape[2] * x.shape[3]
+                L.check(L.lib().pmf_normalise_inplace(x.data_ptr(), x.stride(0), m.data_ptr(), self.mean.data_ptr(),
+                                                      self.std.data_ptr(), x.shape[0], 5, hw,
+                                                      C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)),
+                        "pmf_normalise_inplace")
+            else:
+                input_feature[:, 0:5] = (input_feature[:, 0:5] - self.mean) / self.std * input_mask.unsqueeze(1)
         return input_feature[:, 0:5], input_feature[:, 5:8]
 
     def forward_loss(self, pcd, rgb, label):

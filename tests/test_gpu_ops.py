@@ -408,3 +408,36 @@ def test_sgd_range_matches_torch(n, off, nesterov, wd):
     torch.cuda.synchronize()
     assert torch.allclose(p2.cpu(), p0 - 0.5)
     assert L.lib().pmf_sgd_range(p2.data_ptr(), gd.data_ptr(), None, n + off, 0.5, 0.0, 0.0, 0.0, 1, 0, st) == L.PMF_E_ARG
+
+
+def test_normalise_inplace_is_bit_identical_to_the_torch_expression():
+    """trainer.py:291-295 as one launch: same bits as (x[:, :5] - mean) / std * mask.unsqueeze(1), channels 5..7 untouched;
+    through TrainEngine.prepare (contiguous float32 -> the kernel; a strided view -> the torch expression)"""
+    import ctypes as C
+    from pmf_amd.engine import TrainEngine
+    g = torch.Generator().manual_seed(4)
+    n, h, w = 3, 17, 70
+    x0 = (torch.randn(n, 8, h, w, generator=g) * 30).to(DEV)
+    mask = (torch.rand(n, h, w, generator=g) > 0.3).float().to(DEV)
+    mean = torch.tensor([12.12, 10.88, 0.23, -1.04, 0.21], device=DEV).view(1, 5, 1, 1)
+    std = torch.tensor([12.32, 11.47, 6.91, 0.86, 0.16], device=DEV).view(1, 5, 1, 1)
+    want = x0.clone()
+    want[:, 0:5] = (want[:, 0:5] - mean) / std * mask.unsqueeze(1)
+    got = x0.clone()
+    rc = L.lib().pmf_normalise_inplace(got.data_ptr(), got.stride(0), mask.data_ptr(), mean.data_ptr(), std.data_ptr(), n, 5,
+                                       h * w, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    assert L.lib().pmf_normalise_inplace(got.data_ptr(), 4 * h * w, mask.data_ptr(), mean.data_ptr(), std.data_ptr(), n, 5,
+                                         h * w, None) == L.PMF_E_ARG            # samples would overlap
+    eng = TrainEngine.__new__(TrainEngine)
+    eng.mean, eng.std = mean, std
+    a = x0.clone()
+    pcd, rgb = eng.prepare(a, mask)
+    assert torch.equal(a, want) and pcd.data_ptr() == a.data_ptr() and torch.equal(rgb, x0[:, 5:8])
+    big = torch.zeros(n, 9, h, w, device=DEV)
+    b = big[:, 1:]                                   # non-contiguous view: torch expression
+    b.copy_(x0)
+    eng.prepare(b, mask)
+    assert torch.equal(b, want)
