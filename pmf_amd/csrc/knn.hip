@@ -94,7 +94,7 @@ template <int S>
 __global__ __launch_bounds__(64) void knn_batch_k(const float* __restrict__ pr, const float* __restrict__ ur,
                                                   const int64_t* __restrict__ am, const int64_t* __restrict__ px,
                                                   const int64_t* __restrict__ py, const int64_t* __restrict__ offsets,
-                                                  int B, int H, int W, int64_t P, int knn, const float* __restrict__ invg,
+                                                  int B, int H, int W, int knn, const float* __restrict__ invg,
                                                   float cutoff, int nclasses, int64_t* __restrict__ labels) {
   constexpr int S2 = S * S, PAD = (S - 1) / 2, CENTER = (S2 - 1) / 2;
   __shared__ float wsh[S2];
@@ -153,6 +153,159 @@ __global__ __launch_bounds__(64) void knn_batch_k(const float* __restrict__ pr, 
   labels[i] = best_cls;
 }
 
+// ---- the same vote with the window staged through LDS ------------------------------------------------------------------
+// A gather of one window tap touches one cache line PER LANE when the lanes of a wave sit on different image rows -- and in
+// sweep-file order (azimuth by azimuth) consecutive points are the lasers of one column: 50 fully divergent gathers per
+// point, the texture-address unit processes them line by line (21 us for 102 k points; random order 33 us).  Here a workgroup
+// of 256 consecutive points of ONE frame takes the bounding box of its points (+ the window margin): in sweep order that is
+// ~5 columns x all rows, a few hundred pixels; (range, label) of the box are staged into LDS once (rows of the box are
+// contiguous: ~10 wave loads per map) and all window taps are read from there.  Zero padding / negative-range handling
+// happen at staging time with the same rules, the selection and the vote are the code above: bit-identical labels.  A box
+// above KNN_LDS_PIX pixels (points in random order) uses the global gathers as before, decided per workgroup.
+#define KNN_LDS_PIX 4096
+template <int S>
+__global__ __launch_bounds__(256) void knn_batch_lds_k(const float* __restrict__ pr, const float* __restrict__ ur,
+                                                       const int64_t* __restrict__ am, const int64_t* __restrict__ px,
+                                                       const int64_t* __restrict__ py, const int64_t* __restrict__ offsets,
+                                                       int B, int H, int W, int64_t P, int knn, const float* __restrict__ invg,
+                                                       float cutoff, int nclasses, int64_t* __restrict__ labels) {
+  constexpr int S2 = S * S, PAD = (S - 1) / 2, CENTER = (S2 - 1) / 2;
+  __shared__ float wsh[S2];
+  __shared__ float s_v[KNN_LDS_PIX];
+  __shared__ int s_l[KNN_LDS_PIX];
+  __shared__ int s_box[4];
+  // frame of this workgroup: frame b owns ceil(n_b / 256) consecutive workgroups.  B is small; the walk has no early exit so
+  // that its scalar loads are independent of each other (one memory latency, not one per frame).  (Measured: indexing the
+  // concatenated list directly, so that the point loads do not wait for this walk, is SLOWER -- 13.2 vs 11.7 us -- the
+  // per-thread frame search and the mixed-frame handling cost more than the overlap gives.)
+  int b = -1, wg = 0;
+  int64_t lo = 0, hi = 0;
+  {
+    int first = 0;
+    int64_t o0 = offsets[0];
+    for (int k = 0; k < B; ++k) {
+      const int64_t o1 = offsets[k + 1];
+      const int nb = (int)((o1 - o0 + 255) >> 8);
+      if (b < 0 && (int)blockIdx.x < first + nb) { b = k; wg = (int)blockIdx.x - first; lo = o0; hi = o1; }
+      first += nb;
+      o0 = o1;
+    }
+  }
+  if (b < 0) return;                                    // (the grid is an upper bound)
+  if (threadIdx.x < S2) wsh[threadIdx.x] = invg[threadIdx.x];
+  if (threadIdx.x == 0) { s_box[0] = 0x7fffffff; s_box[1] = -0x7fffffff; s_box[2] = 0x7fffffff; s_box[3] = -0x7fffffff; }
+  __syncthreads();
+  const int64_t i = lo + (int64_t)wg * 256 + threadIdx.x;
+  const bool valid = i < hi;
+  const float* __restrict__ prb = pr + (size_t)b * H * W;
+  const int64_t* __restrict__ amb = am + (size_t)b * H * W;
+  int cx = 0, cy = 0;
+  float r = 0.f;
+  if (valid) { cx = (int)px[i]; cy = (int)py[i]; r = ur[i]; }
+  {
+    // bounding box: butterfly over the wave, one LDS atomic per wave and bound.  (Points far outside the image only enlarge
+    // the box: it then exceeds the LDS budget and the global path, which clips tap by tap, takes over.)
+    int mnx = valid ? cx : 0x7fffffff, mxx = valid ? cx : -0x7fffffff, mny = valid ? cy : 0x7fffffff, mxy = valid ? cy : -0x7fffffff;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      mnx = min(mnx, __shfl_xor(mnx, o)); mxx = max(mxx, __shfl_xor(mxx, o));
+      mny = min(mny, __shfl_xor(mny, o)); mxy = max(mxy, __shfl_xor(mxy, o));
+    }
+    if ((threadIdx.x & 63) == 0) {
+      atomicMin(&s_box[0], mnx); atomicMax(&s_box[1], mxx); atomicMin(&s_box[2], mny); atomicMax(&s_box[3], mxy);
+    }
+  }
+  __syncthreads();
+  const int x0 = s_box[0] - PAD, y0 = s_box[2] - PAD;
+  const long bw = (long)s_box[1] - s_box[0] + 1 + 2 * PAD, bh = (long)s_box[3] - s_box[2] + 1 + 2 * PAD;
+  const bool staged = bw > 0 && bh > 0 && bw * bh <= KNN_LDS_PIX;
+  if (staged) {
+    // all loads of the box first (up to 16 pixels per thread, independent), then the LDS stores: one memory latency
+    constexpr int PER = KNN_LDS_PIX / 256;
+    const int n = (int)(bw * bh), w_ = (int)bw;
+    const float inv_w = 1.f / (float)w_;
+    float vv[PER];
+    int ll[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int j = threadIdx.x + u * 256;
+      vv[u] = 0.f; ll[u] = 0;   // F.unfold zero padding: range 0, label 0
+      if (j < n) {
+        int yy = (int)(((float)j + 0.5f) * inv_w);       // j < 4096, w_ >= S: exact up to one step, corrected below
+        int xx = j - yy * w_;
+        if (xx < 0) { --yy; xx += w_; } else if (xx >= w_) { ++yy; xx -= w_; }
+        const int y = y0 + yy, x = x0 + xx;
+        if (y >= 0 && y < H && x >= 0 && x < W) {
+          vv[u] = prb[(size_t)y * W + x];
+          ll[u] = (int)amb[(size_t)y * W + x];
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int j = threadIdx.x + u * 256;
+      if (j < n) { s_v[j] = vv[u] < 0.f ? INFINITY : vv[u]; s_l[j] = ll[u]; }
+    }
+  }
+  __syncthreads();
+  if (!valid) return;
+  float dist[S2];
+  int lab[S2];
+  if (staged) {
+    const int w_ = (int)bw, base = (cy - PAD - y0) * w_ + (cx - PAD - x0);
+#pragma unroll
+    for (int t = 0; t < S2; ++t) {
+      const int j = base + (t / S) * w_ + (t % S);
+      float v = s_v[j];
+      if (t == CENTER) v = r;
+      dist[t] = fabsf(v - r) * wsh[t];
+      lab[t] = s_l[j];
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < S2; ++t) {
+      const int y = cy + t / S - PAD, x = cx + t % S - PAD;
+      float v = 0.f;
+      int l = 0;
+      if (y >= 0 && y < H && x >= 0 && x < W) {
+        v = prb[(size_t)y * W + x];
+        l = (int)amb[(size_t)y * W + x];
+        if (v < 0.f) v = INFINITY;
+      }
+      if (t == CENTER) v = r;
+      dist[t] = fabsf(v - r) * wsh[t];
+      lab[t] = l;
+    }
+  }
+  // k x first-minimum selection (ties -> smaller window index), the same rule as knn_k with a 32-bit taken mask (S2 <= 25 on
+  // this path) and the label carried along the scan
+  static_assert(S2 <= 32, "taken mask");
+  unsigned used = 0u;
+  int sel[8];
+  int nsel = knn < 8 ? knn : 8;
+  for (int k = 0; k < nsel; ++k) {
+    float best = 0.f;
+    int bi = -1, l = 0;
+#pragma unroll
+    for (int t = 0; t < S2; ++t) {
+      const bool take = !(used & (1u << t)) && (bi < 0 || dist[t] < best);
+      best = take ? dist[t] : best; l = take ? lab[t] : l; bi = take ? t : bi;
+    }
+    used |= 1u << bi;
+    if (cutoff > 0.f && best > cutoff) l = nclasses;
+    sel[k] = l;
+  }
+  int best_cnt = 0, best_cls = 1;
+  for (int a = 0; a < nsel; ++a) {
+    const int cls = sel[a];
+    if (cls < 1 || cls >= nclasses) continue;
+    int cnt = 0;
+    for (int c = 0; c < nsel; ++c) cnt += sel[c] == cls;
+    if (cnt > best_cnt || (cnt == best_cnt && cls < best_cls)) { best_cnt = cnt; best_cls = cls; }
+  }
+  labels[i] = best_cls;
+}
+
 extern "C" int pmf_knn_vote_batch(const float* proj_range, const float* unproj_range, const int64_t* proj_argmax,
                                   const int64_t* px, const int64_t* py, const int64_t* offsets, int32_t B, int32_t H,
                                   int32_t W, int64_t P_total, int32_t knn, int32_t search, const float* inv_gauss,
@@ -161,8 +314,16 @@ extern "C" int pmf_knn_vote_batch(const float* proj_range, const float* unproj_r
   if (B < 1 || B > 1024 || !offsets) return PMF_E_ARG;
   if (knn < 1 || knn > 8 || knn > search * search) return PMF_E_UNSUPPORTED;
   if (P_total <= 0) return 0;
-  dim3 grid((unsigned)cdiv64(P_total, 64)), block(64);
   hipStream_t st = (hipStream_t)s;
+  static const bool no_lds = getenv("PMF_KNN_LDS") && atoi(getenv("PMF_KNN_LDS")) == 0;     // A/B knob
+  if (!no_lds && search <= 5) {       // (7x7: 49 + 49 window registers next to 32 KB of LDS -- stays on the gather form)
+    const dim3 g2((unsigned)(cdiv64(P_total, 256) + B)), b2(256);      // sum_b ceil(n_b / 256) <= ceil(P / 256) + B
+    if (search == 3) hipLaunchKernelGGL(knn_batch_lds_k<3>, g2, b2, 0, st, proj_range, unproj_range, proj_argmax, px, py, offsets, B, H, W, knn, inv_gauss, cutoff, nclasses, labels);
+    else hipLaunchKernelGGL(knn_batch_lds_k<5>, g2, b2, 0, st, proj_range, unproj_range, proj_argmax, px, py, offsets, B, H, W, knn, inv_gauss, cutoff, nclasses, labels);
+    PMF_LAUNCH_CHECK();
+    return 0;
+  }
+  dim3 grid((unsigned)cdiv64(P_total, 64)), block(64);
   switch (search) {
     case 3: hipLaunchKernelGGL(knn_batch_k<3>, grid, block, 0, st, proj_range, unproj_range, proj_argmax, px, py, offsets, B, H, W, P_total, knn, inv_gauss, cutoff, nclasses, labels); break;
     case 5: hipLaunchKernelGGL(knn_batch_k<5>, grid, block, 0, st, proj_range, unproj_range, proj_argmax, px, py, offsets, B, H, W, P_total, knn, inv_gauss, cutoff, nclasses, labels); break;
