@@ -337,7 +337,9 @@ int pmf_knn_vote(const float* proj_range, const float* unproj_range, const int64
 /* The same vote for all B frames of a batch in one launch (BASELINE configs[1] runs bs = 4; the reference's infer.py
  * calls knn.py once per frame, tasks/pmf_eval_semantickitti/infer.py:100-112): proj_range / proj_argmax are [B][H][W], the
  * points of all frames are concatenated and frame b owns [offsets[b], offsets[b+1]) (offsets: int64[B+1] on the device,
- * offsets[B] = P_total).  Labels bit-identical to B calls of pmf_knn_vote. */
+ * offsets[B] = P_total).  Labels bit-identical to B calls of pmf_knn_vote.  search <= 5: a workgroup of 256 consecutive
+ * points stages the bounding box of its windows through LDS (sweep-file order: a few columns); a box above 4096 pixels and
+ * search 7 use global gathers. */
 int pmf_knn_vote_batch(const float* proj_range, const float* unproj_range, const int64_t* proj_argmax, const int64_t* px,
                        const int64_t* py, const int64_t* offsets, int32_t B, int32_t H, int32_t W, int64_t P_total,
                        int32_t knn, int32_t search, const float* inv_gauss, float cutoff, int32_t nclasses,

@@ -94,7 +94,7 @@ template <int S>
 __global__ __launch_bounds__(64) void knn_batch_k(const float* __restrict__ pr, const float* __restrict__ ur,
                                                   const int64_t* __restrict__ am, const int64_t* __restrict__ px,
                                                   const int64_t* __restrict__ py, const int64_t* __restrict__ offsets,
-                                                  int B, int H, int W, int knn, const float* __restrict__ invg,
+                                                  int B, int H, int W, int64_t P, int knn, const float* __restrict__ invg,
                                                   float cutoff, int nclasses, int64_t* __restrict__ labels) {
   constexpr int S2 = S * S, PAD = (S - 1) / 2, CENTER = (S2 - 1) / 2;
   __shared__ float wsh[S2];
@@ -167,7 +167,7 @@ template <int S>
 __global__ __launch_bounds__(256) void knn_batch_lds_k(const float* __restrict__ pr, const float* __restrict__ ur,
                                                        const int64_t* __restrict__ am, const int64_t* __restrict__ px,
                                                        const int64_t* __restrict__ py, const int64_t* __restrict__ offsets,
-                                                       int B, int H, int W, int64_t P, int knn, const float* __restrict__ invg,
+                                                       int B, int H, int W, int knn, const float* __restrict__ invg,
                                                        float cutoff, int nclasses, int64_t* __restrict__ labels) {
   constexpr int S2 = S * S, PAD = (S - 1) / 2, CENTER = (S2 - 1) / 2;
   __shared__ float wsh[S2];

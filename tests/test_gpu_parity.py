@@ -1551,3 +1551,39 @@ def test_objective_row_mapping_is_bit_identical():
         assert len(fp) == 1, r.stdout
         out.append(fp[0])
     assert out[0] == out[1], out
+
+
+@pytest.mark.parametrize("search,knn_k,cutoff", [(5, 5, 1.0), (3, 3, 0.0), (7, 5, 1.0)])
+def test_knn_batch_equals_per_frame_calls(search, knn_k, cutoff):
+    """pmf_knn_vote_batch (window staged through LDS per 256-point workgroup for search <= 5; global gathers when the
+    workgroup's bounding box is too large, and for 7x7) against one pmf_knn_vote call per frame: bit-identical labels for
+    sweep-ordered points, shuffled points (fallback), an EMPTY frame, frame sizes that are no multiple of 256, points on
+    the image border and points far outside the image, sparse range images (-1 pixels)."""
+    from pmf_amd.postproc import KNN
+    H, W, B = 64, 512, 4
+    g = torch.Generator().manual_seed(search * 10 + knn_k)
+    knn = KNN({"knn": knn_k, "search": search, "sigma": 1.0, "cutoff": cutoff}, 20)
+    pr = torch.rand(B, H, W, generator=g) * 40 + 2
+    pr = torch.where(torch.rand(B, H, W, generator=g) < 0.5, pr, torch.full_like(pr, -1.0))
+    am = torch.randint(0, 20, (B, H, W), generator=g)
+    counts = [3001, 0, 777, 5000]
+    for order in ("sweep", "shuffled"):
+        frames = []
+        for b in range(B):
+            n = counts[b]
+            y = torch.randint(0, H, (n,), generator=g)
+            x = torch.randint(0, W, (n,), generator=g)
+            if n:
+                y[:8] = torch.tensor([0, 0, H - 1, H - 1, 0, H - 1, 5, 9])                 # borders and corners
+                x[:8] = torch.tensor([0, W - 1, 0, W - 1, 7, 11, 0, W - 1])
+            if order == "sweep" and n:
+                o = torch.argsort(x * H + y, stable=True)
+                x, y = x[o], y[o]
+            if b == 3 and n:                                                              # far outside: every tap is padding
+                x[100], y[100] = 10 * W, -3 * H
+            ur = torch.rand(n, generator=g) * 40 + 2
+            frames.append((pr[b].cuda(), ur.cuda(), am[b].cuda(), x.cuda(), y.cuda()))
+        got = knn.batch(frames)
+        for b, f in enumerate(frames):
+            want = knn(f[0], f[1], f[2], f[3], f[4]) if counts[b] else torch.empty(0, dtype=torch.int64, device="cuda")
+            assert got[b].shape == want.shape and torch.equal(got[b], want), (order, b)
