@@ -170,10 +170,9 @@ __global__ __launch_bounds__(256) void knn_batch_lds_k(const float* __restrict__
                                                        int B, int H, int W, int knn, const float* __restrict__ invg,
                                                        float cutoff, int nclasses, int64_t* __restrict__ labels) {
   constexpr int S2 = S * S, PAD = (S - 1) / 2, CENTER = (S2 - 1) / 2;
-  __shared__ float wsh[S2];
   __shared__ float s_v[KNN_LDS_PIX];
   __shared__ int s_l[KNN_LDS_PIX];
-  __shared__ int s_box[4];
+  __shared__ int s_wbox[4][4];          // per wave: min x, max x, min y, max y (no initialisation, no atomics: one barrier less)
   // frame of this workgroup: frame b owns ceil(n_b / 256) consecutive workgroups.  B is small; the walk has no early exit so
   // that its scalar loads are independent of each other (one memory latency, not one per frame).  (Measured: indexing the
   // concatenated list directly, so that the point loads do not wait for this walk, is SLOWER -- 13.2 vs 11.7 us -- the
@@ -192,9 +191,6 @@ __global__ __launch_bounds__(256) void knn_batch_lds_k(const float* __restrict__
     }
   }
   if (b < 0) return;                                    // (the grid is an upper bound)
-  if (threadIdx.x < S2) wsh[threadIdx.x] = invg[threadIdx.x];
-  if (threadIdx.x == 0) { s_box[0] = 0x7fffffff; s_box[1] = -0x7fffffff; s_box[2] = 0x7fffffff; s_box[3] = -0x7fffffff; }
-  __syncthreads();
   const int64_t i = lo + (int64_t)wg * 256 + threadIdx.x;
   const bool valid = i < hi;
   const float* __restrict__ prb = pr + (size_t)b * H * W;
@@ -212,12 +208,17 @@ __global__ __launch_bounds__(256) void knn_batch_lds_k(const float* __restrict__
       mny = min(mny, __shfl_xor(mny, o)); mxy = max(mxy, __shfl_xor(mxy, o));
     }
     if ((threadIdx.x & 63) == 0) {
-      atomicMin(&s_box[0], mnx); atomicMax(&s_box[1], mxx); atomicMin(&s_box[2], mny); atomicMax(&s_box[3], mxy);
+      int* wb = s_wbox[threadIdx.x >> 6];
+      wb[0] = mnx; wb[1] = mxx; wb[2] = mny; wb[3] = mxy;
     }
   }
   __syncthreads();
-  const int x0 = s_box[0] - PAD, y0 = s_box[2] - PAD;
-  const long bw = (long)s_box[1] - s_box[0] + 1 + 2 * PAD, bh = (long)s_box[3] - s_box[2] + 1 + 2 * PAD;
+  const int bx0 = min(min(s_wbox[0][0], s_wbox[1][0]), min(s_wbox[2][0], s_wbox[3][0]));
+  const int bx1 = max(max(s_wbox[0][1], s_wbox[1][1]), max(s_wbox[2][1], s_wbox[3][1]));
+  const int by0 = min(min(s_wbox[0][2], s_wbox[1][2]), min(s_wbox[2][2], s_wbox[3][2]));
+  const int by1 = max(max(s_wbox[0][3], s_wbox[1][3]), max(s_wbox[2][3], s_wbox[3][3]));
+  const int x0 = bx0 - PAD, y0 = by0 - PAD;
+  const long bw = (long)bx1 - bx0 + 1 + 2 * PAD, bh = (long)by1 - by0 + 1 + 2 * PAD;
   const bool staged = bw > 0 && bh > 0 && bw * bh <= KNN_LDS_PIX;
   if (staged) {
     // all loads of the box first (up to 16 pixels per thread, independent), then the LDS stores: one memory latency
@@ -258,7 +259,7 @@ __global__ __launch_bounds__(256) void knn_batch_lds_k(const float* __restrict__
       const int j = base + (t / S) * w_ + (t % S);
       float v = s_v[j];
       if (t == CENTER) v = r;
-      dist[t] = fabsf(v - r) * wsh[t];
+      dist[t] = fabsf(v - r) * invg[t];
       lab[t] = s_l[j];
     }
   } else {
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(256) void knn_batch_lds_k(const float* __restrict__
         if (v < 0.f) v = INFINITY;
       }
       if (t == CENTER) v = r;
-      dist[t] = fabsf(v - r) * wsh[t];
+      dist[t] = fabsf(v - r) * invg[t];
       lab[t] = l;
     }
   }
