@@ -66,6 +66,12 @@ __global__ __launch_bounds__(256) void knn_k(const float* __restrict__ pr, const
   labels[i] = best_cls;
 }
 
+template <int S>
+__global__ void knn_batch_lds_k(const float* __restrict__ pr, const float* __restrict__ ur, const int64_t* __restrict__ am,
+                                const int64_t* __restrict__ px, const int64_t* __restrict__ py,
+                                const int64_t* __restrict__ offsets, int B, int H, int W, int64_t P1, int knn,
+                                const float* __restrict__ invg, float cutoff, int nclasses, int64_t* __restrict__ labels);
+
 extern "C" int pmf_knn_vote(const float* proj_range, const float* unproj_range, const int64_t* proj_argmax,
                             const int64_t* px, const int64_t* py, int32_t H, int32_t W, int64_t P, int32_t knn,
                             int32_t search, const float* inv_gauss, float cutoff, int32_t nclasses, int64_t* labels,
@@ -75,6 +81,13 @@ extern "C" int pmf_knn_vote(const float* proj_range, const float* unproj_range, 
   if (P <= 0) return 0;
   dim3 grid((unsigned)cdiv64(P, 256)), block(256);
   hipStream_t st = (hipStream_t)s;
+  static const bool no_lds = getenv("PMF_KNN_LDS") && atoi(getenv("PMF_KNN_LDS")) == 0;     // A/B knob
+  if (!no_lds && search <= 5) {        // the LDS-staged form (below), one frame, no offsets table
+    if (search == 3) hipLaunchKernelGGL(knn_batch_lds_k<3>, grid, block, 0, st, proj_range, unproj_range, proj_argmax, px, py, (const int64_t*)nullptr, 1, H, W, P, knn, inv_gauss, cutoff, nclasses, labels);
+    else hipLaunchKernelGGL(knn_batch_lds_k<5>, grid, block, 0, st, proj_range, unproj_range, proj_argmax, px, py, (const int64_t*)nullptr, 1, H, W, P, knn, inv_gauss, cutoff, nclasses, labels);
+    PMF_LAUNCH_CHECK();
+    return 0;
+  }
   switch (search) {
     case 3: hipLaunchKernelGGL(knn_k<3>, grid, block, 0, st, proj_range, unproj_range, proj_argmax, px, py, H, W, P, knn, inv_gauss, cutoff, nclasses, labels); break;
     case 5: hipLaunchKernelGGL(knn_k<5>, grid, block, 0, st, proj_range, unproj_range, proj_argmax, px, py, H, W, P, knn, inv_gauss, cutoff, nclasses, labels); break;
@@ -167,7 +180,7 @@ template <int S>
 __global__ __launch_bounds__(256) void knn_batch_lds_k(const float* __restrict__ pr, const float* __restrict__ ur,
                                                        const int64_t* __restrict__ am, const int64_t* __restrict__ px,
                                                        const int64_t* __restrict__ py, const int64_t* __restrict__ offsets,
-                                                       int B, int H, int W, int knn, const float* __restrict__ invg,
+                                                       int B, int H, int W, int64_t P1, int knn, const float* __restrict__ invg,
                                                        float cutoff, int nclasses, int64_t* __restrict__ labels) {
   constexpr int S2 = S * S, PAD = (S - 1) / 2, CENTER = (S2 - 1) / 2;
   __shared__ float s_v[KNN_LDS_PIX];
@@ -179,7 +192,8 @@ __global__ __launch_bounds__(256) void knn_batch_lds_k(const float* __restrict__
   // per-thread frame search and the mixed-frame handling cost more than the overlap gives.)
   int b = -1, wg = 0;
   int64_t lo = 0, hi = 0;
-  {
+  if (!offsets) { b = 0; wg = (int)blockIdx.x; hi = P1; }        // one frame of P1 points (pmf_knn_vote): no table
+  else {
     int first = 0;
     int64_t o0 = offsets[0];
     for (int k = 0; k < B; ++k) {
@@ -319,8 +333,8 @@ extern "C" int pmf_knn_vote_batch(const float* proj_range, const float* unproj_r
   static const bool no_lds = getenv("PMF_KNN_LDS") && atoi(getenv("PMF_KNN_LDS")) == 0;     // A/B knob
   if (!no_lds && search <= 5) {       // (7x7: 49 + 49 window registers next to 32 KB of LDS -- stays on the gather form)
     const dim3 g2((unsigned)(cdiv64(P_total, 256) + B)), b2(256);      // sum_b ceil(n_b / 256) <= ceil(P / 256) + B
-    if (search == 3) hipLaunchKernelGGL(knn_batch_lds_k<3>, g2, b2, 0, st, proj_range, unproj_range, proj_argmax, px, py, offsets, B, H, W, knn, inv_gauss, cutoff, nclasses, labels);
-    else hipLaunchKernelGGL(knn_batch_lds_k<5>, g2, b2, 0, st, proj_range, unproj_range, proj_argmax, px, py, offsets, B, H, W, knn, inv_gauss, cutoff, nclasses, labels);
+    if (search == 3) hipLaunchKernelGGL(knn_batch_lds_k<3>, g2, b2, 0, st, proj_range, unproj_range, proj_argmax, px, py, offsets, B, H, W, (int64_t)0, knn, inv_gauss, cutoff, nclasses, labels);
+    else hipLaunchKernelGGL(knn_batch_lds_k<5>, g2, b2, 0, st, proj_range, unproj_range, proj_argmax, px, py, offsets, B, H, W, (int64_t)0, knn, inv_gauss, cutoff, nclasses, labels);
     PMF_LAUNCH_CHECK();
     return 0;
   }
