@@ -373,8 +373,9 @@ int pmf_project_v2_scatter(const float* points, const int32_t* sem, const int32_
                            int32_t iw, const int32_t* lut, int32_t nlut, int32_t x_min, int32_t y_min, int32_t h,
                            int32_t w, float* proj_out, int32_t* pix_idx, pmf_stream_t s);
 /* pmf_project_scatter in TWO launches and without the per-call memset (the loader's per-frame path): pix_tag u32[h*w] and
- * slots u64[ceil(P/1024)] are PERSISTENT workspaces of the caller, zeroed once and again whenever `generation` (1..4095,
- * +1 per call on the same workspaces) wraps; P <= 2^20.  Outputs bit-identical to pmf_project_scatter. */
+ * slots u64[1 + ceil(P/1024)] (slots[0] = the block-ticket counter, left at 0 by every call) are PERSISTENT workspaces of the
+ * caller, zeroed once and again whenever `generation` (1..4095, +1 per call on the same workspaces) wraps; calls that share
+ * workspaces must be ordered (one stream); P <= 2^20.  Outputs bit-identical to pmf_project_scatter. */
 int pmf_project_scatter2(const float* points, const int32_t* sem, int64_t P, const uint8_t* image, int32_t h, int32_t w,
                          const double* proj, const int32_t* lut, int32_t nlut, float* proj_out, uint8_t* keep,
                          int32_t* x_data, int32_t* y_data, float* depth, int32_t* n_kept, uint32_t* pix_tag, uint64_t* slots,

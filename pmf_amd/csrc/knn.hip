@@ -66,6 +66,73 @@ __global__ __launch_bounds__(256) void knn_k(const float* __restrict__ pr, const
   labels[i] = best_cls;
 }
 
+// ---- any odd window (search = 1, 9, 11, ...; the reference accepts every odd size, knn.py:73-74; the nuScenes config ships
+// search 11, tasks/pmf_eval_nuscenes/config_server_nus.yaml) -------------------------------------------------------------
+// One lane per point, window size at run time.  k x first-minimum with ties -> smaller window index is what a STABLE
+// insertion into an ascending list of length k produces (an equal distance seen later never moves in front of an earlier
+// one); the vote only counts labels, so the order inside the list does not matter.  Same float32 arithmetic as knn_k:
+// bit-identical labels where both apply (tests).  Frames of a batch through the offsets table (nullptr: one frame).
+__global__ __launch_bounds__(64) void knn_any_k(const float* __restrict__ pr, const float* __restrict__ ur,
+                                                const int64_t* __restrict__ am, const int64_t* __restrict__ px,
+                                                const int64_t* __restrict__ py, const int64_t* __restrict__ offsets, int B,
+                                                int H, int W, int64_t P, int knn, int S, const float* __restrict__ invg,
+                                                float cutoff, int nclasses, int64_t* __restrict__ labels) {
+  const int64_t i = blockIdx.x * (int64_t)64 + threadIdx.x;
+  if (i >= P) return;
+  int b = 0;
+  if (offsets) for (int k = 1; k < B; ++k) b += offsets[k] <= i;
+  const float* __restrict__ prb = pr + (size_t)b * H * W;
+  const int64_t* __restrict__ amb = am + (size_t)b * H * W;
+  const int cx = (int)px[i], cy = (int)py[i], PAD = (S - 1) / 2, CENTER = (S * S - 1) / 2;
+  const float r = ur[i];
+  float bd[8];
+  int bl[8];
+  const int nsel = knn < 8 ? knn : 8;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { bd[k] = INFINITY; bl[k] = 0; }
+  int filled = 0;
+  for (int ty = 0, t = 0; ty < S; ++ty)
+    for (int tx = 0; tx < S; ++tx, ++t) {
+      const int y = cy + ty - PAD, x = cx + tx - PAD;
+      float v = 0.f;
+      int l = 0;
+      if (y >= 0 && y < H && x >= 0 && x < W) {
+        v = prb[(size_t)y * W + x];
+        l = (int)amb[(size_t)y * W + x];
+        if (v < 0.f) v = INFINITY;
+      }
+      if (t == CENTER) v = r;
+      float d = fabsf(v - r) * invg[t];
+      // position = number of kept entries with distance <= d (stable); NaN-free: distances are >= 0 or +inf
+      int pos = 0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) pos += (k < filled && bd[k] <= d) ? 1 : 0;
+      if (pos < nsel) {
+#pragma unroll
+        for (int k = 7; k > 0; --k)
+          if (k > pos && k < nsel) { bd[k] = bd[k - 1]; bl[k] = bl[k - 1]; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (k == pos) { bd[k] = d; bl[k] = l; }
+        filled = filled < nsel ? filled + 1 : filled;
+      }
+    }
+  int best_cnt = 0, best_cls = 1;
+  for (int a = 0; a < nsel; ++a) {
+    int cls = bl[a];
+    if (cutoff > 0.f && bd[a] > cutoff) cls = nclasses;
+    if (cls < 1 || cls >= nclasses) continue;
+    int cnt = 0;
+    for (int c = 0; c < nsel; ++c) {
+      int cc = bl[c];
+      if (cutoff > 0.f && bd[c] > cutoff) cc = nclasses;
+      cnt += cc == cls;
+    }
+    if (cnt > best_cnt || (cnt == best_cnt && cls < best_cls)) { best_cnt = cnt; best_cls = cls; }
+  }
+  labels[i] = best_cls;
+}
+
 template <int S>
 __global__ void knn_batch_lds_k(const float* __restrict__ pr, const float* __restrict__ ur, const int64_t* __restrict__ am,
                                 const int64_t* __restrict__ px, const int64_t* __restrict__ py,
@@ -82,7 +149,8 @@ extern "C" int pmf_knn_vote(const float* proj_range, const float* unproj_range, 
   dim3 grid((unsigned)cdiv64(P, 256)), block(256);
   hipStream_t st = (hipStream_t)s;
   static const bool no_lds = getenv("PMF_KNN_LDS") && atoi(getenv("PMF_KNN_LDS")) == 0;     // A/B knob
-  if (!no_lds && search <= 5) {        // the LDS-staged form (below), one frame, no offsets table
+  if (search < 1 || search > 255) return PMF_E_ARG;
+  if (!no_lds && (search == 3 || search == 5)) {        // the LDS-staged form (below), one frame, no offsets table
     if (search == 3) hipLaunchKernelGGL(knn_batch_lds_k<3>, grid, block, 0, st, proj_range, unproj_range, proj_argmax, px, py, (const int64_t*)nullptr, 1, H, W, P, knn, inv_gauss, cutoff, nclasses, labels);
     else hipLaunchKernelGGL(knn_batch_lds_k<5>, grid, block, 0, st, proj_range, unproj_range, proj_argmax, px, py, (const int64_t*)nullptr, 1, H, W, P, knn, inv_gauss, cutoff, nclasses, labels);
     PMF_LAUNCH_CHECK();
@@ -92,7 +160,8 @@ extern "C" int pmf_knn_vote(const float* proj_range, const float* unproj_range, 
     case 3: hipLaunchKernelGGL(knn_k<3>, grid, block, 0, st, proj_range, unproj_range, proj_argmax, px, py, H, W, P, knn, inv_gauss, cutoff, nclasses, labels); break;
     case 5: hipLaunchKernelGGL(knn_k<5>, grid, block, 0, st, proj_range, unproj_range, proj_argmax, px, py, H, W, P, knn, inv_gauss, cutoff, nclasses, labels); break;
     case 7: hipLaunchKernelGGL(knn_k<7>, grid, block, 0, st, proj_range, unproj_range, proj_argmax, px, py, H, W, P, knn, inv_gauss, cutoff, nclasses, labels); break;
-    default: return PMF_E_UNSUPPORTED;
+    default:     // every other odd window (1, 9, 11, ...): run-time window size
+      hipLaunchKernelGGL(knn_any_k, dim3((unsigned)cdiv64(P, 64)), dim3(64), 0, st, proj_range, unproj_range, proj_argmax, px, py, (const int64_t*)nullptr, 1, H, W, P, knn, search, inv_gauss, cutoff, nclasses, labels);
   }
   PMF_LAUNCH_CHECK();
   return 0;
@@ -331,7 +400,8 @@ extern "C" int pmf_knn_vote_batch(const float* proj_range, const float* unproj_r
   if (P_total <= 0) return 0;
   hipStream_t st = (hipStream_t)s;
   static const bool no_lds = getenv("PMF_KNN_LDS") && atoi(getenv("PMF_KNN_LDS")) == 0;     // A/B knob
-  if (!no_lds && search <= 5) {       // (7x7: 49 + 49 window registers next to 32 KB of LDS -- stays on the gather form)
+  if (search < 1 || search > 255) return PMF_E_ARG;
+  if (!no_lds && (search == 3 || search == 5)) {       // (7x7: 49 + 49 window registers next to 32 KB of LDS -- stays on the gather form)
     const dim3 g2((unsigned)(cdiv64(P_total, 256) + B)), b2(256);      // sum_b ceil(n_b / 256) <= ceil(P / 256) + B
     if (search == 3) hipLaunchKernelGGL(knn_batch_lds_k<3>, g2, b2, 0, st, proj_range, unproj_range, proj_argmax, px, py, offsets, B, H, W, (int64_t)0, knn, inv_gauss, cutoff, nclasses, labels);
     else hipLaunchKernelGGL(knn_batch_lds_k<5>, g2, b2, 0, st, proj_range, unproj_range, proj_argmax, px, py, offsets, B, H, W, (int64_t)0, knn, inv_gauss, cutoff, nclasses, labels);
@@ -343,7 +413,8 @@ extern "C" int pmf_knn_vote_batch(const float* proj_range, const float* unproj_r
     case 3: hipLaunchKernelGGL(knn_batch_k<3>, grid, block, 0, st, proj_range, unproj_range, proj_argmax, px, py, offsets, B, H, W, P_total, knn, inv_gauss, cutoff, nclasses, labels); break;
     case 5: hipLaunchKernelGGL(knn_batch_k<5>, grid, block, 0, st, proj_range, unproj_range, proj_argmax, px, py, offsets, B, H, W, P_total, knn, inv_gauss, cutoff, nclasses, labels); break;
     case 7: hipLaunchKernelGGL(knn_batch_k<7>, grid, block, 0, st, proj_range, unproj_range, proj_argmax, px, py, offsets, B, H, W, P_total, knn, inv_gauss, cutoff, nclasses, labels); break;
-    default: return PMF_E_UNSUPPORTED;
+    default:
+      hipLaunchKernelGGL(knn_any_k, grid, block, 0, st, proj_range, unproj_range, proj_argmax, px, py, offsets, B, H, W, P_total, knn, search, inv_gauss, cutoff, nclasses, labels);
   }
   PMF_LAUNCH_CHECK();
   return 0;

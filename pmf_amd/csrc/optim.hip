@@ -10,16 +10,17 @@
 
 __global__ __launch_bounds__(256) void adamw_range_k(float* __restrict__ p, const float* __restrict__ g,
                                                      float* __restrict__ m, float* __restrict__ v, int64_t n4, int64_t n,
-                                                     float lr, float beta1, float beta2, float eps, float wd,
+                                                     float lr, float beta1, float beta2, float eps, float keep,
                                                      double beta1d, double beta2d, const float* __restrict__ step) {
   // bias corrections from the step counter on the device (the caller incremented it for this step): no host read
   const double st = (double)*step;
   const float bc1 = (float)(1.0 - pow(beta1d, st)), bc2 = (float)(1.0 - pow(beta2d, st));
   // 1 - beta in double first: float(1 - 0.999) and 1.f - float(0.999) differ by 5e-5 relative
-  const float step_size = lr / bc1, bc2_sqrt = sqrtf(bc2), decay = lr * wd, w1 = (float)(1.0 - beta1d), w2 = (float)(1.0 - beta2d);
+  const float step_size = lr / bc1, bc2_sqrt = sqrtf(bc2), w1 = (float)(1.0 - beta1d), w2 = (float)(1.0 - beta2d);
   const int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x;
   auto upd = [&](float& pp, float gg, float& mm, float& vv) {
-    pp -= decay * pp;                          // param.mul_(1 - lr * weight_decay)
+    pp = pp * keep;                            // param.mul_(1 - lr * weight_decay): the factor is formed in double by
+                                               // Python and rounded once to float32 (the host passes it), as torch does
     mm = mm + w1 * (gg - mm);                  // exp_avg.lerp_(grad, 1 - beta1)
     vv = beta2 * vv + w2 * (gg * gg);          // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
     const float denom = sqrtf(vv) / bc2_sqrt + eps;
@@ -78,7 +79,7 @@ extern "C" int pmf_adamw_range(float* param, const float* grad, float* exp_avg, 
   const int64_t n4 = (al16(param) && al16(grad) && al16(exp_avg) && al16(exp_avg_sq)) ? n / 4 : 0;
   const int64_t threads = n4 + (n - 4 * n4);
   hipLaunchKernelGGL(adamw_range_k, dim3((unsigned)cdiv64(threads, 256)), dim3(256), 0, (hipStream_t)s, param, grad, exp_avg,
-                     exp_avg_sq, n4, n, (float)lr, (float)beta1, (float)beta2, (float)eps, (float)weight_decay, beta1, beta2,
+                     exp_avg_sq, n4, n, (float)lr, (float)beta1, (float)beta2, (float)eps, (float)(1.0 - lr * weight_decay), beta1, beta2,
                      step);
   PMF_LAUNCH_CHECK();
   return 0;

@@ -119,6 +119,9 @@ static hipStream_t g_lane[PMF_MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
 static hipEvent_t g_fork = nullptr, g_join[PMF_MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
 static hipEvent_t g_ev[PMF_MAX_EVENTS];
 static int g_nev = 0;
+// true while the latest enqueued run recorded its plan events only as NODES of a multi-branch hipGraph ("single" mode): a
+// stream wait on such an event would look at a stale or never-made stream record -- pmf_plan_event_wait refuses
+static bool g_ev_graph_only = false;
 // The lane streams and events above belong to ONE device (one process per GPU): they are created on the
 // device that is current at the first lane use, and a plan run with another device current is refused instead of being
 // enqueued on foreign streams.  (The lazily created objects are not guarded against concurrent first use either: plans
@@ -277,6 +280,10 @@ static int run_range(const pmf_op_t* ops, int32_t begin, int32_t end, hipStream_
   for (int32_t j = begin; j < end; ++j) {
     const int r = ((ops[j].pad_ >> 16) & 0xff) - 1;
     if (r >= 0 && rec_at[r] < 0) rec_at[r] = j;
+  }
+  {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(main_s, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone) g_ev_graph_only = false;  // eager: real records
   }
   int32_t k = begin;
   for (size_t oi = 0; oi < order.size() && rc == 0; ++oi) {
@@ -476,7 +483,8 @@ extern "C" int pmf_graph_launch(void* graph_exec, pmf_stream_t s) {
   if (!graph_exec) return PMF_E_ARG;
   PlanProgram* prog = (PlanProgram*)graph_exec;
   hipStream_t main_s = (hipStream_t)s;
-  if (prog->single) return (int)hipGraphLaunch(prog->single, main_s);
+  if (prog->single) { g_ev_graph_only = true; return (int)hipGraphLaunch(prog->single, main_s); }
+  g_ev_graph_only = false;
   hipStream_t st[PMF_MAX_LANES] = {main_s, nullptr, nullptr, nullptr};
   int rc = 0;
   for (int l = 1; l < PMF_MAX_LANES && rc == 0; ++l) {
@@ -529,7 +537,7 @@ extern "C" int pmf_graph_destroy(void* graph_exec) {
 // of cutting the backward plan into segments).  PMF_E_UNSUPPORTED when the event has never been recorded (lanes off).
 extern "C" int pmf_plan_event_wait(int32_t e, pmf_stream_t s) {
   if (e < 0 || e >= PMF_MAX_EVENTS) return PMF_E_ARG;
-  if (e >= g_nev || !lanes_enabled()) return PMF_E_UNSUPPORTED;
+  if (e >= g_nev || !lanes_enabled() || g_ev_graph_only) return PMF_E_UNSUPPORTED;
   if (int rc = lane_device_ok()) return rc;
   return (int)hipStreamWaitEvent((hipStream_t)s, g_ev[e], 0);
 }

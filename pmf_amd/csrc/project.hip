@@ -144,8 +144,10 @@ extern "C" int pmf_project_scatter(const float* points, const int32_t* sem, int6
 // pmf_project_scatter is five enqueues (memset, count, scan, scatter, gather) for ~2 MB of data: launch latency, not work.
 // Here (1) ONE kernel projects, compacts and scatters: a block publishes its kept-point count in a slot tagged with the
 // call's generation (relaxed agent-scope atomics: the value travels in the same word as the tag, no fence needed) and reads
-// the slots of the blocks in front of it -- dispatch is in order and a frame is ~120 blocks, all resident, so the wait is
-// short and cannot deadlock; the winner of a pixel is an atomicMax over (generation << 20 | point index), so entries of
+// the slots of the blocks in front of it.  "In front" is by TICKET, not by blockIdx: a block's logical index is what it
+// draws from a device counter when it starts (slots[0]; the block that draws the last ticket puts the counter back to 0
+// for the next call on this workspace, which is stream-ordered behind this one), so every block it waits for has already
+// started -- no assumption about the dispatch order of HIP, which promises none, and no deadlock; the winner of a pixel is an atomicMax over (generation << 20 | point index), so entries of
 // earlier frames lose against the current one and the per-pixel table is never cleared (the caller zeroes it once every
 // 4095 frames); (2) the gather pass.  Same outputs, bit for bit.
 __global__ __launch_bounds__(PB) void proj_fused_k(const float* __restrict__ pts, int64_t P, const double* __restrict__ m,
@@ -155,7 +157,12 @@ __global__ __launch_bounds__(PB) void proj_fused_k(const float* __restrict__ pts
                                                    unsigned gen, int32_t* __restrict__ n_kept) {
   __shared__ int wave_cnt[PB / 64];
   __shared__ int red[PB / 64];
-  const int64_t i = blockIdx.x * (int64_t)PB + threadIdx.x;
+  __shared__ unsigned s_bid;
+  if (threadIdx.x == 0) s_bid = (unsigned)atomicAdd(slots, 1ull);       // ticket = logical block index
+  __syncthreads();
+  const unsigned bid = s_bid;
+  slots += 1;
+  const int64_t i = bid * (int64_t)PB + threadIdx.x;
   int r = 0, c = 0;
   const bool k = i < P && project_point(pts + i * 4, m, h, w, r, c);
   if (i < P) {
@@ -171,11 +178,11 @@ __global__ __launch_bounds__(PB) void proj_fused_k(const float* __restrict__ pts
   int woff = 0, cnt = 0;
   for (int j = 0; j < PB / 64; ++j) { if (j < wv) woff += wave_cnt[j]; cnt += wave_cnt[j]; }
   if (threadIdx.x == 0)
-    __hip_atomic_store(slots + blockIdx.x, ((unsigned long long)gen << 32) | (unsigned)cnt, __ATOMIC_RELAXED,
+    __hip_atomic_store(slots + bid, ((unsigned long long)gen << 32) | (unsigned)cnt, __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);
   // counts of the blocks in front: thread t waits for slot t, t + 1024, ...
   int part = 0;
-  for (int b = threadIdx.x; b < (int)blockIdx.x; b += PB) {
+  for (int b = threadIdx.x; b < (int)bid; b += PB) {
     unsigned long long v;
     do { v = __hip_atomic_load(slots + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((unsigned)(v >> 32) != gen);
     part += (int)(unsigned)v;
@@ -192,7 +199,10 @@ __global__ __launch_bounds__(PB) void proj_fused_k(const float* __restrict__ pts
     y_data[dst] = c;
     atomicMax(pix_tag + (size_t)r * w + c, (gen << 20) | (unsigned)i);
   }
-  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *n_kept = boff + cnt;
+  if (bid == gridDim.x - 1 && threadIdx.x == 0) {
+    *n_kept = boff + cnt;
+    __hip_atomic_store(slots - 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // every ticket of this call is drawn
+  }
 }
 
 __global__ void proj_gather_tag_k(const float* __restrict__ pts, const int32_t* __restrict__ sem,

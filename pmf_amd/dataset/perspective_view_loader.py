@@ -110,13 +110,18 @@ _CONST_CACHE = {}                  # small host constants (projection matrix, la
 
 
 def _proj_workspace(dev, h, w, nblk):
-    """(pix_tag u32[h*w], slots u64[>= nblk], generation) of pmf_project_scatter2 for this thread: allocated once per image
-    size, zeroed once and whenever the generation counter wraps (4095 frames)"""
+    """(pix_tag u32[h*w], slots u64[>= nblk + 1], generation) of pmf_project_scatter2 for this thread AND stream: allocated once per
+    image size, zeroed once and whenever the generation counter wraps (4095 frames).  Keyed by the current stream as well:
+    two calls of one thread on different streams may overlap on the GPU, and call N + 1's atomicMax with generation g + 1
+    would overwrite the tags call N's gather pass still reads; calls on ONE stream are ordered."""
     tab = _PROJ_TLS.__dict__.setdefault("ws", {})
-    ent = tab.get((str(dev), h, w))
-    if ent is None or ent[1].numel() < nblk:
-        ent = tab[(str(dev), h, w)] = [torch.zeros(h * w, dtype=torch.int32, device=dev),
-                                       torch.zeros(max(nblk, 256), dtype=torch.int64, device=dev), 0]
+    key = (str(dev), h, w, int(torch.cuda.current_stream(dev).cuda_stream))
+    ent = tab.get(key)
+    if ent is None or ent[1].numel() < nblk + 1:
+        if len(tab) > 64:        # streams come and go (prefetch workers): do not grow without bound
+            tab.clear()
+        ent = tab[key] = [torch.zeros(h * w, dtype=torch.int32, device=dev),
+                          torch.zeros(max(nblk + 1, 256), dtype=torch.int64, device=dev), 0]
     ent[2] += 1
     if ent[2] > 4095:
         ent[0].zero_()

@@ -37,6 +37,12 @@ def _build(kind):
         return (lambda: deterministic_init(EPMFNet(5, 3, 20, 32, False, "resnet34")),
                 lambda: deterministic_init(E.EPMFNet(5, 3, 20, 32, False, "resnet34")), 20, (2, 64, 2048), 0.3)
     from pmf_amd.models import PMFNet
+    if kind == "pmf_r34_sb":
+        # S_B of SURVEY 8d: both streams 480 x 640 (the "+ 480x640" of BASELINE.json's metric).  H / 16 = 30 rows at the
+        # bottleneck: the only BASELINE shape where all nine taps of the dilation-12 / 18 ASPP branches are in bounds
+        # (pc_processor/models/pmf_net.py:110-115), forward and backward
+        return (lambda: deterministic_init(PMFNet(5, 3, 20, 32, False, "resnet34")),
+                lambda: deterministic_init(O.PMFNet(5, 3, 20, 32, False, "resnet34")), 20, (2, 480, 640), 0.25)
     if kind == "r50":
         return (lambda: deterministic_init(PMFNet(5, 3, 17, 32, False, "resnet50")),
                 lambda: deterministic_init(O.PMFNet(5, 3, 17, 32, False, "resnet50")), 17, (2, 32, 1024), 0.25)
@@ -73,8 +79,10 @@ def _oracle_grads(kind):
 
 
 # (the headline configuration with both tile-configuration sources; configs[3] / [4] with the reproducible heuristics)
-@pytest.mark.parametrize("kind,tune", [("pmf_r34", "0"), ("pmf_r34", "1"), ("r50", "0"), ("epmf", "0")],
-                         ids=["pmf_r34-heuristic", "pmf_r34-autotuned", "r50-heuristic", "epmf-heuristic"])
+@pytest.mark.parametrize("kind,tune", [("pmf_r34", "0"), ("pmf_r34", "1"), ("r50", "0"), ("r50", "1"), ("epmf", "0"),
+                                       ("epmf", "1"), ("pmf_r34_sb", "0"), ("pmf_r34_sb", "1")],
+                         ids=["pmf_r34-heuristic", "pmf_r34-autotuned", "r50-heuristic", "r50-autotuned", "epmf-heuristic",
+                              "epmf-autotuned", "pmf_r34_sb-heuristic", "pmf_r34_sb-autotuned"])
 def test_full_size_backward_vs_oracle(kind, tune):
     from pmf_amd.engine import TrainEngine
     from pmf_amd import plan as PL
@@ -145,15 +153,17 @@ def test_full_size_backward_vs_oracle(kind, tune):
     assert gmean < 1.25 and p90 < 1.6, (gmean, p90)
 
 
-def test_infer_bs4_logits_and_knn_vs_oracle():
-    """BASELINE configs[1]: eval forward of FOUR 64 x 2048 frames in one call + the KNN vote of every frame"""
+@pytest.mark.parametrize("h,w", [(64, 2048), (480, 640)], ids=["S_A-64x2048", "S_B-480x640"])
+def test_infer_bs4_logits_and_knn_vs_oracle(h, w):
+    """BASELINE configs[1]: eval forward of FOUR frames in one call + the KNN vote of every frame, at both shapes the
+    metric names (S_A: both streams 64 x 2048; S_B: both 480 x 640)"""
     from pmf_amd.models import PMFNet
     from pmf_amd.postproc import KNN
     from oracle import pmf_torch as O
     from oracle import knn_ref
     hip = deterministic_init(PMFNet(5, 3, 20, 32, False, "resnet34")).cuda().eval()
     ref = deterministic_init(O.PMFNet(5, 3, 20, 32, False, "resnet34")).eval()
-    bs, h, w = 4, 64, 2048
+    bs = 4
     pcd, rgb, _, mask = synthetic_batch(bs, h, w, 20, seed=31, fill=0.3)
     torch.set_num_threads(min(32, os.cpu_count() or 1))
     with torch.no_grad():

@@ -1587,3 +1587,32 @@ def test_knn_batch_equals_per_frame_calls(search, knn_k, cutoff):
         for b, f in enumerate(frames):
             want = knn(f[0], f[1], f[2], f[3], f[4]) if counts[b] else torch.empty(0, dtype=torch.int64, device="cuda")
             assert got[b].shape == want.shape and torch.equal(got[b], want), (order, b)
+
+
+@pytest.mark.parametrize("search,knn_k,cutoff", [(1, 1, 1.0), (9, 5, 1.0), (11, 5, 1.0), (11, 7, 0.0), (13, 8, 0.5)])
+def test_knn_any_odd_window_vs_oracle(search, knn_k, cutoff):
+    """Every odd search window the reference accepts (pc_processor/postproc/knn.py:73-74 only rejects even sizes; the nuScenes
+    config ships search 11): the run-time-window kernel against the numpy oracle, one frame and batched, incl. border
+    pixels, sparse maps and quantised ranges (distance ties).  search = 1 used to fall into the 5 x 5 LDS kernel."""
+    from pmf_amd.postproc import KNN
+    from oracle import knn_ref
+    H, W, n = 32, 256, 4000
+    rng = np.random.default_rng(search * 100 + knn_k)
+    frames, want = [], []
+    for b in range(2):
+        pr = (np.round(rng.random((H, W)) * 40 * 4) / 4 + 2).astype(np.float32)          # quantised: ties
+        pr[rng.random((H, W)) < 0.4] = -1.0
+        am = rng.integers(0, 20, (H, W)).astype(np.int64)
+        py = rng.integers(0, H, n).astype(np.int64)
+        px = rng.integers(0, W, n).astype(np.int64)
+        py[:4], px[:4] = [0, 0, H - 1, H - 1], [0, W - 1, 0, W - 1]
+        ur = (np.round(rng.random(n) * 40 * 4) / 4 + 2).astype(np.float32)
+        frames.append((pr, ur, am, px, py))
+        want.append(knn_ref.knn_vote(pr, ur, am, px, py, knn=knn_k, search=search, sigma=1.0, cutoff=cutoff, nclasses=20))
+    knn = KNN({"knn": knn_k, "search": search, "sigma": 1.0, "cutoff": cutoff}, 20)
+    t = lambda a: torch.from_numpy(a).cuda()
+    for f, w_ in zip(frames, want):
+        np.testing.assert_array_equal(knn(*[t(a) for a in f]).cpu().numpy(), w_)
+    got = knn.batch([tuple(t(a) for a in f) for f in frames])
+    for g_, w_ in zip(got, want):
+        np.testing.assert_array_equal(g_.cpu().numpy(), w_)
