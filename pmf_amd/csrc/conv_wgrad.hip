@@ -12,6 +12,18 @@
 // order (deterministic) and writes the gradient directly in PyTorch's OIHW layout.
 #include "common.h"
 #include <stdlib.h>
+#include <utility>
+
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>) -- unrolled by the front end (a
+// "#pragma unroll" the optimiser declines leaves the accumulator arrays dynamically indexed, i.e. in scratch memory)
+template <class F, int... Is>
+__device__ __forceinline__ void wg_static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void wg_static_for(F&& f) {
+  wg_static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
 
 #define WG_ROWS 4
 #define WG_CI 32
@@ -1093,6 +1105,377 @@ __global__ __launch_bounds__(256) void conv_wgrad_s3_swp_k(const pmf_wgrad_desc_
   conv_wgrad_s3_swp_body<TB, XSL>(d, g, smem);
 }
 
+// ---- N-split form (S3N): the four waves own DIFFERENT output-channel tiles of one staged input tile ----------------------
+// In conv_wgrad_s3_swp_body all four waves carry the same (32 ci x 32 co) tile for a quarter of the pixels each: the input
+// tile -- whose transform + three-way split + LDS store is ~300 of the ~770 instructions a wave issues per tile -- feeds
+// only 108 MFMAs per wave, and the loop is bound by instruction issue, not by the matrix pipe (round 3 phase stamps: the
+// same time with the MFMAs compiled out).  Here a workgroup owns 32 ci x (32 NCO) co: wave w carries output-channel tile
+// w % NCO for the pixel group w / NCO (NCO = 4: every wave sees all eight 16-pixel slabs of a tile; NCO = 2: four), so one
+// staged tile feeds NCO x as many MFMAs per wave (432 / 216 per tile at nine taps) for the same staging work.
+//   * dz never passes through LDS: the B fragment of a slab (pixel 8 lh + e, channel co0 + li) is eight 4-byte buffer
+//     loads per lane -- 128 contiguous bytes per pixel and half wave -- issued one slab ahead and split in registers at
+//     the end of the slab before; the tile/slab/pixel part of the address is a scalar (soffset);
+//   * the input tile is double-buffered in LDS and tile t + 1 is split and stored between the tap groups of tile t, as in
+//     the SWP body; one barrier per tile; LDS = the two input buffers only;
+//   * pixel groups (NCO = 2) are folded in a fixed order through LDS at the end; every wave with pixel group 0 writes its
+//     co tile of the partial slab.  Partial-slab layout, stage 2 and arithmetic are those of the SWP body.
+template <int TB, int XSL, int NCO>
+__device__ __forceinline__ void conv_wgrad_s3n_body(const pmf_wgrad_desc_t& d, const WgGeom& g, float* __restrict__ smem) {
+  constexpr int NPX = 4 / NCO;              // pixel groups
+  constexpr int NSL = 8 / NPX;              // 16-pixel slabs of a 4 x 32 tile per wave
+  char* __restrict__ Xs0 = (char*)smem;
+  char* __restrict__ Xs1 = (char*)(smem + g.x_floats);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cw = wave % NCO, pg = wave / NCO;
+  const int li = lane & 31, lh = lane >> 5;
+  const int split = blockIdx.x, chunk = blockIdx.y;
+  const int co0 = ((int)blockIdx.z * NCO + cw) * 32;
+  const int in_cols = g.in_cols;
+
+  int wtri_ = 0;
+  (void)wtri_;
+  WTR();
+  int si = 0, c0 = 0, k0 = 0;
+  {
+    int rem = chunk;
+    for (;;) {
+      const int nch = (d.src[si].C + WG_CI - 1) / WG_CI;
+      if (rem < nch) { c0 = rem * WG_CI; k0 += c0; break; }
+      rem -= nch; k0 += d.src[si].C; ++si;
+    }
+  }
+  const int sld = d.src[si].ldc, sflags = d.src[si].flags;
+  const int sH = d.OH, sW = d.OW;
+  const bool aff = d.src[si].scale != nullptr, has_cm = d.src[si].cmul != nullptr;
+  const int q = tid & 7, cch = c0 + q * 4;
+  const int kc = min(WG_CI, d.src[si].C - c0);
+  const bool qok = q * 4 < kc;
+  const int totalX = g.in_rows * in_cols * 8;
+  int sr[XSL], sc[XSL], so[XSL];
+  const float rcols = 1.f / (float)in_cols;
+#pragma unroll
+  for (int j = 0; j < XSL; ++j) {
+    const int f = tid + 256 * j, pix = f >> 3;
+    const int r = pmf_fdiv(pix, in_cols, rcols), c = pix - r * in_cols;
+    sr[j] = (f < totalX && qok) ? r : 0x7fff;
+    sc[j] = c;
+    so[j] = ((r * sW + c) * sld + cch) * 4;
+  }
+  int toff[TB];
+#pragma unroll
+  for (int j = 0; j < TB; ++j)
+    toff[j] = (((int)d.tdy[j] - g.dy_min) * in_cols + ((int)d.tdx[j] - g.dx_min)) * WS3_XPB;
+  const int trofs = (((lane >> 5) * 8 + ((lane & 15) >> 2)) * WS3_XPB) + ((((lane >> 4) & 1) * 16 + (lane & 3) * 4) * 2);
+
+  f32x16 acc[TB];
+#pragma unroll
+  for (int j = 0; j < TB; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  const __amdgpu_buffer_rsrc_t xrs_on =
+      __builtin_amdgcn_make_buffer_rsrc((void*)d.src[si].x, 0, d.N * sH * sW * sld * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t xrs_off = __builtin_amdgcn_make_buffer_rsrc((void*)d.src[si].x, 0, 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(has_cm ? d.src[si].cmul : d.src[si].x), 0, (has_cm && qok) ? d.N * d.src[si].cmul_ld * 4 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t zrs =
+      __builtin_amdgcn_make_buffer_rsrc((void*)d.dz, 0, d.N * d.OH * d.OW * d.dz_ldc * 4, 0x00020000);
+  const int zvoff = (lh * 8 * d.dz_ldc + co0 + li) * 4;          // the lane's part of a B-fragment address
+  const int zpix = d.dz_ldc * 4;                                  // bytes per pixel of dz
+  f32x4 sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
+  if (aff && qok) { sc4 = *(const f32x4*)(d.src[si].scale + cch); sh4 = *(const f32x4*)(d.src[si].shift + cch); }
+  f32x4 rX[XSL], rC;
+  float mX[XSL];
+  const int tiles_per_n = g.tiles_x * g.tiles_y;
+  typedef __attribute__((address_space(3))) ws16x4* lds_tr_t;
+  auto afrag = [&](const char* __restrict__ base, wbf16x8 (&a)[3]) {
+#ifdef PMF_WG_NOTR       /* ablation build: no transposing LDS reads */
+#pragma unroll
+    for (int p = 0; p < 3; ++p) { wu32x4 t = {(unsigned)(size_t)base, (unsigned)p, 1u, 2u}; asm volatile("" : "+v"(t)); a[p] = __builtin_bit_cast(wbf16x8, t); }
+    return;
+#endif
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      const ws16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_t)(base + p * 64));
+      const ws16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_t)(base + p * 64 + 4 * WS3_XPB));
+      a[p] = __builtin_bit_cast(wbf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    }
+  };
+  // slab i of this wave: tile row / first column, and the scalar byte offset of its first pixel relative to the tile's
+  auto slab_rr = [&](int i) { return (i * NPX + pg) >> 1; };
+  auto slab_xs = [&](int i) { return ((i * NPX + pg) & 1) * 16; };
+  const int trash = g.in_rows * in_cols;
+  f32x4 cmS = {1.f, 1.f, 1.f, 1.f};
+  const float lo = (sflags & PMF_SRC_RELU) ? 0.f : -__builtin_inff();
+  auto store_slot = [&](int j, char* __restrict__ Xd) {
+    f32x4 t;
+    t.x = ws3_fma(rX[j].x, sc4.x, sh4.x); t.y = ws3_fma(rX[j].y, sc4.y, sh4.y);
+    t.z = ws3_fma(rX[j].z, sc4.z, sh4.z); t.w = ws3_fma(rX[j].w, sc4.w, sh4.w);
+    t.x = ws3_vmax(t.x, lo); t.y = ws3_vmax(t.y, lo); t.z = ws3_vmax(t.z, lo); t.w = ws3_vmax(t.w, lo);
+    const float m = mX[j];
+    t.x = ws3_mul(t.x, ws3_mul(cmS.x, m)); t.y = ws3_mul(t.y, ws3_mul(cmS.y, m));
+    t.z = ws3_mul(t.z, ws3_mul(cmS.z, m)); t.w = ws3_mul(t.w, ws3_mul(cmS.w, m));
+    unsigned l0, l1, l2, h0, h1, h2;
+    ws3_split2_np(t.x, t.y, l0, l1, l2);
+    ws3_split2_np(t.z, t.w, h0, h1, h2);
+    const int pix = (tid + 256 * j) < totalX ? ((tid + 256 * j) >> 3) : trash;
+    char* o = Xd + pix * WS3_XPB + q * 8;
+    *(wu32x2*)(o) = wu32x2{l0, h0};
+    *(wu32x2*)(o + 64) = wu32x2{l1, h1};
+    *(wu32x2*)(o + 128) = wu32x2{l2, h2};
+  };
+  constexpr int G = TB % 3 == 0 ? 3 : (TB % 2 == 0 ? 2 : 1), NG = TB / G;
+  constexpr int NGT = NSL * NG;                                // tap groups per tile and wave
+  int f_by = 0, f_bx = 0, f_base = 0, f_n = 0, f_ty = 0, f_tx = 0;
+  bool f_on = false;
+  const int st_n = d.nsplit / tiles_per_n, st_r = d.nsplit - st_n * tiles_per_n;
+  const int st_ty = st_r / g.tiles_x, st_tx = st_r - st_ty * g.tiles_x;
+  auto coords_set = [&]() {
+    f_by = f_ty * WG_ROWS + g.dy_min; f_bx = f_tx * 32 + g.dx_min;
+    f_base = ((f_n * sH + f_by) * sW + f_bx) * sld * 4;
+  };
+  auto fetch_first = [&](int tile) {
+    f_n = tile / tiles_per_n;
+    const int rem = tile - f_n * tiles_per_n;
+    f_ty = rem / g.tiles_x; f_tx = rem - f_ty * g.tiles_x;
+    f_on = true;
+    coords_set();
+  };
+  auto fetch_next = [&](bool on) {
+    if (on) {
+      f_tx += st_tx;
+      if (f_tx >= g.tiles_x) { f_tx -= g.tiles_x; ++f_ty; }
+      f_ty += st_ty;
+      if (f_ty >= g.tiles_y) { f_ty -= g.tiles_y; ++f_n; }
+      f_n += st_n;
+      coords_set();
+    }
+    f_on = on;
+  };
+  auto zbase_f = [&]() { return ((f_n * d.OH + f_ty * WG_ROWS) * d.OW + f_tx * 32) * zpix; };   // dz of the tile at the fetch coordinates
+  auto fetch_slot = [&](int j) {
+    const bool ok = (unsigned)(f_by + sr[j]) < (unsigned)sH && (unsigned)(f_bx + sc[j]) < (unsigned)sW;
+    mX[j] = ok ? 1.f : 0.f;
+    const unsigned off = ok ? (unsigned)(f_base + so[j]) : 0x80000000u;
+    rX[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(f_on ? xrs_on : xrs_off, off, 0, 0));
+    if (j == XSL - 1)
+      rC = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(crs, (f_n * d.src[si].cmul_ld + cch) * 4, 0, 0));
+  };
+  // ---- one tile as a STATIC SCHEDULE of MFMA slots ------------------------------------------------------------------------
+  // Left to itself hipcc emits the MFMAs of a tap group back to back and the split / store / address work in bursts between
+  // the groups (phase stamps: a tile took 22.6k cycles where its 432 MFMAs need 13.8k; without the A reads -4.4k, without the
+  // split of tile t + 1 -3.1k, without the dz path -5.3k: none of it ran under the MFMAs).  One wave per SIMD hides about five
+  // single-issue instructions in the shadow of an 8-pass MFMA (MI355X_MICROARCH), so the tile is written as NSL * TB * 6
+  // slots = { one MFMA; one ds_read_b64_tr_b16 of the NEXT tap group's A fragments; at most a few "micro-ops" of <= 6
+  // instructions; sched_barrier(0) }, nothing crosses a slot boundary.  Micro-op streams:
+  //   Z (per slab i): slots 0, 1: the eight dz loads of slab i + 2 (two register sets alternate); the last 13 slots: wait for
+  //     the loads of slab i + 1 and split it pair by pair, step by step, into the other B-fragment buffer;
+  //   S: transform + split + store of input tile t + 1, ten micro-ops per 16-byte slot, spread over the free slots;
+  //   F: the loads of input tile t + 2 in the last XSL free slots of the tile (slab NSL - 1; behind the last S micro-op: rX /
+  //     mX are free).  Vector-memory queue at the wait behind F: [dz i+1][dz i+2: 8][F: XSL + 1] -> vmcnt(8 + XSL + 1).
+  constexpr int SL = TB * 6;                                   // MFMA slots per slab
+  constexpr int NMF = NSL * SL;                                // ... per tile
+  constexpr int GM = G * 6;                                    // ... per tap group (= A reads of a group)
+  constexpr int ZS0 = SL - 13;                                 // first slot of a slab's wait + split run
+  constexpr int FREE = ZS0 - 2;                                // free slots per slab (behind the two load slots)
+  constexpr int TFREE = NSL * FREE;                            // ... per tile
+  static_assert(FREE >= XSL && NSL >= 2 && NSL % 2 == 0, "schedule");
+  constexpr int NS_OPS = XSL * 10;                             // S micro-ops
+  constexpr int NF_OPS = XSL;                                  // F micro-ops (one load each; the last also fetches the multiplier):
+  constexpr int F_SLOT0 = TFREE - NF_OPS;                      // ... the LAST free slots of the tile, all in slab NSL - 1
+  constexpr int S_PER = (NS_OPS + F_SLOT0 - 1) / F_SLOT0;      // S micro-ops per free slot (the free slots before F)
+  wu32x4 bq[2][3];                          // B fragments (three planes) of the current / the next slab
+  float zr[2][8];                           // dz of slab i + 1 (being split) / slab i + 2 (in flight)
+  ws16x4 ah[2][G][3][2];                    // A fragments of the current / the next tap group: [tap][plane][pixel half]
+  f32x4 st_t, st_m;                         // S stream state (one 16-byte slot at a time)
+  unsigned st_l0 = 0, st_l1 = 0, st_l2 = 0, st_h0 = 0, st_h1 = 0, st_h2 = 0;
+  float st_a = 0.f, st_b = 0.f, st_c = 0.f, st_d = 0.f;
+  char* st_o = nullptr;
+  auto lo16 = [](unsigned p) { return __builtin_bit_cast(float, p << 16); };
+  auto hi16 = [](unsigned p) { return __builtin_bit_cast(float, p & 0xffff0000u); };
+  auto zload4 = [&](int tile_base, int i, int par, int e0) {
+    const int sb = tile_base + (slab_rr(i) * d.OW + slab_xs(i)) * zpix;
+#pragma unroll
+    for (int e = e0; e < e0 + 4; ++e)
+      zr[par][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(zrs, zvoff, sb + e * zpix, 0));
+  };
+  auto zsplit_op = [&](int par, int bsel, int e, int step) {     // pair e of zr[par] -> planes of bq[bsel], one step
+    float& a = zr[par][2 * e];
+    float& b = zr[par][2 * e + 1];
+    const unsigned pk = ws3_pk(wf32x2{a, b});
+    bq[bsel][step][e] = pk;
+    if (step < 2) { a = ws3_sub(a, lo16(pk)); b = ws3_sub(b, hi16(pk)); }
+  };
+  auto store_op = [&](int j, int k, char* __restrict__ Xd) {     // micro-op k of the transform + split + store of slot j
+    switch (k) {
+      case 0: st_t.x = ws3_fma(rX[j].x, sc4.x, sh4.x); st_t.y = ws3_fma(rX[j].y, sc4.y, sh4.y);
+              st_t.z = ws3_fma(rX[j].z, sc4.z, sh4.z); st_t.w = ws3_fma(rX[j].w, sc4.w, sh4.w); break;
+      case 1: st_t.x = ws3_vmax(st_t.x, lo); st_t.y = ws3_vmax(st_t.y, lo); st_t.z = ws3_vmax(st_t.z, lo); st_t.w = ws3_vmax(st_t.w, lo); break;
+      case 2: st_m.x = ws3_mul(cmS.x, mX[j]); st_m.y = ws3_mul(cmS.y, mX[j]); st_m.z = ws3_mul(cmS.z, mX[j]); st_m.w = ws3_mul(cmS.w, mX[j]); break;
+      case 3: st_t.x = ws3_mul(st_t.x, st_m.x); st_t.y = ws3_mul(st_t.y, st_m.y); st_t.z = ws3_mul(st_t.z, st_m.z); st_t.w = ws3_mul(st_t.w, st_m.w); break;
+      case 4: st_l0 = ws3_pk(wf32x2{st_t.x, st_t.y}); st_a = ws3_sub(st_t.x, lo16(st_l0)); st_b = ws3_sub(st_t.y, hi16(st_l0)); break;
+      case 5: st_l1 = ws3_pk(wf32x2{st_a, st_b}); st_a = ws3_sub(st_a, lo16(st_l1)); st_b = ws3_sub(st_b, hi16(st_l1)); break;
+      case 6: st_l2 = ws3_pk(wf32x2{st_a, st_b});
+              st_h0 = ws3_pk(wf32x2{st_t.z, st_t.w}); st_c = ws3_sub(st_t.z, lo16(st_h0)); st_d = ws3_sub(st_t.w, hi16(st_h0)); break;
+      case 7: st_h1 = ws3_pk(wf32x2{st_c, st_d}); st_c = ws3_sub(st_c, lo16(st_h1)); st_d = ws3_sub(st_d, hi16(st_h1)); break;
+      case 8: { st_h2 = ws3_pk(wf32x2{st_c, st_d});
+                const int pix = (tid + 256 * j) < totalX ? ((tid + 256 * j) >> 3) : trash;
+                st_o = Xd + pix * WS3_XPB + q * 8; } break;
+      default: *(wu32x2*)(st_o) = wu32x2{st_l0, st_h0};
+               *(wu32x2*)(st_o + 64) = wu32x2{st_l1, st_h1};
+               *(wu32x2*)(st_o + 128) = wu32x2{st_l2, st_h2}; break;
+    }
+  };
+  auto aread = [&](const char* __restrict__ base, int buf, int r) {     // read r of a tap group's 6 G: plane-major, tap, pixel half
+    const int p = r / (2 * G), t = (r % (2 * G)) / 2, h = r % 2;
+    (void)t;
+    ah[buf][(r % (2 * G)) / 2][p][h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_t)(base + p * 64 + h * 4 * WS3_XPB));
+  };
+  auto tile_mma = [&](const char* __restrict__ Xc, char* __restrict__ Xn, int zb_cur, int zb_nxt) {
+    constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PB[6] = {2, 1, 0, 1, 0, 0};   // smallest terms first
+    auto xb = [&](int i) { return Xc + (slab_rr(i) * in_cols + slab_xs(i)) * WS3_XPB + trofs; };
+    wg_static_for<GM>([&](auto R) {           // A fragments of the first tap group (exposed once per tile)
+      constexpr int r = decltype(R)::value;
+      aread(xb(0) + toff[(r % (2 * G)) / 2], 0, r);
+    });
+    wg_static_for<NMF>([&](auto SI) {
+      constexpr int s = decltype(SI)::value;
+      constexpr int i = s / SL, ss = s % SL;                       // slab, slot inside the slab
+      constexpr int gt = s / GM, gs = s % GM;                      // tap group of the tile, slot inside the group
+      constexpr int gq = gt % NG, cur = gt & 1, nxt = cur ^ 1;
+      constexpr int pr = gs / G, t = gs % G;
+      {
+        const wbf16x8 av = __builtin_bit_cast(wbf16x8, __builtin_shufflevector(ah[cur][t][PA[pr]][0], ah[cur][t][PA[pr]][1], 0, 1, 2, 3, 4, 5, 6, 7));
+#ifdef PMF_WG_NOMFMA
+        acc[gq * G + t][pr] += __builtin_bit_cast(float, __builtin_bit_cast(wu32x4, av)[pr & 3] ^ bq[i & 1][PB[pr]][pr & 3]);
+#else
+        acc[gq * G + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(wbf16x8, bq[i & 1][PB[pr]]), acc[gq * G + t], 0, 0, 0);
+#endif
+      }
+#ifndef PMF_WG_NOTR
+      if constexpr (s + GM - gs < NMF) {                           // one A read of the next tap group
+        constexpr int s2 = s - gs + GM, i2 = s2 / SL, g2 = (s2 / GM) % NG;
+        aread(xb(i2) + toff[g2 * G + (gs % (2 * G)) / 2], nxt, gs);
+      }
+#endif
+#ifndef PMF_WG_NOZ
+      if constexpr (ss < 2) {                                      // dz loads of slab i + 2
+        if constexpr (i + 2 < NSL) zload4(zb_cur, i + 2, i & 1, 4 * ss); else zload4(zb_nxt, i + 2 - NSL, i & 1, 4 * ss);
+      } else if constexpr (ss >= ZS0) {
+        constexpr int k = ss - ZS0;                                // 0: wait (+ nothing), 1 .. 12: split steps
+        if constexpr (k == 0) {
+          if constexpr (i == NSL - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + XSL + 1) : "memory");
+          else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else {
+          zsplit_op((i + 1) & 1, (i + 1) & 1, (k - 1) / 3, (k - 1) % 3);
+        }
+      }
+#endif
+      if constexpr (ss >= 2 && ss < ZS0) {
+        constexpr int fs = i * FREE + ss - 2;                      // free slot of the tile
+        if constexpr (fs < F_SLOT0) {
+#ifndef PMF_WG_NOSPLIT
+          wg_static_for<S_PER>([&](auto KK) {
+            constexpr int k = fs * S_PER + decltype(KK)::value;
+            if constexpr (k < NS_OPS) store_op(k / 10, k % 10, Xn);
+          });
+#endif
+        } else {
+          fetch_slot(fs - F_SLOT0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+
+  int tile = split;
+  int cur = 0;
+  int zb_cur = 0, zb_nxt = 0;
+  // prologue: input tile 0 split + stored, B fragment of slab 0 ready, dz of slab 1 and input tile 1 in flight
+  if (tile < g.total_tiles) {
+    fetch_first(tile);
+    zb_cur = zbase_f();
+#pragma unroll
+    for (int j = 0; j < XSL; ++j) fetch_slot(j);
+    zload4(zb_cur, 0, 0, 0);
+    zload4(zb_cur, 0, 0, 4);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (has_cm) cmS = rC;
+#pragma unroll
+    for (int j = 0; j < XSL; ++j) store_slot(j, Xs0);
+#pragma unroll
+    for (int k = 0; k < 12; ++k) zsplit_op(0, 0, k / 3, k % 3);
+    zload4(zb_cur, 1, 1, 0);
+    zload4(zb_cur, 1, 1, 4);
+    fetch_next(tile + d.nsplit < g.total_tiles);
+    zb_nxt = zbase_f();
+#pragma unroll
+    for (int j = 0; j < XSL; ++j) fetch_slot(j);
+  }
+  WTR();
+  while (tile < g.total_tiles) {
+    const int next = tile + d.nsplit;
+    const char* Xc = cur ? Xs1 : Xs0;
+    char* Xn = cur ? Xs0 : Xs1;
+    __syncthreads();                       // tile t complete in Xc; everyone finished reading Xn (tile t - 1)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // dz of slab 1 and the input tile t + 1 landed
+    WTR();
+    cmS.x = has_cm ? rC.x : 1.f; cmS.y = has_cm ? rC.y : 1.f; cmS.z = has_cm ? rC.z : 1.f; cmS.w = has_cm ? rC.w : 1.f;
+    // coordinates of tile t + 2 before the schedule runs (its F micro-ops use them); dz bases: t (cur), t + 1 (nxt)
+    const int zb_c = zb_cur, zb_n = zb_nxt;
+    fetch_next(next + d.nsplit < g.total_tiles);
+    zb_cur = zb_nxt;
+    zb_nxt = zbase_f();
+    tile_mma(Xc, Xn, zb_c, zb_n);
+    WTR();
+    WTR();
+    tile = next;
+    cur ^= 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  WTR();
+
+  // ---- fold the pixel groups (fixed order) and write the partial slab: wave (cw, 0) owns co tile cw
+  if constexpr (NPX > 1) {
+    float* red = smem;   // [NCO][16][64]
+#pragma unroll
+    for (int j = 0; j < TB; ++j) {
+      __syncthreads();
+      if (pg > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[((cw * (NPX - 1) + pg - 1) * 16 + r) * 64 + lane] = acc[j][r];
+      }
+      __syncthreads();
+      if (pg == 0) {
+#pragma unroll
+        for (int p = 1; p < NPX; ++p)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[j][r] += red[((cw * (NPX - 1) + p - 1) * 16 + r) * 64 + lane];
+      }
+    }
+  }
+  if (pg == 0) {
+    float* part = d.partial + (size_t)split * d.ntaps * g.Ktot * g.Cout32;
+    const int co = co0 + li;
+#pragma unroll
+    for (int j = 0; j < TB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ci = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (ci < kc) part[((size_t)j * g.Ktot + k0 + ci) * g.Cout32 + co] = acc[j][r];
+      }
+  }
+  WTR();
+  WTR_END();
+}
+
+template <int TB, int XSL, int NCO>
+__global__ __launch_bounds__(256) void conv_wgrad_s3n_k(const pmf_wgrad_desc_t d, const WgGeom g) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  conv_wgrad_s3n_body<TB, XSL, NCO>(d, g, smem);
+}
+
 // ---- eight waves per workgroup (W8): two waves per SIMD ----------------------------------------------------------------
 // What bounds conv_wgrad_s3_swp_body is the instruction stream of the ONE wave a SIMD holds (144 accumulator registers
 // per wave): ~770 instructions per tile at one issue slot every four cycles plus dependent-issue latency -- the loop
@@ -2075,6 +2458,21 @@ static void wg_config(const pmf_wgrad_desc_t* d, int* TB, int* NT) {
   *NT = wide_1x1 ? 4 : (d->Cout > 32 ? 2 : 1);
 }
 
+// output-channel tiles per workgroup of the N-split split-bf16 kernel (conv_wgrad_s3n_k): 4 / 2, or 0 = not this kernel.
+// PMF_WG_S3N=0 switches it off (A/B), =2 caps it at two tiles.
+static int wg_s3n_nco(const pmf_wgrad_desc_t* d, const WgGeom& g, int TB) {
+  const char* e_n = getenv("PMF_WG_S3N");     // (read per call, not cached: the tests switch variants)
+  const int mode = e_n ? atoi(e_n) : 4;
+  if (mode <= 1 || TB <= 1 || !(d->flags & PMF_WGRAD_S3) || !wg_simple(d, g, TB, 32, 16)) return 0;
+  if ((int64_t)d->N * d->OH * d->OW * d->dz_ldc * 4 >= (1ll << 31)) return 0;
+  const char* e_w8 = getenv("PMF_WG_W8");
+  const char* e_swp = getenv("PMF_WG_SWP");
+  if ((e_w8 && e_w8[0] == '1') || (e_swp && e_swp[0] == '0')) return 0;        // the test switches for the older variants
+  if (mode >= 4 && d->Cout % 128 == 0) return 4;
+  if (d->Cout % 64 == 0) return 2;
+  return mode == 3 ? 0 : 1;       // (3: 32-channel tiles on the round-3 software-pipelined kernel)
+}
+
 static bool wg_fewc(const pmf_wgrad_desc_t* d);
 extern "C" int pmf_conv_wgrad_nsplit(const pmf_wgrad_desc_t* d) {
   if (wg_fewc(d)) {   // one output-channel tile pair per workgroup: split the pixel tiles 256 ways
@@ -2095,6 +2493,7 @@ extern "C" int pmf_conv_wgrad_nsplit(const pmf_wgrad_desc_t* d) {
   wg_config(d, &TB, &NT);
   wg_geometry(d, TB, NT * 32, &g, &lds);
   int other = g.nchunks * g.co_tiles * g.tap_batches;
+  if (NT == 1) { const int nco = wg_s3n_nco(d, g, TB); if (nco) other = g.nchunks * (d->Cout / (32 * nco)); }
   // workgroups per launch: one per TWO CUs.  More make the launch itself faster in isolation (512: 4.8 ms over the 110 layers,
   // 256: 5.4 ms), but the weight gradients run on side lanes next to the input-gradient launches of the main lane -- which IS
   // the step -- and a weight-gradient workgroup holds 80-110 KiB of its CU's LDS: with one on every CU a main-lane conv
@@ -2190,6 +2589,34 @@ static int wg_launch(const pmf_wgrad_desc_t* d, hipStream_t s, int phase) {
       const bool swp = !(e_swp && e_swp[0] == '0');
       const bool small7 = g.in_rows * g.in_cols * 8 <= 256 * 7;
       const bool w8 = e_w8 && e_w8[0] == '1';
+      const int nco = wg_s3n_nco(d, g, TB);
+      if (nco) {
+        if constexpr (TB > 1) {
+          static unsigned long long attr6 = 0ull;
+          if (pmf_first_on_device(&attr6)) {
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_s3n_k<TB, 7, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_s3n_k<TB, 9, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_s3n_k<TB, 7, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_s3n_k<TB, 9, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_s3n_k<TB, 7, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_s3n_k<TB, 9, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+          }
+          g.x_floats += WS3_XPB / 4;           // the spare pixel that slots beyond the tile write to
+          int lds6 = 2 * g.x_floats * 4;
+          if (lds6 < 16 * 1024) lds6 = 16 * 1024;
+          const dim3 grid6(d->nsplit, g.nchunks, d->Cout / (32 * nco));
+          if (nco == 4) {
+            if (small7) hipLaunchKernelGGL((conv_wgrad_s3n_k<TB, 7, 4>), grid6, dim3(256), lds6, s, *d, g);
+            else hipLaunchKernelGGL((conv_wgrad_s3n_k<TB, 9, 4>), grid6, dim3(256), lds6, s, *d, g);
+          } else if (nco == 2) {
+            if (small7) hipLaunchKernelGGL((conv_wgrad_s3n_k<TB, 7, 2>), grid6, dim3(256), lds6, s, *d, g);
+            else hipLaunchKernelGGL((conv_wgrad_s3n_k<TB, 9, 2>), grid6, dim3(256), lds6, s, *d, g);
+          } else {
+            if (small7) hipLaunchKernelGGL((conv_wgrad_s3n_k<TB, 7, 1>), grid6, dim3(256), lds6, s, *d, g);
+            else hipLaunchKernelGGL((conv_wgrad_s3n_k<TB, 9, 1>), grid6, dim3(256), lds6, s, *d, g);
+          }
+        }
+      } else
       // eight waves (the taps of a slab on two waves, two waves per SIMD): 3-10 % faster launch by launch, but 110 KiB
       // of LDS and 512 threads leave no room for the input-gradient launches the weight gradients run next to:
       // 16.08 vs 15.97 ms per step -- off unless PMF_WG_W8=1

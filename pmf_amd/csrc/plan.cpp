@@ -8,9 +8,26 @@
 
 extern "C" int pmf_pack_weights_batched(const pmf_pack_job_t*, int32_t, int32_t, pmf_stream_t);
 
+// PMF_SKIP_OPS=kind,kind,... (pmf_op_kind_t numbers): these launches are left out -- a WHAT-IF measurement ("how long is
+// the step without the weight gradients / the BatchNorm finalize launches?"), the results of such a run are garbage
+static uint64_t skip_mask() {
+  static const uint64_t m = [] {
+    uint64_t v = 0;
+    const char* e = getenv("PMF_SKIP_OPS");
+    while (e && *e) {
+      const long k = strtol(e, (char**)&e, 10);
+      if (k > 0 && k < 64) v |= 1ull << k;
+      while (*e == ',' || *e == ' ') ++e;
+    }
+    return v;
+  }();
+  return m;
+}
+
 static int run_one(const pmf_op_t& o, pmf_stream_t s) {
   const pmf_small_args_t& a = o.u.sm;
   const int32_t* i = a.i;
+  if (skip_mask() >> (o.kind & 63) & 1ull) return 0;
   switch (o.kind) {
     case PMF_OP_CONV: return pmf_conv_fwd(&o.u.conv, s);
     case PMF_OP_WGRAD: return pmf_conv_wgrad(&o.u.wgrad, s);

@@ -603,6 +603,9 @@ class FlatState:
             for p in ps:
                 gid[id(p)] = g
         self.offset, self.ranges, self.members = {}, [], []
+        # writes to ``param`` through raw pointers (the range optimiser kernels) -- torch's version counter does not see
+        # them; (param._version, raw_writes) is what a plan remembers its packed weights by (stamp())
+        self.raw_writes = 0
         off = 0
         for g in range(len(groups)):
             start = off
@@ -700,7 +703,14 @@ def _forward_impl(model, inputs):
         st.view(x.shape).copy_(x)             # strided channel slices (trainer.py:296-297) / other dtypes: one copy
     if model.training:
         _fill_masks(plan, model)
-    plan.run(plan.fwd_ops, plan.n_fwd, "forward", sig=())
+    # weights already re-packed behind the optimiser update of the last step (engine.py _behind_events) and untouched since
+    # (torch bumps the version counter of the flat buffer on every in-place write through a view): start behind the
+    # forward-format pack launches
+    begin = 0
+    pv = getattr(plan, "packed_version", None)
+    if pv is not None and plan.flat is not None and plan.flat.stamp() == pv:
+        begin = plan.fwd_pack_skip
+    plan.run(plan.fwd_ops, plan.n_fwd, "forward", begin, sig=())
     if model.training and plan.bn_counters:
         torch._foreach_add_(plan.bn_counters, 1)
     plan.generation += 1
@@ -714,6 +724,16 @@ class _PlanFunction(torch.autograd.Function):
     Parameters are explicit inputs so their gradients reach the leaf tensors (and DDP's reducer hooks)."""
 
     @staticmethod
+    def stamp(self):
+        """changes whenever a parameter is written: by torch through the flat buffer or a group leaf (their shared version
+        counter), through a module parameter (each keeps a counter of its own: ``p.data = view`` does not share it), or by
+        the range optimiser kernels, which write through raw pointers (raw_writes).  NOT seen: in-place writes through
+        ``p.data`` / ``p.detach()`` made after a training step -- call invalidate() after those."""
+        return (self.param._version, self.raw_writes, sum(p._version for mem in self.members for p in mem))
+
+    def invalidate(self):
+        self.raw_writes += 1
+
     def forward(ctx, model, n_inputs, *args):
         inputs, params = args[:n_inputs], args[n_inputs:]
         plan, outs = _forward_impl(model, inputs)

@@ -565,6 +565,7 @@ class Plan(PlanConvMixin, PlanTuneMixin, PlanRunMixin):
     def global_mean(self, v, name=""):
         t = v.t
         out = T(self, t.N, 1, 1, t.C, name, arena=self.zero_fwd)
+        self.zero_fwd_lanes = getattr(self, "zero_fwd_lanes", set()) | {self.lane}    # (the fill of this arena runs on that lane)
 
         def f(op):
             s = op.u.sm
@@ -671,13 +672,20 @@ class Plan(PlanConvMixin, PlanTuneMixin, PlanRunMixin):
         # layers: the first op of a lane that reads a late-packed weight waits for that launch's event.
         self.pack_tables = []
         PACK_EARLY = int(os.environ.get("PMF_PACK_EARLY", "8"))
+        # Tables: per lane the FORWARD-format packs of its first layers ("early"), one table of the later forward packs on
+        # lane 2 (its launch records the event the first late readers wait for), and -- behind all of those in list order --
+        # the INPUT-GRADIENT packs (read by the backward plan only).  The forward-format tables lead the op list so that a
+        # training step whose weights were already re-packed behind the optimiser (engine: pack_ranges) starts the
+        # forward range behind them (fwd_pack_skip).
         late, late_event = [], None
-        groups = []
+        groups, dgroups = [], []
+        side_ok = self.n_lanes >= 3 and dev.type == "cuda"
         for lane in sorted({j[6] for j in self.pack_jobs}):
             mine = [j for j in self.pack_jobs if j[6] == lane]
             fwdj = [j for j in mine if j[8] is not None]
-            early = mine
-            if PACK_EARLY > 0 and self.n_lanes >= 3 and len(fwdj) > PACK_EARLY + 4 and dev.type == "cuda":
+            dgj = [j for j in mine if j[8] is None]
+            early = fwdj
+            if PACK_EARLY > 0 and side_ok and len(fwdj) > PACK_EARLY + 4:
                 first_late = fwdj[PACK_EARLY]
                 waiter = self.fwd[first_late[8]]
                 if not ((waiter[2] >> 8) & 0xff) and (waiter[2] & 3) == lane:      # its wait slot is free
@@ -686,12 +694,21 @@ class Plan(PlanConvMixin, PlanTuneMixin, PlanRunMixin):
                         self.n_events += 1
                     waiter[2] |= (late_event + 1) << 8
                     early = fwdj[:PACK_EARLY]
-                    keep = {id(j) for j in early}
-                    late += [j for j in mine if id(j) not in keep]
-            groups.append((lane, early))
+                    late += fwdj[PACK_EARLY:]
+            if early:
+                groups.append((lane, early))
+            if dgj:
+                if side_ok:
+                    if dgroups and dgroups[0][0] == 2:
+                        dgroups[0][1].extend(dgj)
+                    else:
+                        dgroups.insert(0, (2, list(dgj)))
+                else:
+                    dgroups.append((lane, dgj))
         if late:
             groups.append((2, late))
-        for lane, mine in groups:
+
+        def make_table(mine):
             jobs = (L.PackJob * len(mine))()
             blocks = 0
             for j, (w, buf, tap_idx, transpose, K_pad, ldw, _, fmt, _o, cin) in enumerate(mine):
@@ -708,11 +725,19 @@ class Plan(PlanConvMixin, PlanTuneMixin, PlanRunMixin):
                 for i, ti in enumerate(tap_idx):
                     J.tap_idx[i] = ti
                 blocks += J.tiles_ci * ((Cout + 31) // 32)
-            dev_tab = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(dev)
-            bits = lane
-            if late and mine is late:
-                bits |= (late_event + 1) << 16          # records the event the first late readers wait for
-            self.pack_tables.append((lane, dev_tab, len(mine), blocks, bits))
+            return torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(dev), blocks
+
+        self._make_pack_table = make_table
+        # (list order: forward-format tables with the higher lanes first -- a side lane forks from the main stream at its
+        # first op and must not wait for lane 0's packing --, then the input-gradient tables)
+        for is_dgrad, grp in ((False, sorted(groups, key=lambda t: -t[0])), (True, dgroups)):
+            for lane, mine in grp:
+                dev_tab, blocks = make_table(mine)
+                bits = lane
+                if late and mine is late:
+                    bits |= (late_event + 1) << 16          # records the event the first late readers wait for
+                self.pack_tables.append((lane, dev_tab, len(mine), blocks, bits, is_dgrad))
+        self.fwd_pack_skip = sum(1 for t in self.pack_tables if not t[5])
         self.n_pack_jobs = len(self.pack_jobs)
         self.n_pack_blocks = sum(t[3] for t in self.pack_tables)
 
@@ -750,11 +775,16 @@ class Plan(PlanConvMixin, PlanTuneMixin, PlanRunMixin):
                 a.p[0], a.f[0], a.l[0] = arena.base, 0.0, arena.size // 4
             return z
 
-        # lane 0 first: a side lane forks from the main stream at its first op and must not wait for lane 0's packing
-        pro_f = [(L.OP_PACK, pack_op(tab, n, blocks), bits)
-                 for lane, tab, n, blocks, bits in sorted(self.pack_tables, key=lambda t: -t[0])]
+        pro_f = [(L.OP_PACK, pack_op(tab, n, blocks), bits) for lane, tab, n, blocks, bits, _dg in self.pack_tables]
         if self.zero_fwd.size:
-            pro_f.insert(0, (L.OP_FILL, zero_arena(self.zero_fwd)))
+            # (behind the pack launches, so that a range starting at fwd_pack_skip still runs it; on the lane of its only
+            # users -- the ASPP global mean accumulates into it -- or in front of everything when more than one lane uses it)
+            zl = getattr(self, "zero_fwd_lanes", {0})
+            if len(zl) == 1:
+                pro_f.append((L.OP_FILL, zero_arena(self.zero_fwd), next(iter(zl))))
+            else:
+                pro_f.insert(0, (L.OP_FILL, zero_arena(self.zero_fwd)))
+                self.fwd_pack_skip = 0
         self.fwd_shift = len(pro_f)
         self.fwd_ops, self.n_fwd = build(self.fwd, pro_f, self.meta_fwd)
         if self.training:

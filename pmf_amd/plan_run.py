@@ -105,6 +105,34 @@ class PlanRunMixin(object):
         cache[op_end] = out
         return out
 
+    def pack_ranges(self, ranges, stream):
+        """re-pack, on `stream`, the FORWARD-format weights whose parameters lie in the float ranges [a, b) of the flat
+        parameter buffer -- the engine calls this right behind the optimiser update of a gradient range (engine.py
+        _behind_events), i.e. while the backward plan is still running: the forward pass is over, nothing reads these
+        buffers until the next forward.  (The input-gradient packs ARE still being read by the running backward plan: they
+        stay in the forward plan's prologue, on lane 2.)  Returns the number of pack jobs launched."""
+        key = tuple(ranges)
+        cache = self.__dict__.setdefault("_range_packs", {})
+        ent = cache.get(key)
+        if ent is None:
+            base = self.flat.param.data_ptr()
+            mine = []
+            for j in self.pack_jobs:
+                if j[8] is None:
+                    continue
+                off = (j[0].data_ptr() - base) // 4
+                if any(a <= off < b for a, b in ranges):
+                    mine.append(j)
+            ent = cache[key] = (self._make_pack_table(mine) + (len(mine),)) if mine else (None, 0, 0)
+        tab, blocks, n = ent
+        if n:
+            L.check(L.lib().pmf_pack_weights_batched(tab.data_ptr(), n, blocks, C.c_void_p(stream.cuda_stream)),
+                    "pmf_pack_weights_batched")
+        return n
+
+    def n_fwd_pack_jobs(self):
+        return sum(1 for j in self.pack_jobs if j[8] is not None)
+
     def run_profiled(self, what, reps=3):
         """run one pass op by op with a HIP event pair around every launch (on the stream the plan uses, lanes off);
         returns [(op kind name, family or None, algorithmic flops, milliseconds, label, algorithmic bytes)].

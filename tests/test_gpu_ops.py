@@ -102,6 +102,11 @@ CONVS = [
     ("c3x3_wpipe", 2, 8, 64, [32, 64], 64, 3, 1, 1, 1, True, "act_bn", True),
     ("c3x3d2_wpipe", 1, 12, 32, [64], 32, 3, 2, 2, 1, False, "bn_relu", True),
     ("c2x2d2_wpipe", 2, 8, 64, [64], 64, 2, 2, 1, 1, True, "act_bn", True),
+    # 128 / 256 output channels: the N-split weight-gradient kernel with FOUR output-channel tiles per workgroup (every wave sees
+    # all eight slabs of a tile); dilated = the nine-slot input tile; a 16-channel operand = a half-empty chunk
+    ("c3x3_wn4", 2, 8, 64, [64], 128, 3, 1, 1, 1, True, "act_bn", True),
+    ("c3x3d2_wn4", 1, 12, 32, [32, 16], 256, 3, 2, 2, 1, False, "bn_relu", True),
+    ("c2x2d2_wn4", 1, 16, 32, [64], 128, 2, 2, 1, 1, True, "act_bn", True),
     # ResNet-50 bottleneck 1x1 layers at their real channel counts: 1024 / 2048 input channels (the weight fragments of one
     # output-channel tile do not fit LDS: these run on the generic loop), 256 -> 1024, the stride-2 projection
     ("c1x1_k1024", 2, 8, 32, [1024], 256, 1, 1, 0, 1, False, "bn_relu", True),
@@ -147,11 +152,14 @@ def test_conv_unit_bn_backward_three_launch_form(name, monkeypatch):
     _conv_case(next(c for c in CONVS if c[0] == name), 0)
 
 
-@pytest.mark.parametrize("env", [{"PMF_WG_SWP": "0"}, {"PMF_WG_W8": "1"}], ids=["staged", "eight_waves"])
+@pytest.mark.parametrize("env", [{"PMF_WG_SWP": "0"}, {"PMF_WG_W8": "1"}, {"PMF_WG_S3N": "0"}, {"PMF_WG_S3N": "2"}],
+                         ids=["staged", "eight_waves", "swp_pixel_split", "nsplit_two_tiles"])
 def test_conv_unit_wgrad_variants(env, monkeypatch):
     """the split-bf16 weight-gradient kernel's other forms (conv_wgrad.hip): the two-barrier staged loop that the
-    software-pipelined default replaced (PMF_WG_SWP=0) and the 512-thread form with the taps of a slab on two waves
-    (PMF_WG_W8=1); same cases, same float64 bars"""
+    software-pipelined form replaced (PMF_WG_SWP=0), the 512-thread form with the taps of a slab on two waves
+    (PMF_WG_W8=1), the software-pipelined form with the four waves splitting the PIXELS of one 32 x 32 tile (PMF_WG_S3N=0:
+    what layers with 32 output channels run, and the default of rounds 3-4 everywhere) and the N-split form capped at two
+    output-channel tiles per workgroup (PMF_WG_S3N=2); same cases, same float64 bars"""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     ran = 0

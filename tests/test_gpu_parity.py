@@ -609,7 +609,7 @@ def test_projection_two_launch_form_reuses_its_workspace(monkeypatch):
     h, w = 96, 320
     frames = [loader_ref.synthetic_frame(seed, n, h, w) for seed, n in ((1, 30000), (2, 2500), (3, 61000), (4, 1100), (5, 9000))]
     project_frame_gpu(*[frames[0][i] for i in (1, 2, 3, 0, 4)])              # creates this thread's workspace
-    ws = PV._PROJ_TLS.ws[(str(torch.device("cuda")), h, w)]
+    ws = PV._PROJ_TLS.ws[(str(torch.device("cuda")), h, w, int(torch.cuda.current_stream().cuda_stream))]
     ws[2] = 4092                                                             # ... three calls before the wrap
     for rep in range(2):
         for k, (M, pts, sem, img, lut) in enumerate(frames):
@@ -629,6 +629,14 @@ def test_projection_two_launch_form_reuses_its_workspace(monkeypatch):
     monkeypatch.delenv("PMF_PROJECT_LEGACY")
     b = project_frame_gpu(pts, sem, img, M, lut)
     for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    # a second stream gets a workspace of its own (calls of one thread on two streams may overlap on the GPU: ADVICE r04)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        c = project_frame_gpu(pts, sem, img, M, lut)
+    side.synchronize()
+    assert len(PV._PROJ_TLS.ws) == 2
+    for x, y in zip(b, c):
         assert torch.equal(x, y)
 
 
@@ -1616,3 +1624,46 @@ def test_knn_any_odd_window_vs_oracle(search, knn_k, cutoff):
     got = knn.batch([tuple(t(a) for a in f) for f in frames])
     for g_, w_ in zip(got, want):
         np.testing.assert_array_equal(g_.cpu().numpy(), w_)
+
+
+def test_weights_repacked_behind_optimiser_bitwise_and_invalidation(monkeypatch):
+    """Round 5: the forward-format weight packs of a training step are launched right behind the range optimiser's update of
+    their gradient range (engine._behind_events -> Plan.pack_ranges) and the next forward plan starts behind its pack launches
+    (Plan.fwd_pack_skip).  Same arithmetic in another order: four training steps with and without it (PMF_PACK_BEHIND_OPTIM=0)
+    end with BIT-IDENTICAL parameters.  A parameter write torch can see (load_state_dict) invalidates the packed copy: the next
+    forward equals that of a fresh model with those weights."""
+    from pmf_amd.engine import TrainEngine
+    from pmf_amd.models import PMFNet
+    from pmf_amd.utils.detinit import deterministic_init
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("PMF_PACK_BEHIND_OPTIM", mode)
+        torch.manual_seed(3)
+        model = deterministic_init(PMFNet(5, 3, 20, 32, imagenet_pretrained=False, image_backbone="resnet34")).to(DEV)
+        eng = TrainEngine(model, 20, lr=1e-3, momentum=0.9, weight_decay=1e-5, warmup_steps=2, max_steps=10)
+        g = torch.Generator().manual_seed(5)
+        for it in range(4):
+            feat = torch.randn(2, 8, 32, 64, generator=g).to(DEV)
+            mask = (torch.rand(2, 32, 64, generator=g) > 0.2).float().to(DEV)
+            label = torch.randint(0, 20, (2, 32, 64), generator=g).to(DEV)
+            eng.train_step(feat, mask, label)
+        torch.cuda.synchronize()
+        plan = next(p for k, p in model._plans.items() if k[3])
+        skipped = any(k[0] == "forward" and k[1] > 0 for k in list(plan._graphs) + list(plan._graph_seen))
+        assert skipped == (mode == "1"), (mode, list(plan._graph_seen))
+        assert (getattr(plan, "packed_version", None) is not None) == (mode == "1")
+        res[mode] = (eng.flat.param.clone(), model, eng, (feat, mask))
+    assert torch.equal(res["1"][0], res["0"][0])
+    # invalidation: other weights through load_state_dict -> the packed copy is stale and must not be used
+    model, eng, (feat, mask) = res["1"][1], res["1"][2], res["1"][3]
+    fresh = deterministic_init(PMFNet(5, 3, 20, 32, imagenet_pretrained=False, image_backbone="resnet34"), 11).to(DEV)
+    model.load_state_dict(fresh.state_dict())
+    model.train()
+    fresh.train()
+    m = {n: torch.ones(2, c, device=DEV) for n, c in model._mask_sites()}
+    model.set_dropout_masks(m)
+    fresh.set_dropout_masks(m)
+    x = feat.clone()
+    a = model(x[:, 0:5], x[:, 5:8])[0]
+    b = fresh(x[:, 0:5], x[:, 5:8])[0]
+    assert torch.allclose(a, b, atol=1e-6), (a - b).abs().max().item()

@@ -59,7 +59,10 @@ def main(filt, ns):
             name, wd.nsplit, len(t), cnt, span, int(np.median(t[:, cnt - 1] - t[:, 0]))))
         names = ["prologue"]
         per = ["X barrier", "split+store X", "Y barrier", "fetch + dz wait + B prep", "108 MFMAs"]
-        if os.environ.get("PMF_WG_SWP", "1") != "0":     # software-pipelined body: three stamps per tile
+        if os.environ.get("PMF_WG_S3N", "4") not in ("0", "1") and co % 64 == 0 and os.environ.get("PMF_WG_SWP", "1") != "0" \
+                and os.environ.get("PMF_WG_W8", "0") != "1":
+            per = ["barrier + loads landed", "MFMAs + split(t+1) + dz prep", "fetch(t+2)"]     # N-split body: three stamps per tile
+        elif os.environ.get("PMF_WG_SWP", "1") != "0":     # software-pipelined body: three stamps per tile
             per = ["barrier", "dz wait + B prep", "108 MFMAs + split(t+1)", "fetch(t+2)"]
             if os.environ.get("PMF_WG_W8", "0") == "1":
                 per = ["barrier", "dz DMA + input wait", "MFMAs + split(t+1) + fetch(t+2) + B prep(t+1)", "dz wait"]
