@@ -634,6 +634,16 @@ class FlatState:
             fp.grad = self.grad[a:b]
             self.group_params.append(fp)
 
+    def stamp(self):
+        """changes whenever a parameter is written: by torch through the flat buffer or a group leaf (their shared version
+        counter), through a module parameter (each keeps a counter of its own: ``p.data = view`` does not share it), or by
+        the range optimiser kernels, which write through raw pointers (raw_writes).  NOT seen: in-place writes through
+        ``p.data`` / ``p.detach()`` made after a training step -- call invalidate() after those."""
+        return (self.param._version, self.raw_writes, sum(p._version for mem in self.members for p in mem))
+
+    def invalidate(self):
+        self.raw_writes += 1
+
 
 def flatten_training_state(model, groups, device):
     """attach a FlatState to ``model`` (plans are rebuilt on the next call: parameter storage moved)."""
@@ -724,16 +734,6 @@ class _PlanFunction(torch.autograd.Function):
     Parameters are explicit inputs so their gradients reach the leaf tensors (and DDP's reducer hooks)."""
 
     @staticmethod
-    def stamp(self):
-        """changes whenever a parameter is written: by torch through the flat buffer or a group leaf (their shared version
-        counter), through a module parameter (each keeps a counter of its own: ``p.data = view`` does not share it), or by
-        the range optimiser kernels, which write through raw pointers (raw_writes).  NOT seen: in-place writes through
-        ``p.data`` / ``p.detach()`` made after a training step -- call invalidate() after those."""
-        return (self.param._version, self.raw_writes, sum(p._version for mem in self.members for p in mem))
-
-    def invalidate(self):
-        self.raw_writes += 1
-
     def forward(ctx, model, n_inputs, *args):
         inputs, params = args[:n_inputs], args[n_inputs:]
         plan, outs = _forward_impl(model, inputs)

@@ -8,6 +8,29 @@ import torch
 from . import _lib as L
 
 _TUNED = {}      # process-wide autotuner cache: conv shape key -> tile configuration (Plan.autotune)
+_LOADED = set()  # cache files already merged into _TUNED
+
+# The SHIPPED tile configurations: the tuner's choices for every conv shape of the BASELINE configurations (PMF-R34 at 64x2048
+# train / eval, S_B 480x640, the KITTI crop 256x1024, PMF-R50 17 classes 32x1024, EPMF-R34, SalsaNext), measured on an MI355X by
+# tools/make_tune_cache.py and committed, so that tests, bench and every rank of a job run the SAME plan for those shapes,
+# reproducibly across processes.  PMF_AUTOTUNE: "1" (default) shipped choices + live tuning of shapes the file does not know;
+# "cache" shipped choices + the built-in heuristics for unknown shapes (no timing: reproducible; what tests/ run);
+# "0" heuristics only; "live" ignores the shipped file (what make_tune_cache.py runs under).
+SHIPPED = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned", "gfx950.txt")
+
+
+def tune_mode():
+    m = os.environ.get("PMF_AUTOTUNE", "1")
+    return {"0": "off", "cache": "cache", "live": "live"}.get(m, "on")
+
+
+def _merge(path):
+    import ast
+    if path and path not in _LOADED and os.path.exists(path):
+        _LOADED.add(path)
+        with open(path) as f:
+            for k, v in ast.literal_eval(f.read()).items():
+                _TUNED.setdefault(k, v)
 
 
 class PlanTuneMixin(object):
@@ -36,15 +59,14 @@ class PlanTuneMixin(object):
         lib = L.lib()
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         failed = C.c_int32(-1)
-        import ast
-        import os
+        mode = tune_mode()
         cache_file = os.environ.get("PMF_TUNE_CACHE")     # optional: persist / reuse the choices across processes
-        if cache_file and os.path.exists(cache_file) and not _TUNED:
-            with open(cache_file) as f:
-                _TUNED.update(ast.literal_eval(f.read()))
+        _merge(cache_file)                                # (a job's own file wins over the shipped one: merged first)
+        if mode != "live":
+            _merge(SHIPPED)
         n_known = len(_TUNED)
 
-        def time_op(ops, k, reps=5):
+        def time_op(ops, k, reps=int(os.environ.get("PMF_TUNE_REPS", "5"))):
             for _ in range(2):
                 lib.pmf_plan_run_range(C.addressof(ops), k, k + 1, stream, C.byref(failed))
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -74,7 +96,7 @@ class PlanTuneMixin(object):
                     continue
                 d = ops[k].u.conv
                 key = key_of(d)
-                if key not in _TUNED:
+                if key not in _TUNED and mode != "cache":
                     d.cfg = 0
                     stages = lib.pmf_conv_fwd_kstages(C.byref(d))
                     cands = [0]
@@ -96,7 +118,7 @@ class PlanTuneMixin(object):
                         if t < best_t * 0.97 or (cfg == 0 and t <= best_t):   # 3 % hysteresis against timing noise
                             best_t, best = min(t, best_t), cfg
                     _TUNED[key] = best
-                d.cfg = _TUNED[key]
+                d.cfg = _TUNED.get(key, 0)     # ("cache" mode, unknown shape: the built-in heuristics, no timing)
                 fin = fins.get(k - shift)
                 for fi in (fin if isinstance(fin, list) else ([] if fin is None else [fin])):
                     ops[fi + shift].u.sm.i[1] = lib.pmf_conv_fwd_stat_rows(C.byref(d))
@@ -105,4 +127,4 @@ class PlanTuneMixin(object):
         torch.cuda.synchronize(self.device)
         if cache_file and len(_TUNED) != n_known:
             with open(cache_file, "w") as f:
-                f.write(repr(_TUNED))
+                f.write("{\n" + "".join(" %r: %r,\n" % kv for kv in sorted(_TUNED.items(), key=repr)) + "}\n")

@@ -635,7 +635,7 @@ def test_projection_two_launch_form_reuses_its_workspace(monkeypatch):
     with torch.cuda.stream(side):
         c = project_frame_gpu(pts, sem, img, M, lut)
     side.synchronize()
-    assert len(PV._PROJ_TLS.ws) == 2
+    assert len([k for k in PV._PROJ_TLS.ws if k[1:3] == (h, w)]) == 2      # (other tests of this process left theirs)
     for x, y in zip(b, c):
         assert torch.equal(x, y)
 
