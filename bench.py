@@ -663,12 +663,25 @@ def plan_rooflines(plan, prof, model_tag):
             if m.get("family") in convs and kinds[i + shift] == L.OP_CONV and ops[i + shift].u.conv.w_s3:
                 split_fl += m["flops"]
     share = split_fl / max(mfma_fl, 1.0)
+    # the headline fraction covers ALL matrix work of the pass: forward, input-gradient AND
+    # weight-gradient launches; the per-family split rides along
+    allk = [k for k in ("conv_fwd", "conv_dgrad", "conv_wgrad") if k in fam]
+    all_ms, all_fl, all_n = (sum(fam[k][i] for k in allk) for i in (2, 1, 0))
+    achieved_all = all_fl / (all_ms * 1e-3) / 1e12
+    families = {k: {"launches": fam[k][0], "algorithmic_gflop": round(fam[k][1] / 1e9, 1), "ms": round(fam[k][2], 3),
+                    "achieved": round(fam[k][1] / (fam[k][2] * 1e-3) / 1e12, 2),
+                    "frac": round(fam[k][1] / (fam[k][2] * 1e-3) / 1e12 / PEAK_FP32_MFMA, 4)} for k in allk}
     roof = {"bound": "mfma",
-            "kernel": "conv_fwd_k (forward%s launches): fp32 arithmetic, %.0f %% of the flops as 6 bf16 MFMA products per "
-                      "fp32 product (3-way operand split, v_mfma_f32_32x32x16_bf16, fp32 accumulate), the rest on "
-                      "v_mfma_f32_32x32x2_f32" % (" + input-gradient" if "conv_dgrad" in fam else "", 100.0 * share),
-            "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_FP32_MFMA, 4),
+            "kernel": "the matrix kernels of the pass: conv_fwd_k (forward%s launches; fp32 arithmetic, %.0f %% of their flops as "
+                      "6 bf16 MFMA products per fp32 product -- 3-way operand split, v_mfma_f32_32x32x16_bf16, fp32 accumulate "
+                      "--, the rest on v_mfma_f32_32x32x2_f32)%s" % (
+                          " + input-gradient" if "conv_dgrad" in fam else "", 100.0 * share,
+                          " and the weight-gradient kernels (conv_wgrad_s3n_k / wgrad_1x1_s3_k on the same split products, "
+                          "conv_wgrad_k on fp32 MFMA for the few-channel tails)" if "conv_wgrad" in fam else ""),
+            "achieved": round(achieved_all, 3), "peak": PEAK_FP32_MFMA, "unit": "TFLOP/s",
+            "frac": round(achieved_all / PEAK_FP32_MFMA, 4),
+            "families": families,
+            "conv_fwd_k_only": {"achieved": round(achieved, 3), "frac": round(achieved / PEAK_FP32_MFMA, 4)},
             "peak_note": "peak = dense fp32 MFMA (the arithmetic type); achieved = algorithmic fp32 flops / launch time; "
                          "launch time = HIP events around 3 back-to-back launches of every conv op, one lane "
                          "(the kernel alone on the chip: profiles/*_bench_kernel_stats_one_lane.csv is the rocprofv3 "
@@ -678,8 +691,9 @@ def plan_rooflines(plan, prof, model_tag):
                           "frac": round(achieved * 6.0 * share / PEAK_BF16_MFMA, 4),
                           "fp32_equivalent_ceiling_tflops": round(PEAK_BF16_MFMA / 6.0, 1)},
             "traffic": None, "traffic_source": None,
-            "launches_per_iter": n_launch, "avg_launch_us": round(1e3 * mfma_ms / n_launch, 2),
-            "algorithmic_gflop_per_iter": round(mfma_fl / 1e9, 1)}
+            "launches_per_iter": all_n, "avg_launch_us": round(1e3 * all_ms / all_n, 2),
+            "algorithmic_gflop_per_iter": round(all_fl / 1e9, 1),
+            "conv_fwd_k_launches_per_iter": n_launch, "conv_fwd_k_avg_launch_us": round(1e3 * mfma_ms / n_launch, 2)}
     hbm = []
     for k, v in sorted(fam.items(), key=lambda kv: -kv[1][3]):
         if v[3] > 0 and v[2] > 0:
@@ -1021,8 +1035,9 @@ def main():
         # read from inside the process); tools/pmc_traffic.py wrote the summary that is committed under profiles/
         headline = args.model == "pmf" and args.backbone == "resnet34" and args.nclasses == 20 and \
             (args.height, args.width, args.bs) == (64, 2048, 2)
-        for tp in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
-            tp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", tp)
+        import glob
+        pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+        for tp in sorted(glob.glob(os.path.join(pdir, "r??_pmc_traffic.json")), reverse=True):     # the newest round first
             if headline and os.path.exists(tp):
                 with open(tp) as f:
                     tj = json.load(f)
@@ -1043,7 +1058,7 @@ def main():
             "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA, 4),
             "bf16_pipe_frac": round(ach * 6.0 * split_share / PEAK_BF16_MFMA, 4),
             "non_matrix_kernel_ms_one_lane": round(sum(v["ms"] for k, v in detail.items() if not v.get("gflop")), 3)}
-        ip = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_in_step.json")
+        ip = (sorted(glob.glob(os.path.join(pdir, "r??_in_step.json")), reverse=True) or [""])[0]
         if headline and os.path.exists(ip):
             with open(ip) as f:
                 roof["in_step"]["trace"] = json.load(f)      # rocprofv3 view of the four-lane replay (tools/in_step.py)

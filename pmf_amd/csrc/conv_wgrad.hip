@@ -41,13 +41,14 @@ struct WgGeom {
 // Operands of pixel pair kp+1 are fetched from LDS BEFORE the MFMAs of pair kp are issued (explicit double
 // buffer + sched_barrier), so the ~100-cycle ds_read latency hides under NA x 64 cycles of MFMA even with one
 // wave per SIMD; left alone, hipcc emits read -> wait -> mfma triplets through a single temporary register.
-template <int UPW, int NA, int BN>
+template <int UPW, int NA, int BN, int IS = 1>
 __device__ __forceinline__ void wg_tile(f32x16 (&acc)[UPW], const float* __restrict__ Xs, const float* __restrict__ zbase,
-                                        const int (&toff)[UPW], int li, int lh, int in_cols) {
-  constexpr int is = 1;                                  // stride-1 convolutions only (offsets fold into ds_read)
+                                        const int (&toff)[UPW], int li, int lh, int in_cols, int row0 = 0, int row1 = WG_ROWS) {
+  constexpr int is = IS;                                 // compile-time stride: the offsets fold into the ds_read
+                                                         // (IS = 2, round 5: the stride-2 3x3 layers ran the scalar-guard loop)
   constexpr int xstep = 2 * is * WG_CI, zstep = 2 * BN;
 #pragma unroll 1
-  for (int row = 0; row < WG_ROWS; ++row) {
+  for (int row = row0; row < row1; ++row) {
     const float* xp = Xs + (row * is * in_cols) * WG_CI + li + lh * is * WG_CI;
     const float* zp = zbase + (row * 32) * BN + lh * BN;
     float ac[NA], an[NA], bc, bn;
@@ -75,9 +76,9 @@ __device__ __forceinline__ void wg_tile(f32x16 (&acc)[UPW], const float* __restr
 template <int UPW>
 __device__ __forceinline__ void wg_tile_any(f32x16 (&acc)[UPW], const float* __restrict__ Xs,
                                             const float* __restrict__ zbase, const int (&toff)[UPW], int nact, int li,
-                                            int lh, int is, int in_cols, int BN) {
+                                            int lh, int is, int in_cols, int BN, int row0 = 0, int row1 = WG_ROWS) {
 #pragma unroll 1
-  for (int row = 0; row < WG_ROWS; ++row) {
+  for (int row = row0; row < row1; ++row) {
     const float* xrow = Xs + (row * is * in_cols) * WG_CI + li;
     const float* zrow = zbase + (row * 32) * BN;
 #pragma unroll 1
@@ -97,15 +98,23 @@ __device__ __forceinline__ void wg_tile_any(f32x16 (&acc)[UPW], const float* __r
 // accumulators are final for the pixels it saw: no cross-wave reduction, and one staged tile feeds
 // 64 pixel-pairs x UPW MFMAs per wave.  Because 4 % NT == 0 a wave's units share one co tile (one B read per
 // pixel pair) and differ only in the tap (one A read each).
+// Fewer units than waves (U = 1: the one-tap layers with <= 32 output channels -- logits, downCntx.s, dec.up1; U = 2): the
+// waves split the ROWS of the staged tile instead (PG = 4 / U pixel groups, wave w = unit w % U of group w / U) and the
+// groups are folded through LDS in a fixed order at the end -- round 4 left three of four waves without an MFMA there
+// (logits 32 -> 20 at 64 x 2048: 73 us for 59 MB).
 template <int TB, int NT>
 __global__ __launch_bounds__(256) void conv_wgrad_k(const pmf_wgrad_desc_t d, const WgGeom g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int BN = NT * 32;
   constexpr int U = TB * NT, UPW = (U + 3) / 4;
+  constexpr int PG = U == 1 ? 4 : (U == 2 ? 2 : 1);             // pixel groups (rows of a tile dealt to the waves)
   float* __restrict__ Xs = smem;
   float* __restrict__ Zs = smem + g.x_floats;
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform (SGPR): unit bookkeeping stays scalar
+  const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = PG > 1 ? wave_id % U : wave_id;             // wave-uniform (SGPR): unit bookkeeping stays scalar
+  const int pgrp = PG > 1 ? wave_id / U : 0;
+  const int row0 = pgrp * (WG_ROWS / PG), row1 = row0 + WG_ROWS / PG;
   const int li = lane & 31, lh = lane >> 5;
   const int split = blockIdx.x, chunk = blockIdx.y;
   const int cot = blockIdx.z % g.co_tiles, tb = blockIdx.z / g.co_tiles;
@@ -231,10 +240,29 @@ __global__ __launch_bounds__(256) void conv_wgrad_k(const pmf_wgrad_desc_t d, co
     }
     __syncthreads();
     const float* zbase = Zs + myc * 32 + li;
-    if (is == 1 && nact == UPW) wg_tile<UPW, UPW, BN>(acc, Xs, zbase, toff, li, lh, g.in_cols);
+    if (is == 1 && nact == UPW) wg_tile<UPW, UPW, BN>(acc, Xs, zbase, toff, li, lh, g.in_cols, row0, row1);
     else if (is == 1 && nact == UPW - 1 && UPW > 1)
-      wg_tile<UPW, (UPW > 1 ? UPW - 1 : 1), BN>(acc, Xs, zbase, toff, li, lh, g.in_cols);
-    else wg_tile_any<UPW>(acc, Xs, zbase, toff, nact, li, lh, is, g.in_cols, BN);
+      wg_tile<UPW, (UPW > 1 ? UPW - 1 : 1), BN>(acc, Xs, zbase, toff, li, lh, g.in_cols, row0, row1);
+    else if (is == 2 && nact == UPW) wg_tile<UPW, UPW, BN, 2>(acc, Xs, zbase, toff, li, lh, g.in_cols, row0, row1);
+    else if (is == 2 && nact == UPW - 1 && UPW > 1)
+      wg_tile<UPW, (UPW > 1 ? UPW - 1 : 1), BN, 2>(acc, Xs, zbase, toff, li, lh, g.in_cols, row0, row1);
+    else wg_tile_any<UPW>(acc, Xs, zbase, toff, nact, li, lh, is, g.in_cols, BN, row0, row1);
+  }
+
+  if constexpr (PG > 1) {       // fold the pixel groups in a fixed order: group 0 of every unit ends up with the sum
+    static_assert(UPW == 1, "pixel groups: one unit per wave");
+    __syncthreads();            // (everyone is through with the staged tile: the fold reuses Xs)
+    float* red = smem;          // [PG - 1][U][16][64]
+    if (pgrp > 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[(((pgrp - 1) * U + wave) * 16 + r) * 64 + lane] = acc[0][r];
+    }
+    __syncthreads();
+    if (pgrp > 0) return;
+#pragma unroll
+    for (int p = 1; p < PG; ++p)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[0][r] += red[(((p - 1) * U + wave) * 16 + r) * 64 + lane];
   }
 
   // ---- every wave owns complete sums for its units: write them straight into the partial slab
@@ -1943,6 +1971,133 @@ __global__ __launch_bounds__(256) void wgrad_fewc_k(const pmf_wgrad_desc_t d, co
 // X times component j' of dz feeds accumulator tile (j, j') whose row m stands for channel 4m + j (a permuted tile --
 // only the final store needs to know).  The four waves take every fourth pixel pair and are folded through LDS in a
 // fixed order; BatchNorm-apply / ReLU / dropout multipliers of the operand are applied in registers.
+// ---- streaming kernel for the full-resolution one-tap layers with few channels (round 5) ------------------------------------
+// logits 32 -> 20, downCntx.s 5 -> 32, downCntx2/3.s 32 -> 32, resBlock1.s 32 -> 64, dec.up1 80 -> 16, upBlock4.e 96 -> 32 at
+// 2 x 64 x 2048: 40-130 MB of operands for 0.1-1.6 GFLOP -- HBM-bound by 10x -- and the tiled kernels spend their time staging
+// 4 x 32-pixel tiles through LDS between barriers for 16 MFMAs per wave (35-73 us where the bytes need 7-22).  Here nothing is
+// staged: the fp32 MFMA operand layout of v_mfma_f32_32x32x2_f32 (A[i = lane & 31][k = lane >> 5]) IS "channel lane & 31 of pixel
+// 2 p + (lane >> 5)", i.e. one dword load per lane and operand, 256 contiguous bytes per wave instruction at a 32-float pixel
+// pitch; the view of an operand (BatchNorm scale / shift, ReLU, Dropout2d multiplier) is a per-lane constant because a lane
+// keeps its channel.  Every wave streams its own pixel pairs with U pairs of loads in flight and KT x NTL accumulator tiles,
+// no barrier until the four waves fold through LDS in a fixed order.  A workgroup stays inside ONE sample (the multiplier is
+// per (sample, channel)): grid.x = N * S.  No LDS while streaming, so the launch is 512 workgroups wide without taking the main
+// lane's LDS.  Partial-slab layout and stage 2 are those of every other kernel here.
+template <int KT, int NTL>
+__global__ __launch_bounds__(256) void wgrad_stream_k(const pmf_wgrad_desc_t d, int Ktot, int Cout32, int S) {
+  constexpr int U = 8;                       // pixel pairs in flight per wave
+  __shared__ float red[3 * 16 * 64];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int split = blockIdx.x, n = split / S, sp = split - n * S;
+  const int P = d.OH * d.OW, PP = (P + 1) >> 1;
+  const int per = (PP + S - 1) / S;
+  const int p0 = sp * per, p1 = min(PP, p0 + per);
+
+  // per-lane view of the A operand: channel k = kt * 32 + li of the virtual concat
+  const float* xp[KT];
+  int xld[KT];
+  float sc[KT], sh[KT], lo[KT], cm[KT];
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) {
+    int k = kt * 32 + li, si = 0;
+    const bool valid = k < Ktot;
+    if (!valid) k = 0;
+    while (si + 1 < d.nsrc && k >= d.src[si].C) { k -= d.src[si].C; ++si; }
+    const pmf_src_t& sv = d.src[si];
+    xp[kt] = sv.x + (size_t)n * P * sv.ldc + k;
+    xld[kt] = sv.ldc;
+    sc[kt] = valid ? (sv.scale ? sv.scale[k] : 1.f) : 0.f;
+    sh[kt] = (valid && sv.scale) ? sv.shift[k] : 0.f;
+    lo[kt] = (sv.flags & PMF_SRC_RELU) ? 0.f : -__builtin_inff();
+    cm[kt] = valid ? (sv.cmul ? sv.cmul[(size_t)n * sv.cmul_ld + k] : 1.f) : 0.f;
+  }
+  const __amdgpu_buffer_rsrc_t zrs =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(d.dz + (size_t)n * P * d.dz_ldc), 0, P * d.dz_ldc * 4, 0x00020000);
+
+  f32x16 acc[KT][NTL];
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+    for (int nt = 0; nt < NTL; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[kt][nt][r] = 0.f;
+
+  for (int pb = p0 + wave * U; pb < p1; pb += 4 * U) {
+    float a[KT][U], b[NTL][U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int pix = 2 * (pb + u) + lh;
+      const bool ok = pb + u < p1 && pix < P;
+      const int pc = ok ? pix : 0;
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) a[kt][u] = xp[kt][(size_t)pc * xld[kt]];
+#pragma unroll
+      for (int nt = 0; nt < NTL; ++nt)       // (a channel beyond the pitch reads the next pixel: a column stage 2 never looks at)
+        b[nt][u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+            zrs, ok ? (unsigned)((pix * d.dz_ldc + nt * 32 + li) * 4) : 0xffffffffu, 0, 0));
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool ok = pb + u < p1 && 2 * (pb + u) + lh < P;
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) {
+        const float v = ok ? fmaxf(a[kt][u] * sc[kt] + sh[kt], lo[kt]) * cm[kt] : 0.f;
+#pragma unroll
+        for (int nt = 0; nt < NTL; ++nt) acc[kt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(v, b[nt][u], acc[kt][nt], 0, 0, 0);
+      }
+    }
+  }
+
+  // fold the four waves in a fixed order, one accumulator tile at a time (12 KiB of LDS); wave 0 writes the slab
+  float* part = d.partial + (size_t)split * Ktot * Cout32;
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+    for (int nt = 0; nt < NTL; ++nt) {
+      if (kt + nt > 0) __syncthreads();
+      if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[((wave - 1) * 16 + r) * 64 + lane] = acc[kt][nt][r];
+      }
+      __syncthreads();
+      if (wave == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[kt][nt][r];
+#pragma unroll
+          for (int w = 1; w < 4; ++w) v += red[((w - 1) * 16 + r) * 64 + lane];
+          const int k = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (k < Ktot) part[(size_t)k * Cout32 + nt * 32 + li] = v;
+        }
+      }
+    }
+}
+
+// conditions of the streaming kernel: one tap at (0, 0), stride 1, operands of the gradient's size, <= 96 input and <= 64
+// output channels, >= 32768 pixels (PMF_WGRAD_STREAM=0 switches it off, PMF_WGRAD_STREAM_WGS sets the launch width)
+static bool wg_stream(const pmf_wgrad_desc_t* d) {
+  static const bool off = getenv("PMF_WGRAD_STREAM") && atoi(getenv("PMF_WGRAD_STREAM")) == 0;
+  if (off || d->ntaps != 1 || d->gather || d->in_stride != 1 || d->tdy[0] || d->tdx[0]) return false;
+  int Ktot = 0;
+  for (int i = 0; i < d->nsrc; ++i) {
+    const pmf_src_t& s = d->src[i];
+    if ((s.flags & PMF_SRC_BCAST) || s.H != d->OH || s.W != d->OW || (s.flags & ~PMF_SRC_RELU)) return false;
+    if ((int64_t)d->OH * d->OW * s.ldc * 4 >= (1ll << 31)) return false;
+    Ktot += s.C;
+  }
+  if (Ktot > 96 || d->Cout > 64) return false;
+  if ((int64_t)d->OH * d->OW * d->dz_ldc * 4 >= (1ll << 31)) return false;
+  return (int64_t)d->N * d->OH * d->OW >= 32768;
+}
+static int wg_stream_splits(const pmf_wgrad_desc_t* d) {     // S: workgroups per sample
+  static const int target = getenv("PMF_WGRAD_STREAM_WGS") ? atoi(getenv("PMF_WGRAD_STREAM_WGS")) : 512;
+  int S = target / (d->N > 0 ? d->N : 1);
+  const int pairs = (d->OH * d->OW + 1) / 2;
+  if (S > pairs / 64) S = pairs / 64;           // >= 64 pixel pairs per workgroup
+  return S < 1 ? 1 : S;
+}
+
 template <int NCO>
 __global__ __launch_bounds__(256, 2) void wgrad_1x1_k(const pmf_wgrad_desc_t d, int Ktot, int Cout32) {
   extern __shared__ __attribute__((aligned(16))) float fold[];       // [4 * NCO tiles][16][64]
@@ -2210,7 +2365,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_1x1_s3_k(const pmf_wgrad_desc_t 
 // conditions of the split-bf16 direct 1x1 kernel (64 x 64 output blocks)
 static bool wg_direct_s3(const pmf_wgrad_desc_t* d) {
   static const bool off = getenv("PMF_WGRAD_NODIRECT_S3") != nullptr;
-  static const int min_pix = getenv("PMF_WGRAD_DIRECT_S3_MIN_PIX") ? atoi(getenv("PMF_WGRAD_DIRECT_S3_MIN_PIX")) : 16384;
+  // smallest map: rounds 2-4 16384 pixels (measured under 256-wide launches); round 5, at the 128-workgroup width of the step:
+  // resBlock4.r5 768 -> 256 at 2 x 8 x 256 100 -> 26 us, resBlock4.s 256 -> 256 27 -> 15, upBlock1.e 384 -> 128 27 -> 14,
+  // resBlock5.r5 768 -> 256 at 2 x 4 x 128 27 -> 13 -- but 256 -> 256 at 1024 pixels 10 -> 13: from 4096 pixels, or from 1024
+  // with >= 512 input channels
+  static const int min_pix = getenv("PMF_WGRAD_DIRECT_S3_MIN_PIX") ? atoi(getenv("PMF_WGRAD_DIRECT_S3_MIN_PIX")) : 0;
   if (off || !(d->flags & PMF_WGRAD_S3) || ((d->cfg >> 8) & 0xff) == 2) return false;
   if (d->ntaps != 1 || d->gather || d->in_stride != 1 || d->tdy[0] || d->tdx[0] || (d->Cout & 1) || (d->dz_ldc & 1)) return false;
   const int64_t npix = (int64_t)d->N * d->OH * d->OW;
@@ -2220,7 +2379,10 @@ static bool wg_direct_s3(const pmf_wgrad_desc_t* d) {
     if ((s.flags & PMF_SRC_BCAST) || s.H != d->OH || s.W != d->OW || (s.C & 63) || (s.ldc & 1)) return false;
     if (s.flags & ~(PMF_SRC_RELU)) return false;
   }
-  return npix >= min_pix;
+  if (min_pix > 0) return npix >= min_pix;
+  int Ktot = 0;
+  for (int i = 0; i < d->nsrc; ++i) Ktot += d->src[i].C;
+  return npix >= 4096 || (npix >= 1024 && Ktot >= 512);
 }
 
 // conditions of the direct 1x1 kernel + its grid
@@ -2239,7 +2401,8 @@ static bool wg_direct_1x1(const pmf_wgrad_desc_t* d) {
   if (d->Cout > 128 && Ktot < 256) return false;     // X is re-read once per 64 output channels
   // measured (64x2048, bs 2): 192->64 158 -> 119 us, 384->128 115 -> 92, 768->256 111 -> 95; below ~16 k pixels the
   // tiled kernels win (fewer, larger tiles; the per-workgroup fold and slab dominate here)
-  return (int64_t)d->N * d->OH * d->OW >= 16384;
+  static const int min_pix1 = getenv("PMF_WGRAD_DIRECT_MIN_PIX") ? atoi(getenv("PMF_WGRAD_DIRECT_MIN_PIX")) : 16384;
+  return (int64_t)d->N * d->OH * d->OW >= min_pix1;
 }
 static void wg_direct_grid(const pmf_wgrad_desc_t* d, int* kblocks, int* oblocks, int* nco) {
   int Ktot = 0;
@@ -2415,11 +2578,14 @@ static int wg_geometry(const pmf_wgrad_desc_t* d, int TB, int BN, WgGeom* g, int
 
 // conditions of the software-pipelined kernel
 // cmod: operand channel counts must be multiples of it (32; the split-bf16 kernel also takes half-empty chunks: 16)
-static bool wg_simple(const pmf_wgrad_desc_t* d, const WgGeom& g, int TB, int BN, int cmod = WG_CI) {
+// ragged: Cout need not fill its last 32-channel tile (only the N-split kernel, which reads dz straight from global memory:
+// a lane beyond Cout reads the next pixel's channels -- or the buffer's hardware zero -- into a column of the partial slab
+// that stage 2 never looks at)
+static bool wg_simple(const pmf_wgrad_desc_t* d, const WgGeom& g, int TB, int BN, int cmod = WG_CI, bool ragged = false) {
   static const bool no_half = getenv("PMF_WGRAD_S3_C32") != nullptr;   // A/B switch: no half-empty chunks
   if (no_half) cmod = WG_CI;
   if (d->gather || d->in_stride != 1 || d->ntaps != TB) return false;
-  if (d->OH % WG_ROWS || d->OW % 32 || d->Cout % BN) return false;
+  if (d->OH % WG_ROWS || d->OW % 32 || (!ragged && d->Cout % BN)) return false;
   if (g.in_rows * g.in_cols * 8 > 256 * 9 || g.in_cols > 255) return false;
   for (int i = 0; i < d->nsrc; ++i) {
     if (d->src[i].C % cmod || (d->src[i].flags & PMF_SRC_BCAST)) return false;
@@ -2463,11 +2629,13 @@ static void wg_config(const pmf_wgrad_desc_t* d, int* TB, int* NT) {
 static int wg_s3n_nco(const pmf_wgrad_desc_t* d, const WgGeom& g, int TB) {
   const char* e_n = getenv("PMF_WG_S3N");     // (read per call, not cached: the tests switch variants)
   const int mode = e_n ? atoi(e_n) : 4;
-  if (mode <= 1 || TB <= 1 || !(d->flags & PMF_WGRAD_S3) || !wg_simple(d, g, TB, 32, 16)) return 0;
+  static const bool no_ragged = getenv("PMF_WG_S3N_NORAGGED") != nullptr;      // A/B switch (round 4: those layers on fp32 MFMA)
+  if (mode <= 1 || TB <= 1 || !(d->flags & PMF_WGRAD_S3) || !wg_simple(d, g, TB, 32, 16, !no_ragged)) return 0;
   if ((int64_t)d->N * d->OH * d->OW * d->dz_ldc * 4 >= (1ll << 31)) return 0;
   const char* e_w8 = getenv("PMF_WG_W8");
   const char* e_swp = getenv("PMF_WG_SWP");
   if ((e_w8 && e_w8[0] == '1') || (e_swp && e_swp[0] == '0')) return 0;        // the test switches for the older variants
+  if (d->Cout % 32) return mode == 3 ? 0 : 1;          // ragged last tile: one tile per workgroup
   if (mode >= 4 && d->Cout % 128 == 0) return 4;
   if (d->Cout % 64 == 0) return 2;
   return mode == 3 ? 0 : 1;       // (3: 32-channel tiles on the round-3 software-pipelined kernel)
@@ -2479,6 +2647,7 @@ extern "C" int pmf_conv_wgrad_nsplit(const pmf_wgrad_desc_t* d) {
     const int tiles = cdiv(d->OW, 32) * cdiv(d->OH, WG_ROWS) * d->N, ns = 256 / cdiv(d->Cout, 64);
     return tiles < ns ? tiles : (ns < 1 ? 1 : ns);
   }
+  if (wg_stream(d)) return d->N * wg_stream_splits(d);
   if (wg_direct_1x1(d)) {  // two resident workgroups per CU in total; every workgroup gets >= 64 pixel pairs
     int kb, ob, nco;
     wg_direct_grid(d, &kb, &ob, &nco);
@@ -2493,7 +2662,7 @@ extern "C" int pmf_conv_wgrad_nsplit(const pmf_wgrad_desc_t* d) {
   wg_config(d, &TB, &NT);
   wg_geometry(d, TB, NT * 32, &g, &lds);
   int other = g.nchunks * g.co_tiles * g.tap_batches;
-  if (NT == 1) { const int nco = wg_s3n_nco(d, g, TB); if (nco) other = g.nchunks * (d->Cout / (32 * nco)); }
+  if (NT == 1) { const int nco = wg_s3n_nco(d, g, TB); if (nco) other = g.nchunks * cdiv(d->Cout, 32 * nco); }
   // workgroups per launch: one per TWO CUs.  More make the launch itself faster in isolation (512: 4.8 ms over the 110 layers,
   // 256: 5.4 ms), but the weight gradients run on side lanes next to the input-gradient launches of the main lane -- which IS
   // the step -- and a weight-gradient workgroup holds 80-110 KiB of its CU's LDS: with one on every CU a main-lane conv
@@ -2574,7 +2743,7 @@ static int wg_launch(const pmf_wgrad_desc_t* d, hipStream_t s, int phase) {
   dim3 grid(d->nsplit, g.nchunks, g.co_tiles * g.tap_batches);
   bool piped = false;
   if constexpr (NT == 1) {
-    if ((d->flags & PMF_WGRAD_S3) && wg_simple(d, g, TB, 32, 16)) {
+    if ((d->flags & PMF_WGRAD_S3) && (wg_simple(d, g, TB, 32, 16) || wg_s3n_nco(d, g, TB))) {
       static unsigned long long attr3 = 0ull;
       if (pmf_first_on_device(&attr3)) {
         (void)hipFuncSetAttribute((const void*)conv_wgrad_s3_k<TB, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -2604,7 +2773,7 @@ static int wg_launch(const pmf_wgrad_desc_t* d, hipStream_t s, int phase) {
           g.x_floats += WS3_XPB / 4;           // the spare pixel that slots beyond the tile write to
           int lds6 = 2 * g.x_floats * 4;
           if (lds6 < 16 * 1024) lds6 = 16 * 1024;
-          const dim3 grid6(d->nsplit, g.nchunks, d->Cout / (32 * nco));
+          const dim3 grid6(d->nsplit, g.nchunks, cdiv(d->Cout, 32 * nco));
           if (nco == 4) {
             if (small7) hipLaunchKernelGGL((conv_wgrad_s3n_k<TB, 7, 4>), grid6, dim3(256), lds6, s, *d, g);
             else hipLaunchKernelGGL((conv_wgrad_s3n_k<TB, 9, 4>), grid6, dim3(256), lds6, s, *d, g);
@@ -2720,6 +2889,22 @@ static int wgrad_phases(const pmf_wgrad_desc_t* d, pmf_stream_t st, int phase) {
     if (d->src[i].C % 8 || d->src[i].ldc % 4) return PMF_E_ARG;
   if (d->gather && false) return PMF_E_ARG;
   if (wg_fewc(d)) return wg_launch_fewc(d, s, phase);
+  if (wg_stream(d)) {
+    WgGeom g;
+    int lds;
+    wg_geometry(d, 1, 32, &g, &lds);
+    if (phase & 1) {
+      if (d->nsplit % d->N) return PMF_E_ARG;               // (pmf_conv_wgrad_nsplit: N x S workgroups, one sample each)
+      const int S = d->nsplit / d->N, KT = cdiv(g.Ktot, 32), NTL = g.Cout32 / 32;
+      const dim3 grid(d->nsplit);
+#define WS_CASE(kt, ntl) if (KT == kt && NTL == ntl) hipLaunchKernelGGL((wgrad_stream_k<kt, ntl>), grid, dim3(256), 0, s, *d, g.Ktot, g.Cout32, S)
+      WS_CASE(1, 1); else WS_CASE(1, 2); else WS_CASE(2, 1); else WS_CASE(2, 2); else WS_CASE(3, 1); else WS_CASE(3, 2);
+      else return PMF_E_UNSUPPORTED;
+#undef WS_CASE
+      PMF_LAUNCH_CHECK();
+    }
+    return (phase & 2) ? wg_reduce(d, g, s) : 0;
+  }
   if (wg_direct_1x1(d)) {
     WgGeom g;
     int lds, kb, ob, nco;

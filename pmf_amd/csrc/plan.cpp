@@ -15,7 +15,9 @@ static uint64_t skip_mask() {
     uint64_t v = 0;
     const char* e = getenv("PMF_SKIP_OPS");
     while (e && *e) {
+      const char* e0 = e;
       const long k = strtol(e, (char**)&e, 10);
+      if (e == e0) break;                       // not a number: stop (round 5: "none" looped forever here)
       if (k > 0 && k < 64) v |= 1ull << k;
       while (*e == ',' || *e == ' ') ++e;
     }
@@ -24,7 +26,35 @@ static uint64_t skip_mask() {
   return m;
 }
 
+// PMF_DUP_OPS=kind,kind,...: these launches are issued TWICE -- the what-if in the other direction ("what does one more
+// launch of this kind per layer cost the step?"), for idempotent kinds only (BatchNorm finalize would move the running
+// statistics twice: a timing experiment, like PMF_SKIP_OPS; unlike it the data stay finite and non-zero, so the clocks do not
+// change with it -- skipping the finalize launches zeroes every activation behind them, and a chip multiplying zeros runs faster)
+static uint64_t dup_mask() {
+  static const uint64_t m = [] {
+    uint64_t v = 0;
+    const char* e = getenv("PMF_DUP_OPS");
+    while (e && *e) {
+      const char* e0 = e;
+      const long k = strtol(e, (char**)&e, 10);
+      if (e == e0) break;
+      if (k > 0 && k < 64) v |= 1ull << k;
+      while (*e == ',' || *e == ' ') ++e;
+    }
+    return v;
+  }();
+  return m;
+}
+
+static int run_one_(const pmf_op_t& o, pmf_stream_t s);
 static int run_one(const pmf_op_t& o, pmf_stream_t s) {
+  if (dup_mask() >> (o.kind & 63) & 1ull) {
+    const int rc = run_one_(o, s);
+    if (rc) return rc;
+  }
+  return run_one_(o, s);
+}
+static int run_one_(const pmf_op_t& o, pmf_stream_t s) {
   const pmf_small_args_t& a = o.u.sm;
   const int32_t* i = a.i;
   if (skip_mask() >> (o.kind & 63) & 1ull) return 0;

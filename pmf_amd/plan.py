@@ -101,7 +101,7 @@ class Plan(PlanConvMixin, PlanTuneMixin, PlanRunMixin):
         self.colrows_max = 4
 
     def knobs(self):
-        """the environment knobs this plan was built under (DESIGN.md section 6 documents the defaults; tests/test_host.py
+        """the environment knobs this plan was built under (docs/knobs.md documents the defaults; tests/test_host.py
         asserts that a fresh plan in a clean environment carries exactly those)"""
         return {"PMF_CONV_F32": not self.s3, "PMF_S3_MIN_TAPS": self.s3_min_taps, "PMF_S3_DIRECT_MIN_PIX": self.s3_direct_min_pix,
                 "PMF_BN_BWD_FUSED": self.bn_bwd_fused, "lanes": self.n_lanes, "PMF_WGRAD_LANE": self.wgrad_lane,

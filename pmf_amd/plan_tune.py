@@ -33,6 +33,23 @@ def _merge(path):
                 _TUNED.setdefault(k, v)
 
 
+def key_of(d):
+    """what the tuner keys a conv launch by: everything that selects a kernel variant or sizes its grid"""
+    return (d.N, d.OH, d.OW, d.Cout, d.nsrc,
+            tuple((d.src[i].C, d.src[i].H, d.src[i].W, d.src[i].flags, bool(d.src[i].scale), bool(d.src[i].cmul))
+                  for i in range(d.nsrc)),
+            d.ntaps, tuple(d.tdy[i] for i in range(d.ntaps)), tuple(d.tdx[i] for i in range(d.ntaps)),
+            d.in_stride, d.gather, d.act, d.out_sy, d.out_sx, d.accumulate, bool(d.bias), bool(d.ep_cmul),
+            bool(d.ep_relu_x), bool(d.stats), bool(d.ep_pmask), bool(d.ep_stat_mean), d.ep_flags, bool(d.w_s3),
+            tuple((d.dst[i].C, d.dst[i].accumulate, bool(d.dst[i].ep_relu_x), bool(d.dst[i].stats))
+                  for i in range(d.ndst)))
+
+
+def write_cache(path, table):
+    with open(path, "w") as f:
+        f.write("{\n" + "".join(" %r: %r,\n" % kv for kv in sorted(table.items(), key=repr)) + "}\n")
+
+
 class PlanTuneMixin(object):
     # ------------------------------------------------------------------ tile-configuration autotuner
     def force_conv_cfg(self, cfg):
@@ -79,16 +96,6 @@ class PlanTuneMixin(object):
             e1.synchronize()
             return e0.elapsed_time(e1) / reps
 
-        def key_of(d):
-            return (d.N, d.OH, d.OW, d.Cout, d.nsrc,
-                    tuple((d.src[i].C, d.src[i].H, d.src[i].W, d.src[i].flags, bool(d.src[i].scale), bool(d.src[i].cmul))
-                          for i in range(d.nsrc)),
-                    d.ntaps, tuple(d.tdy[i] for i in range(d.ntaps)), tuple(d.tdx[i] for i in range(d.ntaps)),
-                    d.in_stride, d.gather, d.act, d.out_sy, d.out_sx, d.accumulate, bool(d.bias), bool(d.ep_cmul),
-                    bool(d.ep_relu_x), bool(d.stats), bool(d.ep_pmask), bool(d.ep_stat_mean), d.ep_flags, bool(d.w_s3),
-                    tuple((d.dst[i].C, d.dst[i].accumulate, bool(d.dst[i].ep_relu_x), bool(d.dst[i].stats))
-                          for i in range(d.ndst)))
-
         for ops, n, kinds, shift, fins in ((self.fwd_ops, self.n_fwd, self.fwd_kinds, self.fwd_shift, self._conv_fin),
                                            (self.bwd_ops, self.n_bwd, self.bwd_kinds, self.bwd_shift, self._conv_fold)):
             for k in range(n):
@@ -126,5 +133,4 @@ class PlanTuneMixin(object):
         # step -- no gain over the built-in rules -- and removed.)
         torch.cuda.synchronize(self.device)
         if cache_file and len(_TUNED) != n_known:
-            with open(cache_file, "w") as f:
-                f.write("{\n" + "".join(" %r: %r,\n" % kv for kv in sorted(_TUNED.items(), key=repr)) + "}\n")
+            write_cache(cache_file, _TUNED)

@@ -7,10 +7,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-# The plan autotuner picks tile configurations from launch timings, i.e. not reproducibly across processes; the parity
-# tests run the built-in heuristics (reproducible), tests/test_gpu_ops.py::test_conv_tile_configs pins EVERY
-# configuration the tuner can choose, and test_gpu_parity.py::test_autotuned_plan_matches_heuristic_plan runs it.
-os.environ.setdefault("PMF_AUTOTUNE", "0")
+# Tile configurations: the tests run the SHIPPED table (pmf_amd/tuned/gfx950.txt: the tuner's choices for every BASELINE shape,
+# what bench.py and a user run) and the built-in heuristics for shapes the table does not know -- reproducible across processes,
+# no timing inside the tests.  tests/test_gpu_ops.py::test_conv_tile_configs pins EVERY configuration the tuner can choose,
+# test_gpu_fullsize.py runs the full-size plans with the heuristics ("0") and with the shipped table ("cache").
+os.environ.setdefault("PMF_AUTOTUNE", "cache")
 
 
 def pytest_configure(config):

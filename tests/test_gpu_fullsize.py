@@ -79,10 +79,10 @@ def _oracle_grads(kind):
 
 
 # (the headline configuration with both tile-configuration sources; configs[3] / [4] with the reproducible heuristics)
-@pytest.mark.parametrize("kind,tune", [("pmf_r34", "0"), ("pmf_r34", "1"), ("r50", "0"), ("r50", "1"), ("epmf", "0"),
-                                       ("epmf", "1"), ("pmf_r34_sb", "0"), ("pmf_r34_sb", "1")],
-                         ids=["pmf_r34-heuristic", "pmf_r34-autotuned", "r50-heuristic", "r50-autotuned", "epmf-heuristic",
-                              "epmf-autotuned", "pmf_r34_sb-heuristic", "pmf_r34_sb-autotuned"])
+@pytest.mark.parametrize("kind,tune", [("pmf_r34", "0"), ("pmf_r34", "cache"), ("r50", "0"), ("r50", "cache"), ("epmf", "0"),
+                                       ("epmf", "cache"), ("pmf_r34_sb", "0"), ("pmf_r34_sb", "cache")],
+                         ids=["pmf_r34-heuristic", "pmf_r34-shipped", "r50-heuristic", "r50-shipped", "epmf-heuristic",
+                              "epmf-shipped", "pmf_r34_sb-heuristic", "pmf_r34_sb-shipped"])
 def test_full_size_backward_vs_oracle(kind, tune):
     from pmf_amd.engine import TrainEngine
     from pmf_amd import plan as PL
@@ -105,8 +105,10 @@ def test_full_size_backward_vs_oracle(kind, tune):
         torch.cuda.synchronize()
         plan = next(p for k, p in hip._plans.items() if k[3])
         assert len(plan._graphs) >= 2, "the compared pass did not run on captured graphs"
-        if tune == "1":
-            assert len(PL._TUNED) > 20
+        if tune == "cache":     # the shipped table was applied: most conv launches of a BASELINE shape carry a tuned configuration
+            from pmf_amd import _lib as L
+            tuned = sum(1 for k in range(plan.n_fwd) if plan.fwd_kinds[k] == L.OP_CONV and plan.fwd_ops[k].u.conv.cfg != 0)
+            assert tuned > 20, tuned
     finally:
         if old is None:
             os.environ.pop("PMF_AUTOTUNE", None)
@@ -143,11 +145,12 @@ def test_full_size_backward_vs_oracle(kind, tune):
         if k.startswith(HEADS):
             assert e_h < 2e-5, (k, e_h)
     # (2) EVERY parameter: at most 3x as far from float64 as the fp32 CPU oracle for THAT parameter; no outlier allowance.
-    # Floor: 5 % of the network-wide fp32 noise level (median distance of the fp32 CPU oracle over all parameters, ~1.5e-2
-    # here -> 7.5e-4): where the CPU oracle happens to sit at 1e-5 (the camera decoder) another valid fp32 rounding of the
-    # same network -- e.g. another tile configuration picked by the autotuner -- may legitimately sit at 1e-4.
-    noise = float(np.median([r[2] for r in rows]))
-    bad = [r for r in rows if not r[1] <= max(3 * r[2], 2e-4, 0.05 * noise)]
+    # Floor: a fixed 2e-4 (round 5; rounds 3-4 used 5 % of the network-wide fp32 noise level, ~7.5e-4).  What the floor cannot
+    # absorb is a ReLU sitting on its kink: two valid fp32 roundings of this network differ in the sign of a few
+    # pre-activations per tensor, and one such flip in the camera decoder's 16 x 512 map moved these gradients by 1-4e-3 while
+    # the fp32 CPU oracle sat at 1e-5 (tools/bisect_tune.py --flips).  The shipped tile table is chosen
+    # under that constraint (tools/bisect_tune.py --fix), so both plans tested here are deterministic and inside the bar.
+    bad = [r for r in rows if not r[1] <= max(3 * r[2], 2e-4)]
     assert not bad, "gradient error vs float64 (hip, cpu-fp32):\n" + "\n".join("%-55s %.3e %.3e" % r for r in bad[:30])
     # (3) no systematic excess over the fp32 CPU path
     assert gmean < 1.25 and p90 < 1.6, (gmean, p90)

@@ -118,6 +118,21 @@ CONVS = [
     # workgroups per CU); ragged last chunk
     ("c1x1_k768_cat", 2, 16, 64, [256, 256, 256], 256, 1, 1, 0, 1, True, "act_bn", True),
     ("c1x1_k784", 1, 16, 64, [784], 64, 1, 1, 0, 1, False, "bn_relu", True),
+    # round 5, the weight-gradient tails.  One-tap layers with one or two 32 x 32 output tiles per chunk (logits 32 -> 20,
+    # downCntx.s 5 -> 32, resBlock1.s 32 -> 64): the waves of the unit-dealing kernel split the ROWS of a tile and fold at the
+    # end (ragged tile columns: 40 / 72 wide).  3x3 layers with 20 / 16 output channels (dec.logits, dec.up2-4): the N-split
+    # split-bf16 kernel with a ragged last output-channel tile (dz pitch 24 / 16: lanes beyond Cout read the next pixel)
+    ("c1x1_k32_c20", 2, 16, 72, [32], 20, 1, 1, 0, 1, True, "none", False),
+    ("c1x1_k8_c32", 2, 8, 64, [8], 32, 1, 1, 0, 1, True, "lrelu", False),
+    ("c1x1_k32_c64", 1, 12, 40, [32], 64, 1, 1, 0, 1, True, "act_bn", True),
+    ("c3x3_c16_to20", 2, 8, 64, [16], 20, 3, 1, 1, 1, True, "none", False),
+    ("c3x3_cat_to16", 1, 8, 32, [128, 16], 16, 3, 1, 1, 1, False, "bn_relu", True),
+    # >= 32768 pixels, <= 96 input and <= 64 output channels, one tap: the streaming weight-gradient kernel (operands as dword
+    # loads in the fp32 MFMA layout, a workgroup inside one sample); odd pixel count, operands behind BatchNorm / Dropout views
+    ("c1x1_stream_k32_c20", 2, 64, 256, [32], 20, 1, 1, 0, 1, True, "none", False),
+    ("c1x1_stream_cat", 1, 129, 257, [64, 16], 16, 1, 1, 0, 1, True, "act_bn", True),
+    ("c1x1_stream_k8_c64", 2, 64, 256, [8], 64, 1, 1, 0, 1, True, "act_bn", True),
+    ("c1x1_stream_k96_c32", 2, 128, 129, [32, 32, 32], 32, 1, 1, 0, 1, False, "bn_relu", True),
 ]
 
 

@@ -360,7 +360,7 @@ def test_prefetcher_workers_keep_sampler_order():
 
 
 def test_documented_knob_defaults_are_what_a_fresh_plan_uses(monkeypatch):
-    """DESIGN.md section 6 lists the PMF_* knobs and says "defaults are what the bench runs": a plan built in a clean
+    """docs/knobs.md lists the PMF_* knobs and says "defaults are what the bench runs": a plan built in a clean
     environment must carry exactly these values, and every knob named here must be documented there."""
     from pmf_amd.plan import Plan
     for k in list(os.environ):
@@ -373,7 +373,7 @@ def test_documented_knob_defaults_are_what_a_fresh_plan_uses(monkeypatch):
             "PMF_AUTOTUNE": True, "PMF_TUNE_DIRECT": True, "PMF_GRAPH": True, "PMF_DP_MODE": "events", "PMF_DP_SEGMENTS": 4,
             "PMF_PACK_EARLY": 8}
     assert got == want
-    design = open(os.path.join(ROOT, "DESIGN.md")).read()
+    design = open(os.path.join(ROOT, "docs", "knobs.md")).read()
     for k in want:
         if k.startswith("PMF_"):
-            assert k in design, "%s is not documented in DESIGN.md" % k
+            assert k in design, "%s is not documented in docs/knobs.md" % k
