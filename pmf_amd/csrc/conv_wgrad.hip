@@ -1147,7 +1147,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_s3_swp_k(const pmf_wgrad_desc_
 //     the SWP body; one barrier per tile; LDS = the two input buffers only;
 //   * pixel groups (NCO = 2) are folded in a fixed order through LDS at the end; every wave with pixel group 0 writes its
 //     co tile of the partial slab.  Partial-slab layout, stage 2 and arithmetic are those of the SWP body.
-template <int TB, int XSL, int NCO>
+//   * RAG (round 5): output maps whose height is not a multiple of 4 or whose width is not a multiple of 32 (S_B: 60 x 80 and
+//     30 x 40 maps -- those layers ran the fp32-MFMA unit-dealing kernel at 27-37 TFLOP/s): a dz load of a pixel beyond the map
+//     takes an out-of-range offset (hardware zero) instead of wrapping into the next row -- two vector instructions per load,
+//     only in this instantiation; the input tile needs nothing (a product with dz = 0 is 0 whatever the input pixel is).
+template <int TB, int XSL, int NCO, bool RAG>
 __device__ __forceinline__ void conv_wgrad_s3n_body(const pmf_wgrad_desc_t& d, const WgGeom& g, float* __restrict__ smem) {
   constexpr int NPX = 4 / NCO;              // pixel groups
   constexpr int NSL = 8 / NPX;              // 16-pixel slabs of a 4 x 32 tile per wave
@@ -1282,6 +1286,9 @@ __device__ __forceinline__ void conv_wgrad_s3n_body(const pmf_wgrad_desc_t& d, c
     f_on = on;
   };
   auto zbase_f = [&]() { return ((f_n * d.OH + f_ty * WG_ROWS) * d.OW + f_tx * 32) * zpix; };   // dz of the tile at the fetch coordinates
+  // rows << 16 | columns of that tile inside the map (RAG)
+  auto zvalid_f = [&]() { return (min(WG_ROWS, d.OH - f_ty * WG_ROWS) << 16) | min(32, d.OW - f_tx * 32); };
+  const int lh8 = lh * 8;
   auto fetch_slot = [&](int j) {
     const bool ok = (unsigned)(f_by + sr[j]) < (unsigned)sH && (unsigned)(f_bx + sc[j]) < (unsigned)sW;
     mX[j] = ok ? 1.f : 0.f;
@@ -1322,11 +1329,21 @@ __device__ __forceinline__ void conv_wgrad_s3n_body(const pmf_wgrad_desc_t& d, c
   char* st_o = nullptr;
   auto lo16 = [](unsigned p) { return __builtin_bit_cast(float, p << 16); };
   auto hi16 = [](unsigned p) { return __builtin_bit_cast(float, p & 0xffff0000u); };
-  auto zload4 = [&](int tile_base, int i, int par, int e0) {
+  auto zload4 = [&](int tile_base, int tile_zv, int i, int par, int e0) {
     const int sb = tile_base + (slab_rr(i) * d.OW + slab_xs(i)) * zpix;
+    if constexpr (RAG) {
+      const bool rowok = slab_rr(i) < (tile_zv >> 16);
+      const int cols = (tile_zv & 0xffff) - slab_xs(i);                  // columns of this slab's 16 inside the map
 #pragma unroll
-    for (int e = e0; e < e0 + 4; ++e)
-      zr[par][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(zrs, zvoff, sb + e * zpix, 0));
+      for (int e = e0; e < e0 + 4; ++e) {
+        const unsigned vo = (rowok && lh8 < cols - e) ? (unsigned)zvoff : 0x80000000u;
+        zr[par][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(zrs, vo, sb + e * zpix, 0));
+      }
+    } else {
+#pragma unroll
+      for (int e = e0; e < e0 + 4; ++e)
+        zr[par][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(zrs, zvoff, sb + e * zpix, 0));
+    }
   };
   auto zsplit_op = [&](int par, int bsel, int e, int step) {     // pair e of zr[par] -> planes of bq[bsel], one step
     float& a = zr[par][2 * e];
@@ -1360,7 +1377,7 @@ __device__ __forceinline__ void conv_wgrad_s3n_body(const pmf_wgrad_desc_t& d, c
     (void)t;
     ah[buf][(r % (2 * G)) / 2][p][h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_t)(base + p * 64 + h * 4 * WS3_XPB));
   };
-  auto tile_mma = [&](const char* __restrict__ Xc, char* __restrict__ Xn, int zb_cur, int zb_nxt) {
+  auto tile_mma = [&](const char* __restrict__ Xc, char* __restrict__ Xn, int zb_cur, int zb_nxt, int zv_cur, int zv_nxt) {
     constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PB[6] = {2, 1, 0, 1, 0, 0};   // smallest terms first
     auto xb = [&](int i) { return Xc + (slab_rr(i) * in_cols + slab_xs(i)) * WS3_XPB + trofs; };
     wg_static_for<GM>([&](auto R) {           // A fragments of the first tap group (exposed once per tile)
@@ -1389,7 +1406,7 @@ __device__ __forceinline__ void conv_wgrad_s3n_body(const pmf_wgrad_desc_t& d, c
 #endif
 #ifndef PMF_WG_NOZ
       if constexpr (ss < 2) {                                      // dz loads of slab i + 2
-        if constexpr (i + 2 < NSL) zload4(zb_cur, i + 2, i & 1, 4 * ss); else zload4(zb_nxt, i + 2 - NSL, i & 1, 4 * ss);
+        if constexpr (i + 2 < NSL) zload4(zb_cur, zv_cur, i + 2, i & 1, 4 * ss); else zload4(zb_nxt, zv_nxt, i + 2 - NSL, i & 1, 4 * ss);
       } else if constexpr (ss >= ZS0) {
         constexpr int k = ss - ZS0;                                // 0: wait (+ nothing), 1 .. 12: split steps
         if constexpr (k == 0) {
@@ -1419,25 +1436,27 @@ __device__ __forceinline__ void conv_wgrad_s3n_body(const pmf_wgrad_desc_t& d, c
 
   int tile = split;
   int cur = 0;
-  int zb_cur = 0, zb_nxt = 0;
+  int zb_cur = 0, zb_nxt = 0, zv_cur = 0, zv_nxt = 0;
   // prologue: input tile 0 split + stored, B fragment of slab 0 ready, dz of slab 1 and input tile 1 in flight
   if (tile < g.total_tiles) {
     fetch_first(tile);
     zb_cur = zbase_f();
+    zv_cur = zvalid_f();
 #pragma unroll
     for (int j = 0; j < XSL; ++j) fetch_slot(j);
-    zload4(zb_cur, 0, 0, 0);
-    zload4(zb_cur, 0, 0, 4);
+    zload4(zb_cur, zv_cur, 0, 0, 0);
+    zload4(zb_cur, zv_cur, 0, 0, 4);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (has_cm) cmS = rC;
 #pragma unroll
     for (int j = 0; j < XSL; ++j) store_slot(j, Xs0);
 #pragma unroll
     for (int k = 0; k < 12; ++k) zsplit_op(0, 0, k / 3, k % 3);
-    zload4(zb_cur, 1, 1, 0);
-    zload4(zb_cur, 1, 1, 4);
+    zload4(zb_cur, zv_cur, 1, 1, 0);
+    zload4(zb_cur, zv_cur, 1, 1, 4);
     fetch_next(tile + d.nsplit < g.total_tiles);
     zb_nxt = zbase_f();
+    zv_nxt = zvalid_f();
 #pragma unroll
     for (int j = 0; j < XSL; ++j) fetch_slot(j);
   }
@@ -1451,11 +1470,11 @@ __device__ __forceinline__ void conv_wgrad_s3n_body(const pmf_wgrad_desc_t& d, c
     WTR();
     cmS.x = has_cm ? rC.x : 1.f; cmS.y = has_cm ? rC.y : 1.f; cmS.z = has_cm ? rC.z : 1.f; cmS.w = has_cm ? rC.w : 1.f;
     // coordinates of tile t + 2 before the schedule runs (its F micro-ops use them); dz bases: t (cur), t + 1 (nxt)
-    const int zb_c = zb_cur, zb_n = zb_nxt;
+    const int zb_c = zb_cur, zb_n = zb_nxt, zv_c = zv_cur, zv_n = zv_nxt;
     fetch_next(next + d.nsplit < g.total_tiles);
-    zb_cur = zb_nxt;
-    zb_nxt = zbase_f();
-    tile_mma(Xc, Xn, zb_c, zb_n);
+    zb_cur = zb_nxt; zv_cur = zv_nxt;
+    zb_nxt = zbase_f(); zv_nxt = zvalid_f();
+    tile_mma(Xc, Xn, zb_c, zb_n, zv_c, zv_n);
     WTR();
     WTR();
     tile = next;
@@ -1498,10 +1517,10 @@ __device__ __forceinline__ void conv_wgrad_s3n_body(const pmf_wgrad_desc_t& d, c
   WTR_END();
 }
 
-template <int TB, int XSL, int NCO>
+template <int TB, int XSL, int NCO, bool RAG = false>
 __global__ __launch_bounds__(256) void conv_wgrad_s3n_k(const pmf_wgrad_desc_t d, const WgGeom g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  conv_wgrad_s3n_body<TB, XSL, NCO>(d, g, smem);
+  conv_wgrad_s3n_body<TB, XSL, NCO, RAG>(d, g, smem);
 }
 
 // ---- eight waves per workgroup (W8): two waves per SIMD ----------------------------------------------------------------
@@ -2420,26 +2439,26 @@ static void wg_direct_grid(const pmf_wgrad_desc_t* d, int* kblocks, int* oblocks
 // 256 threads = 32 consecutive outputs x 8 split slices (independent, unrolled loads), folded through LDS in a
 // fixed order -> deterministic, and no thread walks hundreds of slabs serially.
 __device__ __forceinline__ void red_flat_body(const pmf_wgrad_desc_t& d, int Ktot, int Cout32, int bid, int nblk) {
-  __shared__ float shr[8][32];
+  __shared__ double shr[8][32];      // (float64 fold of the slabs, see red_tile_body)
   const int64_t total = (int64_t)d.ntaps * Ktot * Cout32;
   const int64_t slab = total;
   const int ol = threadIdx.x & 31, sl = threadIdx.x >> 5;
   for (int64_t base = (int64_t)bid * 32; base < total; base += (int64_t)nblk * 32) {
     const int64_t i = base + ol;
-    float s = 0.f;
+    double sd = 0.0;
     if (i < total) {
       for (int sp0 = sl; sp0 < d.nsplit; sp0 += 64) {   // 8 independent loads in flight per thread, fixed summation order
         float t[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) t[j] = sp0 + 8 * j < d.nsplit ? d.partial[(int64_t)(sp0 + 8 * j) * slab + i] : 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) s += t[j];
+        for (int j = 0; j < 8; ++j) sd += (double)t[j];
       }
     }
-    shr[sl][ol] = s;
+    shr[sl][ol] = sd;
     __syncthreads();
     if (sl == 0 && i < total) {
-      s = ((shr[0][ol] + shr[1][ol]) + (shr[2][ol] + shr[3][ol])) + ((shr[4][ol] + shr[5][ol]) + (shr[6][ol] + shr[7][ol]));
+      const float s = (float)(((shr[0][ol] + shr[1][ol]) + (shr[2][ol] + shr[3][ol])) + ((shr[4][ol] + shr[5][ol]) + (shr[6][ol] + shr[7][ol])));
       const int co = (int)(i % Cout32);
       const int64_t r = i / Cout32;
       const int k = (int)(r % Ktot), t = (int)(r / Ktot);
@@ -2453,17 +2472,17 @@ __device__ __forceinline__ void red_flat_body(const pmf_wgrad_desc_t& d, int Kto
   // conv-bias gradient: fold the partial column sums of dz left by the kernel that produced dz
   // (one output channel per workgroup round, rows split over the threads, LDS tree)
   if (d.dbias_rows) {
-    __shared__ float shb[256];
+    __shared__ double shb[256];
     for (int co = bid; co < d.Cout; co += nblk) {
-      float s = 0.f;
-      for (int r = threadIdx.x; r < d.dbias_nrows; r += blockDim.x) s += d.dbias_rows[(size_t)r * d.dbias_ld + co];
+      double s = 0.0;
+      for (int r = threadIdx.x; r < d.dbias_nrows; r += blockDim.x) s += (double)d.dbias_rows[(size_t)r * d.dbias_ld + co];
       shb[threadIdx.x] = s;
       __syncthreads();
       for (int o = 128; o > 0; o >>= 1) {
         if ((int)threadIdx.x < o) shb[threadIdx.x] += shb[threadIdx.x + o];
         __syncthreads();
       }
-      if (threadIdx.x == 0) d.dbias_out[co] += shb[0];
+      if (threadIdx.x == 0) d.dbias_out[co] += (float)shb[0];
       __syncthreads();
     }
   }
@@ -2486,7 +2505,9 @@ __device__ __forceinline__ void red_tile_body(const pmf_wgrad_desc_t& d, int Kto
   const int64_t slab = (int64_t)T * Ktot * Cout32;
   for (int j = rs; j < RB; j += 32) {
     const int kk = j / T, t = j - kk * T, k = k0 + kk;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    // the slabs are folded in float64 (round 5; the kernel is bound by reading them): the only fp32 accumulation chain left
+    // in a weight gradient is the one inside a partial slab
+    double v[4] = {0.0, 0.0, 0.0, 0.0};
     if (k < Ktot) {
       const float* src = d.partial + ((int64_t)t * Ktot + k) * Cout32 + co0 + q * 4;
       for (int s0 = 0; s0 < d.nsplit; s0 += 8) {
@@ -2494,11 +2515,12 @@ __device__ __forceinline__ void red_tile_body(const pmf_wgrad_desc_t& d, int Kto
 #pragma unroll
         for (int i = 0; i < 8; ++i) if (s0 + i < d.nsplit) u[i] = *(const f32x4*)(src + (int64_t)(s0 + i) * slab);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) if (s0 + i < d.nsplit) v += u[i];
+        for (int i = 0; i < 8; ++i)
+          if (s0 + i < d.nsplit) { v[0] += (double)u[i].x; v[1] += (double)u[i].y; v[2] += (double)u[i].z; v[3] += (double)u[i].w; }
       }
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) tile[j][q * 4 + i] = v[i];
+    for (int i = 0; i < 4; ++i) tile[j][q * 4 + i] = (float)v[i];
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -2514,18 +2536,18 @@ __device__ __forceinline__ void red_tile_body(const pmf_wgrad_desc_t& d, int Kto
     }
   }
   if (d.dbias_rows) {
-    __shared__ float shb[256];
+    __shared__ double shb[256];
     const int nb = nbx * nby;
     for (int co = by * nbx + bx; co < d.Cout; co += nb) {
-      float s = 0.f;
-      for (int r = threadIdx.x; r < d.dbias_nrows; r += blockDim.x) s += d.dbias_rows[(size_t)r * d.dbias_ld + co];
+      double s = 0.0;
+      for (int r = threadIdx.x; r < d.dbias_nrows; r += blockDim.x) s += (double)d.dbias_rows[(size_t)r * d.dbias_ld + co];
       shb[threadIdx.x] = s;
       __syncthreads();
       for (int o = 128; o > 0; o >>= 1) {
         if ((int)threadIdx.x < o) shb[threadIdx.x] += shb[threadIdx.x + o];
         __syncthreads();
       }
-      if (threadIdx.x == 0) d.dbias_out[co] += shb[0];
+      if (threadIdx.x == 0) d.dbias_out[co] += (float)shb[0];
       __syncthreads();
     }
   }
@@ -2585,7 +2607,7 @@ static bool wg_simple(const pmf_wgrad_desc_t* d, const WgGeom& g, int TB, int BN
   static const bool no_half = getenv("PMF_WGRAD_S3_C32") != nullptr;   // A/B switch: no half-empty chunks
   if (no_half) cmod = WG_CI;
   if (d->gather || d->in_stride != 1 || d->ntaps != TB) return false;
-  if (d->OH % WG_ROWS || d->OW % 32 || (!ragged && d->Cout % BN)) return false;
+  if (!ragged && (d->OH % WG_ROWS || d->OW % 32 || d->Cout % BN)) return false;    // (ragged: also partial 4 x 32-pixel tiles)
   if (g.in_rows * g.in_cols * 8 > 256 * 9 || g.in_cols > 255) return false;
   for (int i = 0; i < d->nsrc; ++i) {
     if (d->src[i].C % cmod || (d->src[i].flags & PMF_SRC_BCAST)) return false;
@@ -2769,21 +2791,26 @@ static int wg_launch(const pmf_wgrad_desc_t* d, hipStream_t s, int phase) {
             (void)hipFuncSetAttribute((const void*)conv_wgrad_s3n_k<TB, 9, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void*)conv_wgrad_s3n_k<TB, 7, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void*)conv_wgrad_s3n_k<TB, 9, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_s3n_k<TB, 7, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_s3n_k<TB, 9, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_s3n_k<TB, 7, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_s3n_k<TB, 9, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_s3n_k<TB, 7, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_s3n_k<TB, 9, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
           }
           g.x_floats += WS3_XPB / 4;           // the spare pixel that slots beyond the tile write to
           int lds6 = 2 * g.x_floats * 4;
           if (lds6 < 16 * 1024) lds6 = 16 * 1024;
           const dim3 grid6(d->nsplit, g.nchunks, cdiv(d->Cout, 32 * nco));
-          if (nco == 4) {
-            if (small7) hipLaunchKernelGGL((conv_wgrad_s3n_k<TB, 7, 4>), grid6, dim3(256), lds6, s, *d, g);
-            else hipLaunchKernelGGL((conv_wgrad_s3n_k<TB, 9, 4>), grid6, dim3(256), lds6, s, *d, g);
-          } else if (nco == 2) {
-            if (small7) hipLaunchKernelGGL((conv_wgrad_s3n_k<TB, 7, 2>), grid6, dim3(256), lds6, s, *d, g);
-            else hipLaunchKernelGGL((conv_wgrad_s3n_k<TB, 9, 2>), grid6, dim3(256), lds6, s, *d, g);
-          } else {
-            if (small7) hipLaunchKernelGGL((conv_wgrad_s3n_k<TB, 7, 1>), grid6, dim3(256), lds6, s, *d, g);
-            else hipLaunchKernelGGL((conv_wgrad_s3n_k<TB, 9, 1>), grid6, dim3(256), lds6, s, *d, g);
-          }
+          const bool rag = d->OH % WG_ROWS || d->OW % 32;
+#define S3N_GO(xsl, nc, rg) hipLaunchKernelGGL((conv_wgrad_s3n_k<TB, xsl, nc, rg>), grid6, dim3(256), lds6, s, *d, g)
+#define S3N_PICK(nc) do { if (rag) { if (small7) S3N_GO(7, nc, true); else S3N_GO(9, nc, true); } \
+                          else { if (small7) S3N_GO(7, nc, false); else S3N_GO(9, nc, false); } } while (0)
+          if (nco == 4) S3N_PICK(4);
+          else if (nco == 2) S3N_PICK(2);
+          else S3N_PICK(1);
+#undef S3N_PICK
+#undef S3N_GO
         }
       } else
       // eight waves (the taps of a slab on two waves, two waves per SIMD): 3-10 % faster launch by launch, but 110 KiB

@@ -476,37 +476,18 @@ __device__ __forceinline__ uint8_t cj_blend1(int d, int x, float a, bool interp)
   return t <= 0.f ? (uint8_t)0 : (t >= 255.f ? (uint8_t)255 : (uint8_t)(int)t);
 }
 
-__global__ __launch_bounds__(256) void cj_lsum_k(const uint8_t* __restrict__ img, int64_t npix,
-                                                 unsigned long long* __restrict__ sum) {
-  unsigned long long acc = 0;
-  for (int64_t p = blockIdx.x * (int64_t)256 + threadIdx.x; p < npix; p += (int64_t)gridDim.x * 256)
-    acc += (unsigned)cj_luma(img[p * 3], img[p * 3 + 1], img[p * 3 + 2]);
-  for (int o = 32; o; o >>= 1) acc += __shfl_xor(acc, o);
-  __shared__ unsigned long long sh[4];
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(sum, sh[0] + sh[1] + sh[2] + sh[3]);     // integer sum: order-independent
-}
+// the whole jitter of one pixel in registers: the enabled operations in their drawn order, each on the uint8 result of the one
+// before it (what the PIL pipeline computes).  Round 5: ONE read + ONE write of the frame (plus one read-only pass when contrast
+// is among them: its degenerate image is the mean luma of the frame AS THE OPERATIONS IN FRONT OF IT LEFT IT) instead of one
+// read-modify-write pass per operation.
+struct CjArgs {
+  int nops;          // enabled operations, in order
+  int op[4];         // 0 brightness, 1 contrast, 2 saturation, 3 hue
+  float a[4];        // blend factor of op[k]
+  int shift;         // hue shift (uint8)
+};
 
-// mode 0 brightness, 1 contrast (degenerate = int(mean luma + 0.5) from *sum), 2 saturation
-__global__ __launch_bounds__(256) void cj_blend_k(uint8_t* __restrict__ img, int64_t npix, int mode, float a,
-                                                  const unsigned long long* __restrict__ sum) {
-  const int64_t p = blockIdx.x * (int64_t)256 + threadIdx.x;
-  if (p >= npix) return;
-  const bool interp = a >= 0.f && a <= 1.f;
-  int d = 0;
-  if (mode == 1) d = (int)((double)*sum / (double)npix + 0.5);
-  const int r = img[p * 3], g = img[p * 3 + 1], b = img[p * 3 + 2];
-  if (mode == 2) d = cj_luma(r, g, b);
-  img[p * 3] = cj_blend1(d, r, a, interp);
-  img[p * 3 + 1] = cj_blend1(d, g, a, interp);
-  img[p * 3 + 2] = cj_blend1(d, b, a, interp);
-}
-
-__global__ __launch_bounds__(256) void cj_hue_k(uint8_t* __restrict__ img, int64_t npix, int shift) {
-  const int64_t p = blockIdx.x * (int64_t)256 + threadIdx.x;
-  if (p >= npix) return;
-  const int r = img[p * 3], g = img[p * 3 + 1], b = img[p * 3 + 2];
+__device__ __forceinline__ void cj_hue1(int& r, int& g, int& b, int shift) {
   const int maxc = max(r, max(g, b)), minc = min(r, min(g, b));
   int uh = 0, us = 0;
   const int uv = maxc;
@@ -543,34 +524,98 @@ __global__ __launch_bounds__(256) void cj_hue_k(uint8_t* __restrict__ img, int64
       default: ro = uv; go = pp; bo = q; break;
     }
   }
-  img[p * 3] = (uint8_t)ro; img[p * 3 + 1] = (uint8_t)go; img[p * 3 + 2] = (uint8_t)bo;
+  r = ro; g = go; b = bo;
+}
+
+// operations [k0, k1) of A on one pixel; `mean` = the contrast operation's degenerate value
+__device__ __forceinline__ void cj_pixel(int& r, int& g, int& b, const CjArgs& A, int k0, int k1, int mean) {
+  for (int k = k0; k < k1; ++k) {
+    const int op = A.op[k];
+    if (op == 3) { cj_hue1(r, g, b, A.shift); continue; }
+    const float a = A.a[k];
+    const bool interp = a >= 0.f && a <= 1.f;
+    const int d = op == 0 ? 0 : (op == 1 ? mean : cj_luma(r, g, b));
+    const int r2 = cj_blend1(d, r, a, interp), g2 = cj_blend1(d, g, a, interp), b2 = cj_blend1(d, b, a, interp);
+    r = r2; g = g2; b = b2;
+  }
+}
+
+// a thread owns four pixels = three aligned dwords (the frame is 4-byte aligned: a torch allocation); tail pixels byte by byte
+template <bool WRITE>
+__global__ __launch_bounds__(256) void cj_fused_k(uint8_t* __restrict__ img, int64_t npix, const CjArgs A, int k0, int k1,
+                                                  unsigned long long* __restrict__ sum) {
+  const int64_t quads = npix >> 2;
+  int mean = 0;
+  if (WRITE && sum) mean = (int)((double)*sum / (double)npix + 0.5);
+  unsigned long long acc = 0;
+  for (int64_t t = blockIdx.x * (int64_t)256 + threadIdx.x; t < quads + (npix & 3); t += (int64_t)gridDim.x * 256) {
+    if (t < quads) {
+      uint32_t* w = (uint32_t*)img + t * 3;
+      const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
+      int c[12];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { c[i] = (w0 >> (8 * i)) & 255; c[4 + i] = (w1 >> (8 * i)) & 255; c[8 + i] = (w2 >> (8 * i)) & 255; }
+#pragma unroll
+      for (int px = 0; px < 4; ++px) {
+        cj_pixel(c[3 * px], c[3 * px + 1], c[3 * px + 2], A, k0, k1, mean);
+        if (!WRITE) acc += (unsigned)cj_luma(c[3 * px], c[3 * px + 1], c[3 * px + 2]);
+      }
+      if (WRITE) {
+        w[0] = (uint32_t)c[0] | (uint32_t)c[1] << 8 | (uint32_t)c[2] << 16 | (uint32_t)c[3] << 24;
+        w[1] = (uint32_t)c[4] | (uint32_t)c[5] << 8 | (uint32_t)c[6] << 16 | (uint32_t)c[7] << 24;
+        w[2] = (uint32_t)c[8] | (uint32_t)c[9] << 8 | (uint32_t)c[10] << 16 | (uint32_t)c[11] << 24;
+      }
+    } else {
+      const int64_t p = quads * 4 + (t - quads);
+      int r = img[p * 3], g = img[p * 3 + 1], b = img[p * 3 + 2];
+      cj_pixel(r, g, b, A, k0, k1, mean);
+      if (WRITE) { img[p * 3] = (uint8_t)r; img[p * 3 + 1] = (uint8_t)g; img[p * 3 + 2] = (uint8_t)b; }
+      else acc += (unsigned)cj_luma(r, g, b);
+    }
+  }
+  if (!WRITE) {
+    for (int o = 32; o; o >>= 1) acc += __shfl_xor(acc, o);
+    __shared__ unsigned long long sh[4];
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(sum, sh[0] + sh[1] + sh[2] + sh[3]);     // integer sum: order-independent
+  }
 }
 
 extern "C" int pmf_color_jitter(uint8_t* image, int32_t h, int32_t w, const int32_t* order4, const double* factor4,
                                 const int32_t* enabled4, uint64_t* scratch, pmf_stream_t st) {
   hipStream_t s = (hipStream_t)st;
   if (!image || !order4 || !factor4 || !enabled4 || !scratch || h < 1 || w < 1) return PMF_E_ARG;
+  if (((uintptr_t)image & 3) != 0) return PMF_E_ARG;            // dword accesses
   const int64_t npix = (int64_t)h * w;
-  const unsigned grid = (unsigned)cdiv64(npix, 256);
+  CjArgs A;
+  A.nops = 0; A.shift = 0;
+  int kc = -1;                                                  // position of the contrast operation
   for (int k = 0; k < 4; ++k) {
     const int op = order4[k];
     if (op < 0 || op > 3) return PMF_E_ARG;
     if (!enabled4[op]) continue;
     if (op == 3) {
       if (!(factor4[3] >= -0.5 && factor4[3] <= 0.5)) return PMF_E_ARG;
-      hipLaunchKernelGGL(cj_hue_k, dim3(grid), dim3(256), 0, s, image, npix, (int)(factor4[3] * 255.0) & 0xff);
-    } else {
-      if (op == 1) {
-        hipError_t e = hipMemsetAsync(scratch, 0, sizeof(uint64_t), s);
-        if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(cj_lsum_k, dim3(grid < 1024 ? grid : 1024), dim3(256), 0, s, image, npix,
-                           (unsigned long long*)scratch);
-        PMF_LAUNCH_CHECK();
-      }
-      hipLaunchKernelGGL(cj_blend_k, dim3(grid), dim3(256), 0, s, image, npix, op, (float)factor4[op],
-                         (const unsigned long long*)scratch);
+      A.shift = (int)(factor4[3] * 255.0) & 0xff;
     }
+    if (op == 1) kc = A.nops;
+    A.op[A.nops] = op; A.a[A.nops] = (float)factor4[op];
+    ++A.nops;
+  }
+  for (int k = A.nops; k < 4; ++k) { A.op[k] = 0; A.a[k] = 1.f; }
+  if (A.nops == 0) return 0;
+  const int64_t work = (npix >> 2) + (npix & 3);
+  unsigned grid = (unsigned)cdiv64(work, 256);
+  if (kc >= 0) {     // mean luma of the frame as the operations in front of the contrast leave it: a read-only pass
+    hipError_t e = hipMemsetAsync(scratch, 0, sizeof(uint64_t), s);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(cj_fused_k<false>, dim3(grid < 1024 ? grid : 1024), dim3(256), 0, s, image, npix, A, 0, kc,
+                       (unsigned long long*)scratch);
     PMF_LAUNCH_CHECK();
   }
+  hipLaunchKernelGGL(cj_fused_k<true>, dim3(grid), dim3(256), 0, s, image, npix, A, 0, A.nops,
+                     kc >= 0 ? (unsigned long long*)scratch : (unsigned long long*)nullptr);
+  PMF_LAUNCH_CHECK();
   return 0;
 }

@@ -133,6 +133,10 @@ CONVS = [
     ("c1x1_stream_cat", 1, 129, 257, [64, 16], 16, 1, 1, 0, 1, True, "act_bn", True),
     ("c1x1_stream_k8_c64", 2, 64, 256, [8], 64, 1, 1, 0, 1, True, "act_bn", True),
     ("c1x1_stream_k96_c32", 2, 128, 129, [32, 32, 32], 32, 1, 1, 0, 1, False, "bn_relu", True),
+    # S_B's low-resolution maps (60 x 80, 30 x 40): partial 4 x 32-pixel tiles on the N-split kernel (dz loads beyond the map
+    # take the hardware zero); c3x3 (12 x 40) and c3x3d2 (16 x 36) above run the same instantiations with one / two tiles
+    ("c3x3_rag_n4", 2, 30, 40, [64], 128, 3, 1, 1, 1, True, "act_bn", True),
+    ("c2x2d2_rag", 1, 15, 80, [32, 32], 64, 2, 2, 1, 1, False, "bn_relu", True),
 ]
 
 
