@@ -123,6 +123,11 @@ typedef struct {
 int pmf_conv_multi_ok(const pmf_conv_desc_t* d);
 #define PMF_EP_STAT_X_ONLY 1
 #define PMF_CFG_DIRECT_TAPS (1 << 24)
+/* cfg bit 25: a 4- or 9-tap stride-1 launch on split-bf16 weights runs the wave-scheduled N-split kernel (conv_ws.hip: the four
+ * waves of a workgroup own different 32-channel output tiles of one staged 4 x 32-pixel input tile, weights as B fragments
+ * straight from the packed array) where pmf_conv_ws_ok() != 0; ignored elsewhere */
+#define PMF_CFG_WS (1 << 25)
+int pmf_conv_ws_ok(const pmf_conv_desc_t* d);
 /* 1 when the descriptor runs the software-pipelined K loop (stride 1 -- or a stride-2 3x3 with all nine taps --, one halo tile,
  * every operand a multiple of 16 channels, same H x W, no broadcast): the class pmf_conv_fwd accepts w_s3 for.
  * 3 for stem-class descriptors (ONE operand of 8 padded channels, 2..49 taps, e.g. the 7x7 RGB stem): the direct variant

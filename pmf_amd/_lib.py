@@ -16,6 +16,7 @@ EP_STAT_X_ONLY = 1
 WGRAD_S3 = 1
 PMF_E_ARG, PMF_E_UNSUPPORTED = -1, -2
 CFG_DIRECT_TAPS = 1 << 24      # pmf_conv_desc_t.cfg: direct multi-tap variant (PMF_CFG_DIRECT_TAPS)
+CFG_WS = 1 << 25               # ... the wave-scheduled N-split kernel (PMF_CFG_WS, csrc/conv_ws.hip)
 
 (OP_CONV, OP_WGRAD, OP_PACK, OP_BN_FINALIZE, OP_BN_EVAL, OP_BN_BWD_REDUCE, OP_BN_BWD_APPLY, OP_ADD_ACT,
  OP_ADD_ACT_BWD, OP_ACT_BWD, OP_AVGPOOL, OP_AVGPOOL_BWD, OP_MAXPOOL, OP_MAXPOOL_BWD, OP_BILINEAR,
@@ -246,7 +247,7 @@ def lib():
 
 EXPORTS = [
     "pmf_conv_fwd", "pmf_conv_wgrad", "pmf_conv_wgrad_partial", "pmf_conv_wgrad_reduce", "pmf_conv_wgrad_reduce_plan", "pmf_conv_wgrad_reduce_multi", "pmf_conv_wgrad_workspace", "pmf_conv_wgrad_nsplit", "pmf_pack_tile_ci",
-    "pmf_pack_weights_batched", "pmf_conv_fwd_stat_rows", "pmf_conv_s3_eligible", "pmf_conv_fwd_stat_rows_max", "pmf_conv_fwd_kstages", "pmf_col_rows", "pmf_bn_finalize", "pmf_bn_eval_affine", "pmf_bn_bwd_reduce", "pmf_bn_bwd_fold", "pmf_bn_bwd_apply",
+    "pmf_pack_weights_batched", "pmf_conv_fwd_stat_rows", "pmf_conv_s3_eligible", "pmf_conv_ws_ok", "pmf_conv_fwd_stat_rows_max", "pmf_conv_fwd_kstages", "pmf_col_rows", "pmf_bn_finalize", "pmf_bn_eval_affine", "pmf_bn_bwd_reduce", "pmf_bn_bwd_fold", "pmf_bn_bwd_apply",
     "pmf_add_act", "pmf_add_act_bwd", "pmf_act_bwd", "pmf_avgpool3s2", "pmf_avgpool3s2_bwd", "pmf_maxpool3s2",
     "pmf_maxpool3s2_bwd", "pmf_bilinear2x", "pmf_bilinear2x_bwd", "pmf_pixel_shuffle2", "pmf_pixel_shuffle2_bwd",
     "pmf_fusion_gate", "pmf_fusion_gate_bwd", "pmf_global_mean", "pmf_global_mean_bwd", "pmf_colsum", "pmf_colsum_rows",

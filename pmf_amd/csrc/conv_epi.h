@@ -41,7 +41,10 @@ static __device__ unsigned long long* pmf_trace_buf = nullptr;
 // statement makes the compiler fetch them as one batch with a single wait.
 #define PMF_SGPR_BATCH(...) asm volatile("" ::__VA_ARGS__)
 
-template <int BN, int MT>
+// NCO > 1 (conv_ws.hip, the N-split kernel): the workgroup's four waves own NCO DIFFERENT 32-channel output tiles (wave w:
+// tile w % NCO, n0 = that tile's first channel, BN = 32) -- only the statistics reduction differs: the partial sums of a
+// tile come from the 4 / NCO waves that share it.
+template <int BN, int MT, int NCO = 1>
 __device__ __forceinline__ void conv_epilogue(const pmf_conv_desc_t& d, const ConvGeom& g, f32x16 (&acc)[MT][BN / 32],
                                               const int (&segrow)[MT], const int (&segcol)[MT], int n, int n0, int ks,
                                               int oy0, int ox0, int tile, float* smem, int& tri_
@@ -182,6 +185,47 @@ __device__ __forceinline__ void conv_epilogue(const pmf_conv_desc_t& d, const Co
     }
   }
   TR();
+  if constexpr (NCO > 1) {
+    static_assert(BN == 32, "N-split epilogue: one 32-channel tile per wave");
+    // every wave leaves its (sum, second column) per channel; thread t < 32 NCO folds tile t / 32 over the waves that own it
+    // (fixed order) and writes the row of THAT tile's destination (its own e_* describe another tile)
+    const bool any_stats = d.ndst > 0 ? true : d.stats != nullptr;      // (uniform over the workgroup)
+    if (any_stats) {
+      __syncthreads();
+      double* red = (double*)smem;  // [4 waves][32][2]
+      double a = ssum[0] + __shfl_xor(ssum[0], 32);
+      double b = ssq[0] + __shfl_xor(ssq[0], 32);
+      if (lh == 0) { red[(wave * 32 + li) * 2 + 0] = a; red[(wave * 32 + li) * 2 + 1] = b; }
+      __syncthreads();
+      if (tid < 32 * NCO) {
+        const int cwt = tid >> 5, l = tid & 31;
+        const int n0w = n0 - (wave % NCO) * 32;                 // first channel of the workgroup
+        const int n0t = n0w + cwt * 32;                         // first channel of tile cwt
+        double* t_stats = d.stats;
+        int t_Cout = d.Cout, t_n0e = n0t;
+        if (d.ndst > 0) {
+          int k = 0, c0 = 0;
+          while (k + 1 < d.ndst && n0t >= c0 + d.dst[k].C) { c0 += d.dst[k].C; ++k; }
+          t_stats = d.dst[k].stats; t_Cout = d.dst[k].C; t_n0e = n0t - c0;
+        }
+        const int co = t_n0e + l;
+        if (t_stats && co < t_Cout) {
+          double sa = 0.0, sb = 0.0;
+#pragma unroll
+          for (int w = 0; w < 4 / NCO; ++w) {
+            sa += red[((cwt + w * NCO) * 32 + l) * 2 + 0];
+            sb += red[((cwt + w * NCO) * 32 + l) * 2 + 1];
+          }
+          double* row = t_stats + ((size_t)tile + (size_t)gridDim.x * n) * 2 * t_Cout;
+          row[co] = sa;
+          row[t_Cout + co] = sb;
+        }
+      }
+    }
+    TR();
+    TR_END();
+    return;
+  }
   if (e_stats) {
     __syncthreads();
     double* red = (double*)smem;  // [4 waves][NT][32][2]

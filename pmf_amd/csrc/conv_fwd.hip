@@ -1595,8 +1595,26 @@ static int launch(const pmf_conv_desc_t* d, hipStream_t s) {
   return 0;
 }
 
+// the wave-scheduled N-split kernel (conv_ws.hip): on request -- cfg bit 25 (PMF_CFG_WS, set by the plan autotuner where it
+// measured faster) or PMF_CONV_WS=1 (every eligible launch with at least PMF_CONV_WS_MIN_WGS workgroups: A/B) -- and eligible
+extern "C" int pmf_conv_ws_ok(const pmf_conv_desc_t* d);
+extern "C" int pmf_conv_ws_rows(const pmf_conv_desc_t* d);
+extern "C" int pmf_conv_ws_launch(const pmf_conv_desc_t* d, pmf_stream_t st);
+static bool conv_ws_wanted(const pmf_conv_desc_t* d) {
+  static const int force = getenv("PMF_CONV_WS") ? atoi(getenv("PMF_CONV_WS")) : -1;     // 0: never, 1: wherever eligible
+  static const int min_wgs = getenv("PMF_CONV_WS_MIN_WGS") ? atoi(getenv("PMF_CONV_WS_MIN_WGS")) : 128;
+  if (force == 0) return false;
+  const bool asked = (d->cfg >> 25) & 1;
+  if (!asked && force != 1) return false;
+  const int nco = pmf_conv_ws_ok(d);
+  if (!nco) return false;
+  if (asked) return true;
+  return pmf_conv_ws_rows(d) * (d->Cout / (32 * nco)) >= min_wgs;
+}
+
 // number of partial-statistics rows pmf_conv_fwd writes for this descriptor (stats must hold rows*2*Cout doubles)
 extern "C" int pmf_conv_fwd_stat_rows(const pmf_conv_desc_t* d) {
+  if (conv_ws_wanted(d)) return pmf_conv_ws_rows(d);
   int BN, MT, gather, Ktot = 0, cmax = 0, nchunks = 0;
   conv_config(d, &BN, &MT);
   for (int i = 0; i < d->nsrc; ++i) {
@@ -1706,6 +1724,7 @@ extern "C" int pmf_conv_fwd(const pmf_conv_desc_t* d, pmf_stream_t st) {
   if (d->ldw % 4 || d->in_stride < 1 || d->in_stride > 2) return PMF_E_ARG;
   for (int i = 0; i < d->nsrc; ++i)
     if (d->src[i].C % 8 || d->src[i].ldc % 4) return PMF_E_ARG;
+  if (conv_ws_wanted(d)) return pmf_conv_ws_launch(d, st);
   int BN, MT;
   conv_config(d, &BN, &MT);
   if (BN == 64) return MT == 2 ? launch<64, 2>(d, s) : launch<64, 1>(d, s);

@@ -2621,6 +2621,7 @@ static bool wg_simple(const pmf_wgrad_desc_t* d, const WgGeom& g, int TB, int BN
 // Pipelined kernel (when its conditions hold): NT = 1 -- every wave carries all TB taps of one 32-channel tile, the
 // narrow tile keeps the split count (hence the partial-slab traffic) low and measured fastest at every resolution.
 // Unit-dealing kernel: 64 output channels per workgroup (2 waves/SIMD fit; 128 measured slower).
+static int wg_s3n_nco(const pmf_wgrad_desc_t* d, const WgGeom& g, int TB);
 static void wg_config(const pmf_wgrad_desc_t* d, int* TB, int* NT) {
   if (d->gather || d->ntaps == 1) *TB = 1;
   else if (d->ntaps <= 4) *TB = 4;
@@ -2643,6 +2644,7 @@ static void wg_config(const pmf_wgrad_desc_t* d, int* TB, int* NT) {
     return;
   }
   if (!wide_1x1 && wg_simple(d, g, *TB, 32, cmod) && !getenv("PMF_WGRAD_NOPIPE")) { *NT = 1; return; }
+  if (!wide_1x1 && !getenv("PMF_WGRAD_NOPIPE") && wg_s3n_nco(d, g, *TB) > 0) { *NT = 1; return; }   // ragged tiles / last channel tile
   *NT = wide_1x1 ? 4 : (d->Cout > 32 ? 2 : 1);
 }
 

@@ -318,7 +318,7 @@ class TrainEngine:
             self._tail_e0 = torch.cuda.Event(enable_timing=True)
             self._tail_e0.record(cur)                    # fires when the backward plan itself is through
         used_side = False
-        repack = armed and os.environ.get("PMF_PACK_BEHIND_OPTIM", "1") != "0" and getattr(plan, "fwd_pack_skip", 0) > 0
+        repack = armed and os.environ.get("PMF_PACK_BEHIND_OPTIM", "0") == "1" and getattr(plan, "fwd_pack_skip", 0) > 0
         packed = 0
         plan.packed_version = None
         for evs, ranges in plan.dp_schedule():
@@ -338,7 +338,8 @@ class TrainEngine:
                     if repack:
                         # the updated weights of these ranges in the forward plan's GEMM layout, right here: the forward
                         # pass that read the old ones is over, the next one then starts without its pack launches
-                        # (what-if measurement, round 5: the step without them is 1.1 ms shorter; alone they take 0.35 ms)
+                        # (opt-in, PMF_PACK_BEHIND_OPTIM=1: measured neutral on the step -- 15.05 ms without, 15.10 ms with, one box;
+                        # the "1.1 ms" of the PMF_SKIP_OPS what-if was stale weights, not saved launches: docs/rounds/r05.md)
                         packed += plan.pack_ranges(ranges, where)
                 else:
                     self._pending += hs

@@ -118,6 +118,14 @@ class PlanTuneMixin(object):
                         for bn in ((32, 64) if d.Cout > 32 else (32,)):
                             for mt in (1, 2):
                                 cands.append(bn | (mt << 8) | (1 << 16) | L.CFG_DIRECT_TAPS)
+                    if d.w_s3 and os.environ.get("PMF_TUNE_WS", "1") != "0" and lib.pmf_conv_ws_ok(C.byref(d)):
+                        # the wave-scheduled N-split kernel (csrc/conv_ws.hip): its default tile count per workgroup, and
+                        # explicitly one / two / four 32-channel tiles (cfg bits 26-27) where the channel count allows
+                        base = 32 | (1 << 8) | (1 << 16) | L.CFG_WS
+                        cands.append(base)
+                        for code, nco in ((1, 1), (2, 2), (3, 4)):
+                            if d.Cout % (32 * nco) == 0 and d.Cout >= 64:
+                                cands.append(base | (code << 26))
                     best_t, best = float("inf"), 0
                     for cfg in cands:
                         d.cfg = cfg

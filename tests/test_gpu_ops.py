@@ -189,6 +189,17 @@ def test_conv_unit_wgrad_variants(env, monkeypatch):
     assert ran >= 2
 
 
+WS_CASES = [c for c in CONVS if c[6] in (2, 3) and c[9] == 1]
+
+
+@pytest.mark.parametrize("case", WS_CASES, ids=[c[0] for c in WS_CASES])
+def test_conv_unit_wave_scheduled(case):
+    """the wave-scheduled N-split kernel (conv_ws.hip, cfg bit 25) on every 2x2 / 3x3 stride-1 case: forward, input gradients (its
+    transposed launches; launches that do not qualify -- 24 output channels, dilation 6 / 18 -- keep the staged loop), BatchNorm
+    statistics incl. the per-tile statistics fold of one / two / four output-channel tiles per workgroup, float64 bars"""
+    _conv_case(case, 32 | (1 << 8) | (1 << 16) | L.CFG_WS)
+
+
 DIRECT_1X1 = [c for c in CONVS if c[0] in ("c1x1cat3", "c1x1_plain_lrelu", "c1x1s2", "c1x1cat3_big", "c1x1_odd_big",
                                             "c1x1_c20_big", "c1x1_wide_big", "c1x1_odd_wide", "c1x1_to1024", "c1x1_k768_cat",
                                             "c1x1_k784")]
