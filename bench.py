@@ -536,9 +536,12 @@ def parity_block(args, eng, model, feat0, mask, label):
         eng.model.train()
         hooks = _detach_dp_hooks(model)     # (world 1 only: no collective inside this backward)
         pcd, rgb = eng.prepare(feat0.clone(), mask)
-        total = eng.forward_loss(pcd, rgb, label.long())[0]
+        total, _, lp_h, cp_h, _ = eng.forward_loss(pcd, rgb, label.long())
+        lp_h.retain_grad()
+        cp_h.retain_grad()
         total.backward()                    # the timed backward plan (flat state: writes every p.grad in place)
         torch.cuda.synchronize()
+        gobj_h = (lp_h.grad.detach().cpu(), cp_h.grad.detach().cpu())     # d objective / d probability maps, as the HIP path saw it
         plan = next(p for k, p in model._plans.items() if k[3])
         logits = plan.read(plan.tensors["logits"]).float().cpu()
         loss_h = float(total.detach())
@@ -550,13 +553,21 @@ def parity_block(args, eng, model, feat0, mask, label):
     finally:
         model.set_dropout_masks(None)
         _attach_dp_hooks(model, hooks)
-    f = feat0.detach().cpu().clone()
-    pc, rc = ref_eng.prepare(f, mask.cpu())
-    tot_r = ref_eng.forward_loss(pc, rc, label.cpu().long())[0]
-    loss_r = float(tot_r.detach())
-    tot_r.backward()                        # tasks/pmf/trainer.py:214-219 on the CPU oracle, fp32
+    # The objective is DISCONTINUOUS (confidence thresholds of the perception-aware terms, the Lovasz ranking): in a long-trained
+    # state a rounding-level difference in the probabilities moves its gradient by whole terms -- measured (round 5,
+    # tools/soak_tensors.py): BOTH fp32 paths sit 1.1-1.3e-3 from float64 there, in 17 elements beyond 1e-3 of the maximum, and
+    # which elements flip differs from path to path; one such flip shifts every LiDAR-stream gradient by the same factor while
+    # all forward tensors agree to 1.2x.  So the two things are reported separately: (1) the objective's gradient w.r.t. the two
+    # probability maps, each path against float64; (2) the NETWORK's backward pass given ONE upstream gradient -- the oracle
+    # passes below are driven by the gradient the HIP path computed, so that (2) measures the kernels, not the objective's kinks.
+    def oracle_backward(e_, net_, dt):
+        p_, r_ = e_.prepare(feat0.detach().cpu().to(dt), mask.cpu().to(dt))
+        tot_, _, lp_o, cp_o, _ = e_.forward_loss(p_, r_, label.cpu().long())
+        own = torch.autograd.grad(tot_, [lp_o, cp_o], retain_graph=True)        # the oracle's own objective gradient
+        torch.autograd.backward([lp_o, cp_o], [gobj_h[0].to(dt), gobj_h[1].to(dt)])
+        return float(tot_.detach()), [g.detach().double() for g in own]
+    loss_r, gobj_32 = oracle_backward(ref_eng, net, torch.float32)             # tasks/pmf/trainer.py:214-219 on the CPU oracle, fp32
     ref_named = dict(net.named_parameters())
-    del tot_r
     # ... and the same pass in FLOAT64: two fp32 paths with different rounding points are each ~1e-2 away from the exact
     # gradient in this network (the BatchNorm backward subtracts two per-channel means from gy in ~90 layers; measured in
     # tests/test_gpu_fullsize.py), so "HIP vs fp32 oracle" alone cannot tell a rounding difference from a defect -- the
@@ -572,9 +583,16 @@ def parity_block(args, eng, model, feat0, mask, label):
         eng64.mt_loss.double()
         with torch.no_grad():
             eng64.mt_loss.sigma.copy_(eng.mt_loss.sigma.detach().cpu().double())
-    p64, r64 = eng64.prepare(feat0.detach().cpu().double(), mask.cpu().double())
-    eng64.forward_loss(p64, r64, label.cpu().long())[0].backward()
+    _, gobj_64 = oracle_backward(eng64, net64, torch.float64)
     named64 = dict(net64.named_parameters())
+    obj = {}
+    for nm, i in (("lidar", 0), ("camera", 1)):
+        den = gobj_64[i].norm().clamp_min(1e-30)
+        thr = 1e-3 * float(gobj_64[i].abs().max())
+        obj[nm] = {"hip": float((gobj_h[i].double() - gobj_64[i]).norm() / den),
+                   "cpu_fp32_oracle": float((gobj_32[i] - gobj_64[i]).norm() / den),
+                   "elements_beyond_1e-3_of_max": {"hip": int(((gobj_h[i].double() - gobj_64[i]).abs() > thr).sum()),
+                                                   "cpu_fp32_oracle": int(((gobj_32[i] - gobj_64[i]).abs() > thr).sum())}}
     grad_rel, grad_rel_cpu = {}, {}
     for k in picks:
         g64 = named64[k].grad.detach()
@@ -593,14 +611,18 @@ def parity_block(args, eng, model, feat0, mask, label):
     gratio = max(grad_rel[k] / max(grad_rel_cpu[k], 1e-12) for k in picks if max(grad_rel[k], grad_rel_cpu[k]) > 2e-4) \
         if any(max(grad_rel[k], grad_rel_cpu[k]) > 2e-4 for k in picks) else 0.0
     gok = all(grad_rel[k] <= max(3.0 * grad_rel_cpu[k], 2e-4) for k in picks)
+    ook = all(v["hip"] <= max(3.0 * v["cpu_fp32_oracle"], 2e-4) for v in obj.values())
     return {"logits_rel": lrel, "loss_rel": lossrel, "running_stat_rel": rrel,
+            "objective_grad_rel_vs_float64": obj,
             "grad_rel_vs_float64": {k: {"hip": grad_rel[k], "cpu_fp32_oracle": grad_rel_cpu[k]} for k in picks},
             "grad_rel_worst": max(grad_rel.values()) if picks else None,
             "grad_rel_worst_ratio_to_cpu_fp32": gratio,
             "loss_hip": loss_h, "loss_oracle": loss_r,
             "bars": {"logits_rel": 1e-3, "loss_rel": 1e-4, "running_stat_rel": 1e-4,
-                     "grad_rel": "hip <= max(3 x cpu_fp32_oracle, 2e-4) for every listed parameter"},
-            "ok": bool(lrel < 1e-3 and lossrel < 1e-4 and rrel < 1e-4 and gok),
+                     "grad_rel": "hip <= max(3 x cpu_fp32_oracle, 2e-4) for every listed parameter, all three backward passes "
+                                 "driven by the SAME upstream gradient (the HIP path's d objective / d probabilities)",
+                     "objective_grad_rel": "hip <= max(3 x cpu_fp32_oracle, 2e-4) per probability map, each path's own objective"},
+            "ok": bool(lrel < 1e-3 and lossrel < 1e-4 and rrel < 1e-4 and gok and ook),
             "what": "train-mode forward + objective + BACKWARD of the plan that was timed (PMF_AUTOTUNE %s, lanes, %d captured "
                     "graphs) against the CPU oracle: model state after the timed iterations copied into oracle/ (%d host "
                     "threads), same Dropout2d multipliers, same batch; logits / loss / running statistics against the fp32 "
@@ -785,6 +807,16 @@ def dist_probe(world, rank):
     dist.destroy_process_group()
 
 
+_REAL_STDOUT = None
+
+
+def emit(line):
+    """the result line, on the stdout this process was started with (see main)"""
+    out = _REAL_STDOUT if _REAL_STDOUT is not None else sys.stdout
+    out.write(line + "\n")
+    out.flush()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -827,6 +859,14 @@ def main():
             if have < args.gpus:
                 raise SystemExit("bench.py: --gpus %d asked for, %d device(s) visible" % (args.gpus, have))
         raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
+    # ONE JSON line on stdout: libraries that write to file descriptor 1 from native code (RCCL prints a five-line version
+    # banner when its first communicator comes up) get stderr instead; the line itself goes to the descriptor we were given
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+        sys.stdout = _REAL_STDOUT          # Python-level prints (the result line) keep the real stdout
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -955,6 +995,17 @@ def main():
                             "optimiser, engine._behind_events); the earlier ranges were reduced and updated under the "
                             "running backward plan.  PMF_OWN_OPTIM=0 / PMF_DP_MODE=segments: the stream waits for the "
                             "collectives only"}
+        rng = eng.range_allreduce_us() if hasattr(eng, "range_allreduce_us") else None
+        if rng:
+            per_rank["range_allreduce_us_rank0"] = [{"mb": round(4.0 * nfl / 1e6, 2), "us": round(us, 1),
+                                                     "gb_s": round(4.0 * nfl / max(us, 1e-9) / 1e3, 1)} for nfl, us in rng]
+        try:        # which collective library this is (torch's "nccl" backend IS RCCL on ROCm) and how the job was wired
+            per_rank["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception as e:     # noqa: BLE001
+            per_rank["rccl_version"] = "unavailable: %s" % e
+        per_rank["backend"] = dist.get_backend()
+        per_rank["env"] = {k: os.environ.get(k) for k in ("NCCL_DEBUG", "NCCL_ALGO", "NCCL_PROTO", "HSA_ENABLE_IPC_MODE_LEGACY",
+                                                          "PMF_DP_MODE", "RCCL_MSCCL_ENABLE") if os.environ.get(k) is not None}
         if eng.flat is not None:
             # every rank trained on its OWN data: the parameters stay bit-identical only if every gradient range really
             # went through the all-reduce before the optimiser read it (a range reduced too early or left out diverges)
@@ -964,6 +1015,8 @@ def main():
             sigs = [torch.zeros_like(sig) for _ in range(world)]
             dist.all_gather(sigs, sig)
             per_rank["parameters_identical_across_ranks"] = bool(all(torch.equal(x, sigs[0]) for x in sigs))
+            if not per_rank["parameters_identical_across_ranks"]:
+                raise SystemExit("bench.py: the ranks' parameters diverged -- a gradient range missed its all-reduce: %r" % sigs)
     dt = t.item()
     loss_val = float(loss)
     if not np.isfinite(loss_val):
@@ -1127,7 +1180,7 @@ def main():
             ctypes.CDLL(None).fflush(None)
         except Exception:
             pass
-        print(json.dumps(out), flush=True)
+        emit(json.dumps(out))
     if multi:
         dist.barrier()             # rank 0 measured its roofline alone: leave together
         dist.destroy_process_group()

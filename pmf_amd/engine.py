@@ -329,7 +329,17 @@ class TrainEngine:
                 used_side = True
             where = side if evs is not None else cur          # (None: finalised by the last ops of the plan)
             with (torch.cuda.stream(side) if evs is not None else contextlib.nullcontext()):
+                timed = dist_on and getattr(self, "time_allreduce", False)
+                if timed:                   # per-range duration of the collective on the stream it is issued from (bench.py)
+                    r0 = torch.cuda.Event(enable_timing=True)
+                    r0.record(where)
                 hs = [dist.all_reduce(self.flat.grad[a:b], async_op=True) for a, b in ranges] if dist_on else []
+                if timed:
+                    for h in hs:
+                        h.wait()
+                    r1 = torch.cuda.Event(enable_timing=True)
+                    r1.record(where)
+                    self.__dict__.setdefault("range_events", []).append((sum(b - a for a, b in ranges), r0, r1))
                 if armed:
                     for h in hs:
                         h.wait()            # orders `where` behind the collective (no host block)
@@ -413,6 +423,25 @@ class TrainEngine:
         if reset:
             self.allreduce_events = []
         return ms
+
+    def range_allreduce_us(self, reset=True):
+        """[(floats in the range, mean microseconds from issue to completion on the issuing stream)] per gated range of a
+        backward pass, over the steps recorded since the last reset -- includes the wait for the plan events in front of the
+        collective only insofar as the stream was idle before (bench.py reports it next to the exposed tail)"""
+        evs = self.__dict__.get("range_events", [])
+        if not evs:
+            return None
+        torch.cuda.synchronize()
+        by = {}
+        order = []
+        for nfl, a, b in evs:
+            if nfl not in by:
+                by[nfl] = []
+                order.append(nfl)
+            by[nfl].append(a.elapsed_time(b) * 1e3)
+        if reset:
+            self.range_events = []
+        return [(nfl, sum(by[nfl]) / len(by[nfl])) for nfl in order]
 
     def sync_buffers(self):
         """rank 0's BatchNorm running statistics / counters to every rank, as two coalesced broadcasts.

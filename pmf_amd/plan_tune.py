@@ -140,5 +140,6 @@ class PlanTuneMixin(object):
         # (a tuner over the weight-gradient kernel variant / pixel-split count was measured at 25.44 vs 25.45 ms per
         # step -- no gain over the built-in rules -- and removed.)
         torch.cuda.synchronize(self.device)
-        if cache_file and len(_TUNED) != n_known:
+        if cache_file and (len(_TUNED) != n_known or not os.path.exists(cache_file)):   # (also when the shipped table knew every shape:
+            # the other ranks of a job read THIS file)
             write_cache(cache_file, _TUNED)

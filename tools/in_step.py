@@ -52,15 +52,15 @@ def main(trace, mfma, fetch, write, out_path, commit, bench_plain):
     for x, k in evs:
         hist[min(depth, 4)] += x - prev
         prev, depth = x, depth + k
-    is_conv = lambda n: "conv_fwd_k" in n or "conv_finish_k" in n
+    is_conv = lambda n: "conv_fwd_k" in n or "conv_ws_k" in n or "conv_finish_k" in n
     is_mat = lambda n: is_conv(n) or "wgrad" in n
     busy_ns = sum(r[2] - r[1] for r in step)
     res = {"commit": commit, "kernels_in_step": len(step), "step_wall_ms_under_trace": wall_ns / 1e6,
            "sum_of_kernel_durations_ms": busy_ns / 1e6,
            "wall_ms_by_kernels_in_flight": {("%d%s" % (k, "+" if k == 4 else "")): hist[k] / 1e6 for k in range(5)},
-           "conv_fwd_k_in_step": {"launches": sum(1 for r in step if "conv_fwd_k" in r[3]),
+           "conv_fwd_k_in_step": {"launches": sum(1 for r in step if "conv_fwd_k" in r[3] or "conv_ws_k" in r[3]),
                                   "avg_launch_us_incl_finish": sum(r[2] - r[1] for r in step if is_conv(r[3])) / 1e3 /
-                                  max(1, sum(1 for r in step if "conv_fwd_k" in r[3]))}}
+                                  max(1, sum(1 for r in step if "conv_fwd_k" in r[3] or "conv_ws_k" in r[3]))}}
     try:
         with open(bench_plain) as f:
             res["ms_per_step_unprofiled"] = json.loads(f.read().strip().splitlines()[-1])["ms_per_step"]

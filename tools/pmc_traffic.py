@@ -22,11 +22,11 @@ def per_kernel(db, counter):
 
 f = per_kernel(sys.argv[1], "FETCH_SIZE")
 w = per_kernel(sys.argv[2], "WRITE_SIZE")
-sel = [k for k in f if "conv_fwd_k" in k or "conv_finish_k" in k]
-launches = sum(f[k][1] for k in sel if "conv_fwd_k" in k)
+sel = [k for k in f if "conv_fwd_k" in k or "conv_ws_k" in k or "conv_finish_k" in k]
+launches = sum(f[k][1] for k in sel if "conv_fwd_k" in k or "conv_ws_k" in k)
 fetch = 2.0 * sum(f[k][0] for k in sel) * 1024.0            # bytes, gfx950 x2 correction
 write = sum(w[k][0] for k in sel if k in w) * 1024.0
-out = {"kernel": "conv_fwd_k (+ conv_finish_k) launches of bench.py", "launches": launches,
+out = {"kernel": "conv_fwd_k / conv_ws_k (+ conv_finish_k) launches of bench.py", "launches": launches,
        "fetch_bytes_per_launch": fetch / launches, "write_bytes_per_launch": write / launches,
        "hbm_bytes_per_launch": (fetch + write) / launches,
        "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), KiB -> bytes, "

@@ -9,10 +9,10 @@ import sqlite3, sys
 
 
 def klass(name):
-    if "conv_fwd_k" in name: return "C"
+    if "conv_fwd_k" in name or "conv_ws_k" in name: return "C"
     if "conv_finish_k" in name: return "F"
     if "wgrad_reduce" in name: return "R"
-    if "conv_wgrad" in name or "wgrad_fewc" in name or "wgrad_1x1" in name: return "W"
+    if "conv_wgrad" in name or "wgrad_fewc" in name or "wgrad_1x1" in name or "wgrad_stream" in name: return "W"
     return None
 
 

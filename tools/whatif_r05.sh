@@ -1,25 +1,10 @@
 #!/bin/bash
-o=gpurun_out/r05j; mkdir -p $o
-timeout 900 python -m pytest tests/test_gpu_ops.py -x -q -m gpu > $o/pytest_ops.log 2>&1; tail -3 $o/pytest_ops.log
-(time tools/make_tune_cache.sh $o/tuned.txt) > $o/make.log 2>&1; tail -4 $o/make.log
-python - <<'P'
-import ast
-d=ast.literal_eval(open('gpurun_out/r05j/tuned.txt').read())
-print(len(d), 'shapes;', sum(1 for v in d.values() if v>>25&1), 'on the wave-scheduled kernel')
-P
-q="--steps 40 --warmup 8 --no-parity --no-cpu-baseline --no-roofline --no-f32-ref"
-for rep in 1 2; do
-echo -n "shipped table (no WS): " >> $o/ab.txt; timeout 200 python bench.py $q 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'])" >> $o/ab.txt
-echo -n "new table (WS candidates): " >> $o/ab.txt; PMF_TUNE_CACHE=$o/tuned.txt timeout 200 python bench.py $q 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'])" >> $o/ab.txt
-done
-cat $o/ab.txt
-PMF_TUNE_CACHE=$o/tuned.txt timeout 200 python bench.py --steps 10 --warmup 4 --no-parity --no-cpu-baseline --no-f32-ref --profile-out $o/ops.txt > $o/bench.json 2>$o/bench.err
-python -c "
+o=gpurun_out/r05r; mkdir -p $o
+run() { env $2 timeout 400 python bench.py --steps $3 --warmup 10 --no-cpu-baseline --no-f32-ref --no-roofline $4 > $o/soak_$1.json 2>$o/soak_$1.err; python -c "
 import json
-d=json.loads(open('$o/bench.json').read().strip().splitlines()[-1]); print('bench', d['ms_per_step'], d['roofline']['frac'], {k:(v['ms'],v['achieved']) for k,v in d['roofline']['families'].items()})"
-cp $o/tuned.txt $o/tuned_fixed.txt
-for kind in epmf pmf_r34 r50 pmf_r34_sb; do
-  PMF_TUNE_CACHE=$o/tuned_fixed.txt timeout 500 python tools/bisect_tune.py --kind $kind --fix $o/tuned_fixed.txt > $o/fix_$kind.log 2>&1
-  tail -2 $o/fix_$kind.log
-done
-PMF_TUNE_CACHE=$o/tuned_fixed.txt timeout 1200 python -m pytest tests/test_gpu_fullsize.py -q -m gpu > $o/pytest_fullsize.log 2>&1; tail -5 $o/pytest_fullsize.log
+d=json.loads(open('$o/soak_$1.json').read().strip().splitlines()[-1]); p=d['parity']; print('soak $3 $1:', round(d['ms_per_step'],3), p['ok'], round(p['grad_rel_worst_ratio_to_cpu_fp32'],2), {k: (round(v['hip'],6), round(v['cpu_fp32_oracle'],6), v['elements_beyond_1e-3_of_max']) for k,v in p['objective_grad_rel_vs_float64'].items()}, {k.split('.')[1]+'.'+k.split('.')[2]: round(v['hip']/v['cpu_fp32_oracle'],2) for k,v in p['grad_rel_vs_float64'].items()})" || tail -5 $o/soak_$1.err; }
+run d20 "A=1" 20
+run d1500 "A=1" 1500
+run heur1500 "PMF_AUTOTUNE=0" 1500
+run wsall1500 "PMF_CONV_WS=1" 1500
+run epmf300 "A=1" 300 "--model epmf"
