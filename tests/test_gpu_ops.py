@@ -189,7 +189,7 @@ def test_conv_unit_wgrad_variants(env, monkeypatch):
     assert ran >= 2
 
 
-WS_CASES = [c for c in CONVS if c[6] in (2, 3) and c[9] == 1]
+WS_CASES = [c for c in CONVS if c[6] in (2, 3) and (c[9] == 1 or c[0] == "c3x3s2")]     # (stride 2: its 4-tap parity class of the input gradient)
 
 
 @pytest.mark.parametrize("case", WS_CASES, ids=[c[0] for c in WS_CASES])
