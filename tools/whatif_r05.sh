@@ -1,24 +1,4 @@
 #!/bin/bash
-# round-5 evidence batch (GPU box): full -m gpu suite, smoke, rocprofv3 summaries, bench lines of every configuration
-o=gpurun_out/r05s; mkdir -p $o
-(timeout 1500 python -m pytest tests -m gpu -q > $o/pytest_gpu.log 2>&1; echo "pytest rc $?" >> $o/pytest_gpu.log); grep -E "^(FAILED|ERROR)|passed|failed|pytest rc" $o/pytest_gpu.log | tail -6
-python __graft_entry__.py smoke 2>&1 | tail -2
-bash tools/collect_profiles.sh r05 $1 > $o/collect.log 2>&1; head -1 gpurun_out/r05/r05_per_layer_kernel_times.txt
-L=$o/r05_bench_lines.jsonl; : > $L
-python bench.py --steps 20 --warmup 5 >> $L 2>/dev/null
-python bench.py --steps 100 --warmup 10 --no-cpu-baseline >> $L 2>/dev/null
-python bench.py --height 480 --width 640 --steps 30 --warmup 5 --no-cpu-baseline >> $L 2>/dev/null
-python bench.py --mode infer --steps 30 --warmup 5 --no-cpu-baseline >> $L 2>/dev/null
-python bench.py --mode infer --height 480 --width 640 --steps 30 --warmup 5 --no-cpu-baseline >> $L 2>/dev/null
-python bench.py --backbone resnet50 --nclasses 17 --height 32 --width 1024 --steps 50 --warmup 10 --no-cpu-baseline >> $L 2>/dev/null
-python bench.py --model epmf --steps 50 --warmup 10 --no-cpu-baseline >> $L 2>/dev/null
-python bench.py --model salsanext --steps 50 --warmup 10 --no-cpu-baseline >> $L 2>/dev/null
-python bench.py --height 256 --width 1024 --steps 30 --warmup 5 --no-cpu-baseline >> $L 2>/dev/null
-python bench.py --force-dist --steps 50 --warmup 10 --no-cpu-baseline --no-roofline --no-f32-ref >> $L 2>/dev/null
-python bench.py --mode loader >> $L 2>/dev/null
-python -c "
-import json
-for l in open('$L'):
-    l=l.strip()
-    if not l.startswith('{'): print('NON-JSON:', l[:80]); continue
-    d=json.loads(l); print(round(d['value'],2), d['unit'], round(d.get('ms_per_step') or 0,3), (d.get('roofline') or {}).get('frac'), (d.get('parity') or {}).get('ok'), d['config']['workload'][:70])"
+# scratch batch script of round 5 (what-if timings, A/B runs): see tools/r05_evidence.sh for the evidence batch that produced
+# profiles/r05_* and docs/rounds/r05.md for the results of the what-ifs
+echo "edit me: one gpurun call = one batch of measurements"
