@@ -59,10 +59,16 @@ def main():
         e.focal.to(dt)
         p, r = e.prepare(feat0.detach().cpu().to(dt), mask.cpu().to(dt))
         tot, _, lpo, cpo, _ = e.forward_loss(p, r, label.cpu().long())
-        lpo.retain_grad(); cpo.retain_grad()
-        tot.backward()
+        own = torch.autograd.grad(tot, [lpo, cpo], retain_graph=True)
+        for v in cap.values():
+            if isinstance(v, torch.Tensor) and v.requires_grad and not v.is_leaf:
+                v.retain_grad()
+        # the network's backward pass driven by the HIP path's objective gradient (the objective's own kinks stay out of it)
+        torch.autograd.backward([lpo, cpo], [gl_h.to(dt), gc_h.to(dt)])
         caps[tag] = {k: v.detach().double() for k, v in cap.items()}
-        caps[tag + ".g"] = (lpo.grad.detach().double(), cpo.grad.detach().double(), float(tot))
+        caps[tag + ".grad"] = {k: v.grad.detach().double() for k, v in cap.items() if isinstance(v, torch.Tensor) and v.grad is not None}
+        caps[tag + ".pgrad"] = {k: q.grad.detach().double() for k, q in net.named_parameters() if q.grad is not None}
+        caps[tag + ".g"] = (own[0].detach().double(), own[1].detach().double(), float(tot))
         for h in hs:
             h.remove()
     # the gradient of the objective w.r.t. the two probability maps: the objective is discontinuous (confidence thresholds of the
@@ -76,6 +82,33 @@ def main():
             nm, float((gh - g64).norm() / den), big(gh), float((g32 - g64).norm() / den), big(g32)), flush=True)
     print("loss: hip %.7f  f32 %.7f  f64 %.7f" % (float(total), l32, l64))
     print("%-22s %12s %12s %8s" % ("tensor", "hip vs f64", "f32 vs f64", "ratio"))
+    print("---- gradients w.r.t. the same tensors (all three backward passes driven by the HIP path's objective gradient)")
+    for name, ref in caps["f64.grad"].items():
+        t = None
+        if name in plan.views and getattr(plan.views[name], "gy", None) is not None:
+            t = plan.views[name].gy
+        elif name in plan.tensors and getattr(plan.tensors[name], "g", None) is not None:
+            t = plan.tensors[name].g
+        if t is None or name not in caps["f32.grad"]:
+            continue
+        got = plan.read(t).cpu().double()
+        if got.shape != ref.shape:
+            continue
+        den = ref.norm().clamp_min(1e-30)
+        eh, ec = float((got - ref).norm() / den), float((caps["f32.grad"][name] - ref).norm() / den)
+        print("grad %-17s %12.3e %12.3e %8.2f" % (name, eh, ec, eh / max(ec, 1e-30)), flush=True)
+    print("---- parameter gradients, worst ratios")
+    rows = []
+    for k, q in model.named_parameters():
+        if q.grad is None or k not in caps["f64.pgrad"]:
+            continue
+        ref = caps["f64.pgrad"][k]
+        den = ref.norm().clamp_min(1e-30)
+        eh, ec = float((q.grad.detach().cpu().double() - ref).norm() / den), float((caps["f32.pgrad"][k] - ref).norm() / den)
+        rows.append((eh / max(ec, 1e-30), k, eh, ec))
+    for r in sorted(rows, reverse=True)[:25]:
+        print("param %-55s %10.3e %10.3e %8.2f" % (r[1], r[2], r[3], r[0]), flush=True)
+    print("---- forward tensors")
     for name, ref in caps["f64"].items():
         if name in plan.views:
             got = plan.read_view(plan.views[name]).cpu().double()
