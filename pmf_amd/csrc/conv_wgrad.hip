@@ -2654,7 +2654,9 @@ static int wg_s3n_nco(const pmf_wgrad_desc_t* d, const WgGeom& g, int TB) {
   const char* e_n = getenv("PMF_WG_S3N");     // (read per call, not cached: the tests switch variants)
   const int mode = e_n ? atoi(e_n) : 4;
   static const bool no_ragged = getenv("PMF_WG_S3N_NORAGGED") != nullptr;      // A/B switch (round 4: those layers on fp32 MFMA)
-  if (mode <= 1 || TB <= 1 || !(d->flags & PMF_WGRAD_S3) || !wg_simple(d, g, TB, 32, 16, !no_ragged)) return 0;
+  // (operands of 8 channels too -- EPMF's 3x3 5 -> 32 first layer, padded to 8: a quarter-full chunk; the rows of the 32-row
+  // tile beyond the operand's channels are staged as zeros and never written to the slab)
+  if (mode <= 1 || TB <= 1 || !(d->flags & PMF_WGRAD_S3) || !wg_simple(d, g, TB, 32, no_ragged ? 16 : 8, !no_ragged)) return 0;
   if ((int64_t)d->N * d->OH * d->OW * d->dz_ldc * 4 >= (1ll << 31)) return 0;
   const char* e_w8 = getenv("PMF_WG_W8");
   const char* e_swp = getenv("PMF_WG_SWP");

@@ -137,6 +137,9 @@ CONVS = [
     # take the hardware zero); c3x3 (12 x 40) and c3x3d2 (16 x 36) above run the same instantiations with one / two tiles
     ("c3x3_rag_n4", 2, 30, 40, [64], 128, 3, 1, 1, 1, True, "act_bn", True),
     ("c2x2d2_rag", 1, 15, 80, [32, 32], 64, 2, 2, 1, 1, False, "bn_relu", True),
+    # EPMF's first layers: 3x3 over 5 (padded 8) input channels -- a quarter-full chunk on the N-split weight-gradient kernel
+    ("c3x3_k8_c32", 2, 16, 64, [8], 32, 3, 1, 1, 1, True, "lrelu", False),
+    ("c3x3_k8_cat", 1, 8, 64, [8, 32], 64, 3, 1, 1, 1, True, "act_bn", True),
 ]
 
 
