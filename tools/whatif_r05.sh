@@ -1,8 +1,14 @@
 #!/bin/bash
-o=gpurun_out/r05v; mkdir -p $o
-timeout 900 python -m pytest tests/test_gpu_ops.py -x -q -m gpu > $o/pytest_ops.log 2>&1; tail -2 $o/pytest_ops.log
-timeout 300 python bench.py --model epmf --steps 30 --warmup 8 --no-cpu-baseline --no-f32-ref --profile-out $o/ops_epmf.txt > $o/bench_epmf.json 2>$o/err.txt
-python -c "
-import json
-d=json.loads(open('$o/bench_epmf.json').read().strip().splitlines()[-1]); print('epmf', d['ms_per_step'], d['parity']['ok'], d['roofline']['frac'], {k:(v['ms'],v['achieved']) for k,v in d['roofline']['families'].items()})"
-grep "downCntx.*OP_WGRAD\|OP_WGRAD_PART.*downCntx" $o/ops_epmf.txt | cut -c1-140
+o=gpurun_out/r05w; mkdir -p $o
+q="--steps 60 --warmup 10 --no-parity --no-cpu-baseline --no-roofline --no-f32-ref"
+run() { echo -n "$1: " >> $o/ab.txt; env $2 timeout 200 python bench.py $q 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'])" >> $o/ab.txt; }
+for rep in 1 2 3; do
+run "default (batch 4)" "A=1"
+run "wgrad batch 2" "PMF_WGRAD_BATCH=2"
+run "wgrad batch 3" "PMF_WGRAD_BATCH=3"
+done
+run "red batch 16" "PMF_RED_BATCH=16"
+run "pack early 4" "PMF_PACK_EARLY=4"
+run "pack early 16" "PMF_PACK_EARLY=16"
+run "default (batch 4)" "A=1"
+cat $o/ab.txt
