@@ -1,6 +1,6 @@
 #!/bin/bash
 # round-5 evidence batch (GPU box, `gpurun -- "bash tools/r05_evidence.sh <commit>"`): full -m gpu suite, smoke, rocprofv3 summaries (tools/collect_profiles.sh), bench lines of every configuration -> profiles/r05_*
-o=gpurun_out/r05s; mkdir -p $o
+o=gpurun_out/r05z; mkdir -p $o
 (timeout 1500 python -m pytest tests -m gpu -q > $o/pytest_gpu.log 2>&1; echo "pytest rc $?" >> $o/pytest_gpu.log); grep -E "^(FAILED|ERROR)|passed|failed|pytest rc" $o/pytest_gpu.log | tail -6
 python __graft_entry__.py smoke 2>&1 | tail -2
 bash tools/collect_profiles.sh r05 $1 > $o/collect.log 2>&1; head -1 gpurun_out/r05/r05_per_layer_kernel_times.txt
