@@ -550,6 +550,9 @@ def parity_block(args, eng, model, feat0, mask, label):
         picks = [k for k in PARITY_GRADS if k in named and named[k].grad is not None]
         grads_h = {k: named[k].grad.detach().float().cpu().clone() for k in picks}
         graphs = len(plan._graphs)
+        if getattr(args, "parity_masked", False):
+            decisions = plan.act_decisions(model)       # sign masks / argmax positions of THIS forward pass
+            grads_all = {k: p.grad.detach().float().cpu().clone() for k, p in named.items() if p.grad is not None}
     finally:
         model.set_dropout_masks(None)
         _attach_dp_hooks(model, hooks)
@@ -560,9 +563,14 @@ def parity_block(args, eng, model, feat0, mask, label):
     # all forward tensors agree to 1.2x.  So the two things are reported separately: (1) the objective's gradient w.r.t. the two
     # probability maps, each path against float64; (2) the NETWORK's backward pass given ONE upstream gradient -- the oracle
     # passes below are driven by the gradient the HIP path computed, so that (2) measures the kernels, not the objective's kinks.
-    def oracle_backward(e_, net_, dt):
+    def oracle_backward(e_, net_, dt, inject=None):
         p_, r_ = e_.prepare(feat0.detach().cpu().to(dt), mask.cpu().to(dt))
-        tot_, _, lp_o, cp_o, _ = e_.forward_loss(p_, r_, label.cpu().long())
+        if inject is not None:
+            from oracle.act_masks import ActSites
+            with ActSites(net_, inject=inject):
+                tot_, _, lp_o, cp_o, _ = e_.forward_loss(p_, r_, label.cpu().long())
+        else:
+            tot_, _, lp_o, cp_o, _ = e_.forward_loss(p_, r_, label.cpu().long())
         own = torch.autograd.grad(tot_, [lp_o, cp_o], retain_graph=True)        # the oracle's own objective gradient
         torch.autograd.backward([lp_o, cp_o], [gobj_h[0].to(dt), gobj_h[1].to(dt)])
         return float(tot_.detach()), [g.detach().double() for g in own]
@@ -599,6 +607,9 @@ def parity_block(args, eng, model, feat0, mask, label):
         den = g64.norm().clamp_min(1e-30)
         grad_rel[k] = float((grads_h[k].double() - g64).norm() / den)
         grad_rel_cpu[k] = float((ref_named[k].grad.detach().double() - g64).norm() / den)
+    masked = None
+    if getattr(args, "parity_masked", False):
+        masked = _masked_backward(args, Engine, eng, sd, masks, decisions, grads_all, oracle_backward)
     ref_logits = net.lidar_stream.last_logits.detach()
     if logits.shape != ref_logits.shape:                       # the plan stores NHWC
         logits = logits.permute(0, 3, 1, 2)[:, :ref_logits.shape[1]]
@@ -617,18 +628,69 @@ def parity_block(args, eng, model, feat0, mask, label):
             "grad_rel_vs_float64": {k: {"hip": grad_rel[k], "cpu_fp32_oracle": grad_rel_cpu[k]} for k in picks},
             "grad_rel_worst": max(grad_rel.values()) if picks else None,
             "grad_rel_worst_ratio_to_cpu_fp32": gratio,
-            "loss_hip": loss_h, "loss_oracle": loss_r,
+            "loss_hip": loss_h, "loss_oracle": loss_r, "masked": masked,
             "bars": {"logits_rel": 1e-3, "loss_rel": 1e-4, "running_stat_rel": 1e-4,
                      "grad_rel": "hip <= max(3 x cpu_fp32_oracle, 2e-4) for every listed parameter, all three backward passes "
                                  "driven by the SAME upstream gradient (the HIP path's d objective / d probabilities)",
                      "objective_grad_rel": "hip <= max(3 x cpu_fp32_oracle, 2e-4) per probability map, each path's own objective"},
-            "ok": bool(lrel < 1e-3 and lossrel < 1e-4 and rrel < 1e-4 and gok and ook),
+            "ok": bool(lrel < 1e-3 and lossrel < 1e-4 and rrel < 1e-4 and gok and ook and (masked is None or masked["ok"])),
             "what": "train-mode forward + objective + BACKWARD of the plan that was timed (PMF_AUTOTUNE %s, lanes, %d captured "
                     "graphs) against the CPU oracle: model state after the timed iterations copied into oracle/ (%d host "
                     "threads), same Dropout2d multipliers, same batch; logits / loss / running statistics against the fp32 "
                     "oracle; grad_rel_vs_float64 = |g - g64|_2 / |g64|_2 of the named parameter gradients (first / last "
                     "layer of each stream, one layer per kernel family) for the HIP path and for the fp32 CPU oracle, both "
                     "against the oracle in float64" % (os.environ.get("PMF_AUTOTUNE", "on"), graphs, torch.get_num_threads())}
+
+
+def _masked_backward(args, Engine, eng, sd, masks, decisions, grads_h, oracle_backward):
+    """--parity-masked: the float64 and the fp32 oracle passes once more, now with the HIP path's
+    piecewise-linear DECISIONS injected (sign of every LeakyReLU / ReLU pre-activation, the stem max-pool's argmax;
+    oracle/act_masks.py, Plan.act_decisions) and, as before, driven by the HIP path's d objective / d probabilities.  All three
+    backward passes then differentiate the SAME piecewise-linear function (salsanext.py:27-33, pmf_net.py:20-29,94 are the
+    reference's activations): an activation sitting on its kink can no longer move a gradient by a whole term, so what is left
+    between the passes is rounding -- or a kernel defect.  EVERY parameter of the flat state is compared."""
+    from oracle import pmf_torch as O
+    out = {}
+    for tag, dt in (("f32", torch.float32), ("f64", torch.float64)):
+        net_ = _oracle_model(args.model, args.backbone, args.nclasses)
+        net_.load_state_dict(sd)
+        net_ = net_.to(dt).train()
+        O.set_dropout_masks(net_, {k: v.to(dt) for k, v in masks.items()})
+        e_ = Engine(net_, args.nclasses, lambda_=1.0, gamma=0.5, tau=0.7, feature_mean=KITTI_MEAN, feature_std=KITTI_STD,
+                    warmup_steps=10, max_steps=100)
+        if dt == torch.float64:
+            e_.focal.double()
+        if args.model == "epmf":
+            e_.mt_loss.to(dt)
+            with torch.no_grad():
+                e_.mt_loss.sigma.copy_(eng.mt_loss.sigma.detach().cpu().to(dt))
+        oracle_backward(e_, net_, dt, inject=decisions)
+        out[tag] = {k: p.grad.detach().double() for k, p in net_.named_parameters() if p.grad is not None}
+        del net_, e_
+    rows = []
+    for k, gh in grads_h.items():
+        if k not in out["f64"]:
+            continue
+        g64 = out["f64"][k]
+        wk = k.rsplit(".", 1)[0] + ".weight"
+        # (a conv bias in front of a train-mode BatchNorm has a true gradient of exactly 0: its layer's weight gradient sets
+        # the scale, as in tests/test_gpu_fullsize.py)
+        floor = 1e-6 * float(out["f64"][wk].norm()) if wk in out["f64"] else 0.0
+        den = max(float(g64.norm()), floor, 1e-30)
+        rows.append((k, float((gh.double() - g64).norm()) / den, float((out["f32"][k] - g64).norm()) / den))
+    bad = [r for r in rows if not r[1] <= max(3.0 * r[2], 2e-4)]
+    ratio = np.array([r[1] / max(r[2], 1e-12) for r in rows if r[2] > 1e-7])
+    worst = max(rows, key=lambda r: r[1] / max(r[2], 2e-4 / 3))
+    return {"parameters": len(rows), "decision_sites": len(decisions),
+            "flipped_elements_note": "decisions are the HIP path's; both oracle passes replay them",
+            "bad": {r[0]: {"hip": r[1], "cpu_fp32_oracle": r[2]} for r in bad[:40]}, "n_bad": len(bad),
+            "worst": {"name": worst[0], "hip": worst[1], "cpu_fp32_oracle": worst[2]},
+            "ratio_gmean": float(np.exp(np.log(np.maximum(ratio, 1e-6)).mean())) if ratio.size else None,
+            "ratio_p90": float(np.percentile(ratio, 90)) if ratio.size else None,
+            "ratio_max": float(ratio.max()) if ratio.size else None,
+            "bar": "every parameter: hip <= max(3 x cpu_fp32_oracle, 2e-4), relative L2 distance from the float64 oracle, all "
+                   "three passes on the HIP path's activation decisions and upstream gradient",
+            "ok": not bad}
 
 
 # parameter gradients the parity block reports: first / last layer of each stream, one layer per kernel family
@@ -843,6 +905,9 @@ def main():
     ap.add_argument("--knn-random-order", action="store_true",
                     help="--mode infer: KNN points in random order instead of sweep-file (azimuth-major) order")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle parity block of the timed plan")
+    ap.add_argument("--parity-masked", action="store_true",
+                    help="parity block: also compare EVERY parameter gradient with the HIP path's activation decisions injected "
+                         "into the float64 / fp32 oracle passes (separates kinks from kernel defects)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-f32-ref", action="store_true", help="skip the fp32-MFMA-only reference measurement")

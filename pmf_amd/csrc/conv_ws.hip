@@ -363,6 +363,7 @@ static bool ws_geometry(const pmf_conv_desc_t* d, WsGeom* g, ConvGeom* cg, int* 
 
 // eligibility: split-bf16 weights, 9 or 4 taps, stride 1, one halo tile of <= 1280 staging slots, operands multiples of 16
 // channels with the output's H x W, no broadcast, Cout a multiple of 32 (of 32 NCO for the chosen NCO)
+extern "C" int pmf_conv_multi_ok(const pmf_conv_desc_t* d);
 extern "C" int pmf_conv_ws_ok(const pmf_conv_desc_t* d) {
   if (!d->w_s3 || d->in_stride != 1 || d->gather || (d->ntaps != 9 && d->ntaps != 4) || (d->ldw & 31) || (d->Cout & 31)) return 0;
   if (d->out_sy != 1 && d->out_sy != 0) { /* strided outputs (parity classes of a stride-2 input gradient) are fine: epilogue */ }
@@ -371,9 +372,7 @@ extern "C" int pmf_conv_ws_ok(const pmf_conv_desc_t* d) {
     if (s.C % 16 || (s.flags & PMF_SRC_BCAST) || s.H != d->src[0].H || s.W != d->src[0].W) return 0;
     if ((int64_t)d->N * s.H * s.W * s.ldc * 4 >= (1ll << 31)) return 0;
   }
-  if (d->ndst > 0) {
-    for (int i = 0; i < d->ndst; ++i) if (d->dst[i].C % 32) return 0;
-  }
+  if (d->ndst > 0 && !pmf_conv_multi_ok(d)) return 0;     // (ranges start on 32-channel tiles and add up to Cout; no bias)
   WsGeom g; ConvGeom cg; int asl;
   if (!ws_geometry(d, &g, &cg, &asl)) return 0;
   if ((int64_t)d->N * d->out_H * d->out_W * d->out_ldc * 4 >= (1ll << 31)) return 0;
@@ -381,7 +380,8 @@ extern "C" int pmf_conv_ws_ok(const pmf_conv_desc_t* d) {
   // cfg bits 26-27 / PMF_CONV_WS_NCO: at most 1 / 2 / 4 tiles per workgroup; default: as many as the channel count allows while
   // the launch keeps >= 256 workgroups (a 16 x 512 map has 128 tiles: four tiles per workgroup would leave half the CUs idle)
   static const int env_nco = getenv("PMF_CONV_WS_NCO") ? atoi(getenv("PMF_CONV_WS_NCO")) : 0;
-  const int want = ((d->cfg >> 26) & 3) ? (1 << (((d->cfg >> 26) & 3) - 1)) : env_nco;
+  const int code = ((d->cfg >> 25) & 1) ? ((d->cfg >> 26) & 3) : 0;     // (bits 26-27 mean something only next to bit 25)
+  const int want = code ? (1 << (code - 1)) : env_nco;
   if (want == 1 || want == 2 || want == 4) { while (nco > want) nco >>= 1; return nco; }
   const int tiles = g.tiles_x * g.tiles_y * d->N;
   while (nco > 1 && tiles * (d->Cout / (32 * nco)) < 256) nco >>= 1;

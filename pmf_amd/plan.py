@@ -97,6 +97,7 @@ class Plan(PlanConvMixin, PlanTuneMixin, PlanRunMixin):
         self.bn_modules = []
         self.in_slots, self.out_slots = {}, {}
         self.tensors, self.views = {}, {}   # debug registry: name -> T / V
+        self.act_sites = []                 # (conv module, debug name, activation, relu-on-view): the piecewise-linear decisions
         self.meta_fwd, self.meta_bwd = {}, {}   # op index (before prologue shift) -> dict(family, flops)
         self.colrows_max = 4
 
@@ -443,6 +444,7 @@ class Plan(PlanConvMixin, PlanTuneMixin, PlanRunMixin):
                 s.p[1] = idx.ptr if idx is not None else None
             s.i[0], s.i[1], s.i[2], s.i[3], s.i[4] = t.N, t.H, t.W, _ru(t.C, 4), out.ldc
         self.emit(self.fwd, kind_f, f)
+        out.pool_idx, out.pool_of = idx, v  # (debug: argmax positions 0..8 as uint8 [N, OH, OW, round4(C)])
         self.note_bytes(self.fwd, "pool", 4.0 * t.C * (t.npix + out.npix) + (out.npix * t.C if with_idx else 0))
         if self.training and t.needs_grad:
             def backward():

@@ -181,6 +181,7 @@ class PlanConvMixin(object):
                 self.bn_modules.append(bn)
         if name:
             self.views[name] = view
+            self.act_sites.append((conv, name, k_act, bool(relu_view)))
         if not self.training:
             return view
 

@@ -8,6 +8,10 @@ import torch
 from . import _lib as L
 
 
+def _ru4(c):
+    return (c + 3) // 4 * 4
+
+
 class PlanRunMixin(object):
     # ------------------------------------------------------------------ debug readers (tests / tools only)
     def read(self, t):
@@ -27,6 +31,43 @@ class PlanRunMixin(object):
             cm = self.masks[v.cmul:v.cmul + v.t.N * v.cmul_ld].view(v.t.N, v.cmul_ld)[:, :v.t.C]
             x = x * cm[:, :, None, None]
         return x
+
+    def act_decisions(self, model):
+        """debug: the piecewise-linear DECISIONS this plan's last forward pass took, keyed the way a checker keys the same
+        sites of the reference's module tree (qualified module names = state-dict prefixes):
+            ("lrelu", conv)      bool NCHW, stored conv output > 0                (conv -> LeakyReLU -> BN, salsanext.py:27-33)
+            ("relu", conv)       bool NCHW, x * scale + shift > 0 of the view     (conv -> BN -> ReLU, pmf_net.py:20-29)
+            ("relu_out", block)  bool NCHW, stored residual sum > 0               (ResNet block output)
+            ("maxpool", conv)    int64 [N, C, OH, OW] flat input positions        (the stem's MaxPool2d, pmf_net.py:94)
+        Lets a checker run ITS backward pass through the same piecewise-linear function (tests/, bench.py --parity-masked);
+        the product never calls this."""
+        names = {id(m): n for n, m in model.named_modules()}
+        dec = {}
+        for conv, name, act, relu_view in self.act_sites:
+            q = names.get(id(conv))
+            if q is None:
+                continue
+            if act in (L.ACT_LRELU, L.ACT_RELU):
+                dec[("lrelu" if act == L.ACT_LRELU else "relu", q)] = (self.read(self.tensors[name]) > 0).cpu()
+            elif relu_view:
+                v = self.views[name]
+                x = self.read(v.t)
+                x = x * v.scale.tensor((v.t.C,)).view(1, -1, 1, 1) + v.shift.tensor((v.t.C,)).view(1, -1, 1, 1)
+                dec[("relu", q)] = (x > 0).cpu()
+        enc = next((n for n, m in model.named_modules() if n.endswith("camera_stream_encoder")), None)
+        for name, t in self.tensors.items():
+            if enc is not None and name.startswith("enc.layer") and name.endswith(".out"):
+                dec[("relu_out", enc + "." + name[4:-4])] = (self.read(t) > 0).cpu()
+            idx = getattr(t, "pool_idx", None)
+            if idx is not None and enc is not None:
+                src = t.pool_of.t
+                cq = _ru4(src.C)
+                pos = idx.tensor((t.N, t.H, t.W, cq), torch.uint8)[..., :t.C].permute(0, 3, 1, 2).long()
+                oy = torch.arange(t.H, device=pos.device).view(1, 1, -1, 1)
+                ox = torch.arange(t.W, device=pos.device).view(1, 1, 1, -1)
+                y, x = 2 * oy + pos // 3 - 1, 2 * ox + pos % 3 - 1
+                dec[("maxpool", enc + ".conv1")] = (y * src.W + x).cpu()
+        return dec
 
     def segment_cuts(self, k):
         """op indices that split the backward plan into at most k segments for the data-parallel engine: after every

@@ -143,17 +143,20 @@ CONVS = [
 ]
 
 
-TILE_CFGS = [bn | (2 << 8) | (1 << 16) for bn in (32, 64)] + \
+TILE_CFGS = [32 | (1 << 8) | (1 << 16) | L.CFG_WS | (code << 26) for code in (0, 2, 3)] + \
+            [bn | (2 << 8) | (1 << 16) for bn in (32, 64)] + \
             [bn | (1 << 8) | (ks << 16) for bn in (32, 64) for ks in (1, 2, 4, 8, 16)] + \
             [bn | (mt << 8) | (1 << 16) | L.CFG_DIRECT_TAPS for bn in (32, 64) for mt in (1, 2)]     # direct multi-tap variant
 
 
-@pytest.mark.parametrize("cfg", TILE_CFGS, ids=["bn%d_mt%d_ks%d%s" % (c & 255, (c >> 8) & 255, (c >> 16) & 255, "_direct" if c >> 24 else "")
+@pytest.mark.parametrize("cfg", TILE_CFGS, ids=["bn%d_mt%d_ks%d%s" % (c & 255, (c >> 8) & 255, (c >> 16) & 255,
+                                                                        "_direct" if (c >> 24) & 1 else ("_ws%d" % ((c >> 26) & 3) if (c >> 25) & 1 else ""))
                                               for c in TILE_CFGS])
 def test_conv_tile_configs(cfg):
     """every tile configuration the plan autotuner may write into a conv op (output-channel tile 32/64, 128/256-pixel
     tile, 1-16 K splits), forward + input gradient + BatchNorm statistics, against float64 -- on a 3x3 dilated conv
-    with BN, a 3-operand 1x1 (64-channel stages), a stride-2 3x3 (parity-class input gradients) and a deep small map"""
+    with BN, a 3-operand 1x1 (64-channel stages), a stride-2 3x3 (parity-class input gradients) and a deep small map; plus
+    the wave-scheduled N-split kernel with its output-tile cap (cfg bits 25-27: default rule / two / four tiles)"""
     for case in CONVS:
         if case[0] in ("c3x3d2", "c1x1cat3", "c3x3s2", "c3x3_big", "c7x7") or \
                 (cfg >> 24 and case[0] in ("c3x3", "c2x2d2", "c3x3cat2", "c1x1_512_cat", "c3x3_wpipe", "c2x2d2_wpipe", "c3x3d6")):
@@ -201,6 +204,16 @@ def test_conv_unit_wave_scheduled(case):
     transposed launches; launches that do not qualify -- 24 output channels, dilation 6 / 18 -- keep the staged loop), BatchNorm
     statistics incl. the per-tile statistics fold of one / two / four output-channel tiles per workgroup, float64 bars"""
     _conv_case(case, 32 | (1 << 8) | (1 << 16) | L.CFG_WS)
+
+
+@pytest.mark.parametrize("code", [1, 2, 3], ids=["nco1", "nco2", "nco4"])
+@pytest.mark.parametrize("case", [c for c in WS_CASES if c[5] % 64 == 0], ids=[c[0] for c in WS_CASES if c[5] % 64 == 0])
+def test_conv_unit_wave_scheduled_nco(case, code):
+    """the default rule of pmf_conv_ws_ok (tiles x Cout / (32 NCO) >= 256) sends every unit shape to ONE
+    output-channel tile per workgroup, while the shipped tile table asks for two / four on 102 shapes (cfg bits 26-27).  The
+    cap is set explicitly here: conv_ws_k<*, 1 / 2 / 4, *> and the per-tile statistics fold of conv_epi.h (plain BatchNorm
+    statistics and the multi-destination merged input gradients of the concatenated cases) against float64"""
+    _conv_case(case, 32 | (1 << 8) | (1 << 16) | L.CFG_WS | (code << 26))
 
 
 DIRECT_1X1 = [c for c in CONVS if c[0] in ("c1x1cat3", "c1x1_plain_lrelu", "c1x1s2", "c1x1cat3_big", "c1x1_odd_big",
