@@ -747,9 +747,22 @@ def plan_rooflines(plan, prof, model_tag):
             if m.get("family") in convs and kinds[i + shift] == L.OP_CONV and ops[i + shift].u.conv.w_s3:
                 split_fl += m["flops"]
     share = split_fl / max(mfma_fl, 1.0)
+    # (weight gradients: the N-split / 1x1 split kernels run the same six products; the few-channel tails run fp32 MFMA -- their
+    # flops are < 3 % of the family, so the family is priced as split)
+    share_all = (split_fl + (fam["conv_wgrad"][1] if "conv_wgrad" in fam else 0.0)) / max(
+        mfma_fl + (fam["conv_wgrad"][1] if "conv_wgrad" in fam else 0.0), 1.0)
     # the headline fraction covers ALL matrix work of the pass: forward, input-gradient AND
     # weight-gradient launches; the per-family split rides along
     allk = [k for k in ("conv_fwd", "conv_dgrad", "conv_wgrad") if k in fam]
+    # the stage-2 reductions of the weight-gradient slabs (wgrad_reduce_multi_k / wgrad_reduce_k) ARE weight-gradient time: their
+    # launches count in the denominator of the headline fraction and of the weight-gradient family
+    red_ms = sum(v[2] for k, v in fam.items() if k in ("OP_WGRAD_RED", "OP_WGRAD_RED_MULTI"))
+    red_n = sum(v[0] for k, v in fam.items() if k in ("OP_WGRAD_RED", "OP_WGRAD_RED_MULTI"))
+    if "conv_wgrad" in fam:
+        fam["conv_wgrad"][2] += red_ms
+        fam["conv_wgrad"][0] += red_n
+        for k in ("OP_WGRAD_RED", "OP_WGRAD_RED_MULTI"):
+            fam.pop(k, None)
     all_ms, all_fl, all_n = (sum(fam[k][i] for k in allk) for i in (2, 1, 0))
     achieved_all = all_fl / (all_ms * 1e-3) / 1e12
     families = {k: {"launches": fam[k][0], "algorithmic_gflop": round(fam[k][1] / 1e9, 1), "ms": round(fam[k][2], 3),
@@ -764,6 +777,10 @@ def plan_rooflines(plan, prof, model_tag):
                           "conv_wgrad_k on fp32 MFMA for the few-channel tails)" if "conv_wgrad" in fam else ""),
             "achieved": round(achieved_all, 3), "peak": PEAK_FP32_MFMA, "unit": "TFLOP/s",
             "frac": round(achieved_all / PEAK_FP32_MFMA, 4),
+            # the same work priced against the pipe the split products execute on: 6 bf16 MFMA products per fp32 product
+            # (for the share of the flops that runs split; the fp32-MFMA share is priced at the fp32 peak)
+            "bf16_pipe_frac": round(achieved_all * (6.0 * share_all / PEAK_BF16_MFMA + (1.0 - share_all) / PEAK_FP32_MFMA), 4),
+            "stage2_reduce_ms_included": round(red_ms, 3),
             "families": families,
             "conv_fwd_k_only": {"achieved": round(achieved, 3), "frac": round(achieved / PEAK_FP32_MFMA, 4)},
             "peak_note": "peak = dense fp32 MFMA (the arithmetic type); achieved = algorithmic fp32 flops / launch time; "

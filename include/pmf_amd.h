@@ -327,6 +327,12 @@ int pmf_softmax_nhwc_to_nchw(const float* logits, int32_t ldc, int32_t N, int32_
                              pmf_stream_t s);
 int pmf_softmax_bwd_nchw_to_nhwc(const float* prob_nchw, const float* g_nchw, int32_t N, int32_t HW, int32_t C,
                                  float* dlogits, int32_t ldc, pmf_stream_t s);
+/* the same two layout changes WITHOUT the softmax: SalsaNext(softmax=False) returns its logits
+ * (pc_processor/models/salsanext.py:167,206-207); the backward is the transposed copy */
+int pmf_logits_nhwc_to_nchw(const float* logits, int32_t ldc, int32_t N, int32_t HW, int32_t C, float* out_nchw,
+                            pmf_stream_t s);
+int pmf_logits_bwd_nchw_to_nhwc(const float* g_nchw, int32_t N, int32_t HW, int32_t C, float* dlogits, int32_t ldc,
+                                pmf_stream_t s);
 /* model-boundary layout change with channel padding; input may be a strided NCHW view (trainer.py:296-297) */
 int pmf_nchw_to_nhwc(const float* x, int64_t stride_n, int64_t stride_c, int32_t N, int32_t C, int32_t HW,
                      float* out, int32_t out_ldc, pmf_stream_t s);
@@ -378,7 +384,8 @@ int pmf_project_v2_scatter(const float* points, const int32_t* sem, const int32_
                            int32_t iw, const int32_t* lut, int32_t nlut, int32_t x_min, int32_t y_min, int32_t h,
                            int32_t w, float* proj_out, int32_t* pix_idx, pmf_stream_t s);
 /* pmf_project_scatter in TWO launches and without the per-call memset (the loader's per-frame path): pix_tag u32[h*w] and
- * slots u64[1 + ceil(P/1024)] (slots[0] = the block-ticket counter, left at 0 by every call) are PERSISTENT workspaces of the
+ * slots u64[1 + ceil(P/1024)] (slots[0] = the block-ticket counter, left at 0 by every call; a call that finds it non-zero -- unzeroed
+ * or foreign workspace -- writes nothing out of bounds, does not hang and reports *n_kept = -1) are PERSISTENT workspaces of the
  * caller, zeroed once and again whenever `generation` (1..4095, +1 per call on the same workspaces) wraps; calls that share
  * workspaces must be ordered (one stream); P <= 2^20.  Outputs bit-identical to pmf_project_scatter. */
 int pmf_project_scatter2(const float* points, const int32_t* sem, int64_t P, const uint8_t* image, int32_t h, int32_t w,
@@ -437,7 +444,8 @@ int pmf_flip_rotate_crop(const float* src, int32_t C, int32_t h, int32_t w, int3
  * Image.blend with a degenerate image; hue through Pillow's HSV conversion), each operation on the uint8 result of the
  * previous one.  HOST arrays: order4 = the drawn permutation of {0 brightness, 1 contrast, 2 saturation, 3 hue};
  * factor4[op] / enabled4[op] = the drawn factor of operation op / whether it is applied (a zero-width range draws
- * nothing).  scratch: one device uint64 (luma sum of the contrast step). */
+ * nothing).  scratch: one device uint64 (luma sum of the contrast step).  `image` must be 4-byte aligned (dword accesses):
+ * PMF_E_ARG otherwise -- the Python wrapper sends an unaligned slice through an aligned device copy. */
 int pmf_color_jitter(uint8_t* image, int32_t h, int32_t w, const int32_t* order4, const double* factor4,
                      const int32_t* enabled4, uint64_t* scratch, pmf_stream_t s);
 

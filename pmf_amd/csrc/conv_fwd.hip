@@ -1423,13 +1423,13 @@ static int conv_pipe_mode(const pmf_conv_desc_t* d, const ConvGeom& g, int gathe
 // weights, operands multiples of 16 channels with the same H x W, all weight fragments of one output-channel tile
 // resident in LDS.  PMF_NO_DIRECT=1 switches the variant off.
 static bool conv_stem_class(const pmf_conv_desc_t* d) {
-  // OPT-IN (PMF_STEM_DIRECT=1).  Per launch the variant is pinned against float64 like every other (tests), and it is faster
-  // (7x7 stem 172 -> 121-134 us).  But it sits on the camera lane, where it does not move the step (16.41 vs 16.40 ms), and
-  // with it the full-size gradient parity of the camera decoder's low-resolution layers goes from 1e-5 to 1e-3 against
-  // float64 (EPMF, and PMF-R34 with the 32-wide / 256-pixel tile; tests/test_gpu_fullsize.py): those gradients have a condition
-  // number of ~1000 with respect to a COHERENT 1e-6 perturbation of the stem output (tools/sens_stem_cpu.py shows it in float64
-  // on the CPU), and the dropped product terms of the split-bf16 scheme are one.  No step gain, tighter parity bars: off.
-  static const bool on = [] { const char* e = getenv("PMF_STEM_DIRECT"); return e && e[0] == '1'; }();
+  // Default since round 6 (PMF_STEM_DIRECT=0 switches it off).  Per launch the variant is pinned against float64 like every
+  // other (tests) and it is faster (7x7 stem 172-185 -> 121-134 us).  Rounds 4-5 kept it opt-in because the full-size gradient
+  // parity of the camera decoder's low-resolution layers went from 1e-5 to 1e-3 against float64 with it; round 6's
+  // mask-injected backward check (bench.py --parity-masked: the float64 / fp32 oracle passes replay the HIP path's activation
+  // decisions) shows that residual is ReLU-kink flips, not arithmetic: with the decisions shared every parameter gradient sits
+  // within 7e-5 of float64 with the variant on (tests/test_gpu_fullsize.py::test_masked_backward_parity).
+  static const bool on = [] { const char* e = getenv("PMF_STEM_DIRECT"); return !(e && e[0] == '0'); }();
   return on && d->nsrc == 1 && d->src[0].C == 8 && d->ntaps >= 2 && d->ntaps <= PMF_MAX_TAPS &&
          !(d->src[0].flags & PMF_SRC_BCAST);
 }

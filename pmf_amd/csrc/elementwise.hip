@@ -642,7 +642,8 @@ extern "C" int pmf_fusion_gate_bwd(const float* gout, int32_t g_ldc, const pmf_v
 #define SM_MAXC 32
 // VEC: the NHWC side moves as 16-byte vectors (ldc a multiple of 4, base 16-byte aligned): a thread owns one pixel, so a
 // scalar access per channel touches as many cache lines per instruction as a vector access that moves four channels
-template <bool VEC>
+// IDENT: no softmax, the logits themselves go out (SalsaNext(softmax=False), salsanext.py:167,206-207)
+template <bool VEC, bool IDENT = false>
 __global__ void softmax_k(const float* __restrict__ lg, int ldc, int N, int HW, int C, float* __restrict__ prob) {
   const int64_t total = (int64_t)N * HW;
   for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < total; p += (int64_t)gridDim.x * blockDim.x) {
@@ -661,15 +662,18 @@ __global__ void softmax_k(const float* __restrict__ lg, int ldc, int N, int HW, 
       for (int c = 0; c < SM_MAXC; ++c)
         if (c < C) v[c] = lg[p * ldc + c];
     }
-    float m = -INFINITY;
+    float inv = 1.f;
+    if (!IDENT) {
+      float m = -INFINITY;
 #pragma unroll
-    for (int c = 0; c < SM_MAXC; ++c)
-      if (c < C) m = fmaxf(m, v[c]);
-    float sum = 0.f;
+      for (int c = 0; c < SM_MAXC; ++c)
+        if (c < C) m = fmaxf(m, v[c]);
+      float sum = 0.f;
 #pragma unroll
-    for (int c = 0; c < SM_MAXC; ++c)
-      if (c < C) { v[c] = expf(v[c] - m); sum += v[c]; }
-    const float inv = 1.f / sum;
+      for (int c = 0; c < SM_MAXC; ++c)
+        if (c < C) { v[c] = expf(v[c] - m); sum += v[c]; }
+      inv = 1.f / sum;
+    }
 #pragma unroll
     for (int c = 0; c < SM_MAXC; ++c)
       if (c < C) prob[((int64_t)n * C + c) * HW + hw] = v[c] * inv;
@@ -686,7 +690,18 @@ extern "C" int pmf_softmax_nhwc_to_nchw(const float* logits, int32_t ldc, int32_
   PMF_LAUNCH_CHECK();
   return 0;
 }
-template <bool VEC>
+extern "C" int pmf_logits_nhwc_to_nchw(const float* logits, int32_t ldc, int32_t N, int32_t HW, int32_t C, float* out_nchw,
+                                       pmf_stream_t s) {
+  if (C > SM_MAXC || C < 1) return PMF_E_UNSUPPORTED;
+  const bool vec = (ldc & 3) == 0 && ((uintptr_t)logits & 15) == 0 && ((C + 3) & ~3) <= ldc;
+  if (vec) hipLaunchKernelGGL((softmax_k<true, true>), dim3(ew_grid((int64_t)N * HW)), dim3(EW_BLOCK), 0, (hipStream_t)s,
+                              logits, ldc, N, HW, C, out_nchw);
+  else hipLaunchKernelGGL((softmax_k<false, true>), dim3(ew_grid((int64_t)N * HW)), dim3(EW_BLOCK), 0, (hipStream_t)s, logits,
+                          ldc, N, HW, C, out_nchw);
+  PMF_LAUNCH_CHECK();
+  return 0;
+}
+template <bool VEC, bool IDENT = false>
 __global__ void softmax_bwd_k(const float* __restrict__ prob, const float* __restrict__ g, int N, int HW, int C,
                               float* __restrict__ dl, int ldc) {
   const int64_t total = (int64_t)N * HW;
@@ -698,9 +713,9 @@ __global__ void softmax_bwd_k(const float* __restrict__ prob, const float* __res
 #pragma unroll
     for (int c = 0; c < SM_MAXC; ++c)
       if (c < C) {
-        pv[c] = prob[((int64_t)n * C + c) * HW + hw];
+        pv[c] = IDENT ? 1.f : prob[((int64_t)n * C + c) * HW + hw];
         gv[c] = g[((int64_t)n * C + c) * HW + hw];
-        dot += pv[c] * gv[c];
+        dot += IDENT ? 0.f : pv[c] * gv[c];
       }
     if (VEC) {
 #pragma unroll
@@ -728,6 +743,18 @@ extern "C" int pmf_softmax_bwd_nchw_to_nhwc(const float* prob_nchw, const float*
                               g_nchw, N, HW, C, dlogits, ldc);
   else hipLaunchKernelGGL(softmax_bwd_k<false>, dim3(ew_grid((int64_t)N * HW)), dim3(EW_BLOCK), 0, (hipStream_t)s, prob_nchw,
                           g_nchw, N, HW, C, dlogits, ldc);
+  PMF_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pmf_logits_bwd_nchw_to_nhwc(const float* g_nchw, int32_t N, int32_t HW, int32_t C, float* dlogits, int32_t ldc,
+                                           pmf_stream_t s) {
+  if (C > SM_MAXC || ldc > SM_MAXC) return PMF_E_UNSUPPORTED;
+  const bool vec = (ldc & 3) == 0 && ((uintptr_t)dlogits & 15) == 0;
+  if (vec) hipLaunchKernelGGL((softmax_bwd_k<true, true>), dim3(ew_grid((int64_t)N * HW)), dim3(EW_BLOCK), 0, (hipStream_t)s,
+                              nullptr, g_nchw, N, HW, C, dlogits, ldc);
+  else hipLaunchKernelGGL((softmax_bwd_k<false, true>), dim3(ew_grid((int64_t)N * HW)), dim3(EW_BLOCK), 0, (hipStream_t)s,
+                          nullptr, g_nchw, N, HW, C, dlogits, ldc);
   PMF_LAUNCH_CHECK();
   return 0;
 }

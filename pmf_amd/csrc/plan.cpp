@@ -127,9 +127,11 @@ static int run_one_(const pmf_op_t& o, pmf_stream_t s) {
     case PMF_OP_COLSUM:  // p: x out [scratch] | i: ldc C nz | l0 npix
       if (a.p[2]) return pmf_colsum_rows((const float*)a.p[0], i[0], a.l[0], i[1], (float*)a.p[1], i[2], (float*)a.p[2], s);
       return pmf_colsum((const float*)a.p[0], i[0], a.l[0], i[1], (float*)a.p[1], i[2], s);
-    case PMF_OP_SOFTMAX:  // p: logits prob | i: ldc N HW C
+    case PMF_OP_SOFTMAX:  // p: logits prob | i: ldc N HW C ident (1: the logits go out as they are)
+      if (i[4]) return pmf_logits_nhwc_to_nchw((const float*)a.p[0], i[0], i[1], i[2], i[3], (float*)a.p[1], s);
       return pmf_softmax_nhwc_to_nchw((const float*)a.p[0], i[0], i[1], i[2], i[3], (float*)a.p[1], s);
-    case PMF_OP_SOFTMAX_BWD:  // p: prob g dlogits | i: N HW C ldc
+    case PMF_OP_SOFTMAX_BWD:  // p: prob g dlogits | i: N HW C ldc ident
+      if (i[4]) return pmf_logits_bwd_nchw_to_nhwc((const float*)a.p[1], i[0], i[1], i[2], (float*)a.p[2], i[3], s);
       return pmf_softmax_bwd_nchw_to_nhwc((const float*)a.p[0], (const float*)a.p[1], i[0], i[1], i[2], (float*)a.p[2],
                                           i[3], s);
     case PMF_OP_NCHW2NHWC:  // p: x out | l: stride_n stride_c | i: N C HW out_ldc

@@ -145,11 +145,12 @@ extern "C" int pmf_project_scatter(const float* points, const int32_t* sem, int6
 // Here (1) ONE kernel projects, compacts and scatters: a block publishes its kept-point count in a slot tagged with the
 // call's generation (relaxed agent-scope atomics: the value travels in the same word as the tag, no fence needed) and reads
 // the slots of the blocks in front of it.  "In front" is by TICKET, not by blockIdx: a block's logical index is what it
-// draws from a device counter when it starts (slots[0]; the block that draws the last ticket puts the counter back to 0
+// draws from a device counter when it starts (slots[0]; the gather pass behind this kernel puts the counter back to 0
 // for the next call on this workspace, which is stream-ordered behind this one), so every block it waits for has already
 // started -- no assumption about the dispatch order of HIP, which promises none, and no deadlock; the winner of a pixel is an atomicMax over (generation << 20 | point index), so entries of
 // earlier frames lose against the current one and the per-pixel table is never cleared (the caller zeroes it once every
 // 4095 frames); (2) the gather pass.  Same outputs, bit for bit.
+#define PROJ_SPIN_MAX (1 << 22)      // ~0.5 s of polling: far beyond any healthy wait (the whole kernel runs < 40 us)
 __global__ __launch_bounds__(PB) void proj_fused_k(const float* __restrict__ pts, int64_t P, const double* __restrict__ m,
                                                    int h, int w, uint8_t* __restrict__ keep, float* __restrict__ depth,
                                                    int32_t* __restrict__ x_data, int32_t* __restrict__ y_data,
@@ -161,6 +162,14 @@ __global__ __launch_bounds__(PB) void proj_fused_k(const float* __restrict__ pts
   if (threadIdx.x == 0) s_bid = (unsigned)atomicAdd(slots, 1ull);       // ticket = logical block index
   __syncthreads();
   const unsigned bid = s_bid;
+  // A ticket beyond the grid means the counter was not 0 on entry (an unzeroed or foreign workspace, a call that aborted
+  // mid-way): write nothing out of bounds and wait for nobody; bit 63 of the counter tells the gather pass, which is
+  // stream-ordered behind this kernel, to report *n_kept = -1 to the host; it puts the counter back to 0 whatever happened
+  // here.
+  if (bid >= gridDim.x) {
+    if (threadIdx.x == 0) atomicOr(slots, 1ull << 63);
+    return;
+  }
   slots += 1;
   const int64_t i = bid * (int64_t)PB + threadIdx.x;
   int r = 0, c = 0;
@@ -184,7 +193,11 @@ __global__ __launch_bounds__(PB) void proj_fused_k(const float* __restrict__ pts
   int part = 0;
   for (int b = threadIdx.x; b < (int)bid; b += PB) {
     unsigned long long v;
-    do { v = __hip_atomic_load(slots + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((unsigned)(v >> 32) != gen);
+    int spins = 0;
+    do {    // (bounded: a slot that is never published -- see the ticket check above -- must not hang the device)
+      v = __hip_atomic_load(slots + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } while ((unsigned)(v >> 32) != gen && ++spins < PROJ_SPIN_MAX);
+    if ((unsigned)(v >> 32) != gen) { atomicOr(slots - 1, 1ull << 63); v = 0ull; }
     part += (int)(unsigned)v;
   }
 #pragma unroll
@@ -199,16 +212,20 @@ __global__ __launch_bounds__(PB) void proj_fused_k(const float* __restrict__ pts
     y_data[dst] = c;
     atomicMax(pix_tag + (size_t)r * w + c, (gen << 20) | (unsigned)i);
   }
-  if (bid == gridDim.x - 1 && threadIdx.x == 0) {
-    *n_kept = boff + cnt;
-    __hip_atomic_store(slots - 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // every ticket of this call is drawn
-  }
+  if (bid == gridDim.x - 1 && threadIdx.x == 0) *n_kept = boff + cnt;
 }
 
 __global__ void proj_gather_tag_k(const float* __restrict__ pts, const int32_t* __restrict__ sem,
                                   const float* __restrict__ depth, const uint8_t* __restrict__ img,
                                   const int32_t* __restrict__ lut, int nlut, const unsigned* __restrict__ pix_tag, unsigned gen,
-                                  int h, int w, float* __restrict__ out) {
+                                  int h, int w, float* __restrict__ out, unsigned long long* __restrict__ ticket,
+                                  int32_t* __restrict__ n_kept) {
+  // every ticket of this call's projection kernel is drawn (stream order): the counter goes back to 0 for the next call;
+  // bit 63 = that kernel met a ticket beyond its grid or a slot that was never published
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (__hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 63) *n_kept = -1;
+    __hip_atomic_store(ticket, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   const int64_t hw = (int64_t)h * w;
   for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < hw; p += (int64_t)gridDim.x * blockDim.x) {
     const unsigned tag = pix_tag[p];
@@ -244,7 +261,7 @@ extern "C" int pmf_project_scatter2(const float* points, const int32_t* sem, int
   const int64_t hw = (int64_t)h * w;
   const int g = (int)cdiv64(hw, 256);
   hipLaunchKernelGGL(proj_gather_tag_k, dim3(g > 2048 ? 2048 : g), dim3(256), 0, st, points, sem, depth, image, lut, nlut,
-                     (const unsigned*)pix_tag, (unsigned)generation, h, w, proj_out);
+                     (const unsigned*)pix_tag, (unsigned)generation, h, w, proj_out, (unsigned long long*)slots, n_kept);
   PMF_LAUNCH_CHECK();
   return 0;
 }

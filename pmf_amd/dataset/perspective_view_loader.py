@@ -92,6 +92,12 @@ class ColorJitter(object):
         """img: uint8 [h, w, 3] DEVICE tensor, jittered in place (and returned)."""
         if not (isinstance(img, torch.Tensor) and img.is_cuda and img.dtype == torch.uint8 and img.is_contiguous()):
             raise RuntimeError("ColorJitter runs on a contiguous uint8 GPU tensor only (no CPU fallback)")
+        if img.data_ptr() % 4:
+            # the kernel reads dwords (include/pmf_amd.h): a frame that starts off a 4-byte boundary -- a slice batch[b] of a
+            # [B, h, w, 3] tensor with h * w % 4 != 0, e.g. 375 x 1242 KITTI frames -- goes through an aligned device copy
+            tmp = img.clone()
+            self.apply(tmp, order, factors)
+            return img.copy_(tmp)
         scratch = torch.empty(1, dtype=torch.int64, device=img.device)
         o = (C.c_int32 * 4)(*order)
         f = (C.c_double * 4)(*[0.0 if x is None else x for x in factors])
@@ -193,6 +199,9 @@ def project_frame_gpu(points, sem_label, image_u8, proj_matrix, label_lut, devic
     if not need_uproj:
         return out, xd, yd, depth[:P], keep[:P].bool()
     k = int(nk.item())
+    if k < 0:       # the projection kernel found its workspace in a bad state (csrc/project.hip: ticket beyond the grid)
+        _PROJ_TLS.__dict__.pop("ws", None)
+        raise RuntimeError("pmf_project_scatter2: corrupt ticket workspace (it has been dropped; the next call starts clean)")
     return out, xd[:k], yd[:k], depth[:P], keep[:P].bool()
 
 

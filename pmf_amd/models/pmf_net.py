@@ -230,13 +230,11 @@ class SalsaNext(_Holder):
         u = self.upBlock3.emit(P, u, d1b, "upBlock3", um(3))
         u = self.upBlock4.emit(P, u, d0b, "upBlock4", None)
         lg = P.conv([u], self.logits, name="logits")
-        P.softmax_out(lg.t, "lidar", "lidar")
+        P.softmax_out(lg.t, "lidar", "lidar", softmax=self.softmax)
         return lg
 
     # ---- stand-alone use -------------------------------------------------------------------------
     def forward(self, x):
-        if not self.softmax:
-            raise NotImplementedError("SalsaNext(softmax=False) is not built for the HIP path")
         return _run_model(self, (x,))[0]
 
     def _build(self, N, H, W, training, device, dry=False):

@@ -590,15 +590,17 @@ class Plan(PlanConvMixin, PlanTuneMixin, PlanRunMixin):
             self.on_backward(backward)
         return out
 
-    def softmax_out(self, logits, slot, name=""):
-        """logits T -> NCHW probabilities written to an external tensor patched per call (slot index)."""
+    def softmax_out(self, logits, slot, name="", softmax=True):
+        """logits T -> NCHW probabilities written to an external tensor patched per call (slot index); softmax=False: the logits
+        themselves (SalsaNext(softmax=False), salsanext.py:167,206-207)."""
         t = logits
+        ident = int(not softmax)
 
         def f(op):
             s = op.u.sm
             s.p[0] = t.buf.ptr
             s.p[1] = None   # patched per call
-            s.i[0], s.i[1], s.i[2], s.i[3] = t.ldc, t.N, t.H * t.W, t.C
+            s.i[0], s.i[1], s.i[2], s.i[3], s.i[4] = t.ldc, t.N, t.H * t.W, t.C, ident
         self.emit(self.fwd, L.OP_SOFTMAX, f)
         self.note_bytes(self.fwd, "softmax", 8.0 * t.C * t.npix)
         self.out_slots[slot] = dict(fwd_index=len(self.fwd) - 1, shape=(t.N, t.C, t.H, t.W))
@@ -613,7 +615,7 @@ class Plan(PlanConvMixin, PlanTuneMixin, PlanRunMixin):
                     s = op.u.sm
                     s.p[0] = s.p[1] = None   # prob / grad_output patched per call
                     s.p[2] = t.g.buf.ptr
-                    s.i[0], s.i[1], s.i[2], s.i[3] = t.N, t.H * t.W, t.C, t.ldc
+                    s.i[0], s.i[1], s.i[2], s.i[3], s.i[4] = t.N, t.H * t.W, t.C, t.ldc, ident
                 self.emit(self.bwd, L.OP_SOFTMAX_BWD, fb)
                 self.note_bytes(self.bwd, "softmax_bwd", 12.0 * t.C * t.npix)
                 self.out_slots[slot]["bwd_index"] = len(self.bwd) - 1

@@ -170,3 +170,41 @@ def compare_plan_to_oracle(plan, cap, skip=()):
             continue
         rows.append((name, (rel_err if name in ("logits", "dec.logits") else scale_err)(got.numpy(), ref.numpy())))
     return rows
+
+
+def masked_grad_rows(hip, plan, ref, drop_masks, pcd, rgb, upstream):
+    """[(parameter, hip error, fp32-oracle error)]: relative L2 distance of every parameter gradient from the FLOAT64 oracle,
+    with the HIP path's piecewise-linear decisions (Plan.act_decisions: LeakyReLU / ReLU signs, the stem pool's argmax) replayed
+    by both oracle passes (oracle/act_masks.py) and both driven by ``upstream`` = the HIP path's (d loss / d lidar
+    probabilities, d loss / d camera probabilities).  All three backward passes differentiate one piecewise-linear function:
+    an activation on its kink cannot move a gradient by a whole term, what is left is rounding -- or a kernel defect.
+    ``ref``: a PRISTINE oracle module (no forward pass run on it yet) holding the same parameters."""
+    import copy
+    from oracle import pmf_torch as O
+    from oracle.act_masks import ActSites
+    dec = plan.act_decisions(hip)
+    grads = {}
+    for tag, dt in (("f32", torch.float32), ("f64", torch.float64)):
+        m = copy.deepcopy(ref).to(dt).train()
+        O.set_dropout_masks(m, {k: v.to(dt) for k, v in drop_masks.items()})
+        with ActSites(m, inject=dec) as inj:
+            a, b = m(pcd.to(dt), rgb.to(dt))
+        assert not inj.unused, inj.unused
+        torch.autograd.backward([a, b], [upstream[0].cpu().to(dt), upstream[1].cpu().to(dt)])
+        grads[tag] = {k: p.grad.detach().double() for k, p in m.named_parameters()}
+    rows = []
+    for k, p in hip.named_parameters():
+        g64 = grads["f64"][k]
+        wk = k.rsplit(".", 1)[0] + ".weight"
+        floor = 1e-6 * grads["f64"][wk].norm().item() if wk in grads["f64"] else 0.0
+        den = max(g64.norm().item(), floor, 1e-30)
+        rows.append((k, (p.grad.cpu().double() - g64).norm().item() / den, (grads["f32"][k] - g64).norm().item() / den))
+    return rows
+
+
+def assert_masked_bar(rows, what=""):
+    """every parameter: at most 3x as far from float64 as the fp32 CPU oracle for THAT parameter (floor 2e-4) -- the bar of
+    tests/test_gpu_fullsize.py, which masked passes can hold at any size"""
+    bad = [r for r in rows if not r[1] <= max(3 * r[2], 2e-4)]
+    assert not bad, "%s gradient error vs float64, decisions injected (hip, cpu-fp32):\n" % what + "\n".join(
+        "%-55s %.3e %.3e" % r for r in sorted(bad, key=lambda t: -t[1])[:30])

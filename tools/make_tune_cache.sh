@@ -13,6 +13,8 @@ python bench.py $q --mode infer > /dev/null                                     
 python bench.py $q --height 480 --width 640 > /dev/null                             # S_B train
 python bench.py $q --height 480 --width 640 --mode infer > /dev/null                # S_B eval bs 4
 python bench.py $q --backbone resnet50 --nclasses 17 --height 32 --width 1024 > /dev/null   # configs[3] family
+python bench.py $q --backbone resnet50 --nclasses 17 --height 480 --width 640 > /dev/null   # configs[3] at its RGB size
+python bench.py $q --backbone resnet50 --nclasses 17 --height 512 --width 640 --mode infer > /dev/null   # S_G eval bs 4
 python bench.py $q --model epmf > /dev/null                                         # configs[4]
 python bench.py $q --model salsanext > /dev/null                                    # f-2
 python bench.py $q --height 256 --width 1024 > /dev/null                            # KITTI training crop (S_C)
