@@ -1415,7 +1415,7 @@ static int conv_pipe_mode(const pmf_conv_desc_t* d, const ConvGeom& g, int gathe
     c64 = c64 && d->src[i].C % 64 == 0;
   }
   if (g.in_rows * g.in_cols * 4 > 256 * (MT == 2 ? 7 : 5)) return 0;
-  if (d->ntaps == 1 && MT == 1 && c64 && g.in_rows * g.in_cols == 128 && !getenv("PMF_CONV_NOVT")) return 4;
+  if (d->ntaps == 1 && MT == 1 && c64 && g.in_rows * g.in_cols == 128) return 4;
   return 1;
 }
 
@@ -1434,8 +1434,8 @@ static bool conv_stem_class(const pmf_conv_desc_t* d) {
          !(d->src[0].flags & PMF_SRC_BCAST);
 }
 static int conv_direct_lds(const pmf_conv_desc_t* d, int BN, int* kchunk) {
-  static const bool off = getenv("PMF_NO_DIRECT") != nullptr;
-  static const int stream_kib = getenv("PMF_DIRECT_STREAM_KIB") ? atoi(getenv("PMF_DIRECT_STREAM_KIB")) : 96;
+  constexpr bool off = false;
+  constexpr int stream_kib = 96;
   if (kchunk) *kchunk = 0;
   // more than one tap: only on request (cfg bit 24, set by the plan autotuner when the variant measured faster), <= 9 taps
   const bool mtap = d->ntaps > 1;
@@ -1474,7 +1474,6 @@ static int conv_direct_lds(const pmf_conv_desc_t* d, int BN, int* kchunk) {
 // split-bf16 path: 16-channel slabs per stage (1, 2 or 4) -- see conv_kloop_s3
 static int conv_s3_slabs(const pmf_conv_desc_t* d, const ConvGeom& g) {
   int cap = 4;
-  if (const char* e = getenv("PMF_S3_SL")) cap = atoi(e);
   for (int c = 4; c >= 2; c >>= 1) {
     if (c > cap || d->ntaps * c > TAPG || g.in_rows * g.in_cols * 4 * c > 256 * 8) continue;
     bool ok = true;
@@ -1543,8 +1542,8 @@ static int launch(const pmf_conv_desc_t* d, hipStream_t s) {
     mode = sl == 4 ? 7 : (sl == 2 ? 6 : 5);
     g.a_floats = sl * round_up(g.in_rows * g.in_cols * (S3_APB / 4), 4);
     lds = g.a_floats * 4 + d->ntaps * sl * (BN / 32) * 3 * 1024 + 2048;   // + per-thread scratch of the staging stores
-    if (sl == 1 && d->ntaps == 9 && !getenv("PMF_S3_NO9")) mode = 8;
-    if (sl == 2 && d->ntaps == 4 && !getenv("PMF_S3_NO9")) mode = 10;
+    if (sl == 1 && d->ntaps == 9) mode = 8;
+    if (sl == 2 && d->ntaps == 4) mode = 10;
     nchunks = 0;
     for (int i = 0; i < d->nsrc; ++i) nchunks += d->src[i].C / (KC * sl);
     if (lds < 2 * 4 * 64 * 2 * 8) lds = 2 * 4 * 64 * 2 * 8;
@@ -1561,8 +1560,7 @@ static int launch(const pmf_conv_desc_t* d, hipStream_t s) {
   g.ksplit = d->ndst > 0 ? 1 : choose_ksplit(d, g.tiles_x * g.tiles_y * d->N * co_tiles, nchunks, d->ntaps * 8 * MT * (BN / 32));
   g.ws = d->splitk_ws;
   g.ws_ld = round_up(d->Cout, 4);
-  static const bool no_one = getenv("PMF_NO_ONE") != nullptr;
-  g.one = (d->nsrc == 1 && g.ksplit == 1 && !no_one) ? 1 : 0;
+  g.one = (d->nsrc == 1 && g.ksplit == 1) ? 1 : 0;
   dim3 grid(g.tiles_x * g.tiles_y, co_tiles * g.ksplit, d->N);
   if (mode == 12) {
     if constexpr (MT == 1) hipLaunchKernelGGL((conv_fwd_k<BN, 1, 12>), grid, dim3(256), lds, s, dd, g);
@@ -1602,7 +1600,7 @@ extern "C" int pmf_conv_ws_rows(const pmf_conv_desc_t* d);
 extern "C" int pmf_conv_ws_launch(const pmf_conv_desc_t* d, pmf_stream_t st);
 static bool conv_ws_wanted(const pmf_conv_desc_t* d) {
   static const int force = getenv("PMF_CONV_WS") ? atoi(getenv("PMF_CONV_WS")) : -1;     // 0: never, 1: wherever eligible
-  static const int min_wgs = getenv("PMF_CONV_WS_MIN_WGS") ? atoi(getenv("PMF_CONV_WS_MIN_WGS")) : 128;
+  constexpr int min_wgs = 128;
   if (force == 0) return false;
   const bool asked = (d->cfg >> 25) & 1;
   if (!asked && force != 1) return false;
@@ -1658,8 +1656,7 @@ extern "C" int pmf_conv_s3_eligible(const pmf_conv_desc_t* d) {
 // stride-2 3x3 layers on the split loop (PIPE 12): all nine taps live, halo tile of the 4 x 32-pixel output tile
 // (9 x 65 input pixels) within ten staging slots per thread and the LDS budget of the 64-wide tile
 static bool conv_s3_stride2(const pmf_conv_desc_t* d) {
-  static const bool off = getenv("PMF_S3_NO_STRIDE2") != nullptr;
-  if (off || d->in_stride != 2 || d->ntaps != 9 || d->gather) return false;
+  if (d->in_stride != 2 || d->ntaps != 9 || d->gather) return false;
   for (int i = 0; i < d->nsrc; ++i) {
     if (d->src[i].C % 16 || (d->src[i].flags & PMF_SRC_BCAST)) return false;
     if (d->src[i].H != d->src[0].H || d->src[i].W != d->src[0].W) return false;

@@ -2094,10 +2094,9 @@ __global__ __launch_bounds__(256) void wgrad_stream_k(const pmf_wgrad_desc_t d, 
 }
 
 // conditions of the streaming kernel: one tap at (0, 0), stride 1, operands of the gradient's size, <= 96 input and <= 64
-// output channels, >= 32768 pixels (PMF_WGRAD_STREAM=0 switches it off, PMF_WGRAD_STREAM_WGS sets the launch width)
+// output channels, >= 32768 pixels
 static bool wg_stream(const pmf_wgrad_desc_t* d) {
-  static const bool off = getenv("PMF_WGRAD_STREAM") && atoi(getenv("PMF_WGRAD_STREAM")) == 0;
-  if (off || d->ntaps != 1 || d->gather || d->in_stride != 1 || d->tdy[0] || d->tdx[0]) return false;
+  if (d->ntaps != 1 || d->gather || d->in_stride != 1 || d->tdy[0] || d->tdx[0]) return false;
   int Ktot = 0;
   for (int i = 0; i < d->nsrc; ++i) {
     const pmf_src_t& s = d->src[i];
@@ -2110,7 +2109,7 @@ static bool wg_stream(const pmf_wgrad_desc_t* d) {
   return (int64_t)d->N * d->OH * d->OW >= 32768;
 }
 static int wg_stream_splits(const pmf_wgrad_desc_t* d) {     // S: workgroups per sample
-  static const int target = getenv("PMF_WGRAD_STREAM_WGS") ? atoi(getenv("PMF_WGRAD_STREAM_WGS")) : 512;
+  constexpr int target = 512;
   int S = target / (d->N > 0 ? d->N : 1);
   const int pairs = (d->OH * d->OW + 1) / 2;
   if (S > pairs / 64) S = pairs / 64;           // >= 64 pixel pairs per workgroup
@@ -2383,13 +2382,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_1x1_s3_k(const pmf_wgrad_desc_t 
 
 // conditions of the split-bf16 direct 1x1 kernel (64 x 64 output blocks)
 static bool wg_direct_s3(const pmf_wgrad_desc_t* d) {
-  static const bool off = getenv("PMF_WGRAD_NODIRECT_S3") != nullptr;
   // smallest map: rounds 2-4 16384 pixels (measured under 256-wide launches); round 5, at the 128-workgroup width of the step:
   // resBlock4.r5 768 -> 256 at 2 x 8 x 256 100 -> 26 us, resBlock4.s 256 -> 256 27 -> 15, upBlock1.e 384 -> 128 27 -> 14,
   // resBlock5.r5 768 -> 256 at 2 x 4 x 128 27 -> 13 -- but 256 -> 256 at 1024 pixels 10 -> 13: from 4096 pixels, or from 1024
   // with >= 512 input channels
-  static const int min_pix = getenv("PMF_WGRAD_DIRECT_S3_MIN_PIX") ? atoi(getenv("PMF_WGRAD_DIRECT_S3_MIN_PIX")) : 0;
-  if (off || !(d->flags & PMF_WGRAD_S3) || ((d->cfg >> 8) & 0xff) == 2) return false;
+  constexpr int min_pix = 0;
+  if (!(d->flags & PMF_WGRAD_S3) || ((d->cfg >> 8) & 0xff) == 2) return false;
   if (d->ntaps != 1 || d->gather || d->in_stride != 1 || d->tdy[0] || d->tdx[0] || (d->Cout & 1) || (d->dz_ldc & 1)) return false;
   const int64_t npix = (int64_t)d->N * d->OH * d->OW;
   if (d->Cout < 64) return false;   // full 64 x 64 blocks only (measured: narrower layers are faster on the other kernels)
@@ -2407,7 +2405,7 @@ static bool wg_direct_s3(const pmf_wgrad_desc_t* d) {
 // conditions of the direct 1x1 kernel + its grid
 static bool wg_direct_1x1(const pmf_wgrad_desc_t* d) {
   if (wg_direct_s3(d)) return true;
-  if (getenv("PMF_WGRAD_NODIRECT") || ((d->cfg >> 8) & 0xff) == 2) return false;
+  if (((d->cfg >> 8) & 0xff) == 2) return false;
   if (d->ntaps != 1 || d->gather || d->in_stride != 1 || d->tdy[0] || d->tdx[0] || (d->Cout & 1) || (d->dz_ldc & 1)) return false;
   for (int i = 0; i < d->nsrc; ++i) {
     const pmf_src_t& s = d->src[i];
@@ -2420,7 +2418,7 @@ static bool wg_direct_1x1(const pmf_wgrad_desc_t* d) {
   if (d->Cout > 128 && Ktot < 256) return false;     // X is re-read once per 64 output channels
   // measured (64x2048, bs 2): 192->64 158 -> 119 us, 384->128 115 -> 92, 768->256 111 -> 95; below ~16 k pixels the
   // tiled kernels win (fewer, larger tiles; the per-workgroup fold and slab dominate here)
-  static const int min_pix1 = getenv("PMF_WGRAD_DIRECT_MIN_PIX") ? atoi(getenv("PMF_WGRAD_DIRECT_MIN_PIX")) : 16384;
+  constexpr int min_pix1 = 16384;
   return (int64_t)d->N * d->OH * d->OW >= min_pix1;
 }
 static void wg_direct_grid(const pmf_wgrad_desc_t* d, int* kblocks, int* oblocks, int* nco) {
@@ -2604,8 +2602,6 @@ static int wg_geometry(const pmf_wgrad_desc_t* d, int TB, int BN, WgGeom* g, int
 // a lane beyond Cout reads the next pixel's channels -- or the buffer's hardware zero -- into a column of the partial slab
 // that stage 2 never looks at)
 static bool wg_simple(const pmf_wgrad_desc_t* d, const WgGeom& g, int TB, int BN, int cmod = WG_CI, bool ragged = false) {
-  static const bool no_half = getenv("PMF_WGRAD_S3_C32") != nullptr;   // A/B switch: no half-empty chunks
-  if (no_half) cmod = WG_CI;
   if (d->gather || d->in_stride != 1 || d->ntaps != TB) return false;
   if (!ragged && (d->OH % WG_ROWS || d->OW % 32 || d->Cout % BN)) return false;    // (ragged: also partial 4 x 32-pixel tiles)
   if (g.in_rows * g.in_cols * 8 > 256 * 9 || g.in_cols > 255) return false;
@@ -2643,8 +2639,8 @@ static void wg_config(const pmf_wgrad_desc_t* d, int* TB, int* NT) {
     *NT = nt;
     return;
   }
-  if (!wide_1x1 && wg_simple(d, g, *TB, 32, cmod) && !getenv("PMF_WGRAD_NOPIPE")) { *NT = 1; return; }
-  if (!wide_1x1 && !getenv("PMF_WGRAD_NOPIPE") && wg_s3n_nco(d, g, *TB) > 0) { *NT = 1; return; }   // ragged tiles / last channel tile
+  if (!wide_1x1 && wg_simple(d, g, *TB, 32, cmod)) { *NT = 1; return; }
+  if (!wide_1x1 && wg_s3n_nco(d, g, *TB) > 0) { *NT = 1; return; }   // ragged tiles / last channel tile
   *NT = wide_1x1 ? 4 : (d->Cout > 32 ? 2 : 1);
 }
 
@@ -2653,10 +2649,9 @@ static void wg_config(const pmf_wgrad_desc_t* d, int* TB, int* NT) {
 static int wg_s3n_nco(const pmf_wgrad_desc_t* d, const WgGeom& g, int TB) {
   const char* e_n = getenv("PMF_WG_S3N");     // (read per call, not cached: the tests switch variants)
   const int mode = e_n ? atoi(e_n) : 4;
-  static const bool no_ragged = getenv("PMF_WG_S3N_NORAGGED") != nullptr;      // A/B switch (round 4: those layers on fp32 MFMA)
   // (operands of 8 channels too -- EPMF's 3x3 5 -> 32 first layer, padded to 8: a quarter-full chunk; the rows of the 32-row
   // tile beyond the operand's channels are staged as zeros and never written to the slab)
-  if (mode <= 1 || TB <= 1 || !(d->flags & PMF_WGRAD_S3) || !wg_simple(d, g, TB, 32, no_ragged ? 16 : 8, !no_ragged)) return 0;
+  if (mode <= 1 || TB <= 1 || !(d->flags & PMF_WGRAD_S3) || !wg_simple(d, g, TB, 32, 8, true)) return 0;
   if ((int64_t)d->N * d->OH * d->OW * d->dz_ldc * 4 >= (1ll << 31)) return 0;
   const char* e_w8 = getenv("PMF_WG_W8");
   const char* e_swp = getenv("PMF_WG_SWP");
@@ -2677,7 +2672,7 @@ extern "C" int pmf_conv_wgrad_nsplit(const pmf_wgrad_desc_t* d) {
   if (wg_direct_1x1(d)) {  // two resident workgroups per CU in total; every workgroup gets >= 64 pixel pairs
     int kb, ob, nco;
     wg_direct_grid(d, &kb, &ob, &nco);
-    static const int dtarget = getenv("PMF_WGRAD_DIRECT_WGS") ? atoi(getenv("PMF_WGRAD_DIRECT_WGS")) : 512;
+    constexpr int dtarget = 512;
     int ns = dtarget / (kb * ob);
     const int64_t pairs = ((int64_t)d->N * d->OH * d->OW + 1) / 2;
     if (ns > pairs / 64) ns = (int)(pairs / 64);
@@ -2712,7 +2707,7 @@ extern "C" int64_t pmf_conv_wgrad_workspace(const pmf_wgrad_desc_t* d) {
 // which stage-2 kernel and grid a layer gets
 static void red_plan(const pmf_wgrad_desc_t* d, int Ktot, int Cout32, int* kind, int* KB, int* gx, int* gy) {
   const int64_t total = (int64_t)d->ntaps * Ktot * Cout32;
-  if (total >= 131072 && d->nsplit <= 32 && d->ntaps <= WGR_ROWS && !getenv("PMF_WGRAD_RED_FLAT")) {
+  if (total >= 131072 && d->nsplit <= 32 && d->ntaps <= WGR_ROWS) {
     int kb = WGR_ROWS / d->ntaps;
     if (kb > Ktot) kb = Ktot;
     const int cog = Cout32 / 32;
@@ -2845,7 +2840,7 @@ static int wg_launch(const pmf_wgrad_desc_t* d, hipStream_t s, int phase) {
       } else if (small7) hipLaunchKernelGGL((conv_wgrad_s3_k<TB, 7>), grid, dim3(256), lds3, s, *d, g);
       else hipLaunchKernelGGL((conv_wgrad_s3_k<TB, 9>), grid, dim3(256), lds3, s, *d, g);
       piped = true;
-    } else if (wg_simple(d, g, TB, 32) && !getenv("PMF_WGRAD_NOPIPE") && ((d->cfg >> 8) & 0xff) != 2) {
+    } else if (wg_simple(d, g, TB, 32) && ((d->cfg >> 8) & 0xff) != 2) {
       const int lds2 = lds < 16 * 1024 ? 16 * 1024 : lds;   // room for the pixel-group reduction
       if (g.in_rows * g.in_cols * 8 <= 256 * 7) hipLaunchKernelGGL((conv_wgrad_pipe_k<TB, 1, 7>), grid, dim3(256), lds2, s, *d, g);
       else hipLaunchKernelGGL((conv_wgrad_pipe_k<TB, 1, 9>), grid, dim3(256), lds2, s, *d, g);
@@ -2859,7 +2854,6 @@ static int wg_launch(const pmf_wgrad_desc_t* d, hipStream_t s, int phase) {
 
 // few-input-channel path (ResNet stem): conditions
 static bool wg_fewc(const pmf_wgrad_desc_t* d) {
-  if (getenv("PMF_WGRAD_NOFEWC")) return false;
   if (d->nsrc != 1 || d->in_stride != 1 || d->Cin_real > 4 || d->ntaps < 9) return false;
   if (d->ntaps * d->Cin_real > 160 || d->Cout % 64 || d->OH % WG_ROWS || d->OW % 32) return false;
   if (d->src[0].flags || d->src[0].scale || d->src[0].cmul) return false;        // raw input only

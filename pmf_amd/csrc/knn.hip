@@ -148,7 +148,7 @@ extern "C" int pmf_knn_vote(const float* proj_range, const float* unproj_range, 
   if (P <= 0) return 0;
   dim3 grid((unsigned)cdiv64(P, 256)), block(256);
   hipStream_t st = (hipStream_t)s;
-  static const bool no_lds = getenv("PMF_KNN_LDS") && atoi(getenv("PMF_KNN_LDS")) == 0;     // A/B knob
+  constexpr bool no_lds = false;
   if (search < 1 || search > 255) return PMF_E_ARG;
   if (!no_lds && (search == 3 || search == 5)) {        // the LDS-staged form (below), one frame, no offsets table
     if (search == 3) hipLaunchKernelGGL(knn_batch_lds_k<3>, grid, block, 0, st, proj_range, unproj_range, proj_argmax, px, py, (const int64_t*)nullptr, 1, H, W, P, knn, inv_gauss, cutoff, nclasses, labels);
@@ -399,7 +399,7 @@ extern "C" int pmf_knn_vote_batch(const float* proj_range, const float* unproj_r
   if (knn < 1 || knn > 8 || knn > search * search) return PMF_E_UNSUPPORTED;
   if (P_total <= 0) return 0;
   hipStream_t st = (hipStream_t)s;
-  static const bool no_lds = getenv("PMF_KNN_LDS") && atoi(getenv("PMF_KNN_LDS")) == 0;     // A/B knob
+  constexpr bool no_lds = false;
   if (search < 1 || search > 255) return PMF_E_ARG;
   if (!no_lds && (search == 3 || search == 5)) {       // (7x7: 49 + 49 window registers next to 32 KB of LDS -- stays on the gather form)
     const dim3 g2((unsigned)(cdiv64(P_total, 256) + B)), b2(256);      // sum_b ceil(n_b / 256) <= ceil(P / 256) + B

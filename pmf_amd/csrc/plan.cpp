@@ -186,18 +186,7 @@ static int lane_device_ok() {
 static int lane_stream(int lane, hipStream_t* out) {
   if (int rc = lane_device_ok()) return rc;
   if (!g_lane[lane]) {
-    // PMF_LANE_PRIO=<mask>: the lanes in the mask get the LOWEST stream priority (weight-gradient lanes: leaves of the
-    // backward graph, they should fill what the critical path leaves idle, not compete with it)
-    static const int low_mask = [] { const char* m = getenv("PMF_LANE_PRIO"); return m ? atoi(m) : 0; }();
-    hipError_t e;
-    if ((low_mask >> lane) & 1) {
-      int least = 0, greatest = 0;
-      e = hipDeviceGetStreamPriorityRange(&least, &greatest);
-      if (e != hipSuccess) return (int)e;
-      e = hipStreamCreateWithPriority(&g_lane[lane], hipStreamNonBlocking, least);
-    } else {
-      e = hipStreamCreateWithFlags(&g_lane[lane], hipStreamNonBlocking);
-    }
+    hipError_t e = hipStreamCreateWithFlags(&g_lane[lane], hipStreamNonBlocking);
     if (e != hipSuccess) return (int)e;
     e = hipEventCreateWithFlags(&g_join[lane], hipEventDisableTiming);
     if (e != hipSuccess) return (int)e;

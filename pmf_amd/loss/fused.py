@@ -27,8 +27,7 @@ def _sort_workspace(lib, c, p, dev):
 
 
 def _use_torch_sort():
-    import os
-    return os.environ.get("PMF_LOVASZ_TORCH_SORT") == "1"      # A/B switch: torch.sort + pmf_loss_lovasz
+    return False       # (rounds 3-4 A/B: torch.sort + pmf_loss_lovasz; the in-library radix sort is the product path)
 
 
 class _FusedPMFLoss(torch.autograd.Function):

@@ -499,7 +499,7 @@ class PMFNet(nn.Module):
         lazy = (getattr(self, "_bwd_segment_hook", None) is not None) if lazy is None else lazy != "0"
         # ... one fusion block EARLY: its backward then sits one block later in the list, which measured best in segments
         # (12.17 vs 12.54 ms; as one range 11.65 = the plain order)
-        P.enc_ahead = int(os.environ.get("PMF_ENC_AHEAD", "1"))
+        P.enc_ahead = 1
         if lazy:
             feats = self.camera_stream_encoder.emit_lazy(P, rgb, M, P.feat_ready, 1)
         else:

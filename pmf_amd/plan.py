@@ -67,19 +67,6 @@ class Plan(PlanConvMixin, PlanTuneMixin, PlanRunMixin):
         self._wgrad_lane_of = (lambda home: 2 + (home & 1)) if self.wgrad_lane == 23 else (lambda home: self.wgrad_lane)
         self.wgrad_batch = int(_os.environ.get("PMF_WGRAD_BATCH", "4"))
         self._wg_deferred = {}
-        # PMF_WGRAD_POLICY=phase: only the weight gradients of the FIRST full-resolution stretch of a lane's backward
-        # are deferred; they are released in one batch at the lane's first small-map layer (<= PMF_WGRAD_THIN_PIX output
-        # pixels), whose latency-bound launches leave most of the chip to them; everything after runs inline
-        self.wgrad_policy = _os.environ.get("PMF_WGRAD_POLICY", "batch")
-        self.wgrad_homes = int(_os.environ.get("PMF_WGRAD_HOMES", "3"))      # bit h: lane h defers its weight gradients
-        self.wgrad_thin_pix = int(_os.environ.get("PMF_WGRAD_THIN_PIX", "16384"))
-        self._wg_phase_done = {}
-        # PMF_WGRAD_DELAY=n: a released batch is emitted n home-lane ops AFTER its release point (it still waits only for
-        # the event at the release point).  hipGraph replay enqueues nodes in capture order and resolves a cross-stream
-        # edge against the source stream's tail at that moment: a batch captured directly behind its release point makes
-        # the home lane's next op wait for the batch's first launches (measured: 0.5 ms stalls of the critical path).
-        self.wgrad_delay = int(_os.environ.get("PMF_WGRAD_DELAY", "0"))
-        self._wg_armed = {}                 # home lane -> [closures, event, home ops still to emit first]
         self.n_events = 0
         self._event_pos = {}                # event -> list position of its record op
         self._last_op = {}                  # (id(op list), lane) -> last entry emitted on that lane
@@ -106,8 +93,7 @@ class Plan(PlanConvMixin, PlanTuneMixin, PlanRunMixin):
         asserts that a fresh plan in a clean environment carries exactly those)"""
         return {"PMF_CONV_F32": not self.s3, "PMF_S3_MIN_TAPS": self.s3_min_taps, "PMF_S3_DIRECT_MIN_PIX": self.s3_direct_min_pix,
                 "PMF_BN_BWD_FUSED": self.bn_bwd_fused, "lanes": self.n_lanes, "PMF_WGRAD_LANE": self.wgrad_lane,
-                "PMF_WGRAD_BATCH": self.wgrad_batch, "PMF_WGRAD_POLICY": self.wgrad_policy, "PMF_WGRAD_HOMES": self.wgrad_homes,
-                "PMF_WGRAD_DELAY": self.wgrad_delay, "PMF_RED_BATCH": self.red_batch,
+                "PMF_WGRAD_BATCH": self.wgrad_batch, "PMF_RED_BATCH": self.red_batch,
                 "PMF_BN_SMALL": os.environ.get("PMF_BN_SMALL", "1") != "0",
                 "PMF_DGRAD_MERGE": os.environ.get("PMF_DGRAD_MERGE", "1") != "0",
                 "PMF_DGRAD_MERGE_MINPIX": int(os.environ.get("PMF_DGRAD_MERGE_MINPIX", "1024")),
@@ -134,12 +120,6 @@ class Plan(PlanConvMixin, PlanTuneMixin, PlanRunMixin):
     def emit(self, lst, kind, fill):
         """fill(op) populates a zeroed L.Op at finalise time (pointers are known only then).  The op runs on the
         current lane; a wait registered for this lane (wait_event) is attached to it."""
-        arm = self._wg_armed.get(self.lane) if (self._wg_armed and lst is self.bwd) else None
-        if arm is not None:
-            if arm[2] > 0:
-                arm[2] -= 1
-            else:
-                self._release_armed(self.lane)
         ent = [kind, fill, self.lane]       # [kind, fill, scheduling bits (pmf_amd.h)]
         key = (id(lst), self.lane)
         w = self._pending_wait.pop(key, None)
@@ -231,7 +211,7 @@ class Plan(PlanConvMixin, PlanTuneMixin, PlanRunMixin):
                     first[2] = (first[2] & ~0xff00) | ((wait[0] + 1) << 8)
             for g in touched:
                 g._last_touch = (lane, last)
-        for home in sorted(set(self._wg_deferred) | set(self._wg_armed)):
+        for home in sorted(self._wg_deferred):
             self.flush_wgrads(home, final=True)
         for lane in sorted(self.pending_reds):
             self.flush_reds(lane)

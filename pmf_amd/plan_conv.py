@@ -602,8 +602,6 @@ class PlanConvMixin(object):
         boff = self.pgrad(conv.bias) if dbias_rows else None
         home = self.lane
         lane = self._wgrad_lane_of(home) if (self.wgrad_lane and self._wgrad_lane_of(home) != home) else home
-        if not (self.wgrad_homes >> home) & 1:
-            lane = home
         self.n_wgrad += 1
         meta = dict(family="conv_wgrad", flops=2.0 * dz.N * dz.H * dz.W * Cout * conv.in_channels * len(taps), name=name,
                     shape="%dx%dx%d %d->%d t%d" % (dz.N, dz.H, dz.W, conv.in_channels, Cout, len(taps)))
@@ -634,12 +632,6 @@ class PlanConvMixin(object):
                 self.grad_done[id(conv.weight)] = len(self.bwd) - 1
                 if dbias_rows:
                     self.grad_done[id(conv.bias)] = len(self.bwd) - 1
-        if lane != home and self.wgrad_policy == "phase":
-            if self._wg_phase_done.get(home) or dz.N * dz.H * dz.W <= self.wgrad_thin_pix:
-                if not self._wg_phase_done.get(home):
-                    self._wg_phase_done[home] = True
-                    self.flush_wgrads(home)
-                lane = home
         if lane == home:
             emit_ops()
         else:
@@ -647,26 +639,15 @@ class PlanConvMixin(object):
             # dz stays alive in the arena until the end of the pass, so running a weight gradient late is always legal)
             q = self._wg_deferred.setdefault(home, [])
             q.append(emit_ops)
-            if len(q) >= self.wgrad_batch and self.wgrad_policy != "phase":
+            if len(q) >= self.wgrad_batch:
                 self.flush_wgrads(home)
 
     def flush_wgrads(self, home, final=False):
-        if final or self.wgrad_delay <= 0:
-            self._release_armed(home)
         q = self._wg_deferred.pop(home, [])
         if not q:
             return
         ready = self.record_event(self.bwd, lane=home)      # everything the batch reads is complete after this op
-        if self.wgrad_delay > 0 and not final:
-            self._release_armed(home)
-            self._wg_armed[home] = [q, ready, self.wgrad_delay]
-            return
         self._emit_batch(home, q, ready)
-
-    def _release_armed(self, home):
-        arm = self._wg_armed.pop(home, None)
-        if arm is not None:
-            self._emit_batch(home, arm[0], arm[1])
 
     def _emit_batch(self, home, q, ready):
         prev = self.lane

@@ -76,7 +76,7 @@ class PlanRunMixin(object):
         (OP_WGRAD_RED_MULTI, a handful per pass), so the cuts sit RIGHT BEHIND those ops -- a cut placed a few ops in front
         of one (round 3: segments of equal flops) leaves its whole payload (84 MB of the 146 MB at 64x2048) to the end of
         the pass, fully exposed.  Of more candidates than k - 1 the ones with the largest payload are kept; a reduction in
-        the last 2 % of the list is not a cut (nothing left to overlap with).  PMF_DP_CUTS=flops: equal-work segments."""
+        the last 2 % of the list is not a cut (nothing left to overlap with).  Plans without a flat state: equal-work segments."""
         if getattr(self, "_cuts", None) is not None and self._cuts[0] == k:
             return self._cuts[1]
         n = self.n_bwd
@@ -84,7 +84,7 @@ class PlanRunMixin(object):
         if not kinds:       # dry plan: the entry list is still there
             kinds = [None] * self.bwd_shift + [e[0] for e in self.bwd]
         cuts = None
-        if self.flat is not None and k > 1 and os.environ.get("PMF_DP_CUTS", "reds") != "flops":
+        if self.flat is not None and k > 1:
             cand = [i + 1 for i in range(n) if kinds[i] == L.OP_WGRAD_RED_MULTI and i + 1 <= n - max(4, n // 50)]
             if cand:
                 self.__dict__.pop("_frontiers", None)

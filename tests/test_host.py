@@ -368,7 +368,7 @@ def test_documented_knob_defaults_are_what_a_fresh_plan_uses(monkeypatch):
             monkeypatch.delenv(k)
     got = Plan(torch.device("cpu"), True).knobs()
     want = {"PMF_CONV_F32": False, "PMF_S3_MIN_TAPS": 2, "PMF_S3_DIRECT_MIN_PIX": 1, "PMF_BN_BWD_FUSED": True, "lanes": 4,
-            "PMF_WGRAD_LANE": 23, "PMF_WGRAD_BATCH": 4, "PMF_WGRAD_POLICY": "batch", "PMF_WGRAD_HOMES": 3, "PMF_WGRAD_DELAY": 0,
+            "PMF_WGRAD_LANE": 23, "PMF_WGRAD_BATCH": 4,
             "PMF_RED_BATCH": 32, "PMF_BN_SMALL": True, "PMF_DGRAD_MERGE": True, "PMF_DGRAD_MERGE_MINPIX": 1024,
             "PMF_AUTOTUNE": True, "PMF_TUNE_DIRECT": True, "PMF_GRAPH": True, "PMF_DP_MODE": "events", "PMF_DP_SEGMENTS": 4,
             "PMF_PACK_EARLY": 8}
@@ -377,3 +377,14 @@ def test_documented_knob_defaults_are_what_a_fresh_plan_uses(monkeypatch):
     for k in want:
         if k.startswith("PMF_"):
             assert k in design, "%s is not documented in docs/knobs.md" % k
+    # ... and every PMF_* variable the product sources READ is listed there (no undocumented code paths)
+    import glob
+    import re
+    read = set()
+    for f in glob.glob(os.path.join(ROOT, "pmf_amd", "**", "*"), recursive=True) + [os.path.join(ROOT, "bench.py")]:
+        if f.endswith((".py", ".hip", ".cpp", ".h")):
+            src = open(f).read()
+            read |= set(re.findall(r'getenv\("(PMF_[A-Z0-9_]+)"', src))
+            read |= set(re.findall(r'environ(?:\.get|\.pop|\.setdefault)?[\[(]"(PMF_[A-Z0-9_]+)"', src))
+    undocumented = sorted(k for k in read if k not in design)
+    assert not undocumented, undocumented
