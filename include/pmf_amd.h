@@ -355,6 +355,14 @@ int pmf_knn_vote_batch(const float* proj_range, const float* unproj_range, const
                        const int64_t* py, const int64_t* offsets, int32_t B, int32_t H, int32_t W, int64_t P_total,
                        int32_t knn, int32_t search, const float* inv_gauss, float cutoff, int32_t nclasses,
                        int64_t* labels, pmf_stream_t s);
+/* The batched vote straight from the network's probability maps prob_nchw f32[B][nclasses][H][W] (replaces
+ * `argmax = pred.argmax(dim=1)` + KNN of tasks/pmf_eval_semantickitti/infer.py:96-112): launch 1 writes the channel argmax
+ * (ties -> lowest class, NaN wins: torch.argmax's rule) as an int32 map into argmax_ws i32[B*H*W] (caller's workspace),
+ * launch 2 is the vote on it.  Labels bit-identical to torch.argmax + pmf_knn_vote_batch. */
+int pmf_knn_vote_batch_prob(const float* proj_range, const float* unproj_range, const float* prob_nchw, const int64_t* px,
+                            const int64_t* py, const int64_t* offsets, int32_t B, int32_t H, int32_t W, int64_t P_total,
+                            int32_t knn, int32_t search, const float* inv_gauss, float cutoff, int32_t nclasses,
+                            int32_t* argmax_ws, int64_t* labels, pmf_stream_t s);
 
 /* ---- perspective projection + scatter (perspective_view_loader.py:77-135, parser.py:209-227) ------------- */
 /* points f32[P][4], sem i32[P], image u8[h][w][3], proj f64[12] (device), lut i32[nlut].

@@ -150,6 +150,9 @@ def lib():
     L.pmf_knn_vote_batch.restype = C.c_int
     L.pmf_knn_vote_batch.argtypes = [C.c_void_p] * 6 + [C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32,
                                                         C.c_void_p, C.c_float, C.c_int32, C.c_void_p, C.c_void_p]
+    L.pmf_knn_vote_batch_prob.restype = C.c_int
+    L.pmf_knn_vote_batch_prob.argtypes = [C.c_void_p] * 6 + [C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32,
+                                                             C.c_void_p, C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.pmf_project_scatter.restype = C.c_int
     L.pmf_project_scatter.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32,
                                       C.c_void_p, C.c_void_p, C.c_int32] + [C.c_void_p] * 8 + [C.c_void_p]
@@ -251,7 +254,7 @@ EXPORTS = [
     "pmf_add_act", "pmf_add_act_bwd", "pmf_act_bwd", "pmf_avgpool3s2", "pmf_avgpool3s2_bwd", "pmf_maxpool3s2",
     "pmf_maxpool3s2_bwd", "pmf_bilinear2x", "pmf_bilinear2x_bwd", "pmf_pixel_shuffle2", "pmf_pixel_shuffle2_bwd",
     "pmf_fusion_gate", "pmf_fusion_gate_bwd", "pmf_global_mean", "pmf_global_mean_bwd", "pmf_colsum", "pmf_colsum_rows",
-    "pmf_pmask_from", "pmf_pmask_pool", "pmf_pmask_mul", "pmf_pmask_mul_bwd", "pmf_vec_add", "pmf_softmax_nhwc_to_nchw", "pmf_softmax_bwd_nchw_to_nhwc", "pmf_logits_nhwc_to_nchw", "pmf_logits_bwd_nchw_to_nhwc", "pmf_nchw_to_nhwc", "pmf_fill", "pmf_debug_col", "pmf_bn_bwd_small_ok", "pmf_bn_bwd_small", "pmf_knn_vote", "pmf_knn_vote_batch", "pmf_merge_pred", "pmf_merge_pred_fallback",
+    "pmf_pmask_from", "pmf_pmask_pool", "pmf_pmask_mul", "pmf_pmask_mul_bwd", "pmf_vec_add", "pmf_softmax_nhwc_to_nchw", "pmf_softmax_bwd_nchw_to_nhwc", "pmf_logits_nhwc_to_nchw", "pmf_logits_bwd_nchw_to_nhwc", "pmf_nchw_to_nhwc", "pmf_fill", "pmf_debug_col", "pmf_bn_bwd_small_ok", "pmf_bn_bwd_small", "pmf_knn_vote", "pmf_knn_vote_batch", "pmf_knn_vote_batch_prob", "pmf_merge_pred", "pmf_merge_pred_fallback",
     "pmf_project_scatter", "pmf_project_scatter2", "pmf_project_v2_index", "pmf_project_v2_index_scaled", "pmf_project_v2_scatter", "pmf_points_transform", "pmf_range_project_index", "pmf_range_project_gather", "pmf_crop_pad", "pmf_flip_rotate_crop", "pmf_color_jitter", "pmf_lovasz_grad", "pmf_loss_rows", "pmf_loss_chunks", "pmf_loss_pixel", "pmf_loss_lovasz", "pmf_loss_pixel_w", "pmf_loss_lovasz_w", "pmf_loss_sort_workspace", "pmf_loss_lovasz_sort", "pmf_loss_lovasz_sort_w", "pmf_plan_run", "pmf_plan_run_range", "pmf_plan_capture", "pmf_graph_launch", "pmf_graph_destroy", "pmf_plan_lanes", "pmf_plan_issue_order", "pmf_graph_pieces", "pmf_plan_event_wait", "pmf_adamw_range", "pmf_sgd_range", "pmf_normalise_inplace", "pmf_sizeof", "pmf_version", "pmf_conv_multi_ok",
 ]
 

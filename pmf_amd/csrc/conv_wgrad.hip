@@ -2284,12 +2284,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_1x1_s3_k(const pmf_wgrad_desc_t 
                 g_end = g_begin + per < ngrp ? g_begin + per : ngrp;
   // loads of group s+1 are requested before group s is split and multiplied; branch-free (an out-of-range pixel reads
   // pixel 0 and its dz is zeroed afterwards: 0 * finite = 0)
+  // stride-2 1x1 layers (the ResNet downsample projections, torchvision Bottleneck / BasicBlock `downsample.0`): output pixel
+  // (n, oy, ox) reads input pixel (n, 2 oy, 2 ox) of the operand's own H x W map
+  const int istr = d.in_stride, sH = kok ? d.src[si].H : 1, sW = kok ? d.src[si].W : 1;
   auto issue = [&](int64_t grp, float2 (&xv)[8], float2 (&zv)[8], float2 (&cv)[8]) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int64_t px = grp * 16 + lh * 8 + e;
       const int64_t pxs = (grp < g_end && px < npix) ? px : 0;
-      xv[e] = *(const float2*)(sx + pxs * sld);
+      int64_t pxi = pxs;
+      if (istr != 1) {
+        const int n = (int)(pxs / hw), rem = (int)(pxs - (int64_t)n * hw), oy = rem / d.OW, ox = rem - oy * d.OW;
+        pxi = ((int64_t)n * sH + oy * istr) * sW + ox * istr;
+      }
+      xv[e] = *(const float2*)(sx + pxi * sld);
       if (scm) cv[e] = *(const float2*)(scm + (pxs / hw) * cm_ld + cin);
       zv[e] = *(const float2*)(zp + pxs * d.dz_ldc);
     }
@@ -2388,13 +2396,17 @@ static bool wg_direct_s3(const pmf_wgrad_desc_t* d) {
   // with >= 512 input channels
   constexpr int min_pix = 0;
   if (!(d->flags & PMF_WGRAD_S3) || ((d->cfg >> 8) & 0xff) == 2) return false;
-  if (d->ntaps != 1 || d->gather || d->in_stride != 1 || d->tdy[0] || d->tdx[0] || (d->Cout & 1) || (d->dz_ldc & 1)) return false;
+  if (d->ntaps != 1 || d->gather || (d->in_stride != 1 && d->in_stride != 2) || d->tdy[0] || d->tdx[0] || (d->Cout & 1) || (d->dz_ldc & 1)) return false;
   const int64_t npix = (int64_t)d->N * d->OH * d->OW;
   if (d->Cout < 64) return false;   // full 64 x 64 blocks only (measured: narrower layers are faster on the other kernels)
   for (int i = 0; i < d->nsrc; ++i) {
     const pmf_src_t& s = d->src[i];
-    if ((s.flags & PMF_SRC_BCAST) || s.H != d->OH || s.W != d->OW || (s.C & 63) || (s.ldc & 1)) return false;
+    // (stride 2, round 6: the downsample projections -- 78 us at 13.6 TFLOP/s on the fp32 unit-dealing kernel in PMF-ResNet50)
+    const bool geo = d->in_stride == 1 ? (s.H == d->OH && s.W == d->OW)
+                                       : ((s.H - 1) / 2 + 1 == d->OH && (s.W - 1) / 2 + 1 == d->OW && d->nsrc == 1);
+    if ((s.flags & PMF_SRC_BCAST) || !geo || (s.C & 63) || (s.ldc & 1)) return false;
     if (s.flags & ~(PMF_SRC_RELU)) return false;
+    if ((int64_t)d->N * s.H * s.W * s.ldc * 4 >= (1ll << 40)) return false;
   }
   if (min_pix > 0) return npix >= min_pix;
   int Ktot = 0;

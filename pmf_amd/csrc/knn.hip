@@ -11,7 +11,7 @@ __global__ __launch_bounds__(256) void knn_k(const float* __restrict__ pr, const
                                              const int64_t* __restrict__ am, const int64_t* __restrict__ px,
                                              const int64_t* __restrict__ py, int H, int W, int64_t P, int knn,
                                              const float* __restrict__ invg, float cutoff, int nclasses,
-                                             int64_t* __restrict__ labels) {
+                                             int64_t* __restrict__ labels, const int32_t* __restrict__ am32 = nullptr) {
   constexpr int S2 = S * S, PAD = (S - 1) / 2, CENTER = (S2 - 1) / 2;
   __shared__ float wsh[S2];
   if (threadIdx.x < S2) wsh[threadIdx.x] = invg[threadIdx.x];
@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void knn_k(const float* __restrict__ pr, const
     int l = 0;
     if (y >= 0 && y < H && x >= 0 && x < W) {
       v = pr[(size_t)y * W + x];
-      l = (int)am[(size_t)y * W + x];
+      l = am32 ? am32[(size_t)y * W + x] : (int)am[(size_t)y * W + x];
       if (v < 0.f) v = INFINITY;
     }
     if (t == CENTER) v = r;
@@ -76,13 +76,15 @@ __global__ __launch_bounds__(64) void knn_any_k(const float* __restrict__ pr, co
                                                 const int64_t* __restrict__ am, const int64_t* __restrict__ px,
                                                 const int64_t* __restrict__ py, const int64_t* __restrict__ offsets, int B,
                                                 int H, int W, int64_t P, int knn, int S, const float* __restrict__ invg,
-                                                float cutoff, int nclasses, int64_t* __restrict__ labels) {
+                                                float cutoff, int nclasses, int64_t* __restrict__ labels,
+                                                const int32_t* __restrict__ am32 = nullptr) {
   const int64_t i = blockIdx.x * (int64_t)64 + threadIdx.x;
   if (i >= P) return;
   int b = 0;
   if (offsets) for (int k = 1; k < B; ++k) b += offsets[k] <= i;
   const float* __restrict__ prb = pr + (size_t)b * H * W;
   const int64_t* __restrict__ amb = am + (size_t)b * H * W;
+  const int32_t* __restrict__ amb32 = am32 ? am32 + (size_t)b * H * W : nullptr;
   const int cx = (int)px[i], cy = (int)py[i], PAD = (S - 1) / 2, CENTER = (S * S - 1) / 2;
   const float r = ur[i];
   float bd[8];
@@ -98,7 +100,7 @@ __global__ __launch_bounds__(64) void knn_any_k(const float* __restrict__ pr, co
       int l = 0;
       if (y >= 0 && y < H && x >= 0 && x < W) {
         v = prb[(size_t)y * W + x];
-        l = (int)amb[(size_t)y * W + x];
+        l = amb32 ? amb32[(size_t)y * W + x] : (int)amb[(size_t)y * W + x];
         if (v < 0.f) v = INFINITY;
       }
       if (t == CENTER) v = r;
@@ -137,7 +139,8 @@ template <int S>
 __global__ void knn_batch_lds_k(const float* __restrict__ pr, const float* __restrict__ ur, const int64_t* __restrict__ am,
                                 const int64_t* __restrict__ px, const int64_t* __restrict__ py,
                                 const int64_t* __restrict__ offsets, int B, int H, int W, int64_t P1, int knn,
-                                const float* __restrict__ invg, float cutoff, int nclasses, int64_t* __restrict__ labels);
+                                const float* __restrict__ invg, float cutoff, int nclasses, int64_t* __restrict__ labels,
+                                const int32_t* __restrict__ am32 = nullptr);
 
 extern "C" int pmf_knn_vote(const float* proj_range, const float* unproj_range, const int64_t* proj_argmax,
                             const int64_t* px, const int64_t* py, int32_t H, int32_t W, int64_t P, int32_t knn,
@@ -177,7 +180,8 @@ __global__ __launch_bounds__(64) void knn_batch_k(const float* __restrict__ pr, 
                                                   const int64_t* __restrict__ am, const int64_t* __restrict__ px,
                                                   const int64_t* __restrict__ py, const int64_t* __restrict__ offsets,
                                                   int B, int H, int W, int64_t P, int knn, const float* __restrict__ invg,
-                                                  float cutoff, int nclasses, int64_t* __restrict__ labels) {
+                                                  float cutoff, int nclasses, int64_t* __restrict__ labels,
+                                                  const int32_t* __restrict__ am32 = nullptr) {
   constexpr int S2 = S * S, PAD = (S - 1) / 2, CENTER = (S2 - 1) / 2;
   __shared__ float wsh[S2];
   if (threadIdx.x < S2) wsh[threadIdx.x] = invg[threadIdx.x];
@@ -188,6 +192,7 @@ __global__ __launch_bounds__(64) void knn_batch_k(const float* __restrict__ pr, 
   for (int k = 1; k < B; ++k) b += offsets[k] <= i;     // B is small (a batch): wave-uniform scalar loads
   const float* __restrict__ prb = pr + (size_t)b * H * W;
   const int64_t* __restrict__ amb = am + (size_t)b * H * W;
+  const int32_t* __restrict__ amb32 = am32 ? am32 + (size_t)b * H * W : nullptr;
   const int cx = (int)px[i], cy = (int)py[i];
   const float r = ur[i];
   float dist[S2];
@@ -199,7 +204,7 @@ __global__ __launch_bounds__(64) void knn_batch_k(const float* __restrict__ pr, 
     int l = 0;
     if (y >= 0 && y < H && x >= 0 && x < W) {
       v = prb[(size_t)y * W + x];
-      l = (int)amb[(size_t)y * W + x];
+      l = amb32 ? amb32[(size_t)y * W + x] : (int)amb[(size_t)y * W + x];
       if (v < 0.f) v = INFINITY;
     }
     if (t == CENTER) v = r;
@@ -250,7 +255,8 @@ __global__ __launch_bounds__(256) void knn_batch_lds_k(const float* __restrict__
                                                        const int64_t* __restrict__ am, const int64_t* __restrict__ px,
                                                        const int64_t* __restrict__ py, const int64_t* __restrict__ offsets,
                                                        int B, int H, int W, int64_t P1, int knn, const float* __restrict__ invg,
-                                                       float cutoff, int nclasses, int64_t* __restrict__ labels) {
+                                                       float cutoff, int nclasses, int64_t* __restrict__ labels,
+                                                       const int32_t* __restrict__ am32) {
   constexpr int S2 = S * S, PAD = (S - 1) / 2, CENTER = (S2 - 1) / 2;
   __shared__ float s_v[KNN_LDS_PIX];
   __shared__ int s_l[KNN_LDS_PIX];
@@ -278,6 +284,7 @@ __global__ __launch_bounds__(256) void knn_batch_lds_k(const float* __restrict__
   const bool valid = i < hi;
   const float* __restrict__ prb = pr + (size_t)b * H * W;
   const int64_t* __restrict__ amb = am + (size_t)b * H * W;
+  const int32_t* __restrict__ amb32 = am32 ? am32 + (size_t)b * H * W : nullptr;
   int cx = 0, cy = 0;
   float r = 0.f;
   if (valid) { cx = (int)px[i]; cy = (int)py[i]; r = ur[i]; }
@@ -321,7 +328,7 @@ __global__ __launch_bounds__(256) void knn_batch_lds_k(const float* __restrict__
         const int y = y0 + yy, x = x0 + xx;
         if (y >= 0 && y < H && x >= 0 && x < W) {
           vv[u] = prb[(size_t)y * W + x];
-          ll[u] = (int)amb[(size_t)y * W + x];
+          ll[u] = amb32 ? amb32[(size_t)y * W + x] : (int)amb[(size_t)y * W + x];
         }
       }
     }
@@ -353,7 +360,7 @@ __global__ __launch_bounds__(256) void knn_batch_lds_k(const float* __restrict__
       int l = 0;
       if (y >= 0 && y < H && x >= 0 && x < W) {
         v = prb[(size_t)y * W + x];
-        l = (int)amb[(size_t)y * W + x];
+        l = amb32 ? amb32[(size_t)y * W + x] : (int)amb[(size_t)y * W + x];
         if (v < 0.f) v = INFINITY;
       }
       if (t == CENTER) v = r;
@@ -390,10 +397,10 @@ __global__ __launch_bounds__(256) void knn_batch_lds_k(const float* __restrict__
   labels[i] = best_cls;
 }
 
-extern "C" int pmf_knn_vote_batch(const float* proj_range, const float* unproj_range, const int64_t* proj_argmax,
-                                  const int64_t* px, const int64_t* py, const int64_t* offsets, int32_t B, int32_t H,
-                                  int32_t W, int64_t P_total, int32_t knn, int32_t search, const float* inv_gauss,
-                                  float cutoff, int32_t nclasses, int64_t* labels, pmf_stream_t s) {
+static int knn_vote_batch_impl(const float* proj_range, const float* unproj_range, const int64_t* proj_argmax,
+                               const int32_t* am32, const int64_t* px, const int64_t* py, const int64_t* offsets, int32_t B,
+                               int32_t H, int32_t W, int64_t P_total, int32_t knn, int32_t search, const float* inv_gauss,
+                               float cutoff, int32_t nclasses, int64_t* labels, pmf_stream_t s) {
   if (search % 2 == 0) return PMF_E_ARG;
   if (B < 1 || B > 1024 || !offsets) return PMF_E_ARG;
   if (knn < 1 || knn > 8 || knn > search * search) return PMF_E_UNSUPPORTED;
@@ -403,21 +410,76 @@ extern "C" int pmf_knn_vote_batch(const float* proj_range, const float* unproj_r
   if (search < 1 || search > 255) return PMF_E_ARG;
   if (!no_lds && (search == 3 || search == 5)) {       // (7x7: 49 + 49 window registers next to 32 KB of LDS -- stays on the gather form)
     const dim3 g2((unsigned)(cdiv64(P_total, 256) + B)), b2(256);      // sum_b ceil(n_b / 256) <= ceil(P / 256) + B
-    if (search == 3) hipLaunchKernelGGL(knn_batch_lds_k<3>, g2, b2, 0, st, proj_range, unproj_range, proj_argmax, px, py, offsets, B, H, W, (int64_t)0, knn, inv_gauss, cutoff, nclasses, labels);
-    else hipLaunchKernelGGL(knn_batch_lds_k<5>, g2, b2, 0, st, proj_range, unproj_range, proj_argmax, px, py, offsets, B, H, W, (int64_t)0, knn, inv_gauss, cutoff, nclasses, labels);
+    if (search == 3) hipLaunchKernelGGL(knn_batch_lds_k<3>, g2, b2, 0, st, proj_range, unproj_range, proj_argmax, px, py, offsets, B, H, W, (int64_t)0, knn, inv_gauss, cutoff, nclasses, labels, am32);
+    else hipLaunchKernelGGL(knn_batch_lds_k<5>, g2, b2, 0, st, proj_range, unproj_range, proj_argmax, px, py, offsets, B, H, W, (int64_t)0, knn, inv_gauss, cutoff, nclasses, labels, am32);
     PMF_LAUNCH_CHECK();
     return 0;
   }
   dim3 grid((unsigned)cdiv64(P_total, 64)), block(64);
   switch (search) {
-    case 3: hipLaunchKernelGGL(knn_batch_k<3>, grid, block, 0, st, proj_range, unproj_range, proj_argmax, px, py, offsets, B, H, W, P_total, knn, inv_gauss, cutoff, nclasses, labels); break;
-    case 5: hipLaunchKernelGGL(knn_batch_k<5>, grid, block, 0, st, proj_range, unproj_range, proj_argmax, px, py, offsets, B, H, W, P_total, knn, inv_gauss, cutoff, nclasses, labels); break;
-    case 7: hipLaunchKernelGGL(knn_batch_k<7>, grid, block, 0, st, proj_range, unproj_range, proj_argmax, px, py, offsets, B, H, W, P_total, knn, inv_gauss, cutoff, nclasses, labels); break;
+    case 3: hipLaunchKernelGGL(knn_batch_k<3>, grid, block, 0, st, proj_range, unproj_range, proj_argmax, px, py, offsets, B, H, W, P_total, knn, inv_gauss, cutoff, nclasses, labels, am32); break;
+    case 5: hipLaunchKernelGGL(knn_batch_k<5>, grid, block, 0, st, proj_range, unproj_range, proj_argmax, px, py, offsets, B, H, W, P_total, knn, inv_gauss, cutoff, nclasses, labels, am32); break;
+    case 7: hipLaunchKernelGGL(knn_batch_k<7>, grid, block, 0, st, proj_range, unproj_range, proj_argmax, px, py, offsets, B, H, W, P_total, knn, inv_gauss, cutoff, nclasses, labels, am32); break;
     default:
-      hipLaunchKernelGGL(knn_any_k, grid, block, 0, st, proj_range, unproj_range, proj_argmax, px, py, offsets, B, H, W, P_total, knn, search, inv_gauss, cutoff, nclasses, labels);
+      hipLaunchKernelGGL(knn_any_k, grid, block, 0, st, proj_range, unproj_range, proj_argmax, px, py, offsets, B, H, W, P_total, knn, search, inv_gauss, cutoff, nclasses, labels, am32);
   }
   PMF_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int pmf_knn_vote_batch(const float* proj_range, const float* unproj_range, const int64_t* proj_argmax,
+                                  const int64_t* px, const int64_t* py, const int64_t* offsets, int32_t B, int32_t H,
+                                  int32_t W, int64_t P_total, int32_t knn, int32_t search, const float* inv_gauss,
+                                  float cutoff, int32_t nclasses, int64_t* labels, pmf_stream_t s) {
+  if (!proj_argmax) return PMF_E_ARG;
+  return knn_vote_batch_impl(proj_range, unproj_range, proj_argmax, nullptr, px, py, offsets, B, H, W, P_total, knn, search,
+                             inv_gauss, cutoff, nclasses, labels, s);
+}
+
+// ---- the vote straight from the network's probability maps (tasks/pmf_eval_semantickitti/infer.py:96-112: the reference takes
+// torch's argmax over the class axis -- an int64 [B, H, W] map -- and hands it to KNN) -------------------------------------------
+// Launch 1: channel argmax of the NCHW probabilities into an int32 label map (four pixels per lane, class planes read as
+// 16-byte vectors: 4 C H W bytes in, 4 H W out); ties go to the lowest class and a NaN wins, as torch.argmax decides.
+// Launch 2: the vote above on that map.  Fusing the argmax INTO the vote would recompute it per window: in sweep order a
+// workgroup's bounding box is ~9 x 68 pixels for 256 points, i.e. 2.2 class-axis scans per image pixel on a 120 k-point sweep.
+__global__ __launch_bounds__(256) void argmax_nchw_k(const float* __restrict__ prob, int C, int64_t HW, int64_t total4,
+                                                     int32_t* __restrict__ out) {
+  const int64_t q = blockIdx.x * (int64_t)256 + threadIdx.x;
+  if (q >= total4) return;
+  const int64_t per = (HW + 3) >> 2, b = q / per, p0 = (q - b * per) * 4;
+  const float* base = prob + (size_t)b * C * HW + p0;
+  const bool vec = p0 + 3 < HW && (HW & 3) == 0;
+  float best[4];
+  int bi[4] = {0, 0, 0, 0};
+  for (int c = 0; c < C; ++c) {
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (vec) {
+      const f32x4 t = *(const f32x4*)(base + (size_t)c * HW);
+      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    } else {
+      for (int k = 0; k < 4; ++k) if (p0 + k < HW) v[k] = base[(size_t)c * HW + k];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const bool take = c == 0 || v[k] > best[k] || (v[k] != v[k] && best[k] == best[k]);
+      best[k] = take ? v[k] : best[k];
+      bi[k] = take ? c : bi[k];
+    }
+  }
+  for (int k = 0; k < 4; ++k) if (p0 + k < HW) out[(size_t)b * HW + p0 + k] = bi[k];
+}
+extern "C" int pmf_knn_vote_batch_prob(const float* proj_range, const float* unproj_range, const float* prob_nchw,
+                                       const int64_t* px, const int64_t* py, const int64_t* offsets, int32_t B, int32_t H,
+                                       int32_t W, int64_t P_total, int32_t knn, int32_t search, const float* inv_gauss,
+                                       float cutoff, int32_t nclasses, int32_t* argmax_ws, int64_t* labels, pmf_stream_t s) {
+  if (!prob_nchw || !argmax_ws || B < 1 || H < 1 || W < 1 || nclasses < 1) return PMF_E_ARG;
+  if (search % 2 == 0) return PMF_E_ARG;
+  const int64_t HW = (int64_t)H * W, total4 = (int64_t)B * ((HW + 3) >> 2);
+  hipLaunchKernelGGL(argmax_nchw_k, dim3((unsigned)cdiv64(total4, 256)), dim3(256), 0, (hipStream_t)s, prob_nchw, nclasses, HW,
+                     total4, argmax_ws);
+  PMF_LAUNCH_CHECK();
+  return knn_vote_batch_impl(proj_range, unproj_range, nullptr, argmax_ws, px, py, offsets, B, H, W, P_total, knn, search,
+                             inv_gauss, cutoff, nclasses, labels, s);
 }
 
 // ---- multi-camera merge (tasks/pmf_eval_nuscenes/infer.py:18-38 getMergePred) --------------------------------------

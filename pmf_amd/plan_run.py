@@ -51,8 +51,12 @@ class PlanRunMixin(object):
                 dec[("lrelu" if act == L.ACT_LRELU else "relu", q)] = (self.read(self.tensors[name]) > 0).cpu()
             elif relu_view:
                 v = self.views[name]
-                x = self.read(v.t)
-                x = x * v.scale.tensor((v.t.C,)).view(1, -1, 1, 1) + v.shift.tensor((v.t.C,)).view(1, -1, 1, 1)
+                # the kernels evaluate the view as ONE fused multiply-add (common.h pmf_view_load4 under hipcc's default
+                # contraction, conv_ws.hip ws_fma, the epilogue's ReLU mask): its sign is the sign of the exact x * scale + shift,
+                # which float64 reproduces (24 x 24-bit product exact, one rounding that cannot cross zero); a float32
+                # multiply-then-add rounds twice and disagrees on ~1 element in 10^7 -- one such element is a whole term
+                x = self.read(v.t).double()
+                x = x * v.scale.tensor((v.t.C,)).double().view(1, -1, 1, 1) + v.shift.tensor((v.t.C,)).double().view(1, -1, 1, 1)
                 dec[("relu", q)] = (x > 0).cpu()
         enc = next((n for n, m in model.named_modules() if n.endswith("camera_stream_encoder")), None)
         for name, t in self.tensors.items():

@@ -91,6 +91,35 @@ class KNN(nn.Module):
         L.check(rc, "pmf_knn_vote_batch")
         return out
 
+    def forward_batch_prob(self, proj_range, prob, unproj_range, px, py, offsets, bind=False):
+        """forward_batch straight from the network's probability maps prob f32[B, nclasses, H, W] (pmf_knn_vote_batch_prob): the
+        class argmax is taken inside the library as an int32 map -- no torch.argmax launch, no int64 [B, H, W] tensor
+        (tasks/pmf_eval_semantickitti/infer.py:96-112).  Labels bit-identical to forward_batch(..., prob.argmax(1), ...).
+        bind=True: returns (fn, labels) like bind_batch."""
+        if self.search % 2 == 0:
+            raise ValueError("Nearest neighbor kernel must be odd number")
+        if not (proj_range.is_cuda and prob.is_cuda):
+            raise RuntimeError("pmf_amd KNN runs on the GPU only (no CPU fallback)")
+        dev = proj_range.device
+        B, H, W = proj_range.shape
+        P = unproj_range.shape[0]
+        if px.shape[0] != P or py.shape[0] != P or offsets.shape[0] != B + 1 or tuple(prob.shape) != (B, self.nclasses, H, W):
+            raise ValueError("forward_batch_prob: inconsistent shapes")
+        if self._w is None or self._w.device != dev:
+            self._w = inverse_gaussian_window(self.search, self.sigma).to(dev)
+        keep = (proj_range.contiguous().float(), prob.contiguous().float(), unproj_range.contiguous().float(),
+                px.contiguous().long(), py.contiguous().long(), offsets.contiguous().long(),
+                torch.empty(B * H * W, dtype=torch.int32, device=dev), torch.empty(P, dtype=torch.int64, device=dev), self._w)
+        fn_c = L.lib().pmf_knn_vote_batch_prob
+        args = (keep[0].data_ptr(), keep[2].data_ptr(), keep[1].data_ptr(), keep[3].data_ptr(), keep[4].data_ptr(),
+                keep[5].data_ptr(), B, H, W, P, int(self.knn), int(self.search), self._w.data_ptr(),
+                C.c_float(float(self.cutoff)), int(self.nclasses), keep[6].data_ptr(), keep[7].data_ptr())
+
+        def fn(_keep=keep):
+            return fn_c(*args, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        L.check(fn(), "pmf_knn_vote_batch_prob")
+        return (fn, keep[7]) if bind else keep[7]
+
     def bind_batch(self, proj_range, proj_argmax, unproj_range, px, py, offsets):
         """the launch of forward_batch with every argument resolved once: returns (fn, labels) where fn() enqueues the
         kernel on the current stream and nothing else (no allocation, no checks) -- for loops over fixed buffers and for
@@ -108,6 +137,16 @@ class KNN(nn.Module):
         def fn(_keep=keep):
             return fn_c(*args, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
         return fn, out
+
+    def batch_prob(self, prob, frames):
+        """prob f32[B, nclasses, H, W]; frames: list of (proj_range[H,W], unproj_range[P_b], px[P_b], py[P_b]) -> list of label
+        tensors; argmax + vote inside the library (forward_batch_prob)."""
+        n = [f[1].shape[0] for f in frames]
+        dev = prob.device
+        off = torch.tensor([0] + list(np.cumsum(n)), dtype=torch.int64, device=dev)
+        out = self.forward_batch_prob(torch.stack([f[0] for f in frames]), prob, torch.cat([f[1] for f in frames]),
+                                      torch.cat([f[2] for f in frames]), torch.cat([f[3] for f in frames]), off)
+        return list(out.split(n))
 
     def batch(self, frames):
         """frames: list of (proj_range[H,W], unproj_range[P_b], proj_argmax[H,W], px[P_b], py[P_b]) of equal H, W -> list of

@@ -80,13 +80,17 @@ class Inference(object):
             x[:, 0:5] = (x[:, 0:5] - mean) / std * m.unsqueeze(1)
             pred, _ = self.model(x[:, 0:5], x[:, 5:8])
             pred = pred[:, :, h_pad:h_pad + label.size(0), w_pad:w_pad + label.size(1)]
-            argmax = pred.argmax(dim=1)
-            if s.has_label:
-                self.pixel_eval.addBatch(argmax, label.long()[None])
-            if self.knn_flag:
-                unproj = self.knn_post(proj_depth, udepth, argmax[0], uy, ux)    # (:104-110: x index = column)
+            if self.knn_flag and not s.has_label and pred.is_contiguous() and hasattr(self.knn_post, "batch_prob"):
+                # no pixel-wise evaluation wanted: class argmax (int32 map) + vote inside the library, no torch.argmax
+                unproj = self.knn_post.batch_prob(pred, [(proj_depth, udepth, uy, ux)])[0]
             else:
-                unproj = argmax[0][ux, uy]
+                argmax = pred.argmax(dim=1)
+                if s.has_label:
+                    self.pixel_eval.addBatch(argmax, label.long()[None])
+                if self.knn_flag:
+                    unproj = self.knn_post(proj_depth, udepth, argmax[0], uy, ux)    # (:104-110: x index = column)
+                else:
+                    unproj = argmax[0][ux, uy]
             pred_np = unproj.cpu().numpy().reshape(-1).astype(np.int32)
             if s.has_label:
                 # predictions cover the points that project into the image, in file order (keep mask of the loader)

@@ -114,6 +114,11 @@ CONVS = [
     ("c1x1_to1024", 2, 8, 32, [256], 1024, 1, 1, 0, 1, False, "bn_norelu", True),
     ("c1x1_k1040_cat", 1, 8, 32, [1024, 16], 64, 1, 1, 0, 1, True, "act_bn", True),
     ("c1x1s2_k1024", 2, 8, 32, [1024], 2048, 1, 1, 0, 2, False, "bn_norelu", True),
+    # stride-2 1x1 on the LDS-free split weight-gradient kernel (round 6: >= 4096 output pixels, or >= 1024 with >= 512 input
+    # channels; the ResNet downsample projections): even and odd input maps, operand behind a BatchNorm + ReLU view
+    ("c1x1s2_direct", 2, 64, 128, [64], 128, 1, 1, 0, 2, False, "bn_norelu", True),
+    ("c1x1s2_direct_odd", 1, 63, 131, [128], 64, 1, 1, 0, 2, True, "act_bn", True),
+    ("c1x1s2_direct_k512", 2, 32, 64, [512], 128, 1, 1, 0, 2, False, "bn_relu", True),
     # 768 / 784 input channels: the direct variant streams the weight fragments in chunks through two LDS buffers (two
     # workgroups per CU); ragged last chunk
     ("c1x1_k768_cat", 2, 16, 64, [256, 256, 256], 256, 1, 1, 0, 1, True, "act_bn", True),

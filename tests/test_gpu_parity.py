@@ -297,7 +297,10 @@ def _dump(name, rows):
             f.write("  ".join(("%-52s" % x) if isinstance(x, str) else ("%.3e" % x) for x in r) + "\n")
 
 
-@pytest.mark.parametrize("n,h,w,drop", [(2, 32, 64, False), (2, 32, 64, True), (1, 64, 512, True)])
+# (rounds 1-5 ran the first two cases at 2 x 32 x 64: the deepest BatchNorm layers normalise over 16 values there, which amplifies
+# ANY fp32 rounding into 1e-3..1e-2 of the gradients -- also with every product on fp32 MFMA, gpurun_out/r06e -- so no bar tighter
+# than the old "x20" can hold at that size; at 2 x 64 x 128 (64 values) the full-size bar does)
+@pytest.mark.parametrize("n,h,w,drop", [(2, 64, 128, False), (2, 64, 128, True), (1, 64, 512, True)])
 def test_train_step_matches_oracle(n, h, w, drop):
     """forward (batch-stat BN, Dropout2d masks), 5-term loss, backward.  Ground truth = the oracle in FLOAT64;
     the HIP fp32 gradients must be as close to it as the fp32 CPU oracle is (up to a small factor): tiny-batch
@@ -1384,6 +1387,21 @@ def test_knn_batch_equals_per_frame_calls(search, knn_k, cutoff):
         for b, f in enumerate(frames):
             want = knn(f[0], f[1], f[2], f[3], f[4]) if counts[b] else torch.empty(0, dtype=torch.int64, device="cuda")
             assert got[b].shape == want.shape and torch.equal(got[b], want), (order, b)
+        # pmf_knn_vote_batch_prob: the same labels from probability maps whose channel argmax is `am` -- with exact TIES (two
+        # classes share the maximum: torch.argmax takes the lower one) and a NaN channel (torch.argmax takes it)
+        prob = torch.rand(B, 20, H, W, generator=g) * 0.5
+        prob.scatter_(1, am[:, None], 0.75)
+        tie = torch.rand(B, H, W, generator=g) < 0.1
+        hi = torch.clamp(am + 3, max=19)
+        prob.scatter_(1, hi[:, None], torch.where(tie, torch.tensor(0.75), prob.gather(1, hi[:, None])[:, 0])[:, None])
+        prob[0, 7, 5, 9] = float("nan")
+        am_t = prob.argmax(1)
+        assert bool((am_t == am).float().mean() > 0.99) and int(am_t[0, 5, 9]) == 7
+        frames_t = [(f[0], f[1], am_t[b].cuda(), f[3], f[4]) for b, f in enumerate(frames)]
+        want_p = knn.batch(frames_t)
+        got_p = knn.batch_prob(prob.cuda(), [(f[0], f[1], f[3], f[4]) for f in frames])
+        for b in range(B):
+            assert torch.equal(got_p[b], want_p[b]), (order, b)
 
 
 @pytest.mark.parametrize("search,knn_k,cutoff", [(1, 1, 1.0), (9, 5, 1.0), (11, 5, 1.0), (11, 7, 0.0), (13, 8, 0.5)])
