@@ -118,6 +118,12 @@ typedef struct {
                               * ep_cmul, ep_relu_*, stats, ep_stat_mean and ep_flags per output-channel range; Cout = the sum
                               * of their C, no bias, no K split (pmf_conv_multi_ok) */
   pmf_conv_dst_t dst[PMF_MAX_SRC];
+  uint32_t* splitk_tickets;  /* optional, with splitk_ws: u32[>= N * tiles * output-channel tiles] (<= 16384 entries), ZERO before the
+                              * first launch and left zero by every launch (calls that share it must be stream-ordered).  A split-K
+                              * launch then combines its partial slabs INSIDE the kernel: the last workgroup to arrive at an output
+                              * tile's ticket sums the slabs in slab order (deterministic) and runs the epilogue -- no second
+                              * launch (conv_finish_k); partial-statistics rows = pmf_conv_fwd_stat_rows() as without the split.
+                              * NULL: the two-launch form. */
 } pmf_conv_desc_t;
 /* 1 when a descriptor with ndst > 0 can run as one launch (channel ranges on tile boundaries, no split-K workspace needed) */
 int pmf_conv_multi_ok(const pmf_conv_desc_t* d);

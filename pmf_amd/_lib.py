@@ -52,7 +52,8 @@ class ConvDesc(C.Structure):
                 ("ep_relu_scale", C.c_void_p), ("ep_relu_shift", C.c_void_p), ("ep_relu_ldc", C.c_int32),
                 ("stats", C.c_void_p), ("ep_pmask", C.c_void_p), ("splitk_ws", C.c_void_p),
                 ("splitk_ws_bytes", C.c_int64), ("cfg", C.c_int32), ("ep_flags", C.c_int32),
-                ("ep_stat_mean", C.c_void_p), ("w_s3", C.c_void_p), ("ndst", C.c_int32), ("dst", ConvDst * MAX_SRC)]
+                ("ep_stat_mean", C.c_void_p), ("w_s3", C.c_void_p), ("ndst", C.c_int32), ("dst", ConvDst * MAX_SRC),
+                ("splitk_tickets", C.c_void_p)]
 
 
 class WgradDesc(C.Structure):

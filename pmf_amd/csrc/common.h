@@ -96,4 +96,5 @@ struct ConvGeom {
   int ksplit;       // split-K factor (K chunks dealt round-robin to ksplit workgroups; partials go to ws)
   int ws_ld;        // channel stride of the partial slabs
   float* ws;        // [ksplit][N*OH*OW][ws_ld] partial sums (deterministic split-K)
+  unsigned* tickets;  // non-NULL: the last workgroup to arrive at an output tile combines the slabs in-kernel (conv_epi.h)
 };

@@ -75,13 +75,66 @@ __device__ __forceinline__ void conv_epilogue(const pmf_conv_desc_t& d, const Co
           const unsigned off = (rok && oxb + dx < d.OW) ? (unsigned)(base + dx * estep) : 0xffffffffu;
           float v = acc[m][u][r];
           asm volatile("" : "+v"(v));   // hipcc (ROCm 7.2) otherwise stores element 0 of each accumulator quad 4x
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), wr, off, 0, 0);
+          // (in-kernel combine: write-through `sc1` stores -- MI355X_MICROARCH.md "publish-large": a release fence instead
+          // writes the whole dirty L2 back, 8.2 vs 3.0 us per 64 KB slab)
+          if (g.tickets) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), wr, off, 0, 16);
+          else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), wr, off, 0, 0);
         }
       }
     }
-    TR();
-    TR_END();
-    return;
+    if (!g.tickets) {
+      TR();
+      TR_END();
+      return;
+    }
+    // ---- in-kernel combine (round 6; MI355X_MICROARCH.md "splitk-seam"): every thread releases its slab stores at agent scope,
+    // thread 0 draws the output tile's ticket (atomicInc wraps at ksplit - 1: the counter is back at 0 when the last
+    // workgroup has drawn), and the LAST workgroup to arrive re-reads all ksplit slabs of the tile in slab order -- its own
+    // included, so that the sum does not depend on who arrived last -- and falls through into the ordinary epilogue.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this thread's write-through stores have landed
+    __syncthreads();
+    unsigned* tk = (unsigned*)smem;
+    if (tid == 0) {
+      // (`tile` is the kernel's XCD-aware tile index, not blockIdx.x)
+      const int co_tiles = (int)gridDim.y / g.ksplit;
+      tk[0] = atomicInc(g.tickets + ((size_t)n * (g.tiles_x * g.tiles_y) + tile) * co_tiles + n0 / BN, (unsigned)(g.ksplit - 1));
+    }
+    __syncthreads();
+    const bool last = tk[0] == (unsigned)(g.ksplit - 1);
+    __syncthreads();                                   // (smem is reused by the statistics reduction below)
+    if (!last) {
+      TR();
+      TR_END();
+      return;
+    }
+    // (the slabs are read with `sc1` loads: they come from memory, not from a stale line of this XCD's L2)
+#pragma unroll
+    for (int u = 0; u < NT; ++u)
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][u][r] = 0.f;
+    for (int s = 0; s < g.ksplit; ++s) {
+#pragma unroll
+      for (int u = 0; u < NT; ++u) {
+        const int co = n0 + u * 32 + li;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          const int oy = oy0 + segrow[m], oxb = ox0 + segcol[m] * 32 + 4 * lh;
+          const bool rok = co < g.ws_ld && oy < d.OH;
+          const int base = ((((s * d.N + n) * d.OH + oy) * d.OW + oxb) * g.ws_ld + co) * 4, estep = g.ws_ld * 4;
+          float t[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int dx = (r & 3) + 8 * (r >> 2);
+            const unsigned off = (rok && oxb + dx < d.OW) ? (unsigned)(base + dx * estep) : 0xffffffffu;
+            t[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wr, off, 0, 16));
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[m][u][r] += t[r];
+        }
+      }
+    }
   }
   // BatchNorm statistics in float64: float*float is exact in double, so var = E[x^2] - mean^2 keeps full
   // float32 accuracy even for nearly-constant channels (the classic cancellation), at ~2 DP ops per output

@@ -1308,6 +1308,12 @@ static int finish_rows(const pmf_conv_desc_t* d, bool stats) {
   return (int)(gx > 1024 ? 1024 : (gx < 1 ? 1 : gx));
 }
 
+// the ticket array of the in-kernel combine holds one counter per output tile: PMF_SPLITK_TICKETS entries
+#define PMF_SPLITK_TICKETS 16384
+static bool conv_tickets_ok(const pmf_conv_desc_t* d, int tiles_mn) {
+  return d->splitk_tickets != nullptr && tiles_mn <= PMF_SPLITK_TICKETS;
+}
+
 // deterministic split-K tail of a launch whose workgroups wrote g.ksplit partial slabs
 static int pmf_conv_finish_launch(const pmf_conv_desc_t* d, const ConvGeom& g, hipStream_t s) {
   const int Q = g.ws_ld / 4, Qg = Q < 256 ? Q : 256, rows = 256 / Qg;
@@ -1560,6 +1566,8 @@ static int launch(const pmf_conv_desc_t* d, hipStream_t s) {
   g.ksplit = d->ndst > 0 ? 1 : choose_ksplit(d, g.tiles_x * g.tiles_y * d->N * co_tiles, nchunks, d->ntaps * 8 * MT * (BN / 32));
   g.ws = d->splitk_ws;
   g.ws_ld = round_up(d->Cout, 4);
+  // in-kernel combine by the last-arriving workgroup of an output tile (conv_epi.h) when the caller gave a ticket array
+  g.tickets = (g.ksplit > 1 && conv_tickets_ok(d, g.tiles_x * g.tiles_y * d->N * co_tiles)) ? d->splitk_tickets : nullptr;
   g.one = (d->nsrc == 1 && g.ksplit == 1) ? 1 : 0;
   dim3 grid(g.tiles_x * g.tiles_y, co_tiles * g.ksplit, d->N);
   if (mode == 12) {
@@ -1589,7 +1597,7 @@ static int launch(const pmf_conv_desc_t* d, hipStream_t s) {
     hipLaunchKernelGGL((conv_fwd_k<BN, MT, 0>), grid, dim3(256), lds, s, dd, g);
   }
   PMF_LAUNCH_CHECK();
-  if (g.ksplit > 1) return pmf_conv_finish_launch(&dd, g, s);
+  if (g.ksplit > 1 && !g.tickets) return pmf_conv_finish_launch(&dd, g, s);
   return 0;
 }
 
@@ -1633,7 +1641,8 @@ extern "C" int pmf_conv_fwd_stat_rows(const pmf_conv_desc_t* d) {
   }
   if (conv_direct_lds(d, BN)) nchunks = 1;
   if (d->ndst > 0) return tiles * d->N;
-  if (choose_ksplit(d, tiles * d->N * cdiv(d->Cout, BN), nchunks, d->ntaps * 8 * MT * (BN / 32)) > 1) return finish_rows(d, true);
+  if (choose_ksplit(d, tiles * d->N * cdiv(d->Cout, BN), nchunks, d->ntaps * 8 * MT * (BN / 32)) > 1 &&
+      !conv_tickets_ok(d, tiles * d->N * cdiv(d->Cout, BN))) return finish_rows(d, true);
   return tiles * d->N;
 }
 

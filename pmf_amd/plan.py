@@ -42,6 +42,9 @@ class Plan(PlanConvMixin, PlanTuneMixin, PlanRunMixin):
         self._graphs, self._graph_seen = {}, {}   # hipGraph replay cache (see run)
         # fp32 convolutions on the bf16 matrix pipe (three-way operand split, six products; PMF_CONV_F32=1: fp32 MFMA only)
         self.s3 = os.environ.get("PMF_CONV_F32", "0") != "1"
+        # split-K launches combine their partial slabs in-kernel (last-arriving workgroup per output tile) instead of through
+        # a second launch (conv_finish_k); PMF_SPLITK_FUSED=0: the two-launch form
+        self.sk_fused = os.environ.get("PMF_SPLITK_FUSED", "1") != "0"
         # 1x1 layers never use the LDS-staged split kernel (the split + store of the input tile costs more than the 2.67x
         # shorter MFMA phase saves: 103 vs 149 us on the 192 -> 64 concat conv); they have their own variant that reads
         # the activations straight from global memory (s3_direct_min_pix, 67 us on that layer)
@@ -644,6 +647,9 @@ class Plan(PlanConvMixin, PlanTuneMixin, PlanRunMixin):
         nl = self.n_lanes
         self.wg_bufs = [self.act.alloc(max(self.wg_scratch, 256)) for _ in range(nl)] if self.training else None
         self.sk_bufs = [self.act.alloc(SPLITK_BYTES) for _ in range(nl)]
+        # one ticket per output tile for the in-kernel split-K combine (pmf_conv_desc_t.splitk_tickets): zeroed once with the
+        # arena, every launch leaves them at zero; one array per lane (the ops of a lane run in stream order)
+        self.sk_tickets = [self.persist.alloc(4 * 16384) for _ in range(nl)]
         self.bnpart_bufs = [self.act.alloc(COL_ROWS * 2 * max(self.colrows_max, 4) * 8) for _ in range(nl)]
         for a, zero in ((self.act, False), (self.zero_fwd, True), (self.zero_bwd, True), (self.persist, True)):
             a.materialise(dev, zero)

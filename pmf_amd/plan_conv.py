@@ -106,6 +106,7 @@ class PlanConvMixin(object):
             d.in_stride, d.gather = stride, gather
             d.out_sy = d.out_sx = 1
             d.splitk_ws, d.splitk_ws_bytes = 1, SPLITK_BYTES      # non-NULL: same split decision as the real launch
+            d.splitk_tickets = 1 if self.sk_fused else None          # (... and the same partial-statistics row count)
         fwd_s3 = self.s3_ok(shape_fill)
         if fwd_s3 == 3:
             # the 7x7 RGB stem: 8 padded channels x 49 taps, two taps per 16-deep MFMA step (conv_fwd.hip PIPE 14)
@@ -142,6 +143,7 @@ class PlanConvMixin(object):
             d.stats = stats.ptr if stats is not None else None
             d.ep_pmask = pmask.buf.ptr if pmask is not None else None
             d.splitk_ws, d.splitk_ws_bytes = self.sk_bufs[lane].ptr, self.sk_bufs[lane].nbytes
+            d.splitk_tickets = self.sk_tickets[lane].ptr if self.sk_fused else None
         self.emit(self.fwd, L.OP_CONV, f)
         conv_fwd_index = len(self.fwd) - 1
         conv_flops = 2.0 * N * OH * OW * Cout * conv.in_channels * len(taps)   # algorithmic (SURVEY.md 8d rule)
@@ -509,6 +511,7 @@ class PlanConvMixin(object):
                         d.in_stride, d.gather = 1, gather
                         d.out_sy = d.out_sx = stride
                         d.splitk_ws, d.splitk_ws_bytes = 1, SPLITK_BYTES
+                        d.splitk_tickets = 1 if self.sk_fused else None
                         d.w_s3 = 1 if k3 else None
                     # filled in by the BatchNorm backward of the layer that produced this operand when THIS launch is
                     # the last writer of its output gradient: the launch then also writes the BN-backward partial sums
@@ -531,6 +534,7 @@ class PlanConvMixin(object):
                         d.out_oy, d.out_ox = py, px
                         d.accumulate = acc
                         d.splitk_ws, d.splitk_ws_bytes = self.sk_bufs[lane].ptr, self.sk_bufs[lane].nbytes
+                        d.splitk_tickets = self.sk_tickets[lane].ptr if self.sk_fused else None
                         if s.cmul is not None:
                             d.ep_cmul, d.ep_cmul_ld = self.masks_ptr + 4 * s.cmul, s.cmul_ld
                         if relu_x is not None:

@@ -182,6 +182,16 @@ def test_conv_unit_bn_backward_three_launch_form(name, monkeypatch):
     _conv_case(next(c for c in CONVS if c[0] == name), 0)
 
 
+@pytest.mark.parametrize("name", ["c3x3_big", "c3x3d2", "c1x1cat3", "c3x3s2"])
+def test_conv_unit_splitk_two_launch_form(name, monkeypatch):
+    """split-K launches combine their partial slabs inside the kernel by default (pmf_conv_desc_t.splitk_tickets, round 6) -- what
+    test_conv_tile_configs' ks > 1 configurations exercise; PMF_SPLITK_FUSED=0 keeps them on the second launch (conv_finish_k):
+    forward, input gradients and BatchNorm statistics of both forms against float64"""
+    monkeypatch.setenv("PMF_SPLITK_FUSED", "0")
+    for ks in (2, 8):
+        _conv_case(next(c for c in CONVS if c[0] == name), 32 | (1 << 8) | (ks << 16))
+
+
 @pytest.mark.parametrize("env", [{"PMF_WG_SWP": "0"}, {"PMF_WG_W8": "1"}, {"PMF_WG_S3N": "0"}, {"PMF_WG_S3N": "2"}],
                          ids=["staged", "eight_waves", "swp_pixel_split", "nsplit_two_tiles"])
 def test_conv_unit_wgrad_variants(env, monkeypatch):

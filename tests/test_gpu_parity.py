@@ -150,6 +150,29 @@ def test_conv_fwd_split_bf16_vs_float64(case, cfg):
         st = stats.sum(0).cpu()
         assert torch.isfinite(st).all()
         assert G.rel_err(st[0].numpy() / ref[0, 0].numel(), (ref.sum((0, 2, 3)) / ref[0, 0].numel()).numpy()) < 1e-5
+        if ((cfg >> 16) & 255) > 1 and not (cfg >> 24):
+            # the same split-K launch with a ticket array (round 6): the last-arriving workgroup of an output tile combines the
+            # slabs INSIDE the kernel -- one launch, statistics rows as without the split, tickets back at zero, and the result
+            # does not depend on which workgroup arrived last (three runs, bit for bit)
+            tk = torch.zeros(16384, dtype=torch.int32, device="cuda")
+            d.splitk_tickets = tk.data_ptr()
+            rows_t = lib.pmf_conv_fwd_stat_rows(C.byref(d))
+            outs = []
+            for rep in range(3):
+                out_t = torch.zeros_like(out)
+                stats_t = torch.full((rows_t, 2, Cout), float("nan"), device="cuda", dtype=torch.float64)
+                d.out, d.stats = out_t.data_ptr(), stats_t.data_ptr()
+                _sync_check(lib.pmf_conv_fwd(C.byref(d), G.stream()), "pmf_conv_fwd (tickets)")
+                assert int(tk.abs().sum()) == 0
+                outs.append((out_t, stats_t))
+            got_t = G.from_nhwc(outs[0][0], Cout).double()
+            e_t = float((got_t - ref).abs().max() / ref.abs().max())
+            assert e_t < 2e-6 and e_t <= 4 * errs["f32"] + 1e-7, (kind, e_t, errs)
+            st_t = outs[0][1].sum(0).cpu()
+            assert G.rel_err(st_t[0].numpy() / ref[0, 0].numel(), (ref.sum((0, 2, 3)) / ref[0, 0].numel()).numpy()) < 1e-5
+            for o, s_ in outs[1:]:
+                assert torch.equal(o, outs[0][0]) and torch.equal(s_, outs[0][1])
+            d.splitk_tickets = None
     os.makedirs("gpurun_out", exist_ok=True)
     with open("gpurun_out/s3_conv_errors.txt", "a") as f:
         f.write("%-22s cfg %#8x  f32 %.3e  s3 %.3e\n" % (name, cfg, errs["f32"], errs.get("s3", float("nan"))))
