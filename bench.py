@@ -155,13 +155,17 @@ def infer_bench(args, model, dev):
     if not args.no_cpu_baseline:
         cpu = cpu_baseline(bs, args.height, args.width, args.model, args.backbone, args.nclasses, mode="infer")
     print(json.dumps({
-        "metric": "inference frames/sec PMF-ResNet34 64x2048 bs=%d (eval forward + KNN post-processing)" % bs,
+        "metric": "inference frames/sec PMF-%s %dx%d bs=%d (eval forward + KNN post-processing)" % (
+            {"resnet34": "ResNet34", "resnet50": "ResNet50"}.get(args.backbone, args.backbone), args.height, args.width, bs),
         "value": bs * args.steps / dt, "unit": "frame/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "arithmetic": ARITH_NOTE,
-        "config": {"workload": "PMF-ResNet34 inference, both streams %dx%d (BASELINE configs[1]), bs=%d, KNN 5/5/1.0/1.0 "
-                               "on %d points per frame" % (args.height, args.width, bs, frames[0][1].numel())},
+        "config": {"workload": "PMF-%s inference, both streams %dx%d (BASELINE configs[1]%s), bs=%d, %d classes, KNN 5/5/1.0/1.0 "
+                               "on %d points per frame" % ({"resnet34": "ResNet34", "resnet50": "ResNet50"}.get(args.backbone, args.backbone),
+                                                           args.height, args.width,
+                                                           "" if args.backbone == "resnet34" else "'s loop on configs[3]'s network",
+                                                           bs, args.nclasses, frames[0][1].numel())},
         "parity": parity, "roofline": roof, "roofline_hbm": hbm, "cpu_baseline": cpu}))
 
 
@@ -183,6 +187,12 @@ def infer_parity(args, model, feat, mask, frames, knn, labels_timed):
     logits = plan.read(plan.tensors["logits"]).float().cpu()
     ref_logits = net.lidar_stream.last_logits.detach()
     lrel = float(((logits - ref_logits).abs() / ref_logits.abs().clamp_min(1.0)).max())
+    # the exact answer is the float64 oracle: where the reference's own fp32 CPU path is the outlier (PMF-ResNet50 at 2 x 480 x 640:
+    # 0.9e-3 from float64), the HIP path is held to max(1e-3, 2 x the fp32 oracle's own distance) from float64 instead
+    l64 = net64.lidar_stream.last_logits.detach()
+    lrel64 = float(((logits.double() - l64).abs() / l64.abs().clamp_min(1.0)).max())
+    lrel64_cpu = float(((ref_logits.double() - l64).abs() / l64.abs().clamp_min(1.0)).max())
+    logits_ok = lrel < 1e-3 or lrel64 <= max(1e-3, 2.0 * lrel64_cpu)
     pabs = max(float((lp.cpu() - rl).abs().max()), float((cp.cpu() - rc).abs().max()))
     am_r = rl.argmax(1)
     exact, e2e_diff, total = True, 0, 0
@@ -631,6 +641,12 @@ def parity_block(args, eng, model, feat0, mask, label):
     if logits.shape != ref_logits.shape:                       # the plan stores NHWC
         logits = logits.permute(0, 3, 1, 2)[:, :ref_logits.shape[1]]
     lrel = float(((logits - ref_logits).abs() / ref_logits.abs().clamp_min(1.0)).max())
+    # the exact answer is the float64 oracle: where the reference's own fp32 CPU path is the outlier (PMF-ResNet50 at 2 x 480 x 640:
+    # 0.9e-3 from float64), the HIP path is held to max(1e-3, 2 x the fp32 oracle's own distance) from float64 instead
+    l64 = net64.lidar_stream.last_logits.detach()
+    lrel64 = float(((logits.double() - l64).abs() / l64.abs().clamp_min(1.0)).max())
+    lrel64_cpu = float(((ref_logits.double() - l64).abs() / l64.abs().clamp_min(1.0)).max())
+    logits_ok = lrel < 1e-3 or lrel64 <= max(1e-3, 2.0 * lrel64_cpu)
     rrel = 0.0
     for k, v in net.state_dict().items():
         if "running_" in k:
@@ -640,17 +656,19 @@ def parity_block(args, eng, model, feat0, mask, label):
         if any(max(grad_rel[k], grad_rel_cpu[k]) > 2e-4 for k in picks) else 0.0
     gok = all(grad_rel[k] <= max(3.0 * grad_rel_cpu[k], 2e-4) for k in picks)
     ook = all(v["hip"] <= max(3.0 * v["cpu_fp32_oracle"], 2e-4) for v in obj.values())
-    return {"logits_rel": lrel, "loss_rel": lossrel, "running_stat_rel": rrel,
+    return {"logits_rel": lrel, "logits_rel_vs_float64": {"hip": lrel64, "cpu_fp32_oracle": lrel64_cpu},
+            "loss_rel": lossrel, "running_stat_rel": rrel,
             "objective_grad_rel_vs_float64": obj,
             "grad_rel_vs_float64": {k: {"hip": grad_rel[k], "cpu_fp32_oracle": grad_rel_cpu[k]} for k in picks},
             "grad_rel_worst": max(grad_rel.values()) if picks else None,
             "grad_rel_worst_ratio_to_cpu_fp32": gratio,
             "loss_hip": loss_h, "loss_oracle": loss_r, "masked": masked,
-            "bars": {"logits_rel": 1e-3, "loss_rel": 1e-4, "running_stat_rel": 1e-4,
+            "bars": {"logits_rel": "hip vs fp32 oracle < 1e-3, or hip vs float64 <= max(1e-3, 2 x fp32 oracle vs float64)",
+                     "loss_rel": 1e-4, "running_stat_rel": 1e-4,
                      "grad_rel": "hip <= max(3 x cpu_fp32_oracle, 2e-4) for every listed parameter, all three backward passes "
                                  "driven by the SAME upstream gradient (the HIP path's d objective / d probabilities)",
                      "objective_grad_rel": "hip <= max(3 x cpu_fp32_oracle, 2e-4) per probability map, each path's own objective"},
-            "ok": bool(lrel < 1e-3 and lossrel < 1e-4 and rrel < 1e-4 and gok and ook and (masked is None or masked["ok"])),
+            "ok": bool(logits_ok and lossrel < 1e-4 and rrel < 1e-4 and gok and ook and (masked is None or masked["ok"])),
             "what": "train-mode forward + objective + BACKWARD of the plan that was timed (PMF_AUTOTUNE %s, lanes, %d captured "
                     "graphs) against the CPU oracle: model state after the timed iterations copied into oracle/ (%d host "
                     "threads), same Dropout2d multipliers, same batch; logits / loss / running statistics against the fp32 "

@@ -306,6 +306,10 @@ int pmf_fusion_gate_bwd(const float* gout, int32_t g_ldc, const pmf_view_t* f, c
                         int32_t gpcd_acc, int64_t npix, int32_t C, pmf_stream_t s);
 /* per-(n,c) spatial mean of a view (ASPP image pooling, pmf_net.py:122) and gradient (broadcast / HW) */
 int pmf_global_mean(const pmf_view_t* in, int32_t N, int32_t HW, int32_t C, float* out, pmf_stream_t s);
+/* out[n][p][c] = src[n][c] for the HW pixels of every sample (ASPP's image-level branch, pmf_net.py:124-125, as a materialised
+ * operand); C, src_ldc, out_ldc multiples of 4.  Its backward is pmf_colsum_rows with nz = N. */
+int pmf_broadcast_rows(const float* src, int32_t src_ldc, int32_t N, int64_t HW, int32_t C, float* out, int32_t out_ldc,
+                       pmf_stream_t s);
 int pmf_global_mean_bwd(const float* gout, int32_t N, int32_t HW, int32_t C, const float* cmul, int32_t cmul_ld,
                         float* gin, int32_t gin_ldc, int32_t acc, pmf_stream_t s);
 /* column sums: out[z][c] += sum over the npix pixels of sample z of x[z][p][c], z < nz (x advances npix*ldc,
@@ -524,7 +528,8 @@ enum {
   PMF_OP_MAXPOOL, PMF_OP_MAXPOOL_BWD, PMF_OP_BILINEAR, PMF_OP_BILINEAR_BWD, PMF_OP_PSHUFFLE, PMF_OP_PSHUFFLE_BWD,
   PMF_OP_GATE, PMF_OP_GATE_BWD, PMF_OP_GMEAN, PMF_OP_GMEAN_BWD, PMF_OP_COLSUM, PMF_OP_SOFTMAX, PMF_OP_SOFTMAX_BWD,
   PMF_OP_NCHW2NHWC, PMF_OP_FILL, PMF_OP_PMASK_FROM, PMF_OP_PMASK_POOL, PMF_OP_PMASK_MUL, PMF_OP_PMASK_MUL_BWD,
-  PMF_OP_VEC_ADD, PMF_OP_WGRAD_PART, PMF_OP_WGRAD_RED, PMF_OP_WGRAD_RED_MULTI, PMF_OP_BN_BWD_FOLD, PMF_OP_BN_BWD_SMALL
+  PMF_OP_VEC_ADD, PMF_OP_WGRAD_PART, PMF_OP_WGRAD_RED, PMF_OP_WGRAD_RED_MULTI, PMF_OP_BN_BWD_FOLD, PMF_OP_BN_BWD_SMALL,
+  PMF_OP_BCAST
 };
 
 /* generic argument record for the small ops (slot meaning documented next to each dispatcher case in plan.cpp) */

@@ -22,7 +22,7 @@ CFG_WS = 1 << 25               # ... the wave-scheduled N-split kernel (PMF_CFG_
  OP_ADD_ACT_BWD, OP_ACT_BWD, OP_AVGPOOL, OP_AVGPOOL_BWD, OP_MAXPOOL, OP_MAXPOOL_BWD, OP_BILINEAR,
  OP_BILINEAR_BWD, OP_PSHUFFLE, OP_PSHUFFLE_BWD, OP_GATE, OP_GATE_BWD, OP_GMEAN, OP_GMEAN_BWD, OP_COLSUM,
  OP_SOFTMAX, OP_SOFTMAX_BWD, OP_NCHW2NHWC, OP_FILL, OP_PMASK_FROM, OP_PMASK_POOL, OP_PMASK_MUL, OP_PMASK_MUL_BWD,
- OP_VEC_ADD, OP_WGRAD_PART, OP_WGRAD_RED, OP_WGRAD_RED_MULTI, OP_BN_BWD_FOLD, OP_BN_BWD_SMALL) = range(1, 38)
+ OP_VEC_ADD, OP_WGRAD_PART, OP_WGRAD_RED, OP_WGRAD_RED_MULTI, OP_BN_BWD_FOLD, OP_BN_BWD_SMALL, OP_BCAST) = range(1, 39)
 
 OP_NAMES = {v: k for k, v in list(globals().items()) if k.startswith("OP_")}
 
@@ -254,7 +254,7 @@ EXPORTS = [
     "pmf_pack_weights_batched", "pmf_conv_fwd_stat_rows", "pmf_conv_s3_eligible", "pmf_conv_ws_ok", "pmf_conv_fwd_stat_rows_max", "pmf_conv_fwd_kstages", "pmf_col_rows", "pmf_bn_finalize", "pmf_bn_eval_affine", "pmf_bn_bwd_reduce", "pmf_bn_bwd_fold", "pmf_bn_bwd_apply",
     "pmf_add_act", "pmf_add_act_bwd", "pmf_act_bwd", "pmf_avgpool3s2", "pmf_avgpool3s2_bwd", "pmf_maxpool3s2",
     "pmf_maxpool3s2_bwd", "pmf_bilinear2x", "pmf_bilinear2x_bwd", "pmf_pixel_shuffle2", "pmf_pixel_shuffle2_bwd",
-    "pmf_fusion_gate", "pmf_fusion_gate_bwd", "pmf_global_mean", "pmf_global_mean_bwd", "pmf_colsum", "pmf_colsum_rows",
+    "pmf_fusion_gate", "pmf_fusion_gate_bwd", "pmf_global_mean", "pmf_global_mean_bwd", "pmf_broadcast_rows", "pmf_colsum", "pmf_colsum_rows",
     "pmf_pmask_from", "pmf_pmask_pool", "pmf_pmask_mul", "pmf_pmask_mul_bwd", "pmf_vec_add", "pmf_softmax_nhwc_to_nchw", "pmf_softmax_bwd_nchw_to_nhwc", "pmf_logits_nhwc_to_nchw", "pmf_logits_bwd_nchw_to_nhwc", "pmf_nchw_to_nhwc", "pmf_fill", "pmf_debug_col", "pmf_bn_bwd_small_ok", "pmf_bn_bwd_small", "pmf_knn_vote", "pmf_knn_vote_batch", "pmf_knn_vote_batch_prob", "pmf_merge_pred", "pmf_merge_pred_fallback",
     "pmf_project_scatter", "pmf_project_scatter2", "pmf_project_v2_index", "pmf_project_v2_index_scaled", "pmf_project_v2_scatter", "pmf_points_transform", "pmf_range_project_index", "pmf_range_project_gather", "pmf_crop_pad", "pmf_flip_rotate_crop", "pmf_color_jitter", "pmf_lovasz_grad", "pmf_loss_rows", "pmf_loss_chunks", "pmf_loss_pixel", "pmf_loss_lovasz", "pmf_loss_pixel_w", "pmf_loss_lovasz_w", "pmf_loss_sort_workspace", "pmf_loss_lovasz_sort", "pmf_loss_lovasz_sort_w", "pmf_plan_run", "pmf_plan_run_range", "pmf_plan_capture", "pmf_graph_launch", "pmf_graph_destroy", "pmf_plan_lanes", "pmf_plan_issue_order", "pmf_graph_pieces", "pmf_plan_event_wait", "pmf_adamw_range", "pmf_sgd_range", "pmf_normalise_inplace", "pmf_sizeof", "pmf_version", "pmf_conv_multi_ok",
 ]

@@ -146,6 +146,8 @@ static int run_one_(const pmf_op_t& o, pmf_stream_t s) {
       return pmf_pmask_mul(&a.v[0], (const float*)a.p[0], a.l[0], i[0], i[1], (float*)a.p[1], i[2], s);
     case PMF_OP_PMASK_MUL_BWD:  // p: gy mask gx | i: gy_ldc C gx_ldc acc | l0 npix
       return pmf_pmask_mul_bwd((const float*)a.p[0], i[0], (const float*)a.p[1], a.l[0], i[1], (float*)a.p[2], i[2], i[3], s);
+    case PMF_OP_BCAST:  // p: src out | i: src_ldc N C out_ldc | l0 HW
+      return pmf_broadcast_rows((const float*)a.p[0], i[0], i[1], a.l[0], i[2], (float*)a.p[1], i[3], s);
     case PMF_OP_VEC_ADD:  // p: a b out | i: n
       return pmf_vec_add((const float*)a.p[0], (const float*)a.p[1], (float*)a.p[2], i[0], s);
     default: return PMF_E_ARG;

@@ -502,13 +502,23 @@ class TrainEngine:
                     m.conf_matrix = m.conf_matrix.to(lidar_pred.device)
             total, terms = pmf_total_loss_fused(lidar_pred, camera_pred, label, self.focal.alpha, self.lambda_,
                                                 self.gamma, self.tau, self.focal.gamma, self.metrics.conf_matrix,
-                                                self.metrics_img.conf_matrix)
+                                                self.metrics_img.conf_matrix, grad_out=self._plan_grad_buffers())
             self.metrics.external_update()
             self.metrics_img.external_update()
             return total, terms, lidar_pred, camera_pred, True
         total, terms = pmf_total_loss(lidar_pred, camera_pred, label, self.focal, self.lovasz,
                                       self.lambda_, self.gamma, self.tau)
         return total, terms, lidar_pred, camera_pred, False
+
+    def _plan_grad_buffers(self):
+        """the upstream-gradient staging buffers (lidar, camera) of the plan that just ran the training forward pass, for the
+        fused objective to write into (saves two N C H W copies per step); None when there is no such plan"""
+        plan = getattr(self.model, "_last_plan", None)
+        sg = getattr(plan, "stage_g", None) if (plan is not None and plan.training and self.model.training
+                                                and torch.is_grad_enabled()) else None
+        if not sg or "lidar" not in sg or "camera" not in sg:
+            return None
+        return (sg["lidar"], sg["camera"])
 
     def train_step(self, input_feature, input_mask, input_label):
         """one full iteration; everything stays on the device (no .item())."""
@@ -528,7 +538,12 @@ class TrainEngine:
             total.backward(torch.full_like(total, 1.0 / dist.get_world_size()))
             self._finish_allreduce()
         else:
-            total.backward()        # flat state: the plan zero-fills and rewrites the gradient buffer itself
+            from .loss import fused as _fused
+            _fused.UNIT_UPSTREAM = True       # (d total / d total = 1: the objective's backward hands its gradient maps on as they are)
+            try:
+                total.backward()    # flat state: the plan zero-fills and rewrites the gradient buffer itself
+            finally:
+                _fused.UNIT_UPSTREAM = False
         if own:
             self._finish_range_optim()
             self._step_extra_groups()
@@ -603,7 +618,8 @@ class EPMFEngine(TrainEngine):
             # fused term order (foc, lov, foc_cam, lov_cam, per, per_img) <- sigma order of EPMF_TERMS
             order = [EPMF_TERMS.index(k) for k in ("foc", "lov", "foc_cam", "lov_cam", "per", "per_img")]
             total, terms = weighted_loss_fused(lidar_pred, camera_pred, label, self.focal.alpha, w[order], self.tau,
-                                               self.focal.gamma, self.metrics.conf_matrix, self.metrics_img.conf_matrix)
+                                               self.focal.gamma, self.metrics.conf_matrix, self.metrics_img.conf_matrix,
+                                               grad_out=self._plan_grad_buffers())
             total = total + (sg2 + 1.0).log().sum()
             self.metrics.external_update()
             self.metrics_img.external_update()

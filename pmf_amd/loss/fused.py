@@ -26,13 +26,27 @@ def _sort_workspace(lib, c, p, dev):
     return ws
 
 
+# set by TrainEngine.train_step around its own `total.backward()` (upstream gradient exactly 1): the backward of the fused
+# objective then hands its gradient maps on as they are instead of multiplying 2 x N C H W elements by 1.0
+UNIT_UPSTREAM = False
+
+
+def _grad_buffers(pl, pc, grad_out):
+    """the two gradient maps the fused pass writes: fresh tensors, or -- when the caller owns the model's plan -- the plan's
+    own upstream-gradient staging buffers (pmf_net._PlanFunction.backward then has nothing to copy)"""
+    if grad_out is not None and all(g is not None and g.shape == p.shape and g.dtype == p.dtype and g.device == p.device
+                                    and g.is_contiguous() for g, p in zip(grad_out, (pl, pc))):
+        return grad_out[0], grad_out[1]
+    return torch.empty_like(pl), torch.empty_like(pc)
+
+
 def _use_torch_sort():
     return False       # (rounds 3-4 A/B: torch.sort + pmf_loss_lovasz; the in-library radix sort is the product path)
 
 
 class _FusedPMFLoss(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, lidar_prob, camera_prob, label, alpha, lambda_, gamma_per, tau, focal_gamma, conf_l, conf_c):
+    def forward(ctx, lidar_prob, camera_prob, label, alpha, lambda_, gamma_per, tau, focal_gamma, conf_l, conf_c, grad_out=None):
         lib = L.lib()
         if not (lidar_prob.is_cuda and camera_prob.is_cuda and label.is_cuda):
             raise RuntimeError("pmf_amd fused loss: tensors must live on the GPU (no CPU fallback)")
@@ -41,7 +55,7 @@ class _FusedPMFLoss(torch.autograd.Function):
         n, c, h, w = pl.shape
         hw, p = h * w, n * h * w
         dev = pl.device
-        gl, gc = torch.empty_like(pl), torch.empty_like(pc)
+        gl, gc = _grad_buffers(pl, pc, grad_out)
         key = torch.empty((2 * c, p), dtype=torch.float32, device=dev)
         rows = torch.empty((lib.pmf_loss_rows(p), 4), dtype=torch.float64, device=dev)
         cnt = torch.empty(c, dtype=torch.int64, device=dev)
@@ -74,7 +88,9 @@ class _FusedPMFLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_total, _g_terms):
         gl, gc = ctx.saved_tensors
-        return gl * g_total, gc * g_total, None, None, None, None, None, None, None, None
+        if UNIT_UPSTREAM:        # (the engine's own `total.backward()`: d total / d total = 1, nothing to multiply)
+            return gl, gc, None, None, None, None, None, None, None, None, None
+        return gl * g_total, gc * g_total, None, None, None, None, None, None, None, None, None
 
 
 class _FusedWeightedLoss(torch.autograd.Function):
@@ -82,7 +98,7 @@ class _FusedWeightedLoss(torch.autograd.Function):
     gradients w.r.t. both probability maps (analytic, HIP) and w.r.t. the weights (= the term values)."""
 
     @staticmethod
-    def forward(ctx, lidar_prob, camera_prob, label, alpha, w6, tau, focal_gamma, conf_l, conf_c):
+    def forward(ctx, lidar_prob, camera_prob, label, alpha, w6, tau, focal_gamma, conf_l, conf_c, grad_out=None):
         lib = L.lib()
         if not (lidar_prob.is_cuda and camera_prob.is_cuda and label.is_cuda and w6.is_cuda):
             raise RuntimeError("pmf_amd fused loss: tensors must live on the GPU (no CPU fallback)")
@@ -92,7 +108,7 @@ class _FusedWeightedLoss(torch.autograd.Function):
         n, c, h, wd = pl.shape
         hw, p = h * wd, n * h * wd
         dev = pl.device
-        gl, gc = torch.empty_like(pl), torch.empty_like(pc)
+        gl, gc = _grad_buffers(pl, pc, grad_out)
         key = torch.empty((2 * c, p), dtype=torch.float32, device=dev)
         rows = torch.empty((lib.pmf_loss_rows(p), 4), dtype=torch.float64, device=dev)
         cnt = torch.empty(c, dtype=torch.int64, device=dev)
@@ -125,23 +141,25 @@ class _FusedWeightedLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_total, _g_terms):
         gl, gc, terms = ctx.saved_tensors
-        return gl * g_total, gc * g_total, None, None, terms * g_total, None, None, None, None
+        if UNIT_UPSTREAM:
+            return gl, gc, None, None, terms, None, None, None, None, None
+        return gl * g_total, gc * g_total, None, None, terms * g_total, None, None, None, None, None
 
 
 def weighted_loss_fused(lidar_prob, camera_prob, label, alpha, w6, tau=0.7, focal_gamma=2.0, conf_lidar=None,
-                        conf_camera=None):
+                        conf_camera=None, grad_out=None):
     """total = w6 . (foc, lov, foc_cam, lov_cam, per_p, per_q); w6: device tensor [6] (may require grad).
     returns (total, dict of the six terms)."""
     total, o = _FusedWeightedLoss.apply(lidar_prob, camera_prob, label, alpha, w6, tau, focal_gamma, conf_lidar,
-                                        conf_camera)
+                                        conf_camera, grad_out)
     return total, {"foc": o[1], "lov": o[2], "foc_cam": o[3], "lov_cam": o[4], "per": o[6], "per_img": o[7]}
 
 
 def pmf_total_loss_fused(lidar_prob, camera_prob, label, alpha, lambda_=1.0, gamma_=0.5, tau=0.7, focal_gamma=2.0,
-                         conf_lidar=None, conf_camera=None):
+                         conf_lidar=None, conf_camera=None, grad_out=None):
     """returns (total, {"foc","lov","foc_cam","lov_cam","per"}); conf_* (int64 [C,C], rows = prediction) are updated
     in place when given (same counts as IOUEval.addBatch(argmax, label))."""
     total, out6 = _FusedPMFLoss.apply(lidar_prob, camera_prob, label, alpha, lambda_, gamma_, tau, focal_gamma,
-                                      conf_lidar, conf_camera)
+                                      conf_lidar, conf_camera, grad_out)
     t = {"foc": out6[1], "lov": out6[2], "foc_cam": out6[3], "lov_cam": out6[4], "per": out6[5]}
     return total, t

@@ -170,7 +170,9 @@ class ASPP(_Holder):
     def emit(self, P, x, name):
         gm = P.global_mean(x, name=name + ".mean")
         g = P.conv([V(gm)], self.conv, name=name + ".imgfeat")
-        gb = V(g.t, bcast=True)
+        # the image-level branch as a MATERIALISED operand (round 6; a broadcast-flagged operand, V(g.t, bcast=True), keeps the
+        # projection below on the generic loop and its input gradient in five launches)
+        gb = V(P.broadcast(g.t, x.t.H, x.t.W, name=name + ".imgfeat_b"))
         b1 = P.conv([x], self.atrous_block1, name=name + ".b1")
         b6 = P.conv([x], self.atrous_block6, name=name + ".b6")
         b12 = P.conv([x], self.atrous_block12, name=name + ".b12")
@@ -722,6 +724,7 @@ def _forward_impl(model, inputs):
     if model.training and plan.bn_counters:
         torch._foreach_add_(plan.bn_counters, 1)
     plan.generation += 1
+    model._last_plan = plan            # (engine.py: the fused objective writes its gradient maps into this plan's staging buffers)
     # the caller owns what it gets: copies of the plan's probability maps (2 x 21 MB at 64 x 2048 bs 2: ~10 us)
     outs = [plan.stage_out[slot].clone() for slot in ("lidar", "camera") if slot in plan.out_slots]
     return plan, outs
@@ -749,7 +752,8 @@ class _PlanFunction(torch.autograd.Function):
         for slot, g in zip(slots, gouts):
             if g is None:
                 plan.stage_g[slot].zero_()
-            else:
+            elif not (g.data_ptr() == plan.stage_g[slot].data_ptr() and g.shape == plan.stage_g[slot].shape
+                      and g.is_contiguous()):       # (the fused objective wrote straight into the staging buffer: nothing to copy)
                 plan.stage_g[slot].copy_(g)
         sig = ()
         hook = getattr(ctx.model, "_bwd_segment_hook", None) if plan.flat is not None else None

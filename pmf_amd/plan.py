@@ -573,6 +573,37 @@ class Plan(PlanConvMixin, PlanTuneMixin, PlanRunMixin):
             self.on_backward(backward)
         return out
 
+    def broadcast(self, small, H, W, name=""):
+        """small: T [N, 1, 1, C] -> materialised T [N, H, W, C] with out[n, p, :] = small[n, :] (ASPP's image-level branch:
+        `F.interpolate(1x1 -> size)`, pmf_net.py:124-125).  Backward: per-sample column sums of the gradient map
+        (pmf_colsum_rows, deterministic) accumulated into the gradient of ``small``."""
+        out = T(self, small.N, H, W, small.C, name)
+
+        def f(op):
+            s = op.u.sm
+            s.p[0], s.p[1] = small.buf.ptr, out.buf.ptr
+            s.i[0], s.i[1], s.i[2], s.i[3] = small.ldc, small.N, _ru(small.C, 4), out.ldc
+            s.l[0] = H * W
+        self.emit(self.fwd, L.OP_BCAST, f)
+        self.note_bytes(self.fwd, "broadcast", 4.0 * small.C * out.npix)
+        if self.training and small.needs_grad:
+            def backward():
+                g = self.tgrad(out)
+                if small.g is None:
+                    small.g = T(self, small.N, 1, 1, small.C, small.name + ".g", arena=self.zero_bwd, ldc=small.ldc)
+                small.g_written = True
+                self._touch(small.g)
+                crows = self.act.alloc(COL_ROWS * small.N * _ru(small.g.ldc, 4) * 4)
+
+                def fc(op):
+                    a = op.u.sm
+                    a.p[0], a.p[1], a.p[2] = g.buf.ptr, small.g.buf.ptr, crows.ptr
+                    a.i[0], a.i[1], a.i[2] = g.ldc, small.g.ldc, small.N
+                    a.l[0] = H * W
+                self.emit(self.bwd, L.OP_COLSUM, fc)
+            self.on_backward(backward)
+        return out
+
     def softmax_out(self, logits, slot, name="", softmax=True):
         """logits T -> NCHW probabilities written to an external tensor patched per call (slot index); softmax=False: the logits
         themselves (SalsaNext(softmax=False), salsanext.py:167,206-207)."""
