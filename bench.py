@@ -187,12 +187,6 @@ def infer_parity(args, model, feat, mask, frames, knn, labels_timed):
     logits = plan.read(plan.tensors["logits"]).float().cpu()
     ref_logits = net.lidar_stream.last_logits.detach()
     lrel = float(((logits - ref_logits).abs() / ref_logits.abs().clamp_min(1.0)).max())
-    # the exact answer is the float64 oracle: where the reference's own fp32 CPU path is the outlier (PMF-ResNet50 at 2 x 480 x 640:
-    # 0.9e-3 from float64), the HIP path is held to max(1e-3, 2 x the fp32 oracle's own distance) from float64 instead
-    l64 = net64.lidar_stream.last_logits.detach()
-    lrel64 = float(((logits.double() - l64).abs() / l64.abs().clamp_min(1.0)).max())
-    lrel64_cpu = float(((ref_logits.double() - l64).abs() / l64.abs().clamp_min(1.0)).max())
-    logits_ok = lrel < 1e-3 or lrel64 <= max(1e-3, 2.0 * lrel64_cpu)
     pabs = max(float((lp.cpu() - rl).abs().max()), float((cp.cpu() - rc).abs().max()))
     am_r = rl.argmax(1)
     exact, e2e_diff, total = True, 0, 0
@@ -713,9 +707,9 @@ def _masked_backward(args, Engine, eng, sd, masks, decisions, grads_h, oracle_ba
         floor = 1e-6 * float(out["f64"][wk].norm()) if wk in out["f64"] else 0.0
         den = max(float(g64.norm()), floor, 1e-30)
         rows.append((k, float((gh.double() - g64).norm()) / den, float((out["f32"][k] - g64).norm()) / den, gh.dim() == 1))
-    # weight tensors: 3x / 2e-4; 1-D parameters (conv bias, BatchNorm gamma / beta: column sums under cancellation, where the
+    # weight tensors: 4x / 2e-4 (4x = the per-launch pin of the split products against the fp32-MFMA path); 1-D parameters (conv bias, BatchNorm gamma / beta: column sums under cancellation, where the
     # residual of the six-product split adds coherently -- profiles/r06_masked_precision_class.txt): 8x / 5e-4
-    bad = [r for r in rows if not r[1] <= (max(8.0 * r[2], 5e-4) if r[3] else max(3.0 * r[2], 2e-4))]
+    bad = [r for r in rows if not r[1] <= (max(8.0 * r[2], 5e-4) if r[3] else max(4.0 * r[2], 2e-4))]
     ratio = np.array([r[1] / max(r[2], 1e-12) for r in rows if r[2] > 1e-7])
     worst = max(rows, key=lambda r: r[1] / max(r[2], 2e-4 / 3))
     return {"parameters": len(rows), "decision_sites": len(decisions),
@@ -725,7 +719,7 @@ def _masked_backward(args, Engine, eng, sd, masks, decisions, grads_h, oracle_ba
             "ratio_gmean": float(np.exp(np.log(np.maximum(ratio, 1e-6)).mean())) if ratio.size else None,
             "ratio_p90": float(np.percentile(ratio, 90)) if ratio.size else None,
             "ratio_max": float(ratio.max()) if ratio.size else None,
-            "bar": "every weight tensor: hip <= max(3 x cpu_fp32_oracle, 2e-4); every 1-D parameter: hip <= max(8 x cpu_fp32_oracle, "
+            "bar": "every weight tensor: hip <= max(4 x cpu_fp32_oracle, 2e-4); every 1-D parameter: hip <= max(8 x cpu_fp32_oracle, "
                    "5e-4); relative L2 distance from the float64 oracle, all three passes on the HIP path's activation decisions "
                    "and upstream gradient",
             "ok": not bad}

@@ -21,6 +21,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--kind", default="pmf_r34")
     ap.add_argument("--focus", default="")
+    ap.add_argument("--steps", type=int, default=0, help="training iterations on the batch before the compared pass")
     args = ap.parse_args()
     from tests import test_gpu_fullsize as TF
     from oracle import pmf_torch as O
@@ -36,6 +37,13 @@ def main():
     alpha[0] = 0
     hip = mk_hip().cuda().train()
     eng = TrainEngine(hip, ncls, alpha=alpha.numpy(), warmup_steps=10, max_steps=100)
+    if args.steps:
+        feat = torch.cat([pcd, rgb], 1).cuda()
+        ones = torch.ones(n, h, w, device="cuda")
+        for _ in range(args.steps):
+            eng.train_step(feat.clone(), ones, label.cuda())
+        torch.cuda.synchronize()
+        ref0.load_state_dict({k: v.detach().cpu() for k, v in hip.state_dict().items()})
     hip.set_dropout_masks({k: v.cuda() for k, v in masks.items()})
     for _ in range(3):
         total, _, lp, cp, _ = eng.forward_loss(pcd.cuda(), rgb.cuda(), label.cuda().long())

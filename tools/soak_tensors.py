@@ -17,6 +17,11 @@ import torch  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=1500)
+    ap.add_argument("--backbone", default="resnet34")
+    ap.add_argument("--nclasses", type=int, default=20)
+    ap.add_argument("--height", type=int, default=64)
+    ap.add_argument("--width", type=int, default=2048)
+    ap.add_argument("--masked", action="store_true", help="both oracle passes replay the HIP path's activation decisions")
     args = ap.parse_args()
     import bench as B
     from oracle import pmf_torch as O
@@ -27,10 +32,10 @@ def main():
     dev = torch.device("cuda", 0)
     torch.manual_seed(1)
     torch.cuda.manual_seed(1)
-    model = deterministic_init(PMFNet(5, 3, 20, 32, imagenet_pretrained=False, image_backbone="resnet34")).to(dev)
-    eng = TrainEngine(model, 20, lr=1e-3, momentum=0.9, weight_decay=1e-5, lambda_=1.0, gamma=0.5, tau=0.7,
+    model = deterministic_init(PMFNet(5, 3, args.nclasses, 32, imagenet_pretrained=False, image_backbone=args.backbone)).to(dev)
+    eng = TrainEngine(model, args.nclasses, lr=1e-3, momentum=0.9, weight_decay=1e-5, lambda_=1.0, gamma=0.5, tau=0.7,
                       feature_mean=B.KITTI_MEAN, feature_std=B.KITTI_STD, warmup_steps=10 * 100, max_steps=49 * 100)
-    feat0, mask, label = B.make_batch(2, 64, 2048, 1, dev, 20)
+    feat0, mask, label = B.make_batch(2, args.height, args.width, 1, dev, args.nclasses)
     for _ in range(args.steps):
         eng.train_step(feat0.clone(), mask, label)
     torch.cuda.synchronize()
@@ -46,19 +51,25 @@ def main():
     torch.cuda.synchronize()
     gl_h, gc_h = lp.grad.detach().cpu().double(), cp.grad.detach().cpu().double()
     plan = next(p for k, p in model._plans.items() if k[3])
+    dec = plan.act_decisions(model) if args.masked else None
     caps = {}
     torch.set_num_threads(min(32, os.cpu_count() or 1))
     for tag, dt in (("f32", torch.float32), ("f64", torch.float64)):
-        net = O.PMFNet(5, 3, 20, 32, False, "resnet34")
+        net = O.PMFNet(5, 3, args.nclasses, 32, False, args.backbone)
         net.load_state_dict(sd)
         net = net.to(dt).train()
         O.set_dropout_masks(net, {k: v.to(dt) for k, v in masks.items()})
         cap, hs = G.capture_oracle(net)
-        e = TrainEngine(net, 20, lambda_=1.0, gamma=0.5, tau=0.7, feature_mean=B.KITTI_MEAN, feature_std=B.KITTI_STD,
+        e = TrainEngine(net, args.nclasses, lambda_=1.0, gamma=0.5, tau=0.7, feature_mean=B.KITTI_MEAN, feature_std=B.KITTI_STD,
                         warmup_steps=10, max_steps=100)
         e.focal.to(dt)
         p, r = e.prepare(feat0.detach().cpu().to(dt), mask.cpu().to(dt))
-        tot, _, lpo, cpo, _ = e.forward_loss(p, r, label.cpu().long())
+        if args.masked:
+            from oracle.act_masks import ActSites
+            with ActSites(net, inject=dec):
+                tot, _, lpo, cpo, _ = e.forward_loss(p, r, label.cpu().long())
+        else:
+            tot, _, lpo, cpo, _ = e.forward_loss(p, r, label.cpu().long())
         own = torch.autograd.grad(tot, [lpo, cpo], retain_graph=True)
         for v in cap.values():
             if isinstance(v, torch.Tensor) and v.requires_grad and not v.is_leaf:
