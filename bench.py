@@ -142,6 +142,7 @@ def infer_bench(args, model, dev):
                        "bound": "hbm", "launches": 1, "achieved": round(nb / ms / 1e6, 1), "peak": PEAK_HBM, "unit": "GB/s",
                        "frac": round(nb / ms / 1e6 / PEAK_HBM, 5), "algorithmic_mb_per_iter": round(nb / 1e6, 2),
                        "ms_per_iter": round(ms, 4), "points": int(ur_all.numel()),
+                       "frac_of_launch_floor": round(max(nb / 6.3e12 * 1e3, 4e-3) / ms, 4),
                        "per_frame_launch_us": round(1e3 * ms1, 2), "python_issue_loop_us": round(1e3 * ms_issue, 2),
                        "point_order": "random draw order" if args.knn_random_order else "sweep-file order (azimuth-major)",
                        "random_point_order_us": round(1e3 * ms_rand, 2),
@@ -254,10 +255,14 @@ def loader_bench(args, dev):
     kept = int(xd.numel())
     rows = []
 
-    def add(name, ms, nbytes, note=""):
-        rows.append({"kernel": name, "us_per_frame": round(1e3 * ms, 2), "algorithmic_mb": round(nbytes / 1e6, 3),
-                     "achieved": round(nbytes / ms / 1e6, 1), "peak": PEAK_HBM, "unit": "GB/s",
-                     "frac": round(nbytes / ms / 1e6 / PEAK_HBM, 5), "note": note})
+    def add(name, ms, nbytes, note="", launches=None):
+        row = {"kernel": name, "us_per_frame": round(1e3 * ms, 2), "algorithmic_mb": round(nbytes / 1e6, 3),
+               "achieved": round(nbytes / ms / 1e6, 1), "peak": PEAK_HBM, "unit": "GB/s",
+               "frac": round(nbytes / ms / 1e6 / PEAK_HBM, 5), "note": note}
+        if launches:    # the same yardstick as plan_rooflines: bytes at the achievable copy rate, 4 us per dependent launch
+            row["launches"] = launches
+            row["frac_of_launch_floor"] = round(max(nbytes / 6.3e12 * 1e3, 4e-3 * launches) / ms, 4)
+        rows.append(row)
     # as PerspectiveViewLoader runs it: points / labels / image arrive in ONE packed upload (upload_packed) BEFORE the call,
     # the calibration matrix and the label LUT are per-sequence device constants -- so all of them are resident here; the
     # wrapper's output allocations are inside the timed call
@@ -266,7 +271,7 @@ def loader_bench(args, dev):
     d_lut = torch.from_numpy(np.ascontiguousarray(lut, np.int32)).to(dev)
     add("pmf_project_scatter2 (project + ordered compaction + scatter in one launch, gather in a second; via project_frame_gpu)",
         ev_ms(lambda: PV.project_frame_gpu(d_pts, d_sem, d_img, d_mat, d_lut, dev, need_uproj=False)),
-        16.0 * P + 43.0 * H * W, "P = %d raw points, %d inside the image; inputs resident (the loader's one packed upload "
+        16.0 * P + 43.0 * H * W, launches=2, note="P = %d raw points, %d inside the image; inputs resident (the loader's one packed upload "
         "precedes the call); includes the wrapper's output allocations; the five-launch form with per-call uploads of "
         "labels / matrix / LUT measured 110-126 us" % (P, kept))
     add("pmf_crop_pad (validation: CenterCrop + Pad, 10 channels)",
@@ -1197,7 +1202,10 @@ def main():
         hbm.append({"kernel": "fused objective (loss_pixel_k + Lovasz sort + gradient scatter, both heads, fwd+bwd)",
                     "bound": "hbm", "launches": None, "achieved": round(nb / ms / 1e6, 1), "peak": PEAK_HBM, "unit": "GB/s",
                     "frac": round(nb / ms / 1e6 / PEAK_HBM, 4), "algorithmic_mb_per_iter": round(nb / 1e6, 1),
-                    "ms_per_iter": round(ms, 4)})
+                    "ms_per_iter": round(ms, 4), "launches": 17,
+                    # (loss_pixel, 4 x (histogram, scan, scatter), unkey, Lovasz sums, Lovasz gradient, fold: a chain of 17
+                    # dependent launches at 4 us each is the floor of this form; the sort is what a fifth of the time goes to)
+                    "frac_of_launch_floor": round(max(nb / 6.3e12 * 1e3, 4e-3 * 17) / ms, 4)})
         # HBM-side bytes per conv launch come from a separate rocprofv3 --pmc run of this command (counters cannot be
         # read from inside the process); tools/pmc_traffic.py wrote the summary that is committed under profiles/
         headline = args.model == "pmf" and args.backbone == "resnet34" and args.nclasses == 20 and \
