@@ -1,13 +1,7 @@
 #!/bin/bash
 # scratch batch for gpurun (round 6); edited per call
 cd "$(dirname "$0")/.."
-O=gpurun_out/r06o; mkdir -p $O
+O=gpurun_out/r06p; mkdir -p $O
 export TMPDIR=/tmp
-q="--steps 80 --warmup 10 --no-cpu-baseline --no-f32-ref --no-parity --no-roofline"
-for i in 1 2 3; do
-for t in 1 0; do
-  if [ $t = 1 ]; then export PMF_TIE_LIST=1; else unset PMF_TIE_LIST; fi
-  python bench.py $q 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('r34 tie_list=$t', round(d['ms_per_step'],3))"
-done; done
-unset PMF_TIE_LIST
-timeout 600 python -m pytest tests/test_gpu_graph.py -q 2>&1 | tail -2
+timeout 2400 python -m pytest tests -m gpu -q --durations=6 > $O/gpu_tests.log 2>&1; echo "gpu tests rc=$?"; tail -14 $O/gpu_tests.log | cut -c1-200
+SKIP_PROFILES=1 bash tools/r06_evidence.sh 4c81938

@@ -3,7 +3,7 @@
 # bench lines of every configuration -> gpurun_out/r06z + gpurun_out/r06 (copy to profiles/r06_*)
 o=gpurun_out/r06z; mkdir -p $o
 python __graft_entry__.py smoke 2>&1 | tail -2
-bash tools/collect_profiles.sh r06 $1 > $o/collect.log 2>&1; head -1 gpurun_out/r06/r06_per_layer_kernel_times.txt
+if [ -z "$SKIP_PROFILES" ]; then bash tools/collect_profiles.sh r06 $1 > $o/collect.log 2>&1; head -1 gpurun_out/r06/r06_per_layer_kernel_times.txt; fi
 L=$o/r06_bench_lines.jsonl; : > $L
 python bench.py --steps 20 --warmup 5 --parity-masked >> $L 2>/dev/null
 python bench.py --steps 100 --warmup 10 --no-cpu-baseline >> $L 2>/dev/null
