@@ -1427,7 +1427,7 @@ static int conv_pipe_mode(const pmf_conv_desc_t* d, const ConvGeom& g, int gathe
 
 // PIPE 11 (conv_kloop_direct): LDS bytes of the launch, or 0 when the layer does not qualify -- one tap, split-bf16
 // weights, operands multiples of 16 channels with the same H x W, all weight fragments of one output-channel tile
-// resident in LDS.  PMF_NO_DIRECT=1 switches the variant off.
+// resident in LDS.
 static bool conv_stem_class(const pmf_conv_desc_t* d) {
   // Default since round 6 (PMF_STEM_DIRECT=0 switches it off).  Per launch the variant is pinned against float64 like every
   // other (tests) and it is faster (7x7 stem 172-185 -> 121-134 us).  Rounds 4-5 kept it opt-in because the full-size gradient
@@ -1466,7 +1466,7 @@ static int conv_direct_lds(const pmf_conv_desc_t* d, int BN, int* kchunk) {
   if (lds > 160 * 1024 && !mtap) return 0;           // (multi-tap: streamed below or refused)
   // layers whose resident fragments exceed 96 KiB (768 input channels) stream them in chunks sized so that TWO workgroups
   // fit a CU and the weight DMA runs under the MFMAs instead of in front of them: 768 -> 256 at 16x512 70 -> 59 us
-  // (PMF_DIRECT_STREAM_KIB=n moves the threshold, 0 switches the streaming off; from 64 KiB it is neutral to 4 % slower)
+  // (threshold 96 KiB; from 64 KiB the streaming form measured neutral to 4 % slower)
   if (stream_kib > 0 && lds > stream_kib * 1024) {
     const int kch = ((76 * 1024 - tab) / (2 * NT * 3 * 1024)) & ~3;
     if (kch >= 8 && kch < steps) {
@@ -1602,7 +1602,7 @@ static int launch(const pmf_conv_desc_t* d, hipStream_t s) {
 }
 
 // the wave-scheduled N-split kernel (conv_ws.hip): on request -- cfg bit 25 (PMF_CFG_WS, set by the plan autotuner where it
-// measured faster) or PMF_CONV_WS=1 (every eligible launch with at least PMF_CONV_WS_MIN_WGS workgroups: A/B) -- and eligible
+// measured faster) or PMF_CONV_WS=1 (every eligible launch with at least 128 workgroups: A/B) -- and eligible
 extern "C" int pmf_conv_ws_ok(const pmf_conv_desc_t* d);
 extern "C" int pmf_conv_ws_rows(const pmf_conv_desc_t* d);
 extern "C" int pmf_conv_ws_launch(const pmf_conv_desc_t* d, pmf_stream_t st);

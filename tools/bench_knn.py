@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """KNN vote kernel alone, timed on the GPU (a torch CUDA graph of REPS launches: the ctypes launch path costs ~20 us of host
-time per call, more than the kernel in sweep order).  usage: python tools/bench_knn.py [sweep|random]   (PMF_KNN_LDS=0: gathers)"""
+time per call, more than the kernel in sweep order).  usage: python tools/bench_knn.py [sweep|random]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
