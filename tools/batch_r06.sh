@@ -1,7 +1,5 @@
 #!/bin/bash
 # scratch batch for gpurun (round 6); edited per call
 cd "$(dirname "$0")/.."
-O=gpurun_out/r06p; mkdir -p $O
-export TMPDIR=/tmp
-timeout 2400 python -m pytest tests -m gpu -q --durations=6 > $O/gpu_tests.log 2>&1; echo "gpu tests rc=$?"; tail -14 $O/gpu_tests.log | cut -c1-200
-SKIP_PROFILES=1 bash tools/r06_evidence.sh 4c81938
+O=gpurun_out/r06q; mkdir -p $O
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 tools/probes/mfma_bf16_probe.hip -o /tmp/mfma_probe && timeout 120 /tmp/mfma_probe > $O/mfma_probe.txt 2>&1; echo "rc=$?"; cat $O/mfma_probe.txt
