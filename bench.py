@@ -654,7 +654,10 @@ def parity_block(args, eng, model, feat0, mask, label):
     gratio = max(grad_rel[k] / max(grad_rel_cpu[k], 1e-12) for k in picks if max(grad_rel[k], grad_rel_cpu[k]) > 2e-4) \
         if any(max(grad_rel[k], grad_rel_cpu[k]) > 2e-4 for k in picks) else 0.0
     gok = all(grad_rel[k] <= max(3.0 * grad_rel_cpu[k], 2e-4) for k in picks)
-    ook = all(v["hip"] <= max(3.0 * v["cpu_fp32_oracle"], 2e-4) for v in obj.values())
+    # (a NaN in the fp32 oracle's own objective gradient -- torch's xlogy / KLDiv backward at a probability that is exactly 0 in
+    # fp32, seen with EPMF at 320 x 1280 -- is no yardstick: the HIP path is then held to the floor alone)
+    ook = all(v["hip"] <= max(3.0 * (0.0 if v["cpu_fp32_oracle"] != v["cpu_fp32_oracle"] else v["cpu_fp32_oracle"]), 2e-4)
+              for v in obj.values())
     return {"logits_rel": lrel, "logits_rel_vs_float64": {"hip": lrel64, "cpu_fp32_oracle": lrel64_cpu},
             "loss_rel": lossrel, "running_stat_rel": rrel,
             "objective_grad_rel_vs_float64": obj,

@@ -16,6 +16,7 @@ python bench.py $q --backbone resnet50 --nclasses 17 --height 32 --width 1024 > 
 python bench.py $q --backbone resnet50 --nclasses 17 --height 480 --width 640 > /dev/null   # configs[3] at its RGB size
 python bench.py $q --backbone resnet50 --nclasses 17 --height 512 --width 640 --mode infer > /dev/null   # S_G eval bs 4
 python bench.py $q --model epmf > /dev/null                                         # configs[4]
+python bench.py $q --model epmf --height 320 --width 1280 > /dev/null               # EPMF's native size
 python bench.py $q --model salsanext > /dev/null                                    # f-2
 python bench.py $q --height 256 --width 1024 > /dev/null                            # KITTI training crop (S_C)
 wc -l "$out"

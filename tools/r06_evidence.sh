@@ -14,6 +14,7 @@ python bench.py --backbone resnet50 --nclasses 17 --height 32 --width 1024 --ste
 python bench.py --backbone resnet50 --nclasses 17 --height 480 --width 640 --steps 30 --warmup 5 --no-cpu-baseline --parity-masked >> $L 2>/dev/null
 python bench.py --backbone resnet50 --nclasses 17 --height 512 --width 640 --mode infer --steps 30 --warmup 5 --no-cpu-baseline >> $L 2>/dev/null
 python bench.py --model epmf --steps 50 --warmup 10 --no-cpu-baseline --parity-masked >> $L 2>/dev/null
+python bench.py --model epmf --height 320 --width 1280 --steps 40 --warmup 8 --no-cpu-baseline --parity-masked >> $L 2>/dev/null   # EPMF's native size (tasks/epmf/config_server_kitti.yaml)
 python bench.py --model salsanext --steps 50 --warmup 10 --no-cpu-baseline >> $L 2>/dev/null
 python bench.py --height 256 --width 1024 --steps 30 --warmup 5 --no-cpu-baseline >> $L 2>/dev/null
 python bench.py --force-dist --steps 50 --warmup 10 --no-cpu-baseline --no-roofline --no-f32-ref >> $L 2>/dev/null
